@@ -1,0 +1,185 @@
+/* urcco.h -- C ABI of liburcco: MI355X-native (gfx950 / CDNA4, hand-written HIP) Correlated
+ * Cross-Occurrence model build, the drop-in for the two Mahout calls the Universal Recommender makes
+ * from URAlgorithm.calcAll:
+ *
+ *   SimilarityAnalysis.cooccurrencesIDSs(...)            reference src/main/scala/URAlgorithm.scala:323-329
+ *   SimilarityAnalysis.crossOccurrenceDownsampled(...)   reference src/main/scala/URAlgorithm.scala:343-346
+ *
+ * (Mahout 0.13.0: math-scala/.../math/cf/SimilarityAnalysis.scala; un-vendored dependency, build.sbt:15,34-40.)
+ *
+ * Two levels:
+ *   1. HOST level (what a JNI shim binds): host CSR in, host indicator CSR out.
+ *        urcco_cooccurrences_idss / urcco_cross_occurrence_downsampled / urcco_free_indicators
+ *   2. DEVICE level (what the per-GPU ranks of a multi-GPU job and bench.py drive): every pointer is a
+ *      device pointer, nothing is copied, collectives between stages are the caller's (RCCL through
+ *      torch.distributed).  Stage functions only enqueue on the session's HIP stream unless they say
+ *      "synchronises".
+ *
+ * Conventions: plain C, no exceptions or aborts cross the boundary; every function returns a
+ * urcco_status (0 = OK) and leaves a message for urcco_last_error() (thread local).  Matrices are
+ * binary: values are implicit 1 (Preparator.scala:146,205 stores 1.0 for every event).
+ * The library has no CPU fallback: without a HIP device every compute entry point returns URCCO_NO_DEVICE.
+ */
+#ifndef URCCO_H
+#define URCCO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define URCCO_VERSION 100 /* 0.1.0 */
+
+typedef enum urcco_status {
+  URCCO_OK = 0,
+  URCCO_BAD_ARG = 1,     /* the reference throws IllegalArgumentException for these (URAlgorithm.scala:225,232) */
+  URCCO_OOM_HOST = 2,
+  URCCO_OOM_DEVICE = 3,
+  URCCO_HIP_ERROR = 4,
+  URCCO_INTERNAL = 5,
+  URCCO_NO_DEVICE = 6
+} urcco_status;
+
+/* D9: how sampleDownAndBinarize's perRowSampleRate is evaluated */
+#define URCCO_ROW_RATE_MAHOUT_INT_DIV 0 /* Int / Int as in Mahout 0.13.0: rows with more than max non-zeros are dropped */
+#define URCCO_ROW_RATE_FRACTIONAL 1     /* min(max, n) / n in floating point */
+
+/* One IndexedDataset.matrix (user x item, binary), rows = the shared user dictionary
+ * (Preparator.scala:44-87).  row_ptr has n_rows + 1 entries; col_idx is sorted and unique inside a row. */
+typedef struct urcco_csr {
+  int64_t n_rows;
+  int64_t n_cols;
+  const int64_t* row_ptr;
+  const int32_t* col_idx;
+} urcco_csr;
+
+/* Mahout DownsamplableCrossOccurrenceDataset(iD, maxElementsPerRow, maxInterestingElements, minLLROpt)
+ * as URAlgorithm.scala:334-341 fills it from engine.json `indicators[i]`. */
+typedef struct urcco_dataset {
+  urcco_csr matrix;
+  int32_t max_elements_per_row;     /* indicators[i].maxItemsPerUser      (default 500, URAlgorithm.scala:54) */
+  int32_t max_interesting_elements; /* indicators[i].maxCorrelatorsPerItem (default 50,  URAlgorithm.scala:56) */
+  double min_llr;                   /* indicators[i].minLLR */
+  int32_t has_min_llr;              /* 0 = None */
+  int32_t reserved;
+} urcco_dataset;
+
+typedef struct urcco_options {
+  int32_t device;        /* HIP device ordinal */
+  int32_t row_rate_mode; /* URCCO_ROW_RATE_* */
+  int32_t reserved[6];
+} urcco_options;
+
+/* One returned IndexedDataset: rows = items of the primary matrix A (rowIDs = A.columnIDs), columns = items
+ * of B_i (columnIDs = B_i.columnIDs), values = raw LLR.  Inside a row entries are ordered (llr desc, col asc)
+ * -- the order package.scala:102 (`sortBy(-score)`) produces, with the canonical tie rule.  Library-owned
+ * host memory; release with urcco_free_indicators. */
+typedef struct urcco_indicators {
+  int64_t n_rows;
+  int64_t n_cols;
+  int64_t nnz;
+  int64_t* row_ptr; /* n_rows + 1 */
+  int32_t* col_idx;
+  double* llr;
+} urcco_indicators;
+
+typedef struct urcco_dataset_stats {
+  int64_t nnz_raw;     /* interactions before down-sampling */
+  int64_t nnz_sampled; /* after sampleDownAndBinarize */
+  int64_t pairs;       /* cooccurrence pairs formed: sum_u d_A'(u) * d_B'(u) (the metric's unit) */
+  int64_t nnz_out;     /* indicator entries emitted */
+  int64_t rows_by_bin[4]; /* item rows per accumulator class: wave-LDS, block-LDS, CU-LDS, global */
+  double ms_total;     /* device time of this dataset's stages (HIP events) */
+} urcco_dataset_stats;
+
+int urcco_version(void);
+int urcco_device_count(void); /* 0 when no HIP device is visible */
+const char* urcco_last_error(void);
+const char* urcco_status_string(int status);
+
+/* ---- HOST level ------------------------------------------------------------------------------------- */
+
+/* SimilarityAnalysis.cooccurrencesIDSs(indexedDatasets, randomSeed, maxInterestingItemsPerThing,
+ * maxNumInteractions): datasets[0] is the primary.  out[n_datasets] receives A'A then A'B_i.
+ * stats may be NULL, else stats[n_datasets]. */
+int urcco_cooccurrences_idss(const urcco_csr* datasets, int32_t n_datasets, int32_t random_seed,
+                             int32_t max_interesting_items_per_thing, int32_t max_num_interactions,
+                             const urcco_options* options, urcco_indicators* out, urcco_dataset_stats* stats);
+
+/* SimilarityAnalysis.crossOccurrenceDownsampled(datasets, randomSeed). */
+int urcco_cross_occurrence_downsampled(const urcco_dataset* datasets, int32_t n_datasets, int32_t random_seed,
+                                       const urcco_options* options, urcco_indicators* out, urcco_dataset_stats* stats);
+
+void urcco_free_indicators(urcco_indicators* indicators, int32_t n);
+
+/* ---- DEVICE level ----------------------------------------------------------------------------------- */
+
+typedef struct urcco_session urcco_session;
+
+/* stream: a hipStream_t (NULL = the library creates its own).  The session owns a scratch arena that grows on
+ * demand and is reused by every stage. */
+int urcco_session_create(int32_t device, void* stream, urcco_session** out);
+void urcco_session_destroy(urcco_session* s);
+int urcco_session_synchronize(urcco_session* s);
+/* bytes of device scratch currently held */
+int64_t urcco_session_scratch_bytes(const urcco_session* s);
+
+/* numNonZeroElementsPerColumn: counts[n_cols] = occurrences of each column id in col_idx[0..nnz).
+ * counts is overwritten. */
+int urcco_dev_column_counts(urcco_session* s, int64_t nnz, const int32_t* col_idx, int32_t n_cols, int32_t* counts);
+
+/* sampleDownAndBinarize on a row shard.  raw_counts are the column counts of the WHOLE raw matrix (all shards
+ * summed).  row_base = global index of local row 0 (keys the stateless RNG so results do not depend on
+ * sharding).  out_row_ptr[n_rows+1], out_col_idx[capacity >= nnz], post_counts[n_cols] (nullable) is
+ * overwritten with the kept entries' column counts of THIS shard.  nnz_out (device int64, nullable) receives
+ * the kept total (it is also out_row_ptr[n_rows]). */
+int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx,
+                         int64_t nnz, int32_t n_cols, const int32_t* raw_counts, int32_t seed,
+                         int32_t max_elements_per_row, int32_t row_rate_mode, int64_t row_base,
+                         int64_t* out_row_ptr, int32_t* out_col_idx, int32_t* post_counts);
+
+/* CSR -> CSC of a (down-sampled) matrix.  counts[n_cols] = its column counts.  out_col_ptr[n_cols+1],
+ * out_row_idx[nnz]; order inside a column is unspecified (only integer sums are formed from it). */
+int urcco_dev_transpose(urcco_session* s, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx,
+                        int64_t nnz, int32_t n_cols, const int32_t* counts, int64_t* out_col_ptr,
+                        int32_t* out_row_idx);
+
+/* Upper-bound work per item row of A'B: work[i - item_lo] = sum over users u of item i of d_B(u)
+ * (= the cooccurrence pairs row i forms).  Used for accumulator binning and for work-balanced item ranges. */
+int urcco_dev_row_work(urcco_session* s, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr,
+                       const int32_t* a_row_idx, const int64_t* b_row_ptr, int64_t* work);
+
+/* Splits items [0, n_items) into n_parts contiguous ranges of ~equal summed work.  bounds_host[n_parts+1]
+ * (host memory).  Synchronises. */
+int urcco_dev_partition(urcco_session* s, int32_t n_items, const int64_t* work, int32_t n_parts,
+                        int32_t* bounds_host);
+
+/* Rows [item_lo, item_hi) of A'B, LLR scored, cut to the top k (computeSimilarities fused onto the SpGEMM).
+ *   a_col_ptr/a_row_idx   CSC of down-sampled A          b_row_ptr/b_col_idx   CSR of down-sampled B
+ *   counts_a/counts_b     post-sampling column counts     n_users               nrow of the DRMs (N)
+ *   exclude_self          1 for A'A (crossCooccurrence = false)
+ * Outputs (strided, row r = item_lo + r): out_count[r] entries at out_idx/out_llr[r*k ..], sorted
+ * (llr desc, col asc).  stats_dev (nullable, device int64[8]): [0] pairs, [1..4] rows per accumulator bin. */
+int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a,
+                       const int64_t* a_col_ptr, const int32_t* a_row_idx, const int64_t* b_row_ptr,
+                       const int32_t* b_col_idx, int32_t n_cols_b, const int32_t* counts_a,
+                       const int32_t* counts_b, int64_t n_users, int32_t exclude_self, int32_t k,
+                       int32_t has_min_llr, double min_llr, int32_t* out_count, int32_t* out_idx,
+                       double* out_llr, int64_t* stats_dev);
+
+/* Strided top-k rows -> CSR.  out_row_ptr[n_rows+1]; out_col_idx/out_llr capacity n_rows*k. */
+int urcco_dev_compact_indicators(urcco_session* s, int32_t n_rows, int32_t k, const int32_t* count,
+                                 const int32_t* idx, const double* llr, int64_t* out_row_ptr,
+                                 int32_t* out_col_idx, double* out_llr);
+
+/* Test hooks (device level): LLR of SimilarityAnalysis.logLikelihoodRatio evaluated by the device code for
+ * n argument tuples; u01 of the down-sampling RNG.  All pointers device. */
+int urcco_dev_llr(urcco_session* s, int64_t n, const int64_t* with_a, const int64_t* with_b, const int64_t* with_ab,
+                  const int64_t* n_users, double* out);
+int urcco_dev_u01(urcco_session* s, int64_t n, int32_t seed, const int32_t* row, const int32_t* col, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* URCCO_H */

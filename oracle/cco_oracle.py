@@ -1,0 +1,388 @@
+"""CPU ORACLE (test infrastructure, NOT product code) -- pure-Python restatement of the
+reference's Correlated Cross-Occurrence model-build path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  Nothing under universal-recommender_amd/ imports it; the product path is the
+HIP library behind include/urcco.h and fails loudly when that library is missing.
+
+What is restated, and from where (paths relative to /root/reference):
+
+* Preparator.prepare / object IndexedDatasetSpark      src/main/scala/Preparator.scala:44-87, :102-214
+* URAlgorithm.calcAll parameter resolution              src/main/scala/URAlgorithm.scala:53-57, :213-247, :310-349
+* IndexedDatasetConversions.toStringMapRDD              src/main/scala/package.scala:82-110
+* DataSource event split / empty-event drop             src/main/scala/DataSource.scala:79-89
+* Mahout 0.13.0 (org.apache.mahout:mahout-math-scala_2.11 / mahout-spark_2.11 / mahout-math,
+  build.sbt:15,34-40 -- NOT vendored in /root/reference, restated from its published source):
+    math-scala/.../math/cf/SimilarityAnalysis.scala   cooccurrencesIDSs, crossOccurrenceDownsampled,
+                                                        sampleDownAndBinarize, computeSimilarities,
+                                                        logLikelihoodRatio
+    math/.../math/stats/LogLikelihood.java             xLogX, entropy(a,b), entropy(a,b,c,d),
+                                                        logLikelihoodRatio(k11,k12,k21,k22)
+
+PARITY PINNING.  The reference cannot run here (no JVM, Mahout un-vendored).  This oracle is
+pinned against the only golden vectors the reference holds for the path:
+  data/integration-test-expected.txt (28 queries) and data/integration-test-item-set-expected.txt
+  (7 queries) through the membership checker in tests/test_golden_reference.py, plus the
+  known-answer LLR values in tests/test_oracle.py.
+Those goldens pin: the Preparator user filter (D1), duplicate collapse (D2), secondary-user drop (D3),
+N = size of the user dictionary, and the zero-LLR drop (D5).
+REFERENCE-UNPINNED decisions (no reference test observes them; this oracle is the definition):
+  D4  self pairs excluded for A'A only          D6  raw LLR (no 1-1/(1+llr) squashing)
+  D7  top-k boundary ties -> (score desc, column index asc)
+  D8  integer ids = first appearance in the event stream
+  D9  row sample rate: Mahout's Int/Int division (rows over the cap are dropped) [switchable]
+  D10 down-sample RNG: stateless hash u01(seed,row,col) instead of per-Spark-block java.util.Random
+  D11 sampling uses raw column counts, LLR uses post-sampling counts
+  D12 minLLR applied before the k cap           D13 indicators matched to event matrices by position
+  D14 seed: Long -> .toInt truncation
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+MASK64 = (1 << 64) - 1
+
+ROW_RATE_MAHOUT_INT_DIV = 0   # D9 default: min(max, n) / n evaluated in Int arithmetic -> 1 or 0
+ROW_RATE_FRACTIONAL = 1       # alternative: evaluated in floating point
+
+
+# ----------------------------------------------------------------------------------------------
+# LogLikelihood.java
+# ----------------------------------------------------------------------------------------------
+def x_log_x(x: int) -> float:
+    """LogLikelihood.xLogX: x == 0 ? 0.0 : x * Math.log(x)."""
+    return 0.0 if x == 0 else x * math.log(x)
+
+
+def entropy2(a: int, b: int) -> float:
+    """LogLikelihood.entropy(long a, long b), evaluated left to right."""
+    return x_log_x(a + b) - x_log_x(a) - x_log_x(b)
+
+
+def entropy4(a: int, b: int, c: int, d: int) -> float:
+    """LogLikelihood.entropy(long a, long b, long c, long d), evaluated left to right."""
+    return x_log_x(a + b + c + d) - x_log_x(a) - x_log_x(b) - x_log_x(c) - x_log_x(d)
+
+
+def log_likelihood_ratio(k11: int, k12: int, k21: int, k22: int) -> float:
+    """LogLikelihood.logLikelihoodRatio(k11, k12, k21, k22)."""
+    assert k11 >= 0 and k12 >= 0 and k21 >= 0 and k22 >= 0
+    row_entropy = entropy2(k11 + k12, k21 + k22)
+    column_entropy = entropy2(k11 + k21, k12 + k22)
+    matrix_entropy = entropy4(k11, k12, k21, k22)
+    if row_entropy + column_entropy < matrix_entropy:
+        return 0.0  # round off error
+    return 2.0 * (row_entropy + column_entropy - matrix_entropy)
+
+
+def mahout_llr(num_with_a: int, num_with_b: int, num_with_a_and_b: int, num_interactions: int) -> float:
+    """SimilarityAnalysis.logLikelihoodRatio(numInteractionsWithA, ...WithB, ...WithAandB, numInteractions)."""
+    k11 = num_with_a_and_b
+    k12 = num_with_a - num_with_a_and_b
+    k21 = num_with_b - num_with_a_and_b
+    k22 = num_interactions - num_with_a - num_with_b + num_with_a_and_b
+    return log_likelihood_ratio(k11, k12, k21, k22)
+
+
+# ----------------------------------------------------------------------------------------------
+# D10: stateless down-sampling RNG (identical bit-for-bit in oracle/cco_oracle.c and the HIP kernel)
+# ----------------------------------------------------------------------------------------------
+def u01(seed: int, row: int, col: int) -> float:
+    """Uniform [0,1) double keyed by (seed,row,col): splitmix64 finaliser, top 53 bits."""
+    x = ((row & 0xFFFFFFFF) << 32) | (col & 0xFFFFFFFF)
+    x ^= ((seed & 0xFFFFFFFF) * 0x9E3779B97F4A7C15) & MASK64
+    x = (x + 0x9E3779B97F4A7C15) & MASK64
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & MASK64
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & MASK64
+    x ^= x >> 31
+    return (x >> 11) * (1.0 / 9007199254740992.0)
+
+
+def seed_to_int(seed: int) -> int:
+    """D14: Scala `Long.toInt` truncation (URAlgorithm.scala:240,325,345)."""
+    s = seed & 0xFFFFFFFF
+    return s - (1 << 32) if s >= (1 << 31) else s
+
+
+# ----------------------------------------------------------------------------------------------
+# Preparator.scala
+# ----------------------------------------------------------------------------------------------
+class BiDictionary:
+    """Mahout BiDictionary restated: string <-> dense int, ids in first-appearance order (D8)."""
+
+    def __init__(self, keys: Iterable[str]):
+        self.index: "OrderedDict[str, int]" = OrderedDict()
+        for k in keys:
+            if k not in self.index:
+                self.index[k] = len(self.index)
+        self.keys: List[str] = list(self.index.keys())
+
+    def __contains__(self, k: str) -> bool:
+        return k in self.index
+
+    def __len__(self) -> int:
+        return len(self.keys)
+
+    def get(self, k: str, default: int = -1) -> int:
+        return self.index.get(k, default)
+
+    def inverse(self, i: int) -> str:
+        return self.keys[i]
+
+
+class IndexedDataset:
+    """rows: list (len nrow) of sorted unique column-index lists; binary values implied."""
+
+    def __init__(self, rows: List[List[int]], row_ids: BiDictionary, column_ids: BiDictionary):
+        self.rows = rows
+        self.row_ids = row_ids
+        self.column_ids = column_ids
+
+    @property
+    def nrow(self) -> int:
+        return len(self.rows)
+
+    @property
+    def ncol(self) -> int:
+        return len(self.column_ids)
+
+
+def _ids_with_existing_rows(elements: Sequence[Tuple[str, str]],
+                            existing_row_ids: Optional[BiDictionary]) -> IndexedDataset:
+    """object IndexedDatasetSpark.apply(elements, existingRowIDs: Option[BiDictionary]) Preparator.scala:160-214."""
+    if existing_row_ids is None:
+        row_ids = BiDictionary(u for u, _ in elements)            # :170
+        filtered = list(elements)
+    else:
+        row_ids = existing_row_ids                                 # :173-179 (never extended)
+        filtered = [(u, i) for (u, i) in elements if u in row_ids]
+    column_ids = BiDictionary(i for _, i in filtered)              # :184-186
+    rows: List[set] = [set() for _ in range(len(row_ids))]        # nrow = rowIDDictionary.size :213
+    for u, i in filtered:
+        rows[row_ids.get(u)].add(column_ids.get(i))                # setQuick(col, 1.0): duplicates collapse :205
+    return IndexedDataset([sorted(r) for r in rows], row_ids, column_ids)
+
+
+def _ids_min_events(elements: Sequence[Tuple[str, str]], min_events: int) -> BiDictionary:
+    """object IndexedDatasetSpark.apply(elements, minEventsPerUser: Int) Preparator.scala:102-158.
+    Only the down-sampled user dictionary is used by the caller (Preparator.scala:62)."""
+    counts: "OrderedDict[str, int]" = OrderedDict()
+    for u, _ in elements:
+        counts[u] = counts.get(u, 0) + 1                           # groupByKey ... items.size: RAW events (D2) :129-132
+    return BiDictionary(u for u, c in counts.items() if c >= min_events)
+
+
+def prepare(actions: Sequence[Tuple[str, Sequence[Tuple[str, str]]]],
+            min_events_per_user: Optional[int]) -> List[Tuple[str, IndexedDataset]]:
+    """Preparator.prepare (Preparator.scala:44-87): one binary matrix per event type, one shared,
+    chained user dictionary; minEventsPerUser applies to the primary (first) event only."""
+    # DataSource.scala:89 drops event types with no events (positions shift: reference quirk, kept)
+    actions = [(n, e) for (n, e) in actions if len(e) > 0]
+    out: List[Tuple[str, IndexedDataset]] = []
+    user_dictionary: Optional[BiDictionary] = None
+    for pos, (name, elements) in enumerate(actions):
+        if pos == 0 and min_events_per_user is not None:
+            d_row_ids = _ids_min_events(elements, min_events_per_user)        # :57
+            ids = _ids_with_existing_rows(elements, d_row_ids)                # :62
+        else:
+            ids = _ids_with_existing_rows(elements, user_dictionary)          # :71
+        user_dictionary = ids.row_ids                                         # :63,:72
+        out.append((name, ids))
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# SimilarityAnalysis.scala
+# ----------------------------------------------------------------------------------------------
+def column_counts(rows: Sequence[Sequence[int]], ncol: int) -> List[int]:
+    """numNonZeroElementsPerColumn."""
+    c = [0] * ncol
+    for r in rows:
+        for j in r:
+            c[j] += 1
+    return c
+
+
+def sample_down_and_binarize(rows: Sequence[Sequence[int]], ncol: int, seed: int, max_num_interactions: int,
+                             row_rate_mode: int = ROW_RATE_MAHOUT_INT_DIV, row_base: int = 0) -> List[List[int]]:
+    """SimilarityAnalysis.sampleDownAndBinarize.  Sampling uses RAW column counts (D11)."""
+    num_interactions = column_counts(rows, ncol)
+    out: List[List[int]] = []
+    for r, row in enumerate(rows):
+        n_row = len(row)
+        kept: List[int] = []
+        if n_row > 0:
+            if row_rate_mode == ROW_RATE_MAHOUT_INT_DIV:
+                per_row_rate = float(min(max_num_interactions, n_row) // n_row)   # Int / Int (D9)
+            else:
+                per_row_rate = min(max_num_interactions, n_row) / n_row
+            for j in row:
+                n_thing = float(num_interactions[j])
+                per_thing_rate = min(float(max_num_interactions), n_thing) / n_thing
+                if u01(seed, row_base + r, j) <= min(per_row_rate, per_thing_rate):
+                    kept.append(j)
+        out.append(kept)
+    return out
+
+
+def canonical_key(j: int, llr: float):
+    """D7: (score desc, column index asc)."""
+    return (-llr, j)
+
+
+def compute_similarities(counts_rows: Sequence[Dict[int, int]], num_users: int, max_interesting: int,
+                         num_interactions_rows: Sequence[int], num_interactions_cols: Sequence[int],
+                         cross_cooccurrence: bool = True, min_llr: Optional[float] = None
+                         ) -> List[List[Tuple[int, float]]]:
+    """SimilarityAnalysis.computeSimilarities: per row LLR + top-k.
+    Output rows are sorted as toStringMapRDD sorts them: score desc (package.scala:102), ties col asc (D7)."""
+    out: List[List[Tuple[int, float]]] = []
+    for thing_b, row in enumerate(counts_rows):
+        cands: List[Tuple[int, float]] = []
+        for thing_a, cooc in row.items():
+            if cross_cooccurrence or thing_b != thing_a:                       # D4
+                llr = mahout_llr(num_interactions_rows[thing_b], num_interactions_cols[thing_a], cooc, num_users)
+                if min_llr is None or llr >= min_llr:                          # D12
+                    cands.append((thing_a, llr))
+        cands.sort(key=lambda t: canonical_key(t[0], t[1]))
+        top = cands[:max_interesting]
+        # llrBlock(index, otherThing) = llrScore: a 0.0 assignment leaves the sparse row without the entry (D5)
+        out.append([(j, s) for (j, s) in top if s != 0.0])
+    return out
+
+
+def at_b(rows_a: Sequence[Sequence[int]], rows_b: Sequence[Sequence[int]], ncol_a: int) -> List[Dict[int, int]]:
+    """A' %*% B on binary matrices: integer cooccurrence counts, row i = item i of A."""
+    out: List[Dict[int, int]] = [dict() for _ in range(ncol_a)]
+    for ra, rb in zip(rows_a, rows_b):
+        for i in ra:
+            d = out[i]
+            for j in rb:
+                d[j] = d.get(j, 0) + 1
+    return out
+
+
+def count_pairs(rows_a: Sequence[Sequence[int]], rows_b: Sequence[Sequence[int]]) -> int:
+    """The metric's unit: sum_u d_A'(u) * d_B'(u)."""
+    return sum(len(a) * len(b) for a, b in zip(rows_a, rows_b))
+
+
+class DownsamplableCrossOccurrenceDataset:
+    """Mahout DownsamplableCrossOccurrenceDataset(iD, maxElementsPerRow=500, maxInterestingElements=50, minLLROpt=None)."""
+
+    def __init__(self, iD: IndexedDataset, max_elements_per_row: int = 500, max_interesting_elements: int = 50,
+                 min_llr: Optional[float] = None):
+        self.iD = iD
+        self.max_elements_per_row = max_elements_per_row
+        self.max_interesting_elements = max_interesting_elements
+        self.min_llr = min_llr
+
+
+class Indicators:
+    """One output IndexedDataset: rows = items of A, columns = items of B_i, values = LLR."""
+
+    def __init__(self, rows: List[List[Tuple[int, float]]], row_ids: BiDictionary, column_ids: BiDictionary, pairs: int):
+        self.rows = rows
+        self.row_ids = row_ids
+        self.column_ids = column_ids
+        self.pairs = pairs
+
+
+def cross_occurrence_downsampled(datasets: Sequence[DownsamplableCrossOccurrenceDataset], random_seed: int = 0xdeadbeef,
+                                 row_rate_mode: int = ROW_RATE_MAHOUT_INT_DIV) -> List[Indicators]:
+    """SimilarityAnalysis.crossOccurrenceDownsampled."""
+    seed = seed_to_int(random_seed)
+    primary = datasets[0]
+    a = sample_down_and_binarize(primary.iD.rows, primary.iD.ncol, seed, primary.max_elements_per_row, row_rate_mode)
+    num_users = primary.iD.nrow                                   # drmA.nrow
+    n_a = column_counts(a, primary.iD.ncol)                       # post-sampling counts (D11)
+    out: List[Indicators] = []
+    ata = at_b(a, a, primary.iD.ncol)
+    sim = compute_similarities(ata, num_users, primary.max_interesting_elements, n_a, n_a,
+                               cross_cooccurrence=False, min_llr=primary.min_llr)
+    out.append(Indicators(sim, primary.iD.column_ids, primary.iD.column_ids, count_pairs(a, a)))
+    for ds in datasets[1:]:
+        assert ds.iD.nrow == primary.iD.nrow, "all matrices share the user dictionary"
+        b = sample_down_and_binarize(ds.iD.rows, ds.iD.ncol, seed, ds.max_elements_per_row, row_rate_mode)
+        n_b = column_counts(b, ds.iD.ncol)
+        atb = at_b(a, b, primary.iD.ncol)
+        sim = compute_similarities(atb, num_users, ds.max_interesting_elements, n_a, n_b,
+                                   cross_cooccurrence=True, min_llr=ds.min_llr)
+        out.append(Indicators(sim, primary.iD.column_ids, ds.iD.column_ids, count_pairs(a, b)))
+    return out
+
+
+def cooccurrences_idss(indexed_datasets: Sequence[IndexedDataset], random_seed: int = 0xdeadbeef,
+                       max_interesting_items_per_thing: int = 50, max_num_interactions: int = 500,
+                       row_rate_mode: int = ROW_RATE_MAHOUT_INT_DIV) -> List[Indicators]:
+    """SimilarityAnalysis.cooccurrencesIDSs: one global (k, max) pair for every event type."""
+    ds = [DownsamplableCrossOccurrenceDataset(d, max_num_interactions, max_interesting_items_per_thing, None)
+          for d in indexed_datasets]
+    return cross_occurrence_downsampled(ds, random_seed, row_rate_mode)
+
+
+# ----------------------------------------------------------------------------------------------
+# URAlgorithm.calcAll parameter resolution + package.scala toStringMapRDD
+# ----------------------------------------------------------------------------------------------
+DEFAULT_MAX_EVENTS_PER_EVENT_TYPE = 500      # URAlgorithm.scala:54
+DEFAULT_MAX_CORRELATORS_PER_EVENT_TYPE = 50  # URAlgorithm.scala:56
+
+
+def calc_all(prepared: Sequence[Tuple[str, IndexedDataset]], algo_params: dict,
+             row_rate_mode: int = ROW_RATE_MAHOUT_INT_DIV) -> List[Tuple[str, Indicators]]:
+    """URAlgorithm.calcAll :310-349 up to (and including) the zip of event names at :349."""
+    seed = algo_params.get("seed", 0)  # reference default is wall clock (irreproducible); harness always sets it
+    indicators = algo_params.get("indicators")
+    ids = [d for _, d in prepared]
+    if not indicators:                                             # :322
+        if not algo_params.get("eventNames"):
+            raise ValueError("Must have either \"eventNames\" or \"indicators\" in algorithm parameters.")
+        res = cooccurrences_idss(
+            ids, seed,
+            algo_params.get("maxCorrelatorsPerEventType", DEFAULT_MAX_CORRELATORS_PER_EVENT_TYPE),
+            algo_params.get("maxEventsPerEventType", DEFAULT_MAX_EVENTS_PER_EVENT_TYPE), row_rate_mode)
+    else:
+        if len(indicators) < len(ids):                             # indicators(i) by position :334-340 (D13)
+            raise IndexError("indicators shorter than the list of event matrices")
+        dss = [DownsamplableCrossOccurrenceDataset(
+            d,
+            indicators[i].get("maxItemsPerUser", DEFAULT_MAX_EVENTS_PER_EVENT_TYPE),
+            indicators[i].get("maxCorrelatorsPerItem", DEFAULT_MAX_CORRELATORS_PER_EVENT_TYPE),
+            indicators[i].get("minLLR")) for i, d in enumerate(ids)]
+        res = cross_occurrence_downsampled(dss, seed, row_rate_mode)
+    return list(zip([n for n, _ in prepared], res))               # :349
+
+
+def to_string_map(event_name: str, ind: Indicators) -> Dict[str, Dict[str, List[str]]]:
+    """IndexedDatasetConversions.toStringMapRDD (package.scala:82-110): item -> {event: [ids by score desc]}.
+    Rows without surviving entries are absent (no row in the DRM)."""
+    out: Dict[str, Dict[str, List[str]]] = {}
+    for i, row in enumerate(ind.rows):
+        if not row:
+            continue
+        srt = sorted(row, key=lambda t: canonical_key(t[0], t[1]))
+        out[ind.row_ids.inverse(i)] = {event_name: [ind.column_ids.inverse(j) for j, _ in srt]}
+    return out
+
+
+def read_events(lines: Iterable[str], delimiter: str = ",") -> "OrderedDict[str, List[Tuple[str, str]]]":
+    """Parse `user,event,item` lines as examples/import_handmade.py:34-48 posts them; `$set` lines are item metadata."""
+    by_event: "OrderedDict[str, List[Tuple[str, str]]]" = OrderedDict()
+    for line in lines:
+        line = line.rstrip("\r\n")
+        if not line:
+            continue
+        data = line.split(delimiter)
+        if data[1] == "$set":
+            continue
+        by_event.setdefault(data[1], []).append((data[0], data[2]))
+    return by_event
+
+
+def split_actions(by_event: Dict[str, List[Tuple[str, str]]], event_names: Sequence[str]):
+    """DataSource.readTraining :79-89: one (name, pairs) per configured event name, in engine.json order."""
+    return [(n, by_event.get(n, [])) for n in event_names]

@@ -1,0 +1,212 @@
+// TEST-ONLY host simulator of the HIP subset used by universal-recommender_amd/csrc.
+//
+// This header is NOT part of the product and is never on the include path of the shipped library
+// (liburcco.so is built by hipcc for gfx950 only and fails loudly without a GPU).  It exists because
+// the build container has no GPU: compiling the *unchanged* kernel sources against this header with g++
+// lets the CPU test-suite exercise kernel LOGIC (indexing, hashing, compaction, selection, the C-ABI
+// orchestration) before a scarce MI355X slot is spent.  Parity claims are made only by the `-m gpu`
+// tests on real hardware.
+//
+// Model: a block's threads are fibers on one OS thread; blocks are spread over OS threads (OpenMP).
+//  * __syncthreads() parks a fiber until every live fiber of the block is parked at the barrier.
+//  * wave ops (__ballot/__shfl*) park a fiber until every live lane of its 64-wide wave is parked;
+//    lanes parked at the same wave op then exchange values (lanes that exited or sit at a block
+//    barrier are inactive, as on hardware).  All lanes must sit at the SAME call site, else abort:
+//    kernels are required to call wave ops under wave-uniform control flow.
+//  * `__shared__` is `static thread_local` (one copy per OS thread == per running block).
+//  * atomics are real (__atomic builtins), global memory is the host heap.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <type_traits>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+#define __constant__ static const
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(8) int2 { int x, y; };
+struct alignas(8) uint2 { unsigned x, y; };
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorNoDevice = 100, hipErrorUnknown = 999 };
+typedef void* hipStream_t;
+struct hipsimEvent { std::chrono::steady_clock::time_point t; };
+typedef hipsimEvent* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+struct hipDeviceProp_t { int multiProcessorCount; char name[64]; char gcnArchName[64]; size_t totalGlobalMem; };
+
+namespace hipsim {
+struct Idx { unsigned x, y, z; };
+extern thread_local Idx tIdx, bIdx, bDim, gDim;
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void sync_threads();
+enum WaveOp { OP_BALLOT = 1, OP_SHFL = 2 };
+uint64_t wave_op(int op, uint64_t payload, int arg, const void* site);
+int lane_id();
+}  // namespace hipsim
+
+#define threadIdx (hipsim::tIdx)
+#define blockIdx (hipsim::bIdx)
+#define blockDim (hipsim::bDim)
+#define gridDim (hipsim::gDim)
+#define warpSize 64
+
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
+  hipsim::launch(dim3(grid), dim3(block), [=]() { kern(__VA_ARGS__); })
+
+static inline void __syncthreads() { hipsim::sync_threads(); }
+
+__attribute__((noinline)) static unsigned long long __ballot(int pred) {
+  return hipsim::wave_op(hipsim::OP_BALLOT, pred ? 1 : 0, 0, __builtin_return_address(0));
+}
+template <typename T>
+__attribute__((noinline)) static T __shfl(T v, int src, int width = 64) {
+  static_assert(sizeof(T) <= 8, "shfl payload");
+  uint64_t p = 0;
+  memcpy(&p, &v, sizeof(T));
+  int lane = hipsim::lane_id();
+  int s = (lane & ~(width - 1)) | (src & (width - 1));
+  uint64_t r = hipsim::wave_op(hipsim::OP_SHFL, p, s, __builtin_return_address(0));
+  T out;
+  memcpy(&out, &r, sizeof(T));
+  return out;
+}
+template <typename T>
+__attribute__((noinline)) static T __shfl_xor(T v, int mask, int width = 64) {
+  uint64_t p = 0;
+  memcpy(&p, &v, sizeof(T));
+  int lane = hipsim::lane_id();
+  int s = lane ^ mask;
+  if ((s & ~(width - 1)) != (lane & ~(width - 1))) s = lane;
+  uint64_t r = hipsim::wave_op(hipsim::OP_SHFL, p, s, __builtin_return_address(0));
+  T out;
+  memcpy(&out, &r, sizeof(T));
+  return out;
+}
+template <typename T>
+__attribute__((noinline)) static T __shfl_down(T v, unsigned delta, int width = 64) {
+  uint64_t p = 0;
+  memcpy(&p, &v, sizeof(T));
+  int lane = hipsim::lane_id();
+  int s = lane + (int)delta;
+  if ((s & ~(width - 1)) != (lane & ~(width - 1))) s = lane;
+  uint64_t r = hipsim::wave_op(hipsim::OP_SHFL, p, s, __builtin_return_address(0));
+  T out;
+  memcpy(&out, &r, sizeof(T));
+  return out;
+}
+template <typename T>
+__attribute__((noinline)) static T __shfl_up(T v, unsigned delta, int width = 64) {
+  uint64_t p = 0;
+  memcpy(&p, &v, sizeof(T));
+  int lane = hipsim::lane_id();
+  int s = lane - (int)delta;
+  if (s < 0 || (s & ~(width - 1)) != (lane & ~(width - 1))) s = lane;
+  uint64_t r = hipsim::wave_op(hipsim::OP_SHFL, p, s, __builtin_return_address(0));
+  T out;
+  memcpy(&out, &r, sizeof(T));
+  return out;
+}
+
+static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
+static inline int __popc(unsigned x) { return __builtin_popcount(x); }
+static inline int __ffsll(unsigned long long x) { return __builtin_ffsll((long long)x); }
+static inline int __clz(int x) { return x == 0 ? 32 : __builtin_clz((unsigned)x); }
+static inline int __clzll(long long x) { return x == 0 ? 64 : __builtin_clzll((unsigned long long)x); }
+static inline long long __double_as_longlong(double d) { long long r; memcpy(&r, &d, 8); return r; }
+static inline double __longlong_as_double(long long l) { double r; memcpy(&r, &l, 8); return r; }
+static inline int __double2hiint(double d) { return (int)(__double_as_longlong(d) >> 32); }
+static inline int __double2loint(double d) { return (int)(__double_as_longlong(d) & 0xffffffffll); }
+static inline double __hiloint2double(int hi, int lo) {
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+
+// ---- atomics (relaxed, device scope) -------------------------------------------------------
+template <typename T> static inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+template <typename T> static inline T atomicSub(T* p, T v) { return __atomic_fetch_sub(p, v, __ATOMIC_RELAXED); }
+template <typename T> static inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+template <typename T> static inline T atomicAnd(T* p, T v) { return __atomic_fetch_and(p, v, __ATOMIC_RELAXED); }
+template <typename T> static inline T atomicExch(T* p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
+template <typename T> static inline T atomicCAS(T* p, T cmp, T v) {
+  __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+  return cmp;
+}
+template <typename T> static inline T atomicMax(T* p, T v) {
+  T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+template <typename T> static inline T atomicMin(T* p, T v) {
+  T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old > v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+  return old;
+}
+#define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+#define __HIP_MEMORY_SCOPE_WORKGROUP 3
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+#define __hip_atomic_load(p, order, scope) __atomic_load_n(p, order)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, order)
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, order)
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline void __builtin_amdgcn_s_sleep(int) {}
+
+// ---- runtime API ---------------------------------------------------------------------------
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess(sim)" : "hipError(sim)"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { if (n) memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { if (n) memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+  memset(p, 0, sizeof(*p));
+  p->multiProcessorCount = 8;
+  strcpy(p->name, "hostsim");
+  strcpy(p->gcnArchName, "hostsim");
+  p->totalGlobalMem = (size_t)8 << 30;
+  return hipSuccess;
+}
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipsimEvent(); return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+  return hipSuccess;
+}

@@ -1,0 +1,118 @@
+"""ctypes binding of liburcco (include/urcco.h).
+
+The library is hand-written HIP for gfx950 and has NO CPU fallback: if the shared object is missing, or no HIP
+device is visible, everything here raises.  `use_library()` lets the CPU test-suite point the binding at a build
+of the same sources against the test-only host simulator (tests/hostsim); nothing in the package does that.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_PATH = os.path.join(_HERE, "lib", "liburcco.so")
+
+OK, BAD_ARG, OOM_HOST, OOM_DEVICE, HIP_ERROR, INTERNAL, NO_DEVICE = range(7)
+ROW_RATE_MAHOUT_INT_DIV = 0
+ROW_RATE_FRACTIONAL = 1
+
+
+class UrccoError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"liburcco: {message} (status {status})")
+        self.status = status
+
+
+class Csr(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_cols", C.c_int64), ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p)]
+
+
+class Dataset(C.Structure):
+    _fields_ = [("matrix", Csr), ("max_elements_per_row", C.c_int32), ("max_interesting_elements", C.c_int32),
+                ("min_llr", C.c_double), ("has_min_llr", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Options(C.Structure):
+    _fields_ = [("device", C.c_int32), ("row_rate_mode", C.c_int32), ("reserved", C.c_int32 * 6)]
+
+
+class Indicators(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("n_cols", C.c_int64), ("nnz", C.c_int64), ("row_ptr", C.POINTER(C.c_int64)),
+                ("col_idx", C.POINTER(C.c_int32)), ("llr", C.POINTER(C.c_double))]
+
+
+class DatasetStats(C.Structure):
+    _fields_ = [("nnz_raw", C.c_int64), ("nnz_sampled", C.c_int64), ("pairs", C.c_int64), ("nnz_out", C.c_int64),
+                ("rows_by_bin", C.c_int64 * 4), ("ms_total", C.c_double)]
+
+
+# every symbol include/urcco.h declares: (restype, argtypes)
+_p = C.c_void_p
+SYMBOLS = {
+    "urcco_version": (C.c_int, []),
+    "urcco_device_count": (C.c_int, []),
+    "urcco_last_error": (C.c_char_p, []),
+    "urcco_status_string": (C.c_char_p, [C.c_int]),
+    "urcco_cooccurrences_idss": (C.c_int, [C.POINTER(Csr), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(Options),
+                                           C.POINTER(Indicators), C.POINTER(DatasetStats)]),
+    "urcco_cross_occurrence_downsampled": (C.c_int, [C.POINTER(Dataset), C.c_int32, C.c_int32, C.POINTER(Options),
+                                                     C.POINTER(Indicators), C.POINTER(DatasetStats)]),
+    "urcco_free_indicators": (None, [C.POINTER(Indicators), C.c_int32]),
+    "urcco_session_create": (C.c_int, [C.c_int32, _p, C.POINTER(_p)]),
+    "urcco_session_destroy": (None, [_p]),
+    "urcco_session_synchronize": (C.c_int, [_p]),
+    "urcco_session_scratch_bytes": (C.c_int64, [_p]),
+    "urcco_dev_column_counts": (C.c_int, [_p, C.c_int64, _p, C.c_int32, _p]),
+    "urcco_dev_downsample": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int64, C.c_int32, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                       _p, _p, _p]),
+    "urcco_dev_transpose": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int64, C.c_int32, _p, _p, _p]),
+    "urcco_dev_row_work": (C.c_int, [_p, C.c_int32, C.c_int32, _p, _p, _p, _p]),
+    "urcco_dev_partition": (C.c_int, [_p, C.c_int32, _p, C.c_int32, C.POINTER(C.c_int32)]),
+    "urcco_dev_cco_rows": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, _p, _p, C.c_int32, _p, _p, C.c_int64, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_double, _p, _p, _p, _p]),
+    "urcco_dev_compact_indicators": (C.c_int, [_p, C.c_int32, C.c_int32, _p, _p, _p, _p, _p, _p]),
+    "urcco_dev_llr": (C.c_int, [_p, C.c_int64, _p, _p, _p, _p, _p]),
+    "urcco_dev_u01": (C.c_int, [_p, C.c_int64, C.c_int32, _p, _p, _p]),
+}
+
+_lib: Optional[C.CDLL] = None
+_lib_path: Optional[str] = None
+
+
+def _bind(path: str) -> C.CDLL:
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def use_library(path: Optional[str]) -> None:
+    """Bind to an explicit shared object (test hook); None returns to the in-tree product library."""
+    global _lib, _lib_path
+    _lib = None
+    _lib_path = path
+
+
+def library_path() -> str:
+    return _lib_path or DEFAULT_PATH
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"liburcco HIP library not found at {path}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _lib = _bind(path)
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != OK:
+        msg = lib().urcco_last_error()
+        raise UrccoError(status, (msg or b"").decode("utf-8", "replace") or lib().urcco_status_string(status).decode())

@@ -1,0 +1,89 @@
+// Host-callable launchers of the gfx950 CCO kernels (cco_kernels.hip).  Every pointer is a device pointer;
+// every launcher only enqueues on `st`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace urcco {
+
+constexpr int NBINS = 4;  // accumulator classes: 0 wave-LDS (64 thr, 512 slots), 1 block-LDS (256 thr, 4096 slots),
+                          // 2 CU-LDS (1024 thr, 32768 slots), 3 global dense counters
+
+// Geometry the host side needs for scratch sizing.
+constexpr int SCAN_TILE = 2048;          // elements per scan tile (256 threads x 8)
+constexpr int DS_TILE = 4096;            // entries per down-sample tile (256 threads x 4 x 4)
+constexpr int GLOBAL_BIN_BLOCKS = 64;    // persistent blocks of the global-accumulator kernel
+constexpr int BIN_TILE = 1024;           // items per binning tile
+
+struct CcoArgs {
+  // row lists per bin
+  const int32_t* bin_rows;   // item ids grouped by bin
+  const int32_t* bin_off;    // [NBINS+1] offsets into bin_rows
+  // matrices
+  const int64_t* a_col_ptr;
+  const int32_t* a_row_idx;
+  const int64_t* b_row_ptr;
+  const int32_t* b_col_idx;
+  const int32_t* cnt_a;
+  const int32_t* cnt_b;
+  const double* ent_a;       // rowEntropy per item of A
+  const double* ent_b;       // columnEntropy per item of B
+  const double* xlx_n;       // [1] xLogX(N)
+  long long n_users;
+  int32_t n_cols_b;
+  int32_t item_lo;
+  int32_t exclude_self;
+  int32_t k;
+  int32_t has_min_llr;
+  double min_llr;
+  int32_t count_bits;        // packed LDS entry = ((col+1) << count_bits) | count
+  int32_t g_log2;            // lanes cooperating on one user's B row = 1 << g_log2
+  // outputs (strided by k)
+  int32_t* out_count;
+  int32_t* out_idx;
+  double* out_llr;
+  // global-accumulator scratch (bin 3)
+  int32_t* g_counts;         // [GLOBAL_BIN_BLOCKS][n_cols_b] zero on entry, zero on exit
+  unsigned long long* g_cand_key;  // [GLOBAL_BIN_BLOCKS][n_cols_b]
+  int32_t* g_cand_col;       // [GLOBAL_BIN_BLOCKS][n_cols_b]
+};
+
+hipError_t launch_column_counts(hipStream_t st, int n_cu, const int32_t* col_idx, int64_t nnz, int32_t n_cols, int32_t* counts);
+
+// scans: out[i] = sum_{t<i} in[t], out[n] = total.  tile_sums scratch: ceil(n / SCAN_TILE) + 1 int64.
+hipError_t launch_scan_i32(hipStream_t st, const int32_t* in, int64_t n, int64_t* out, int64_t* tile_sums);
+hipError_t launch_scan_popc64(hipStream_t st, const unsigned long long* in, int64_t n, int64_t* out, int64_t* tile_sums);
+
+hipError_t launch_downsample_flags(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
+                                   const int32_t* raw_counts, uint32_t seed, int32_t max_n, int row_rate_mode, int64_t row_base,
+                                   unsigned long long* flags, int32_t* post_counts);
+hipError_t launch_downsample_compact(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
+                                     const unsigned long long* flags, const int64_t* word_prefix, int64_t* out_row_ptr,
+                                     int32_t* out_col_idx);
+
+hipError_t launch_transpose(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int g_log2,
+                            const int64_t* col_ptr, int32_t* cursor, int32_t* out_row_idx);
+
+hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, double* xlx_n);
+
+hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr, const int32_t* a_row_idx,
+                           const int64_t* b_row_ptr, int g_log2, int64_t* work);
+
+// binning: bin_of[n] from work/cnt_a; tile_counts scratch [(ceil(n/BIN_TILE)+1) * (NBINS+1)] int64;
+// bin_off[NBINS+1] int32, bin_rows[n] int32, stats[8] int64 ([0] pairs, [1..4] rows per bin).
+hipError_t launch_binning(hipStream_t st, int32_t item_lo, int32_t n, const int64_t* work, const int32_t* cnt_a, int32_t n_cols_b,
+                          int32_t count_bits, int64_t* tile_counts, int32_t* bin_off, int32_t* bin_rows, int64_t* stats);
+
+hipError_t launch_cco_rows(hipStream_t st, int n_cu, const CcoArgs& args);
+
+hipError_t launch_compact_indicators(hipStream_t st, int32_t n_rows, int32_t k, const int32_t* count, const int32_t* idx,
+                                     const double* llr, const int64_t* row_ptr, int32_t* out_idx, double* out_llr);
+
+// splits: bounds[p] = first item whose exclusive work prefix >= p * total / n_parts (prefix = scan of work)
+hipError_t launch_partition(hipStream_t st, int32_t n_items, const int64_t* work_prefix, int32_t n_parts, int32_t* bounds);
+hipError_t launch_scan_i64(hipStream_t st, const int64_t* in, int64_t n, int64_t* out, int64_t* tile_sums);
+
+hipError_t launch_llr_test(hipStream_t st, int64_t n, const int64_t* a, const int64_t* b, const int64_t* ab, const int64_t* nu, double* out);
+hipError_t launch_u01_test(hipStream_t st, int64_t n, uint32_t seed, const int32_t* row, const int32_t* col, double* out);
+
+}  // namespace urcco

@@ -1,0 +1,991 @@
+// Hand-written gfx950 (MI355X / CDNA4) kernels of the Correlated Cross-Occurrence model build.
+//
+// Replaces, stage for stage, what Mahout 0.13.0 SimilarityAnalysis does on Spark when called from
+// URAlgorithm.calcAll (reference src/main/scala/URAlgorithm.scala:323-329, :343-346):
+//   column_counts_kernel            numNonZeroElementsPerColumn
+//   downsample_flags_kernel  +      sampleDownAndBinarize  (the "CSR row scan": flat, 16 B/lane coalesced reads,
+//   downsample_compact_kernel         wave-assembled keep bitmask, prefix-sum compaction)
+//   transpose_kernel                the `A.t` of `A.t %*% B`
+//   row_work / binning kernels      row-tile partitioning of the SpGEMM by upper-bound work
+//   cco_rows_kernel<T,E>            `A.t %*% B` (Gustavson over rows of A', LDS hash accumulators) fused with
+//                                   computeSimilarities (fp64 LLR + top-k) -- counts never touch HBM
+//   cco_rows_global_kernel          same, dense global accumulator for rows too heavy for LDS
+// All of it is irregular integer/byte work bounded by HBM / L2 / LDS-atomic throughput: no MFMA.
+// Wave = 64 lanes everywhere.  Wave-level primitives (__shfl*, __ballot) are only ever executed under
+// wave-uniform control flow.
+#include "cco_kernels.h"
+
+#include "cco_device.h"
+
+namespace urcco {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  lo = __shfl_xor(lo, m);
+  hi = __shfl_xor(hi, m);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ long long shfl_up_i64(long long v, unsigned d) {
+  unsigned lo = (unsigned)v, hi = (unsigned)((unsigned long long)v >> 32);
+  lo = __shfl_up(lo, d);
+  hi = __shfl_up(hi, d);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// ============================================================================================
+// K1  column counts (numNonZeroElementsPerColumn)
+// Zipf-headed data puts millions of increments on a handful of addresses and a device-scope atomic on one
+// address retires at ~11 ns, so every block keeps a small open-addressing LDS cache of (column,count):
+// hot columns claim a slot early and cost one global atomic per block; cold ones fall through to L2 atomics.
+// ============================================================================================
+constexpr int CC_THREADS = 256;
+constexpr int CC_SLOTS = 4096;
+
+__device__ __forceinline__ void cc_insert(int* s_key, int* s_cnt, int32_t* __restrict__ counts, int col) {
+  const int key = col + 1;
+  unsigned h = ((unsigned)key * 0x9E3779B1u) >> 20;  // 12 bits
+#pragma unroll
+  for (int probe = 0; probe < 2; ++probe) {
+    int kk = __hip_atomic_load(&s_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (kk == 0) kk = atomicCAS(&s_key[h], 0, key), kk = (kk == 0) ? key : kk;
+    if (kk == key) {
+      atomicAdd(&s_cnt[h], 1);
+      return;
+    }
+    h = (h + 1) & (CC_SLOTS - 1);
+  }
+  atomicAdd(&counts[col], 1);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(CC_THREADS) void column_counts_kernel(const int32_t* __restrict__ ci, int64_t nnz,
+                                                                   int32_t* __restrict__ counts) {
+  __shared__ int s_key[CC_SLOTS];
+  __shared__ int s_cnt[CC_SLOTS];
+  for (int s = threadIdx.x; s < CC_SLOTS; s += CC_THREADS) {
+    s_key[s] = 0;
+    s_cnt[s] = 0;
+  }
+  __syncthreads();
+  const int64_t gtid = (int64_t)blockIdx.x * CC_THREADS + threadIdx.x;
+  const int64_t gstride = (int64_t)gridDim.x * CC_THREADS;
+  if (VEC) {
+    const int64_t nvec = nnz >> 2;
+    const int4* ci4 = reinterpret_cast<const int4*>(ci);
+    for (int64_t v = gtid; v < nvec; v += gstride) {
+      const int4 x = ci4[v];
+      cc_insert(s_key, s_cnt, counts, x.x);
+      cc_insert(s_key, s_cnt, counts, x.y);
+      cc_insert(s_key, s_cnt, counts, x.z);
+      cc_insert(s_key, s_cnt, counts, x.w);
+    }
+    if (blockIdx.x == 0 && (int64_t)threadIdx.x < (nnz & 3)) cc_insert(s_key, s_cnt, counts, ci[(nvec << 2) + threadIdx.x]);
+  } else {
+    for (int64_t e = gtid; e < nnz; e += gstride) cc_insert(s_key, s_cnt, counts, ci[e]);
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < CC_SLOTS; s += CC_THREADS)
+    if (s_key[s] != 0) atomicAdd(&counts[s_key[s] - 1], s_cnt[s]);
+}
+
+hipError_t launch_column_counts(hipStream_t st, int n_cu, const int32_t* col_idx, int64_t nnz, int32_t n_cols, int32_t* counts) {
+  hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)n_cols, st);
+  if (e != hipSuccess || nnz == 0) return e;
+  const bool vec = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
+  const int64_t work_items = vec ? (nnz + 3) / 4 : nnz;
+  int64_t blocks = (work_items + (int64_t)CC_THREADS * 8 - 1) / ((int64_t)CC_THREADS * 8);  // >= 8 vectors per thread
+  const int64_t cap = (int64_t)n_cu * 4;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  if (vec)
+    hipLaunchKernelGGL((column_counts_kernel<true>), dim3((unsigned)blocks), dim3(CC_THREADS), 0, st, col_idx, nnz, counts);
+  else
+    hipLaunchKernelGGL((column_counts_kernel<false>), dim3((unsigned)blocks), dim3(CC_THREADS), 0, st, col_idx, nnz, counts);
+  return hipGetLastError();
+}
+
+// ============================================================================================
+// Exclusive scan (three-kernel tile scan): out[i] = sum_{t<i} f(in[t]), out[n] = total
+// ============================================================================================
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = SCAN_TILE / SCAN_THREADS;  // 8
+
+struct LoadI32 {
+  const int32_t* p;
+  __device__ __forceinline__ long long operator()(int64_t i) const { return p[i]; }
+};
+struct LoadI64 {
+  const int64_t* p;
+  __device__ __forceinline__ long long operator()(int64_t i) const { return p[i]; }
+};
+struct LoadPopc64 {
+  const unsigned long long* p;
+  __device__ __forceinline__ long long operator()(int64_t i) const { return __popcll(p[i]); }
+};
+
+// inclusive scan of one value per thread over the block; returns the exclusive prefix, *total = block sum.
+// All 256 threads must call it.
+__device__ __forceinline__ long long block_exclusive_scan(long long v, long long* s_wave /*[SCAN_THREADS/WAVE]*/, long long* total) {
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+  long long inc = v;
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const long long o = shfl_up_i64(inc, d);
+    if (lane >= d) inc += o;
+  }
+  if (lane == WAVE - 1) s_wave[wave] = inc;
+  __syncthreads();
+  long long base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_THREADS / WAVE; ++w) {
+    const long long sw = s_wave[w];
+    if (w < wave) base += sw;
+    tot += sw;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+template <typename Load>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(Load ld, int64_t n, int64_t* __restrict__ tile_sums) {
+  __shared__ long long s_wave[SCAN_THREADS / WAVE];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+  long long v = 0;
+#pragma unroll
+  for (int q = 0; q < SCAN_ITEMS; ++q) {
+    const int64_t i = base + (int64_t)q * SCAN_THREADS + threadIdx.x;
+    if (i < n) v += ld(i);
+  }
+  long long tot;
+  block_exclusive_scan(v, s_wave, &tot);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// single block: in-place exclusive scan of tile_sums[0..n_tiles), tile_sums[n_tiles] = total
+__global__ __launch_bounds__(SCAN_THREADS) void scan_tiles_kernel(int64_t* __restrict__ tile_sums, int64_t n_tiles) {
+  __shared__ long long s_wave[SCAN_THREADS / WAVE];
+  long long carry = 0;
+  for (int64_t base = 0; base < n_tiles; base += SCAN_THREADS) {  // block-uniform trip count
+    const int64_t i = base + threadIdx.x;
+    const long long v = i < n_tiles ? tile_sums[i] : 0;
+    long long tot;
+    const long long ex = block_exclusive_scan(v, s_wave, &tot);
+    if (i < n_tiles) tile_sums[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) tile_sums[n_tiles] = carry;
+}
+
+template <typename Load>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(Load ld, int64_t n, const int64_t* __restrict__ tile_sums,
+                                                                      int64_t n_tiles, int64_t* __restrict__ out) {
+  __shared__ long long s_wave[SCAN_THREADS / WAVE];
+  // thread t owns SCAN_ITEMS consecutive elements so that the scan order is the element order
+  const int64_t first = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  long long x[SCAN_ITEMS];
+  long long v = 0;
+#pragma unroll
+  for (int q = 0; q < SCAN_ITEMS; ++q) {
+    const int64_t i = first + q;
+    x[q] = i < n ? ld(i) : 0;
+    v += x[q];
+  }
+  long long tot;
+  long long run = block_exclusive_scan(v, s_wave, &tot) + tile_sums[blockIdx.x];
+#pragma unroll
+  for (int q = 0; q < SCAN_ITEMS; ++q) {
+    const int64_t i = first + q;
+    if (i < n) out[i] = run;
+    run += x[q];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_sums[n_tiles];
+}
+
+template <typename Load>
+static hipError_t launch_scan(hipStream_t st, Load ld, int64_t n, int64_t* out, int64_t* tile_sums) {
+  if (n <= 0) return hipMemsetAsync(out, 0, sizeof(int64_t), st);
+  const int64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL((scan_reduce_kernel<Load>), dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, st, ld, n, tile_sums);
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, tile_sums, n_tiles);
+  hipLaunchKernelGGL((scan_downsweep_kernel<Load>), dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, st, ld, n, tile_sums, n_tiles, out);
+  return hipGetLastError();
+}
+hipError_t launch_scan_i32(hipStream_t st, const int32_t* in, int64_t n, int64_t* out, int64_t* tile_sums) {
+  return launch_scan(st, LoadI32{in}, n, out, tile_sums);
+}
+hipError_t launch_scan_i64(hipStream_t st, const int64_t* in, int64_t n, int64_t* out, int64_t* tile_sums) {
+  return launch_scan(st, LoadI64{in}, n, out, tile_sums);
+}
+hipError_t launch_scan_popc64(hipStream_t st, const unsigned long long* in, int64_t n, int64_t* out, int64_t* tile_sums) {
+  return launch_scan(st, LoadPopc64{in}, n, out, tile_sums);
+}
+
+// ============================================================================================
+// K2  sampleDownAndBinarize -- the CSR row scan
+// Pass A (flags): flat over the nnz array, 16 B per lane, the block's row_ptr slice staged in LDS for the
+//   entry -> row lookup; keep decision per entry = u01(seed,row,col) <= min(perRowRate, perThingRate);
+//   the 4-bit nibbles of 16 neighbouring lanes are OR-assembled into one 64-bit keep word (bit e%64 of
+//   word e/64), post-sampling column counts accumulate by L2 atomics (<= ~max per address after the cut).
+// Pass B (compact): prefix over popcounts of the keep words -> out position of every kept entry; the new
+//   row_ptr is the same prefix evaluated at the old row starts.
+// ============================================================================================
+constexpr int DS_THREADS = 256;
+constexpr int DS_ITERS = DS_TILE / (DS_THREADS * 4);  // 4
+constexpr int DS_SLICE = DS_TILE + 2;                 // row_ptr entries staged per tile
+
+// first idx in [lo, hi] with rp[idx] > e   (rp[hi] > e guaranteed by the caller)
+__device__ __forceinline__ int64_t upper_bound_i64(const int64_t* __restrict__ rp, int64_t lo, int64_t hi, int64_t e) {
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (rp[mid] > e) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_rows, const int64_t* __restrict__ rp,
+                                                                      const int32_t* __restrict__ ci, int64_t nnz,
+                                                                      const int32_t* __restrict__ raw_counts, uint32_t seed,
+                                                                      int32_t max_n, int row_rate_mode, int64_t row_base,
+                                                                      unsigned long long* __restrict__ flags,
+                                                                      int32_t* __restrict__ post_counts, int vec_ok) {
+  __shared__ long long s_rp[DS_SLICE];
+  __shared__ long long s_rows[2];
+  const int64_t e0 = (int64_t)blockIdx.x * DS_TILE;
+  const int64_t e1 = (e0 + DS_TILE < nnz) ? e0 + DS_TILE : nnz;
+  if (threadIdx.x < 2) {
+    const int64_t e = threadIdx.x == 0 ? e0 : e1 - 1;
+    s_rows[threadIdx.x] = upper_bound_i64(rp, 0, n_rows, e) - 1;  // row holding entry e
+  }
+  __syncthreads();
+  const int64_t r_first = s_rows[0], r_last = s_rows[1];
+  const int64_t n_slice = r_last - r_first + 2;  // rp[r_first .. r_last+1]
+  const bool in_lds = n_slice <= DS_SLICE;
+  if (in_lds)
+    for (int64_t t = threadIdx.x; t < n_slice; t += DS_THREADS) s_rp[t] = rp[r_first + t];
+  __syncthreads();
+  const double dmax = (double)max_n;
+  const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll 1
+  for (int it = 0; it < DS_ITERS; ++it) {  // block-uniform trip count: wave ops below are legal
+    const int64_t e = e0 + ((int64_t)it * DS_THREADS + threadIdx.x) * 4;
+    unsigned nib = 0;
+    if (e < e1) {
+      int cols[4];
+      if (vec_ok && e + 3 < nnz) {
+        const int4 x = *reinterpret_cast<const int4*>(ci + e);
+        cols[0] = x.x; cols[1] = x.y; cols[2] = x.z; cols[3] = x.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cols[q] = (e + q < nnz) ? ci[e + q] : 0;
+      }
+      // row of the first entry
+      int64_t r;
+      if (in_lds) {
+        int lo = 0, hi = (int)n_slice - 1;  // s_rp[hi] = rp[r_last+1] > e
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (s_rp[mid] > e) hi = mid; else lo = mid + 1;
+        }
+        r = r_first + lo - 1;
+      } else {
+        r = upper_bound_i64(rp, r_first, r_last + 1, e) - 1;
+      }
+      int64_t r_end = in_lds ? s_rp[r + 1 - r_first] : rp[r + 1];
+      int64_t r_beg = in_lds ? s_rp[r - r_first] : rp[r];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t ee = e + q;
+        if (ee < e1) {
+          while (ee >= r_end) {  // next non-empty row
+            ++r;
+            r_beg = r_end;
+            r_end = in_lds ? s_rp[r + 1 - r_first] : rp[r + 1];
+          }
+          const int64_t n_row = r_end - r_beg;
+          const int64_t capped = n_row < (int64_t)max_n ? n_row : (int64_t)max_n;
+          const double per_row = row_rate_mode == 0 ? (double)(capped / n_row) : (double)capped / (double)n_row;
+          const int j = cols[q];
+          const double n_thing = (double)raw_counts[j];
+          const double per_thing = (n_thing < dmax ? n_thing : dmax) / n_thing;
+          const double rate = per_row < per_thing ? per_row : per_thing;
+          if (u01_hash(seed, (uint32_t)(row_base + r), (uint32_t)j) <= rate) {
+            nib |= 1u << q;
+            if (post_counts) atomicAdd(&post_counts[j], 1);
+          }
+        }
+      }
+    }
+    // assemble the keep word of 16 neighbouring lanes (64 consecutive entries)
+    unsigned long long m = (unsigned long long)nib << ((lane & 15) * 4);
+    m |= shfl_xor_u64(m, 1);
+    m |= shfl_xor_u64(m, 2);
+    m |= shfl_xor_u64(m, 4);
+    m |= shfl_xor_u64(m, 8);
+    const int64_t e_grp = e - (int64_t)(lane & 15) * 4;  // first entry of the 16-lane group
+    if ((lane & 15) == 0 && e_grp < e1) flags[e_grp >> 6] = m;
+  }
+}
+
+// prefix position of entry e: kept entries with index < e
+__device__ __forceinline__ int64_t kept_before(const unsigned long long* __restrict__ flags, const int64_t* __restrict__ word_prefix,
+                                               int64_t e) {
+  const int64_t w = e >> 6;
+  const int b = (int)(e & 63);
+  const unsigned long long below = b == 0 ? 0ull : (flags[w] & ((1ull << b) - 1ull));
+  return word_prefix[w] + __popcll(below);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(DS_THREADS) void downsample_compact_kernel(const int32_t* __restrict__ ci, int64_t nnz,
+                                                                        const unsigned long long* __restrict__ flags,
+                                                                        const int64_t* __restrict__ word_prefix,
+                                                                        int32_t* __restrict__ out_ci) {
+  const int64_t nvec = (nnz + 3) >> 2;
+  for (int64_t v = (int64_t)blockIdx.x * DS_THREADS + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * DS_THREADS) {
+    const int64_t e = v << 2;
+    const int64_t w = e >> 6;
+    const int b = (int)(e & 63);
+    const unsigned long long word = flags[w];
+    const unsigned nib = (unsigned)(word >> b) & 0xFu;
+    if (nib == 0) continue;
+    int cols[4];
+    if (VEC && e + 3 < nnz) {
+      const int4 x = *reinterpret_cast<const int4*>(ci + e);
+      cols[0] = x.x; cols[1] = x.y; cols[2] = x.z; cols[3] = x.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cols[q] = (e + q < nnz) ? ci[e + q] : 0;
+    }
+    int64_t pos = word_prefix[w] + __popcll(b == 0 ? 0ull : (word & ((1ull << b) - 1ull)));
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (nib & (1u << q)) out_ci[pos++] = cols[q];
+  }
+}
+
+__global__ __launch_bounds__(256) void downsample_rowptr_kernel(int64_t n_rows, const int64_t* __restrict__ rp, int64_t nnz,
+                                                                const unsigned long long* __restrict__ flags,
+                                                                const int64_t* __restrict__ word_prefix, int64_t n_words,
+                                                                int64_t* __restrict__ out_rp) {
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= n_rows; r += (int64_t)gridDim.x * 256) {
+    const int64_t e = rp[r];
+    out_rp[r] = e >= nnz ? word_prefix[n_words] : kept_before(flags, word_prefix, e);
+  }
+}
+
+hipError_t launch_downsample_flags(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
+                                   const int32_t* raw_counts, uint32_t seed, int32_t max_n, int row_rate_mode, int64_t row_base,
+                                   unsigned long long* flags, int32_t* post_counts) {
+  if (nnz == 0) return hipSuccess;
+  const int64_t tiles = (nnz + DS_TILE - 1) / DS_TILE;
+  const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
+  hipLaunchKernelGGL(downsample_flags_kernel, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, raw_counts,
+                     seed, max_n, row_rate_mode, row_base, flags, post_counts, vec_ok);
+  return hipGetLastError();
+}
+
+hipError_t launch_downsample_compact(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
+                                     const unsigned long long* flags, const int64_t* word_prefix, int64_t* out_row_ptr,
+                                     int32_t* out_col_idx) {
+  const int64_t n_words = (nnz + 63) >> 6;
+  if (nnz > 0) {
+    const int64_t nvec = (nnz + 3) >> 2;
+    int64_t blocks = (nvec + DS_THREADS * 4 - 1) / (DS_THREADS * 4);
+    const int64_t cap = (int64_t)n_cu * 8;
+    if (blocks > cap) blocks = cap;
+    if ((reinterpret_cast<uintptr_t>(col_idx) & 15) == 0)
+      hipLaunchKernelGGL((downsample_compact_kernel<true>), dim3((unsigned)blocks), dim3(DS_THREADS), 0, st, col_idx, nnz, flags, word_prefix,
+                         out_col_idx);
+    else
+      hipLaunchKernelGGL((downsample_compact_kernel<false>), dim3((unsigned)blocks), dim3(DS_THREADS), 0, st, col_idx, nnz, flags, word_prefix,
+                         out_col_idx);
+  }
+  int64_t rblocks = (n_rows + 1 + 255) / 256;
+  const int64_t rcap = (int64_t)n_cu * 8;
+  if (rblocks > rcap) rblocks = rcap;
+  hipLaunchKernelGGL(downsample_rowptr_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, n_rows, row_ptr, nnz, flags, word_prefix, n_words,
+                     out_row_ptr);
+  return hipGetLastError();
+}
+
+// ============================================================================================
+// K3  CSR -> CSC (the A.t of A.t %*% B).  2^g lanes walk one user row; destination slots come from
+// per-column cursors (returning L2 atomics; after the interaction cut a column sees <= ~max of them).
+// Order inside a column is whatever the atomics produce: only integer sums are formed from it.
+// ============================================================================================
+__global__ __launch_bounds__(256) void transpose_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                        int g_log2, const int64_t* __restrict__ col_ptr, int32_t* __restrict__ cursor,
+                                                        int32_t* __restrict__ out_rows) {
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t groups_per_block = 256 >> g_log2;
+  for (int64_t r = (int64_t)blockIdx.x * groups_per_block + (threadIdx.x >> g_log2); r < n_rows;
+       r += (int64_t)gridDim.x * groups_per_block) {
+    const int64_t s = rp[r], e = rp[r + 1];
+    for (int64_t p = s + gl; p < e; p += G) {
+      const int j = ci[p];
+      const int pos = atomicAdd(&cursor[j], 1);
+      out_rows[col_ptr[j] + pos] = (int32_t)r;
+    }
+  }
+}
+
+hipError_t launch_transpose(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int g_log2,
+                            const int64_t* col_ptr, int32_t* cursor, int32_t* out_row_idx) {
+  if (n_rows == 0) return hipSuccess;
+  const int64_t gpb = 256 >> g_log2;
+  int64_t blocks = (n_rows + gpb - 1) / gpb;
+  const int64_t cap = (int64_t)n_cu * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, row_ptr, col_idx, g_log2, col_ptr, cursor, out_row_idx);
+  return hipGetLastError();
+}
+
+// ============================================================================================
+// Per-item entropies: rowEntropy / columnEntropy of LogLikelihood.logLikelihoodRatio are functions of the
+// item's interaction count and N only, so they are evaluated once per item, not once per cooccurrence.
+// ============================================================================================
+__global__ __launch_bounds__(256) void item_entropy_kernel(const int32_t* __restrict__ counts, int32_t n, long long n_users,
+                                                           double* __restrict__ ent, double* __restrict__ xlx_n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const long long c = counts[i];
+    ent[i] = entropy2(c, n_users - c);
+  }
+  if (i == 0 && xlx_n) *xlx_n = x_log_x(n_users);
+}
+
+hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, double* xlx_n) {
+  const int blocks = n > 0 ? (n + 255) / 256 : 1;
+  hipLaunchKernelGGL(item_entropy_kernel, dim3(blocks), dim3(256), 0, st, counts, n, n_users, ent, xlx_n);
+  return hipGetLastError();
+}
+
+// ============================================================================================
+// Row work: w_i = sum over users u of item i of d_B(u) -- exactly the cooccurrence pairs row i forms and an
+// upper bound on its distinct columns.  Drives accumulator binning and work-balanced item ranges.
+// ============================================================================================
+__global__ __launch_bounds__(256) void row_work_kernel(int32_t item_lo, int32_t item_hi, const int64_t* __restrict__ a_cp,
+                                                       const int32_t* __restrict__ a_ri, const int64_t* __restrict__ b_rp, int g_log2,
+                                                       int64_t* __restrict__ work) {
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t gpb = 256 >> g_log2;
+  const int64_t n = (int64_t)item_hi - item_lo;
+  const int64_t stride = (int64_t)gridDim.x * gpb;
+  const int64_t n_round = ((n + stride - 1) / stride) * stride;  // grid-uniform trip count for the shuffles below
+  for (int64_t t = (int64_t)blockIdx.x * gpb + (threadIdx.x >> g_log2); t < n_round; t += stride) {
+    long long w = 0;
+    if (t < n) {
+      const int64_t i = item_lo + t;
+      const int64_t s = a_cp[i], e = a_cp[i + 1];
+      for (int64_t p = s + gl; p < e; p += G) {
+        const int u = a_ri[p];
+        w += b_rp[u + 1] - b_rp[u];
+      }
+    }
+    for (int m = 1; m < G; m <<= 1) w += (long long)shfl_xor_u64((unsigned long long)w, m);
+    if (gl == 0 && t < n) work[t] = w;
+  }
+}
+
+hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr, const int32_t* a_row_idx,
+                           const int64_t* b_row_ptr, int g_log2, int64_t* work) {
+  const int64_t n = (int64_t)item_hi - item_lo;
+  if (n <= 0) return hipSuccess;
+  const int64_t gpb = 256 >> g_log2;
+  int64_t blocks = (n + gpb - 1) / gpb;
+  const int64_t cap = (int64_t)n_cu * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(row_work_kernel, dim3((unsigned)blocks), dim3(256), 0, st, item_lo, item_hi, a_col_ptr, a_row_idx, b_row_ptr, g_log2, work);
+  return hipGetLastError();
+}
+
+// ============================================================================================
+// Binning (row-tile partitioning of the SpGEMM).  A row goes to the smallest accumulator class that
+// (a) is guaranteed to hold its distinct columns: w <= 5/8 of the table, or the table covers every column of B
+//     (then slots are addressed by column and never collide), and packed counts cannot overflow;
+// (b) gives it enough lanes: <= 512 pairs -> one wave, <= 8192 -> 256 threads, else 1024 threads.
+// Lists are built by a deterministic tile count / scan / scatter (a global atomic append would serialise
+// hundreds of thousands of increments on four addresses).
+// ============================================================================================
+constexpr int E0 = 512, E1 = 4096, E2 = 32768;
+
+__device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_cols_b, int32_t count_bits) {
+  if (ca <= 0 || w <= 0) return -1;  // no users or no pairs: empty indicator row
+  if (count_bits < 31 && ca > ((1ll << count_bits) - 1)) return 3;
+  int cap_bin = 3;
+  if (n_cols_b <= E0 || w * 8 <= (long long)E0 * 5) cap_bin = 0;
+  else if (n_cols_b <= E1 || w * 8 <= (long long)E1 * 5) cap_bin = 1;
+  else if (n_cols_b <= E2 || w * 8 <= (long long)E2 * 5) cap_bin = 2;
+  const int work_bin = w <= 512 ? 0 : (w <= 8192 ? 1 : 2);
+  return cap_bin > work_bin ? cap_bin : work_bin;
+}
+
+constexpr int BIN_THREADS = 256;
+constexpr int BIN_ITEMS = BIN_TILE / BIN_THREADS;  // 4
+constexpr int BIN_COLS = NBINS + 1;                // per tile: rows per bin, then pairs
+
+__global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo, int32_t n, const int64_t* __restrict__ work,
+                                                                const int32_t* __restrict__ cnt_a, int32_t n_cols_b, int32_t count_bits,
+                                                                int64_t* __restrict__ tile_counts) {
+  __shared__ long long s_acc[BIN_COLS];
+  if (threadIdx.x < BIN_COLS) s_acc[threadIdx.x] = 0;
+  __syncthreads();
+  int c[NBINS] = {0, 0, 0, 0};
+  long long pairs = 0;
+#pragma unroll
+  for (int q = 0; q < BIN_ITEMS; ++q) {
+    const int64_t t = (int64_t)blockIdx.x * BIN_TILE + (int64_t)threadIdx.x * BIN_ITEMS + q;
+    if (t < n) {
+      const long long w = work[t];
+      pairs += w;
+      const int b = choose_bin(w, cnt_a[item_lo + t], n_cols_b, count_bits);
+#pragma unroll
+      for (int k = 0; k < NBINS; ++k) c[k] += (b == k);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NBINS; ++k)
+    if (c[k]) atomicAdd((unsigned long long*)&s_acc[k], (unsigned long long)c[k]);
+  if (pairs) atomicAdd((unsigned long long*)&s_acc[NBINS], (unsigned long long)pairs);
+  __syncthreads();
+  if (threadIdx.x < BIN_COLS) tile_counts[(int64_t)blockIdx.x * BIN_COLS + threadIdx.x] = s_acc[threadIdx.x];
+}
+
+// single block: per-bin exclusive scan over tiles (in place), totals -> bin_off / stats
+__global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(int64_t* __restrict__ tile_counts, int64_t n_tiles, int32_t* __restrict__ bin_off,
+                                                               int64_t* __restrict__ stats) {
+  __shared__ long long s_wave[SCAN_THREADS / WAVE];
+  __shared__ long long s_tot[BIN_COLS];
+  for (int k = 0; k < BIN_COLS; ++k) {
+    long long carry = 0;
+    for (int64_t base = 0; base < n_tiles; base += BIN_THREADS) {
+      const int64_t i = base + threadIdx.x;
+      const long long v = i < n_tiles ? tile_counts[i * BIN_COLS + k] : 0;
+      long long tot;
+      const long long ex = block_exclusive_scan(v, s_wave, &tot);
+      if (i < n_tiles) tile_counts[i * BIN_COLS + k] = carry + ex;
+      carry += tot;
+    }
+    if (threadIdx.x == 0) s_tot[k] = carry;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t off = 0;
+    for (int k = 0; k < NBINS; ++k) {
+      bin_off[k] = off;
+      off += (int32_t)s_tot[k];
+      if (stats) stats[1 + k] = s_tot[k];
+    }
+    bin_off[NBINS] = off;
+    if (stats) stats[0] = s_tot[NBINS];
+  }
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int32_t item_lo, int32_t n, const int64_t* __restrict__ work,
+                                                                  const int32_t* __restrict__ cnt_a, int32_t n_cols_b, int32_t count_bits,
+                                                                  const int64_t* __restrict__ tile_counts, const int32_t* __restrict__ bin_off,
+                                                                  int32_t* __restrict__ bin_rows) {
+  __shared__ long long s_wave[SCAN_THREADS / WAVE];
+  int b[BIN_ITEMS];
+#pragma unroll
+  for (int q = 0; q < BIN_ITEMS; ++q) {
+    const int64_t t = (int64_t)blockIdx.x * BIN_TILE + (int64_t)threadIdx.x * BIN_ITEMS + q;
+    b[q] = t < n ? choose_bin(work[t], cnt_a[item_lo + t], n_cols_b, count_bits) : -1;
+  }
+  for (int k = 0; k < NBINS; ++k) {  // block-uniform: one block scan per bin
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < BIN_ITEMS; ++q) c += (b[q] == k);
+    long long tot;
+    long long pos = block_exclusive_scan(c, s_wave, &tot) + tile_counts[(int64_t)blockIdx.x * BIN_COLS + k] + bin_off[k];
+#pragma unroll
+    for (int q = 0; q < BIN_ITEMS; ++q)
+      if (b[q] == k) bin_rows[pos++] = item_lo + (int32_t)((int64_t)blockIdx.x * BIN_TILE + (int64_t)threadIdx.x * BIN_ITEMS + q);
+  }
+}
+
+hipError_t launch_binning(hipStream_t st, int32_t item_lo, int32_t n, const int64_t* work, const int32_t* cnt_a, int32_t n_cols_b,
+                          int32_t count_bits, int64_t* tile_counts, int32_t* bin_off, int32_t* bin_rows, int64_t* stats) {
+  if (n <= 0) {
+    hipError_t e = hipMemsetAsync(bin_off, 0, sizeof(int32_t) * (NBINS + 1), st);
+    if (e == hipSuccess && stats) e = hipMemsetAsync(stats, 0, sizeof(int64_t) * 8, st);
+    return e;
+  }
+  const int64_t n_tiles = ((int64_t)n + BIN_TILE - 1) / BIN_TILE;
+  hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)n_tiles), dim3(BIN_THREADS), 0, st, item_lo, n, work, cnt_a, n_cols_b, count_bits, tile_counts);
+  hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(BIN_THREADS), 0, st, tile_counts, n_tiles, bin_off, stats);
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)n_tiles), dim3(BIN_THREADS), 0, st, item_lo, n, work, cnt_a, n_cols_b, count_bits,
+                     tile_counts, bin_off, bin_rows);
+  return hipGetLastError();
+}
+
+// ============================================================================================
+// K4+K5  A'B rows (Gustavson over rows of A') with LDS hash accumulators, fused LLR + top-k.
+//
+// A team of T threads owns one item row i at a time:
+//   1. zero its table of E packed 32-bit entries  ((col+1) << count_bits) | count
+//   2. for every user u of item i (CSC of A'), 2^g lanes stream u's B' row (coalesced 4 B/lane segments) and
+//      insert each column: relaxed LDS read, CAS to claim an empty slot, LDS atomic add to count
+//   3. every thread scores its E/T slots: k11 = count, LLR from the per-item entropies + 4 logs (fp64),
+//      drops self pairs (A'A), zeros and llr < minLLR; keys stay in registers
+//   4. top-k by repeated argmax over (llr desc, col asc): wave shuffles (+ one LDS hop for T > 64); the
+//      winners come out already in output order.
+// Counts never leave the CU.  Hash = Fibonacci multiplicative; when the table covers all of B's columns
+// slots are addressed by column (no probing).
+// ============================================================================================
+struct Best {
+  unsigned long long key;  // llr bits (positive doubles order like unsigned integers); 0 = none
+  int col;
+};
+__device__ __forceinline__ bool best_before(unsigned long long ka, int ca, unsigned long long kb, int cb) {
+  return ka > kb || (ka == kb && ca < cb);
+}
+
+__device__ __forceinline__ void tab_insert(unsigned* tab, unsigned key, int count_bits, unsigned mask, int hshift, bool ident) {
+  unsigned h = ident ? (key - 1u) : ((key * 0x9E3779B1u) >> hshift);
+  const unsigned tagged = key << count_bits;
+  for (;;) {
+    unsigned v = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (v == 0u) {
+      v = atomicCAS(&tab[h], 0u, tagged | 1u);
+      if (v == 0u) return;
+    }
+    if ((v >> count_bits) == key) {
+      atomicAdd(&tab[h], 1u);
+      return;
+    }
+    h = (h + 1u) & mask;
+  }
+}
+
+template <int T, int E>
+__global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a, int bin) {
+  constexpr int BLOCK = T < 256 ? 256 : T;
+  constexpr int TEAMS = BLOCK / T;
+  constexpr int SPT = E / T;
+  constexpr int NW = T / WAVE;  // waves per team
+  constexpr int LOG2E = E == 512 ? 9 : (E == 4096 ? 12 : 15);
+  static_assert((1 << LOG2E) == E, "table size");
+  __shared__ unsigned s_tab[TEAMS * E];
+  __shared__ unsigned long long s_pkey[2][NW > 1 ? NW : 1];
+  __shared__ int s_pcol[2][NW > 1 ? NW : 1];
+
+  const int team = threadIdx.x / T;
+  const int tl = threadIdx.x % T;
+  const int lane = threadIdx.x & (WAVE - 1);
+  unsigned* tab = s_tab + team * E;
+  const int list_start = a.bin_off[bin];
+  const int list_n = a.bin_off[bin + 1] - list_start;
+  const int total_teams = gridDim.x * TEAMS;
+  const int iters = (list_n + total_teams - 1) / total_teams;  // grid-uniform: barriers below are legal
+  const bool ident = a.n_cols_b <= E;
+  const int cb = a.count_bits;
+  const unsigned cmask = (1u << cb) - 1u;
+  const int G = 1 << a.g_log2;
+  const int grp = tl >> a.g_log2, gl = tl & (G - 1), ngrp = T >> a.g_log2;
+  const double xlx_n = *a.xlx_n;
+
+  for (int it = 0; it < iters; ++it) {
+    const int li = it * total_teams + blockIdx.x * TEAMS + team;
+    const bool active = li < list_n;
+    const int i = active ? a.bin_rows[list_start + li] : 0;
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) tab[tl + q * T] = 0u;
+    __syncthreads();
+    if (active) {
+      const int64_t cs = a.a_col_ptr[i], ce = a.a_col_ptr[i + 1];
+      for (int64_t p = cs + grp; p < ce; p += ngrp) {
+        const int u = a.a_row_idx[p];
+        const int64_t s = a.b_row_ptr[u], e = a.b_row_ptr[u + 1];
+        for (int64_t q = s + gl; q < e; q += G) tab_insert(tab, (unsigned)a.b_col_idx[q] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident);
+      }
+    }
+    __syncthreads();
+    // ---- score this thread's slots
+    unsigned long long key[SPT];
+    Best best;
+    best.key = 0ull;
+    best.col = 0x7fffffff;
+    if (active) {
+      const long long ca = a.cnt_a[i];
+      const double row_entropy = a.ent_a[i];
+#pragma unroll
+      for (int q = 0; q < SPT; ++q) {
+        const unsigned v = tab[tl + q * T];
+        key[q] = 0ull;
+        if (v != 0u) {
+          const int j = (int)(v >> cb) - 1;
+          const long long k11 = (long long)(v & cmask);
+          if (!(a.exclude_self && j == i)) {
+            const long long cbj = a.cnt_b[j];
+            const double llr = llr_from_entropies(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11);
+            if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
+              key[q] = (unsigned long long)__double_as_longlong(llr);
+              if (best_before(key[q], j, best.key, best.col)) {
+                best.key = key[q];
+                best.col = j;
+              }
+            }
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < SPT; ++q) key[q] = 0ull;
+    }
+    // ---- top-k by repeated argmax; loop bounds are team-uniform (every lane sees the same winner)
+    int emitted = 0;
+    const int64_t obase = active ? ((int64_t)(i - a.item_lo)) * a.k : 0;
+    for (int r = 0; r < a.k; ++r) {
+      unsigned long long wk = best.key;
+      int wc = best.col;
+#pragma unroll
+      for (int m = WAVE / 2; m >= 1; m >>= 1) {
+        const unsigned long long ok = shfl_xor_u64(wk, m);
+        const int oc = __shfl_xor(wc, m);
+        if (best_before(ok, oc, wk, wc)) {
+          wk = ok;
+          wc = oc;
+        }
+      }
+      if (NW > 1) {
+        const int wv = tl / WAVE;
+        if (lane == 0) {
+          s_pkey[r & 1][wv] = wk;
+          s_pcol[r & 1][wv] = wc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w2 = 0; w2 < NW; ++w2) {
+          const unsigned long long ok = s_pkey[r & 1][w2];
+          const int oc = s_pcol[r & 1][w2];
+          if (best_before(ok, oc, wk, wc)) {
+            wk = ok;
+            wc = oc;
+          }
+        }
+      }
+      if (wk == 0ull) break;  // no candidate left (team-uniform; for TEAMS == 1 block-uniform)
+      if (tl == 0) {
+        a.out_idx[obase + r] = wc;
+        a.out_llr[obase + r] = __longlong_as_double((long long)wk);
+      }
+      ++emitted;
+      if (best.key == wk && best.col == wc) {  // the owner retires it and rescans its slots
+        best.key = 0ull;
+        best.col = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+          if (key[q] != 0ull) {
+            const int j = (int)(tab[tl + q * T] >> cb) - 1;
+            if (key[q] == wk && j == wc) key[q] = 0ull;
+            else if (best_before(key[q], j, best.key, best.col)) {
+              best.key = key[q];
+              best.col = j;
+            }
+          }
+        }
+      }
+    }
+    if (active && tl == 0) a.out_count[i - a.item_lo] = emitted;
+    __syncthreads();  // table is re-zeroed next iteration
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// Global-accumulator variant (bin 3): rows whose distinct columns cannot be bounded below an LDS table or
+// whose counts overflow the packed entry.  One 1024-thread block per row; a dense int32 counter array per
+// resident block (zero on entry, restored to zero by the claim walk), candidates spilled to global scratch,
+// top-k by k strictly-descending argmax sweeps.  Correct for any row; only meant for the rare heavy ones.
+// --------------------------------------------------------------------------------------------
+constexpr int GB_THREADS = 1024;
+
+__global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) {
+  constexpr int NW = GB_THREADS / WAVE;
+  __shared__ unsigned long long s_pkey[2][NW];
+  __shared__ int s_pcol[2][NW];
+  __shared__ int s_ncand;
+  const int bin = 3;
+  const int list_start = a.bin_off[bin];
+  const int list_n = a.bin_off[bin + 1] - list_start;
+  int32_t* cnt = a.g_counts + (int64_t)blockIdx.x * a.n_cols_b;
+  unsigned long long* ckey = a.g_cand_key + (int64_t)blockIdx.x * a.n_cols_b;
+  int32_t* ccol = a.g_cand_col + (int64_t)blockIdx.x * a.n_cols_b;
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+  const int G = 1 << a.g_log2;
+  const int grp = threadIdx.x >> a.g_log2, gl = threadIdx.x & (G - 1), ngrp = GB_THREADS >> a.g_log2;
+  const double xlx_n = *a.xlx_n;
+  for (int li = blockIdx.x; li < list_n; li += gridDim.x) {  // block-uniform
+    const int i = a.bin_rows[list_start + li];
+    const int64_t cs = a.a_col_ptr[i], ce = a.a_col_ptr[i + 1];
+    if (threadIdx.x == 0) s_ncand = 0;
+    for (int64_t p = cs + grp; p < ce; p += ngrp) {
+      const int u = a.a_row_idx[p];
+      const int64_t s = a.b_row_ptr[u], e = a.b_row_ptr[u + 1];
+      for (int64_t q = s + gl; q < e; q += G) atomicAdd(&cnt[a.b_col_idx[q]], 1);
+    }
+    __syncthreads();
+    const long long ca = a.cnt_a[i];
+    const double row_entropy = a.ent_a[i];
+    for (int64_t p = cs + grp; p < ce; p += ngrp) {
+      const int u = a.a_row_idx[p];
+      const int64_t s = a.b_row_ptr[u], e = a.b_row_ptr[u + 1];
+      for (int64_t q = s + gl; q < e; q += G) {
+        const int j = a.b_col_idx[q];
+        const long long k11 = atomicExch(&cnt[j], 0);  // exactly one lane claims (and clears) each column
+        if (k11 > 0 && !(a.exclude_self && j == i)) {
+          const long long cbj = a.cnt_b[j];
+          const double llr = llr_from_entropies(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11);
+          if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
+            const int pos = atomicAdd(&s_ncand, 1);
+            ckey[pos] = (unsigned long long)__double_as_longlong(llr);
+            ccol[pos] = j;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int ncand = s_ncand;
+    unsigned long long last_key = ~0ull;
+    int last_col = -1;
+    int emitted = 0;
+    const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
+    for (int r = 0; r < a.k; ++r) {
+      unsigned long long wk = 0ull;
+      int wc = 0x7fffffff;
+      for (int t = threadIdx.x; t < ncand; t += GB_THREADS) {
+        const unsigned long long kk = ckey[t];
+        const int cc = ccol[t];
+        // strictly after the previous winner in (llr desc, col asc) order
+        if ((kk < last_key || (kk == last_key && cc > last_col)) && best_before(kk, cc, wk, wc)) {
+          wk = kk;
+          wc = cc;
+        }
+      }
+#pragma unroll
+      for (int m = WAVE / 2; m >= 1; m >>= 1) {
+        const unsigned long long ok = shfl_xor_u64(wk, m);
+        const int oc = __shfl_xor(wc, m);
+        if (best_before(ok, oc, wk, wc)) {
+          wk = ok;
+          wc = oc;
+        }
+      }
+      if (lane == 0) {
+        s_pkey[r & 1][wv] = wk;
+        s_pcol[r & 1][wv] = wc;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int w2 = 0; w2 < NW; ++w2) {
+        const unsigned long long ok = s_pkey[r & 1][w2];
+        const int oc = s_pcol[r & 1][w2];
+        if (best_before(ok, oc, wk, wc)) {
+          wk = ok;
+          wc = oc;
+        }
+      }
+      if (wk == 0ull) break;
+      if (threadIdx.x == 0) {
+        a.out_idx[obase + r] = wc;
+        a.out_llr[obase + r] = __longlong_as_double((long long)wk);
+      }
+      last_key = wk;
+      last_col = wc;
+      ++emitted;
+    }
+    if (threadIdx.x == 0) a.out_count[i - a.item_lo] = emitted;
+    __syncthreads();
+  }
+}
+
+hipError_t launch_cco_rows(hipStream_t st, int n_cu, const CcoArgs& args) {
+  // Persistent grids sized to the chip; each kernel reads its own row list length from bin_off on the device,
+  // so no host synchronisation sits between binning and the SpGEMM.
+  hipLaunchKernelGGL((cco_rows_kernel<64, E0>), dim3((unsigned)(n_cu * 8)), dim3(256), 0, st, args, 0);
+  hipLaunchKernelGGL((cco_rows_kernel<256, E1>), dim3((unsigned)(n_cu * 8)), dim3(256), 0, st, args, 1);
+  hipLaunchKernelGGL((cco_rows_kernel<1024, E2>), dim3((unsigned)(n_cu * 2)), dim3(1024), 0, st, args, 2);
+  hipLaunchKernelGGL(cco_rows_global_kernel, dim3(GLOBAL_BIN_BLOCKS), dim3(GB_THREADS), 0, st, args);
+  return hipGetLastError();
+}
+
+// ============================================================================================
+// Strided top-k rows -> CSR
+// ============================================================================================
+__global__ __launch_bounds__(256) void compact_indicators_kernel(int32_t n_rows, int32_t k, const int32_t* __restrict__ count,
+                                                                 const int32_t* __restrict__ idx, const double* __restrict__ llr,
+                                                                 const int64_t* __restrict__ row_ptr, int32_t* __restrict__ out_idx,
+                                                                 double* __restrict__ out_llr) {
+  const int64_t total = (int64_t)n_rows * k;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int64_t r = t / k;
+    const int s = (int)(t - r * k);
+    if (s < count[r]) {
+      const int64_t o = row_ptr[r] + s;
+      out_idx[o] = idx[t];
+      out_llr[o] = llr[t];
+    }
+  }
+}
+
+hipError_t launch_compact_indicators(hipStream_t st, int32_t n_rows, int32_t k, const int32_t* count, const int32_t* idx,
+                                     const double* llr, const int64_t* row_ptr, int32_t* out_idx, double* out_llr) {
+  const int64_t total = (int64_t)n_rows * k;
+  if (total == 0) return hipSuccess;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(compact_indicators_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, k, count, idx, llr, row_ptr, out_idx, out_llr);
+  return hipGetLastError();
+}
+
+// ============================================================================================
+// Work-balanced item ranges: bounds[p] = first item whose exclusive work prefix >= p * total / n_parts
+// ============================================================================================
+__global__ void partition_kernel(int32_t n_items, const int64_t* __restrict__ work_prefix, int32_t n_parts, int32_t* __restrict__ bounds) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > n_parts) return;
+  if (p == 0) { bounds[0] = 0; return; }
+  if (p == n_parts) { bounds[p] = n_items; return; }
+  const long long total = work_prefix[n_items];
+  const long long target = (total / n_parts) * p + ((total % n_parts) * p) / n_parts;  // floor(total * p / n_parts) without overflow
+  int lo = 0, hi = n_items;  // first i with prefix[i] >= target
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (work_prefix[mid] >= target) hi = mid; else lo = mid + 1;
+  }
+  bounds[p] = lo;
+}
+
+hipError_t launch_partition(hipStream_t st, int32_t n_items, const int64_t* work_prefix, int32_t n_parts, int32_t* bounds) {
+  hipLaunchKernelGGL(partition_kernel, dim3(1), dim3(64 * ((n_parts + 64) / 64)), 0, st, n_items, work_prefix, n_parts, bounds);
+  return hipGetLastError();
+}
+
+// ============================================================================================
+// test hooks
+// ============================================================================================
+__global__ void llr_test_kernel(int64_t n, const int64_t* a, const int64_t* b, const int64_t* ab, const int64_t* nu, double* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = llr_full(a[i], b[i], ab[i], nu[i]);
+}
+__global__ void u01_test_kernel(int64_t n, uint32_t seed, const int32_t* row, const int32_t* col, double* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = u01_hash(seed, (uint32_t)row[i], (uint32_t)col[i]);
+}
+hipError_t launch_llr_test(hipStream_t st, int64_t n, const int64_t* a, const int64_t* b, const int64_t* ab, const int64_t* nu, double* out) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(llr_test_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, a, b, ab, nu, out);
+  return hipGetLastError();
+}
+hipError_t launch_u01_test(hipStream_t st, int64_t n, uint32_t seed, const int32_t* row, const int32_t* col, double* out) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(u01_test_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, seed, row, col, out);
+  return hipGetLastError();
+}
+
+}  // namespace urcco

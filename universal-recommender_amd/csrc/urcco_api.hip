@@ -1,0 +1,552 @@
+// C ABI of liburcco (include/urcco.h): session / scratch management, the device-level stage functions and the
+// host-level one-shot entry points that stand in for Mahout's SimilarityAnalysis.cooccurrencesIDSs and
+// crossOccurrenceDownsampled (reference call sites: src/main/scala/URAlgorithm.scala:323-329, :343-346).
+// No CPU fallback: without a HIP device the compute entry points return URCCO_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/urcco.h"
+#include "cco_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int status, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return status;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  return fail(e == hipErrorOutOfMemory ? URCCO_OOM_DEVICE : URCCO_HIP_ERROR, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define HIPC(expr)                                 \
+  do {                                             \
+    hipError_t _e = (expr);                        \
+    if (_e != hipSuccess) return hip_fail(_e, #expr); \
+  } while (0)
+
+#define URC(expr)              \
+  do {                         \
+    int _s = (expr);           \
+    if (_s != URCCO_OK) return _s; \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int ceil_log2_i64(int64_t v) {
+  int l = 0;
+  while (((int64_t)1 << l) < v) ++l;
+  return l;
+}
+
+}  // namespace
+
+struct urcco_session {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int n_cu = 256;
+  char* arena = nullptr;
+  size_t arena_cap = 0;
+  size_t arena_off = 0;
+  // persistent zeroed dense counters + candidate scratch of the global-accumulator kernel
+  int32_t* g_counts = nullptr;
+  unsigned long long* g_cand_key = nullptr;
+  int32_t* g_cand_col = nullptr;
+  int64_t g_cols = 0;
+
+  int reserve(size_t bytes) {
+    arena_off = 0;
+    if (bytes <= arena_cap) return URCCO_OK;
+    if (arena) {
+      HIPC(hipStreamSynchronize(stream));
+      HIPC(hipFree(arena));
+      arena = nullptr;
+      arena_cap = 0;
+    }
+    const size_t want = align_up(bytes + bytes / 4, (size_t)1 << 20);
+    HIPC(hipMalloc((void**)&arena, want));
+    arena_cap = want;
+    return URCCO_OK;
+  }
+  template <typename T>
+  T* take(size_t n) {
+    const size_t bytes = align_up((n ? n : 1) * sizeof(T), 256);
+    char* p = arena + arena_off;
+    arena_off += bytes;
+    return reinterpret_cast<T*>(p);
+  }
+  static size_t need(size_t n, size_t elem) { return align_up((n ? n : 1) * elem, 256); }
+
+  int ensure_global_bin(int64_t n_cols_b) {
+    if (n_cols_b <= g_cols) return URCCO_OK;
+    HIPC(hipStreamSynchronize(stream));
+    if (g_counts) { HIPC(hipFree(g_counts)); HIPC(hipFree(g_cand_key)); HIPC(hipFree(g_cand_col)); }
+    g_counts = nullptr; g_cols = 0;
+    const size_t n = (size_t)urcco::GLOBAL_BIN_BLOCKS * (size_t)n_cols_b;
+    HIPC(hipMalloc((void**)&g_counts, n * sizeof(int32_t)));
+    HIPC(hipMalloc((void**)&g_cand_key, n * sizeof(unsigned long long)));
+    HIPC(hipMalloc((void**)&g_cand_col, n * sizeof(int32_t)));
+    HIPC(hipMemsetAsync(g_counts, 0, n * sizeof(int32_t), stream));
+    g_cols = n_cols_b;
+    return URCCO_OK;
+  }
+};
+
+extern "C" {
+
+int urcco_version(void) { return URCCO_VERSION; }
+
+int urcco_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* urcco_last_error(void) { return g_err; }
+
+const char* urcco_status_string(int status) {
+  switch (status) {
+    case URCCO_OK: return "OK";
+    case URCCO_BAD_ARG: return "BAD_ARG";
+    case URCCO_OOM_HOST: return "OOM_HOST";
+    case URCCO_OOM_DEVICE: return "OOM_DEVICE";
+    case URCCO_HIP_ERROR: return "HIP_ERROR";
+    case URCCO_INTERNAL: return "INTERNAL";
+    case URCCO_NO_DEVICE: return "NO_DEVICE";
+    default: return "UNKNOWN";
+  }
+}
+
+int urcco_session_create(int32_t device, void* stream, urcco_session** out) {
+  if (!out) return fail(URCCO_BAD_ARG, "urcco_session_create: out is NULL");
+  *out = nullptr;
+  const int n = urcco_device_count();
+  if (n <= 0) return fail(URCCO_NO_DEVICE, "no HIP device visible (liburcco has no CPU fallback)");
+  if (device < 0 || device >= n) return fail(URCCO_BAD_ARG, "device %d out of range [0,%d)", device, n);
+  HIPC(hipSetDevice(device));
+  urcco_session* s = new (std::nothrow) urcco_session();
+  if (!s) return fail(URCCO_OOM_HOST, "session alloc");
+  s->device = device;
+  if (stream) {
+    s->stream = (hipStream_t)stream;
+  } else {
+    hipError_t e = hipStreamCreate(&s->stream);
+    if (e != hipSuccess) { delete s; return hip_fail(e, "hipStreamCreate"); }
+    s->own_stream = true;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cu = prop.multiProcessorCount;
+  *out = s;
+  return URCCO_OK;
+}
+
+void urcco_session_destroy(urcco_session* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  (void)hipStreamSynchronize(s->stream);
+  if (s->arena) (void)hipFree(s->arena);
+  if (s->g_counts) { (void)hipFree(s->g_counts); (void)hipFree(s->g_cand_key); (void)hipFree(s->g_cand_col); }
+  if (s->own_stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+int urcco_session_synchronize(urcco_session* s) {
+  if (!s) return fail(URCCO_BAD_ARG, "session is NULL");
+  HIPC(hipStreamSynchronize(s->stream));
+  return URCCO_OK;
+}
+
+int64_t urcco_session_scratch_bytes(const urcco_session* s) {
+  if (!s) return 0;
+  return (int64_t)s->arena_cap + (int64_t)s->g_cols * urcco::GLOBAL_BIN_BLOCKS * 16;
+}
+
+int urcco_dev_column_counts(urcco_session* s, int64_t nnz, const int32_t* col_idx, int32_t n_cols, int32_t* counts) {
+  if (!s || nnz < 0 || n_cols < 0 || (nnz > 0 && !col_idx) || (n_cols > 0 && !counts)) return fail(URCCO_BAD_ARG, "urcco_dev_column_counts: bad argument");
+  if (n_cols == 0) return URCCO_OK;
+  HIPC(urcco::launch_column_counts(s->stream, s->n_cu, col_idx, nnz, n_cols, counts));
+  return URCCO_OK;
+}
+
+int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
+                         const int32_t* raw_counts, int32_t seed, int32_t max_elements_per_row, int32_t row_rate_mode, int64_t row_base,
+                         int64_t* out_row_ptr, int32_t* out_col_idx, int32_t* post_counts) {
+  if (!s || n_rows < 0 || nnz < 0 || n_cols < 0 || !row_ptr || !out_row_ptr || (nnz > 0 && (!col_idx || !raw_counts || !out_col_idx)))
+    return fail(URCCO_BAD_ARG, "urcco_dev_downsample: bad argument");
+  if (max_elements_per_row <= 0) return fail(URCCO_BAD_ARG, "maxElementsPerRow must be positive, got %d", max_elements_per_row);
+  if (row_rate_mode != URCCO_ROW_RATE_MAHOUT_INT_DIV && row_rate_mode != URCCO_ROW_RATE_FRACTIONAL)
+    return fail(URCCO_BAD_ARG, "unknown row_rate_mode %d", row_rate_mode);
+  if (post_counts && n_cols > 0) HIPC(hipMemsetAsync(post_counts, 0, sizeof(int32_t) * (size_t)n_cols, s->stream));
+  if (nnz == 0) {
+    HIPC(hipMemsetAsync(out_row_ptr, 0, sizeof(int64_t) * (size_t)(n_rows + 1), s->stream));
+    return URCCO_OK;
+  }
+  const int64_t n_words = (nnz + 63) >> 6;
+  const int64_t n_tiles = (n_words + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
+  URC(s->reserve(urcco_session::need((size_t)n_words + 1, 8) * 2 + urcco_session::need((size_t)n_tiles + 2, 8)));
+  unsigned long long* flags = s->take<unsigned long long>((size_t)n_words + 1);
+  int64_t* word_prefix = s->take<int64_t>((size_t)n_words + 1);
+  int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
+  HIPC(urcco::launch_downsample_flags(s->stream, n_rows, row_ptr, col_idx, nnz, raw_counts, (uint32_t)seed, max_elements_per_row, row_rate_mode,
+                                      row_base, flags, post_counts));
+  HIPC(urcco::launch_scan_popc64(s->stream, flags, n_words, word_prefix, tile_sums));
+  HIPC(urcco::launch_downsample_compact(s->stream, s->n_cu, n_rows, row_ptr, col_idx, nnz, flags, word_prefix, out_row_ptr, out_col_idx));
+  return URCCO_OK;
+}
+
+int urcco_dev_transpose(urcco_session* s, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
+                        const int32_t* counts, int64_t* out_col_ptr, int32_t* out_row_idx) {
+  if (!s || n_rows < 0 || nnz < 0 || n_cols < 0 || !row_ptr || !out_col_ptr || (n_cols > 0 && !counts) || (nnz > 0 && (!col_idx || !out_row_idx)))
+    return fail(URCCO_BAD_ARG, "urcco_dev_transpose: bad argument");
+  const int64_t n_tiles = ((int64_t)n_cols + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
+  URC(s->reserve(urcco_session::need((size_t)n_cols, 4) + urcco_session::need((size_t)n_tiles + 2, 8)));
+  int32_t* cursor = s->take<int32_t>((size_t)n_cols);
+  int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
+  HIPC(urcco::launch_scan_i32(s->stream, counts, n_cols, out_col_ptr, tile_sums));
+  if (nnz == 0 || n_rows == 0) return URCCO_OK;
+  HIPC(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)n_cols, s->stream));
+  int g = ceil_log2_i64((nnz + n_rows - 1) / n_rows);
+  if (g < 1) g = 1;
+  if (g > 6) g = 6;
+  HIPC(urcco::launch_transpose(s->stream, s->n_cu, n_rows, row_ptr, col_idx, g, out_col_ptr, cursor, out_row_idx));
+  return URCCO_OK;
+}
+
+int urcco_dev_row_work(urcco_session* s, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr, const int32_t* a_row_idx,
+                       const int64_t* b_row_ptr, int64_t* work) {
+  if (!s || item_lo < 0 || item_hi < item_lo || !a_col_ptr || !b_row_ptr || (item_hi > item_lo && !work))
+    return fail(URCCO_BAD_ARG, "urcco_dev_row_work: bad argument");
+  HIPC(urcco::launch_row_work(s->stream, s->n_cu, item_lo, item_hi, a_col_ptr, a_row_idx, b_row_ptr, 3, work));
+  return URCCO_OK;
+}
+
+int urcco_dev_partition(urcco_session* s, int32_t n_items, const int64_t* work, int32_t n_parts, int32_t* bounds_host) {
+  if (!s || n_items < 0 || n_parts <= 0 || n_parts > 4096 || !bounds_host || (n_items > 0 && !work)) return fail(URCCO_BAD_ARG, "urcco_dev_partition: bad argument");
+  const int64_t n_tiles = ((int64_t)n_items + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
+  URC(s->reserve(urcco_session::need((size_t)n_items + 1, 8) + urcco_session::need((size_t)n_tiles + 2, 8) + urcco_session::need((size_t)n_parts + 1, 4)));
+  int64_t* prefix = s->take<int64_t>((size_t)n_items + 1);
+  int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
+  int32_t* bounds = s->take<int32_t>((size_t)n_parts + 1);
+  HIPC(urcco::launch_scan_i64(s->stream, work, n_items, prefix, tile_sums));
+  HIPC(urcco::launch_partition(s->stream, n_items, prefix, n_parts, bounds));
+  HIPC(hipMemcpyAsync(bounds_host, bounds, sizeof(int32_t) * (size_t)(n_parts + 1), hipMemcpyDeviceToHost, s->stream));
+  HIPC(hipStreamSynchronize(s->stream));
+  return URCCO_OK;
+}
+
+int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a, const int64_t* a_col_ptr,
+                       const int32_t* a_row_idx, const int64_t* b_row_ptr, const int32_t* b_col_idx, int32_t n_cols_b,
+                       const int32_t* counts_a, const int32_t* counts_b, int64_t n_users, int32_t exclude_self, int32_t k,
+                       int32_t has_min_llr, double min_llr, int32_t* out_count, int32_t* out_idx, double* out_llr, int64_t* stats_dev) {
+  if (!s || item_lo < 0 || item_hi < item_lo || item_hi > n_items_a || n_cols_b < 0 || n_users < 0 || !a_col_ptr || !b_row_ptr)
+    return fail(URCCO_BAD_ARG, "urcco_dev_cco_rows: bad argument");
+  if (k <= 0) return fail(URCCO_BAD_ARG, "maxInterestingElements must be positive, got %d", k);
+  const int32_t n = item_hi - item_lo;
+  if (n == 0) {
+    if (stats_dev) HIPC(hipMemsetAsync(stats_dev, 0, sizeof(int64_t) * 8, s->stream));
+    return URCCO_OK;
+  }
+  if (!out_count || !out_idx || !out_llr || !counts_a || (n_cols_b > 0 && !counts_b)) return fail(URCCO_BAD_ARG, "urcco_dev_cco_rows: NULL buffer");
+  HIPC(hipMemsetAsync(out_count, 0, sizeof(int32_t) * (size_t)n, s->stream));
+  if (n_cols_b == 0 || n_users == 0) {
+    if (stats_dev) HIPC(hipMemsetAsync(stats_dev, 0, sizeof(int64_t) * 8, s->stream));
+    return URCCO_OK;
+  }
+  // packed LDS entry: key = col + 1 in the high bits, count in the low bits
+  int key_bits = 1;
+  while (((int64_t)1 << key_bits) <= (int64_t)n_cols_b) ++key_bits;  // values 1..n_cols_b
+  const int count_bits = 32 - key_bits;
+  if (count_bits < 1) return fail(URCCO_BAD_ARG, "n_cols_b %d too large for the packed accumulator", n_cols_b);
+  URC(s->ensure_global_bin(n_cols_b));
+  const int64_t n_tiles = ((int64_t)n + urcco::BIN_TILE - 1) / urcco::BIN_TILE;
+  const bool same = (counts_a == counts_b) && (n_items_a == n_cols_b);
+  URC(s->reserve(urcco_session::need((size_t)n, 8) + urcco_session::need((size_t)(n_tiles + 1) * (urcco::NBINS + 1), 8) +
+                 urcco_session::need(urcco::NBINS + 1, 4) + urcco_session::need((size_t)n, 4) + urcco_session::need((size_t)n_items_a, 8) +
+                 urcco_session::need((size_t)n_cols_b, 8) + urcco_session::need(1, 8) + urcco_session::need(8, 8)));
+  int64_t* work = s->take<int64_t>((size_t)n);
+  int64_t* tile_counts = s->take<int64_t>((size_t)(n_tiles + 1) * (urcco::NBINS + 1));
+  int32_t* bin_off = s->take<int32_t>(urcco::NBINS + 1);
+  int32_t* bin_rows = s->take<int32_t>((size_t)n);
+  double* ent_a = s->take<double>((size_t)n_items_a);
+  double* ent_b = same ? ent_a : s->take<double>((size_t)n_cols_b);
+  double* xlx_n = s->take<double>(1);
+  int64_t* stats = stats_dev ? stats_dev : s->take<int64_t>(8);
+
+  HIPC(urcco::launch_row_work(s->stream, s->n_cu, item_lo, item_hi, a_col_ptr, a_row_idx, b_row_ptr, 3, work));
+  HIPC(hipMemsetAsync(stats, 0, sizeof(int64_t) * 8, s->stream));
+  HIPC(urcco::launch_binning(s->stream, item_lo, n, work, counts_a, n_cols_b, count_bits, tile_counts, bin_off, bin_rows, stats));
+  HIPC(urcco::launch_item_entropy(s->stream, counts_a, n_items_a, n_users, ent_a, xlx_n));
+  if (!same) HIPC(urcco::launch_item_entropy(s->stream, counts_b, n_cols_b, n_users, ent_b, nullptr));
+
+  urcco::CcoArgs a;
+  a.bin_rows = bin_rows; a.bin_off = bin_off;
+  a.a_col_ptr = a_col_ptr; a.a_row_idx = a_row_idx; a.b_row_ptr = b_row_ptr; a.b_col_idx = b_col_idx;
+  a.cnt_a = counts_a; a.cnt_b = counts_b; a.ent_a = ent_a; a.ent_b = ent_b; a.xlx_n = xlx_n;
+  a.n_users = n_users; a.n_cols_b = n_cols_b; a.item_lo = item_lo; a.exclude_self = exclude_self ? 1 : 0; a.k = k;
+  a.has_min_llr = has_min_llr ? 1 : 0; a.min_llr = min_llr; a.count_bits = count_bits;
+  a.g_log2 = 4;  // 16 lanes stream one user's B' row: 64 B segments, matches the ~10-40 item rows the cut leaves
+  a.out_count = out_count; a.out_idx = out_idx; a.out_llr = out_llr;
+  a.g_counts = s->g_counts; a.g_cand_key = s->g_cand_key; a.g_cand_col = s->g_cand_col;
+  HIPC(urcco::launch_cco_rows(s->stream, s->n_cu, a));
+  return URCCO_OK;
+}
+
+int urcco_dev_compact_indicators(urcco_session* s, int32_t n_rows, int32_t k, const int32_t* count, const int32_t* idx, const double* llr,
+                                 int64_t* out_row_ptr, int32_t* out_col_idx, double* out_llr) {
+  if (!s || n_rows < 0 || k <= 0 || !out_row_ptr || (n_rows > 0 && (!count || !idx || !llr || !out_col_idx || !out_llr)))
+    return fail(URCCO_BAD_ARG, "urcco_dev_compact_indicators: bad argument");
+  const int64_t n_tiles = ((int64_t)n_rows + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
+  URC(s->reserve(urcco_session::need((size_t)n_tiles + 2, 8)));
+  int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
+  HIPC(urcco::launch_scan_i32(s->stream, count, n_rows, out_row_ptr, tile_sums));
+  HIPC(urcco::launch_compact_indicators(s->stream, n_rows, k, count, idx, llr, out_row_ptr, out_col_idx, out_llr));
+  return URCCO_OK;
+}
+
+int urcco_dev_llr(urcco_session* s, int64_t n, const int64_t* with_a, const int64_t* with_b, const int64_t* with_ab, const int64_t* n_users,
+                  double* out) {
+  if (!s || n < 0) return fail(URCCO_BAD_ARG, "urcco_dev_llr: bad argument");
+  HIPC(urcco::launch_llr_test(s->stream, n, with_a, with_b, with_ab, n_users, out));
+  return URCCO_OK;
+}
+
+int urcco_dev_u01(urcco_session* s, int64_t n, int32_t seed, const int32_t* row, const int32_t* col, double* out) {
+  if (!s || n < 0) return fail(URCCO_BAD_ARG, "urcco_dev_u01: bad argument");
+  HIPC(urcco::launch_u01_test(s->stream, n, (uint32_t)seed, row, col, out));
+  return URCCO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// HOST level
+// ---------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+struct DevBufs {
+  std::vector<void*> ptrs;
+  ~DevBufs() {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+  template <typename T>
+  int alloc(T** out, size_t n) {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    ptrs.push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return URCCO_OK;
+  }
+  void release(void* p) {
+    for (size_t i = 0; i < ptrs.size(); ++i)
+      if (ptrs[i] == p) {
+        (void)hipFree(p);
+        ptrs.erase(ptrs.begin() + (long)i);
+        return;
+      }
+  }
+};
+
+struct SessionGuard {
+  urcco_session* s = nullptr;
+  ~SessionGuard() { urcco_session_destroy(s); }
+};
+
+struct SampledMatrix {
+  int64_t* row_ptr = nullptr;
+  int32_t* col_idx = nullptr;
+  int32_t* counts = nullptr;
+  int64_t nnz = 0;
+};
+
+int validate_csr(const urcco_csr& m, int d) {
+  if (m.n_rows < 0 || m.n_cols < 0 || m.n_rows > 0x7fffffffll || m.n_cols > 0x7ffffff0ll) return fail(URCCO_BAD_ARG, "dataset %d: bad shape", d);
+  if (!m.row_ptr) return fail(URCCO_BAD_ARG, "dataset %d: row_ptr is NULL", d);
+  if (m.row_ptr[0] != 0) return fail(URCCO_BAD_ARG, "dataset %d: row_ptr[0] != 0", d);
+  const int64_t nnz = m.row_ptr[m.n_rows];
+  if (nnz < 0 || (nnz > 0 && !m.col_idx)) return fail(URCCO_BAD_ARG, "dataset %d: bad nnz / col_idx", d);
+  for (int64_t r = 0; r < m.n_rows; ++r)
+    if (m.row_ptr[r + 1] < m.row_ptr[r]) return fail(URCCO_BAD_ARG, "dataset %d: row_ptr not monotone at row %lld", d, (long long)r);
+  return URCCO_OK;
+}
+
+// upload + sampleDownAndBinarize of one matrix
+int sample_matrix(urcco_session* s, DevBufs& bufs, const urcco_dataset& ds, int32_t seed, int32_t row_rate_mode, SampledMatrix* out,
+                  urcco_dataset_stats* st) {
+  const urcco_csr& m = ds.matrix;
+  const int64_t nnz = m.row_ptr[m.n_rows];
+  int64_t* d_rp = nullptr;
+  int32_t* d_ci = nullptr;
+  int32_t* d_raw = nullptr;
+  URC(bufs.alloc(&d_rp, (size_t)m.n_rows + 1));
+  URC(bufs.alloc(&d_ci, (size_t)nnz));
+  URC(bufs.alloc(&d_raw, (size_t)m.n_cols));
+  URC(bufs.alloc(&out->row_ptr, (size_t)m.n_rows + 1));
+  URC(bufs.alloc(&out->col_idx, (size_t)nnz));
+  URC(bufs.alloc(&out->counts, (size_t)m.n_cols));
+  HIPC(hipMemcpyAsync(d_rp, m.row_ptr, sizeof(int64_t) * (size_t)(m.n_rows + 1), hipMemcpyHostToDevice, s->stream));
+  if (nnz > 0) HIPC(hipMemcpyAsync(d_ci, m.col_idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, s->stream));
+  URC(urcco_dev_column_counts(s, nnz, d_ci, (int32_t)m.n_cols, d_raw));
+  URC(urcco_dev_downsample(s, m.n_rows, d_rp, d_ci, nnz, (int32_t)m.n_cols, d_raw, seed, ds.max_elements_per_row, row_rate_mode, 0, out->row_ptr,
+                           out->col_idx, out->counts));
+  HIPC(hipMemcpyAsync(&out->nnz, out->row_ptr + m.n_rows, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
+  HIPC(hipStreamSynchronize(s->stream));  // the host copy of the raw matrix may be unpinned after this point
+  bufs.release(d_rp);
+  bufs.release(d_ci);
+  bufs.release(d_raw);
+  if (st) {
+    st->nnz_raw = nnz;
+    st->nnz_sampled = out->nnz;
+  }
+  return URCCO_OK;
+}
+
+int build_impl(const urcco_dataset* datasets, int32_t n_datasets, int32_t seed, const urcco_options* options, urcco_indicators* out,
+               urcco_dataset_stats* stats) {
+  if (!datasets || n_datasets <= 0 || !out) return fail(URCCO_BAD_ARG, "datasets / out is NULL or n_datasets <= 0");
+  for (int d = 0; d < n_datasets; ++d) {
+    URC(validate_csr(datasets[d].matrix, d));
+    if (datasets[d].matrix.n_rows != datasets[0].matrix.n_rows)
+      return fail(URCCO_BAD_ARG, "dataset %d has %lld rows, the primary has %lld: all matrices share the user dictionary", d,
+                  (long long)datasets[d].matrix.n_rows, (long long)datasets[0].matrix.n_rows);
+    if (datasets[d].max_elements_per_row <= 0 || datasets[d].max_interesting_elements <= 0)
+      return fail(URCCO_BAD_ARG, "dataset %d: maxElementsPerRow / maxInterestingElements must be positive", d);
+    memset(&out[d], 0, sizeof(urcco_indicators));
+    if (stats) memset(&stats[d], 0, sizeof(urcco_dataset_stats));
+  }
+  const int32_t device = options ? options->device : 0;
+  const int32_t row_rate_mode = options ? options->row_rate_mode : URCCO_ROW_RATE_MAHOUT_INT_DIV;
+  SessionGuard guard;
+  URC(urcco_session_create(device, nullptr, &guard.s));
+  urcco_session* s = guard.s;
+  DevBufs bufs;
+
+  const urcco_csr& A = datasets[0].matrix;
+  const int64_t n_users = A.n_rows;
+  const int32_t n_items_a = (int32_t)A.n_cols;
+  hipEvent_t ev0, ev1;
+  HIPC(hipEventCreate(&ev0));
+  HIPC(hipEventCreate(&ev1));
+
+  SampledMatrix a;
+  HIPC(hipEventRecord(ev0, s->stream));
+  URC(sample_matrix(s, bufs, datasets[0], seed, row_rate_mode, &a, stats ? &stats[0] : nullptr));
+  int64_t* a_col_ptr = nullptr;
+  int32_t* a_row_idx = nullptr;
+  URC(bufs.alloc(&a_col_ptr, (size_t)n_items_a + 1));
+  URC(bufs.alloc(&a_row_idx, (size_t)a.nnz));
+  URC(urcco_dev_transpose(s, n_users, a.row_ptr, a.col_idx, a.nnz, n_items_a, a.counts, a_col_ptr, a_row_idx));
+
+  for (int d = 0; d < n_datasets; ++d) {
+    SampledMatrix b = a;
+    if (d > 0) {
+      HIPC(hipEventRecord(ev0, s->stream));
+      URC(sample_matrix(s, bufs, datasets[d], seed, row_rate_mode, &b, stats ? &stats[d] : nullptr));
+    }
+    const int32_t n_cols_b = (int32_t)datasets[d].matrix.n_cols;
+    const int32_t k = datasets[d].max_interesting_elements;
+    int32_t* o_count = nullptr;
+    int32_t* o_idx = nullptr;
+    double* o_llr = nullptr;
+    int64_t* c_rp = nullptr;
+    int32_t* c_idx = nullptr;
+    double* c_llr = nullptr;
+    int64_t* d_stats = nullptr;
+    const size_t strided = (size_t)n_items_a * (size_t)k;
+    URC(bufs.alloc(&o_count, (size_t)n_items_a));
+    URC(bufs.alloc(&o_idx, strided));
+    URC(bufs.alloc(&o_llr, strided));
+    URC(bufs.alloc(&c_rp, (size_t)n_items_a + 1));
+    URC(bufs.alloc(&c_idx, strided));
+    URC(bufs.alloc(&c_llr, strided));
+    URC(bufs.alloc(&d_stats, 8));
+    URC(urcco_dev_cco_rows(s, 0, n_items_a, n_items_a, a_col_ptr, a_row_idx, b.row_ptr, b.col_idx, n_cols_b, a.counts, b.counts, n_users,
+                           d == 0 ? 1 : 0, k, datasets[d].has_min_llr, datasets[d].min_llr, o_count, o_idx, o_llr, d_stats));
+    URC(urcco_dev_compact_indicators(s, n_items_a, k, o_count, o_idx, o_llr, c_rp, c_idx, c_llr));
+    HIPC(hipEventRecord(ev1, s->stream));
+    urcco_indicators& o = out[d];
+    o.n_rows = n_items_a;
+    o.n_cols = n_cols_b;
+    o.row_ptr = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_items_a + 1));
+    if (!o.row_ptr) return fail(URCCO_OOM_HOST, "indicator row_ptr");
+    HIPC(hipMemcpyAsync(o.row_ptr, c_rp, sizeof(int64_t) * ((size_t)n_items_a + 1), hipMemcpyDeviceToHost, s->stream));
+    int64_t h_stats[8];
+    HIPC(hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, s->stream));
+    HIPC(hipStreamSynchronize(s->stream));
+    o.nnz = o.row_ptr[n_items_a];
+    o.col_idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)(o.nnz ? o.nnz : 1));
+    o.llr = (double*)malloc(sizeof(double) * (size_t)(o.nnz ? o.nnz : 1));
+    if (!o.col_idx || !o.llr) return fail(URCCO_OOM_HOST, "indicator arrays");
+    if (o.nnz > 0) {
+      HIPC(hipMemcpyAsync(o.col_idx, c_idx, sizeof(int32_t) * (size_t)o.nnz, hipMemcpyDeviceToHost, s->stream));
+      HIPC(hipMemcpyAsync(o.llr, c_llr, sizeof(double) * (size_t)o.nnz, hipMemcpyDeviceToHost, s->stream));
+      HIPC(hipStreamSynchronize(s->stream));
+    }
+    if (stats) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, ev0, ev1);
+      stats[d].ms_total = ms;
+      stats[d].pairs = h_stats[0];
+      for (int b2 = 0; b2 < 4; ++b2) stats[d].rows_by_bin[b2] = h_stats[1 + b2];
+      stats[d].nnz_out = o.nnz;
+    }
+    bufs.release(o_count); bufs.release(o_idx); bufs.release(o_llr); bufs.release(c_rp); bufs.release(c_idx); bufs.release(c_llr);
+    bufs.release(d_stats);
+    if (d > 0) { bufs.release(b.row_ptr); bufs.release(b.col_idx); bufs.release(b.counts); }
+  }
+  (void)hipEventDestroy(ev0);
+  (void)hipEventDestroy(ev1);
+  return URCCO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void urcco_free_indicators(urcco_indicators* ind, int32_t n) {
+  if (!ind) return;
+  for (int32_t d = 0; d < n; ++d) {
+    free(ind[d].row_ptr);
+    free(ind[d].col_idx);
+    free(ind[d].llr);
+    memset(&ind[d], 0, sizeof(urcco_indicators));
+  }
+}
+
+int urcco_cross_occurrence_downsampled(const urcco_dataset* datasets, int32_t n_datasets, int32_t random_seed, const urcco_options* options,
+                                       urcco_indicators* out, urcco_dataset_stats* stats) {
+  g_err[0] = 0;
+  const int st = build_impl(datasets, n_datasets, random_seed, options, out, stats);
+  if (st != URCCO_OK && out && n_datasets > 0) urcco_free_indicators(out, n_datasets);
+  return st;
+}
+
+int urcco_cooccurrences_idss(const urcco_csr* datasets, int32_t n_datasets, int32_t random_seed, int32_t max_interesting_items_per_thing,
+                             int32_t max_num_interactions, const urcco_options* options, urcco_indicators* out, urcco_dataset_stats* stats) {
+  g_err[0] = 0;
+  if (!datasets || n_datasets <= 0) return fail(URCCO_BAD_ARG, "datasets is NULL or n_datasets <= 0");
+  std::vector<urcco_dataset> ds((size_t)n_datasets);
+  for (int d = 0; d < n_datasets; ++d) {
+    ds[(size_t)d].matrix = datasets[d];
+    ds[(size_t)d].max_elements_per_row = max_num_interactions;
+    ds[(size_t)d].max_interesting_elements = max_interesting_items_per_thing;
+    ds[(size_t)d].min_llr = 0.0;
+    ds[(size_t)d].has_min_llr = 0;
+    ds[(size_t)d].reserved = 0;
+  }
+  return urcco_cross_occurrence_downsampled(ds.data(), n_datasets, random_seed, options, out, stats);
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+"""Device-level driver of liburcco: the CCO model build with every matrix resident in HBM.
+
+PyTorch is plumbing here (device memory, the HIP stream, torch.distributed for the RCCL exchange in
+sharded.py); all arithmetic is the hand-written HIP behind include/urcco.h.  The stage order is the one Mahout's
+SimilarityAnalysis.crossOccurrenceDownsampled runs on Spark (reference call sites URAlgorithm.scala:323-346):
+column counts -> sampleDownAndBinarize -> column counts of the sample -> A.t -> per event type: A.t %*% B fused with
+computeSimilarities (LLR + top-k).  Nothing in this path synchronises with the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class DatasetParams:
+    """Mahout DownsamplableCrossOccurrenceDataset limits, as URAlgorithm.scala:334-341 fills them."""
+    max_elements_per_row: int = 500          # indicators[i].maxItemsPerUser / maxEventsPerEventType
+    max_interesting_elements: int = 50       # indicators[i].maxCorrelatorsPerItem / maxCorrelatorsPerEventType
+    min_llr: Optional[float] = None          # indicators[i].minLLR
+
+
+@dataclass
+class DevCsr:
+    """Binary user x item matrix in HBM.  col_idx may be longer than the live nnz (capacity)."""
+    n_rows: int
+    n_cols: int
+    row_ptr: torch.Tensor   # int64 [n_rows + 1]
+    col_idx: torch.Tensor   # int32 [>= nnz]
+    nnz_bound: int          # upper bound on nnz known to the host without a sync
+
+
+@dataclass
+class DevIndicators:
+    """One indicator matrix (rows = items of A in [item_lo, item_hi), cols = items of B_i), CSR in HBM."""
+    item_lo: int
+    item_hi: int
+    n_cols: int
+    k: int
+    row_ptr: torch.Tensor   # int64 [n + 1]
+    col_idx: torch.Tensor   # int32 [n * k] (first row_ptr[-1] live)
+    llr: torch.Tensor       # float64 [n * k]
+    stats: torch.Tensor     # int64 [8]: pairs, rows per accumulator bin x4
+    sampled_row_ptr: Optional[torch.Tensor] = None  # row_ptr of the down-sampled B (its last entry = nnz')
+
+    def to_host(self):
+        rp = self.row_ptr.cpu().numpy()
+        nnz = int(rp[-1])
+        return rp, self.col_idx[:nnz].cpu().numpy(), self.llr[:nnz].cpu().numpy()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+class DeviceSession:
+    """urcco_session bound to a torch device; launches go on torch's current stream for that device."""
+
+    def __init__(self, device: torch.device):
+        self.device = torch.device(device)
+        self.lib = _lib.lib()
+        handle = C.c_void_p()
+        if self.device.type == "cuda":
+            index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            self.device = torch.device("cuda", index)
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self.lib.urcco_session_create(index, C.c_void_p(stream), C.byref(handle)))
+        else:
+            # only meaningful when the binding points at the test-only host-simulator build
+            _lib.check(self.lib.urcco_session_create(0, None, C.byref(handle)))
+        self.handle = handle
+
+    def close(self):
+        if self.handle:
+            self.lib.urcco_session_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _lib.check(self.lib.urcco_session_synchronize(self.handle))
+
+    def empty(self, n, dtype):
+        return torch.empty(int(n), dtype=dtype, device=self.device)
+
+    # ---- stages ------------------------------------------------------------------------------------
+    def column_counts(self, col_idx: torch.Tensor, nnz: int, n_cols: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = out if out is not None else self.empty(n_cols, torch.int32)
+        _lib.check(self.lib.urcco_dev_column_counts(self.handle, nnz, _ptr(col_idx), n_cols, _ptr(out)))
+        return out
+
+    def downsample(self, m: DevCsr, nnz: int, raw_counts: torch.Tensor, seed: int, max_elements_per_row: int,
+                   row_rate_mode: int = _lib.ROW_RATE_MAHOUT_INT_DIV, row_base: int = 0):
+        out_rp = self.empty(m.n_rows + 1, torch.int64)
+        out_ci = self.empty(max(nnz, 1), torch.int32)
+        post = self.empty(max(m.n_cols, 1), torch.int32)
+        _lib.check(self.lib.urcco_dev_downsample(self.handle, m.n_rows, _ptr(m.row_ptr), _ptr(m.col_idx), nnz, m.n_cols, _ptr(raw_counts),
+                                                 _to_i32(seed), max_elements_per_row, row_rate_mode, row_base, _ptr(out_rp), _ptr(out_ci),
+                                                 _ptr(post)))
+        return DevCsr(m.n_rows, m.n_cols, out_rp, out_ci, nnz), post
+
+    def transpose(self, m: DevCsr, counts: torch.Tensor):
+        col_ptr = self.empty(m.n_cols + 1, torch.int64)
+        row_idx = self.empty(max(m.nnz_bound, 1), torch.int32)
+        _lib.check(self.lib.urcco_dev_transpose(self.handle, m.n_rows, _ptr(m.row_ptr), _ptr(m.col_idx), m.nnz_bound, m.n_cols, _ptr(counts),
+                                                _ptr(col_ptr), _ptr(row_idx)))
+        return col_ptr, row_idx
+
+    def row_work(self, item_lo: int, item_hi: int, a_col_ptr, a_row_idx, b_row_ptr) -> torch.Tensor:
+        work = self.empty(max(item_hi - item_lo, 1), torch.int64)
+        _lib.check(self.lib.urcco_dev_row_work(self.handle, item_lo, item_hi, _ptr(a_col_ptr), _ptr(a_row_idx), _ptr(b_row_ptr), _ptr(work)))
+        return work[: item_hi - item_lo]
+
+    def partition(self, work: torch.Tensor, n_parts: int) -> List[int]:
+        bounds = (C.c_int32 * (n_parts + 1))()
+        _lib.check(self.lib.urcco_dev_partition(self.handle, work.numel(), _ptr(work), n_parts, bounds))
+        return list(bounds)
+
+    def cco_rows(self, item_lo: int, item_hi: int, n_items_a: int, a_col_ptr, a_row_idx, b: DevCsr, counts_a, counts_b, n_users: int,
+                 exclude_self: bool, p: DatasetParams) -> DevIndicators:
+        n = item_hi - item_lo
+        k = p.max_interesting_elements
+        o_count = self.empty(max(n, 1), torch.int32)
+        o_idx = self.empty(max(n * k, 1), torch.int32)
+        o_llr = self.empty(max(n * k, 1), torch.float64)
+        stats = self.empty(8, torch.int64)
+        _lib.check(self.lib.urcco_dev_cco_rows(self.handle, item_lo, item_hi, n_items_a, _ptr(a_col_ptr), _ptr(a_row_idx), _ptr(b.row_ptr),
+                                               _ptr(b.col_idx), b.n_cols, _ptr(counts_a), _ptr(counts_b), n_users, int(exclude_self), k,
+                                               int(p.min_llr is not None), float(p.min_llr) if p.min_llr is not None else 0.0,
+                                               _ptr(o_count), _ptr(o_idx), _ptr(o_llr), _ptr(stats)))
+        c_rp = self.empty(n + 1, torch.int64)
+        c_idx = self.empty(max(n * k, 1), torch.int32)
+        c_llr = self.empty(max(n * k, 1), torch.float64)
+        _lib.check(self.lib.urcco_dev_compact_indicators(self.handle, n, k, _ptr(o_count), _ptr(o_idx), _ptr(o_llr), _ptr(c_rp), _ptr(c_idx),
+                                                         _ptr(c_llr)))
+        return DevIndicators(item_lo, item_hi, b.n_cols, k, c_rp, c_idx, c_llr, stats, b.row_ptr)
+
+    def llr(self, with_a, with_b, with_ab, n_users) -> torch.Tensor:
+        out = self.empty(with_a.numel(), torch.float64)
+        _lib.check(self.lib.urcco_dev_llr(self.handle, with_a.numel(), _ptr(with_a), _ptr(with_b), _ptr(with_ab), _ptr(n_users), _ptr(out)))
+        return out
+
+    def u01(self, seed: int, row, col) -> torch.Tensor:
+        out = self.empty(row.numel(), torch.float64)
+        _lib.check(self.lib.urcco_dev_u01(self.handle, row.numel(), _to_i32(seed), _ptr(row), _ptr(col), _ptr(out)))
+        return out
+
+
+def _to_i32(seed: int) -> int:
+    """Scala `Long.toInt` (URAlgorithm.scala:240,325,345)."""
+    s = int(seed) & 0xFFFFFFFF
+    return s - (1 << 32) if s >= (1 << 31) else s
+
+
+def cross_occurrence_device(sess: DeviceSession, mats: Sequence[DevCsr], params: Sequence[DatasetParams], seed: int,
+                            row_rate_mode: int = _lib.ROW_RATE_MAHOUT_INT_DIV, item_lo: int = 0,
+                            item_hi: Optional[int] = None) -> List[DevIndicators]:
+    """SimilarityAnalysis.crossOccurrenceDownsampled on one GPU, inputs and outputs in HBM, no host sync.
+    mats[0] is the primary matrix A; returns the indicator matrices for A'A, A'B_1, ..."""
+    if len(mats) == 0 or len(mats) != len(params):
+        raise ValueError("need one DatasetParams per matrix and at least the primary matrix")
+    a_raw = mats[0]
+    for m in mats:
+        if m.n_rows != a_raw.n_rows:
+            raise ValueError("all matrices share the user dictionary: row counts differ")
+    if item_hi is None:
+        item_hi = a_raw.n_cols
+    raw = sess.column_counts(a_raw.col_idx, a_raw.nnz_bound, a_raw.n_cols)
+    a, cnt_a = sess.downsample(a_raw, a_raw.nnz_bound, raw, seed, params[0].max_elements_per_row, row_rate_mode)
+    a_col_ptr, a_row_idx = sess.transpose(a, cnt_a)
+    out = []
+    for d, (m, p) in enumerate(zip(mats, params)):
+        if d == 0:
+            b, cnt_b = a, cnt_a
+        else:
+            raw_b = sess.column_counts(m.col_idx, m.nnz_bound, m.n_cols)
+            b, cnt_b = sess.downsample(m, m.nnz_bound, raw_b, seed, p.max_elements_per_row, row_rate_mode)
+        out.append(sess.cco_rows(item_lo, item_hi, a_raw.n_cols, a_col_ptr, a_row_idx, b, cnt_a, cnt_b, a_raw.n_rows, d == 0, p))
+    return out
