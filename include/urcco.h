@@ -122,6 +122,27 @@ typedef struct urcco_session urcco_session;
 int urcco_session_create(int32_t device, void* stream, urcco_session** out);
 void urcco_session_destroy(urcco_session* s);
 int urcco_session_synchronize(urcco_session* s);
+/* Per-stage device timing with HIP events on the session's stream (what bench.py's roofline numbers are made of).
+ * set_timing resets the accumulators; get_timings synchronises and returns, per stage id, the summed event time
+ * in ms and the number of timed launches. */
+#define URCCO_N_STAGES 16
+enum {
+  URCCO_STAGE_COLUMN_COUNTS = 0,
+  URCCO_STAGE_DOWNSAMPLE_FLAGS = 1,
+  URCCO_STAGE_DOWNSAMPLE_SCAN = 2,
+  URCCO_STAGE_DOWNSAMPLE_COMPACT = 3,
+  URCCO_STAGE_TRANSPOSE = 4,
+  URCCO_STAGE_ROW_WORK = 5,
+  URCCO_STAGE_BINNING = 6,
+  URCCO_STAGE_ENTROPY = 7,
+  URCCO_STAGE_CCO_BIN0 = 8, /* wave-LDS accumulator rows   */
+  URCCO_STAGE_CCO_BIN1 = 9, /* block-LDS accumulator rows  */
+  URCCO_STAGE_CCO_BIN2 = 10, /* CU-LDS accumulator rows    */
+  URCCO_STAGE_CCO_BIN3 = 11, /* global accumulator rows    */
+  URCCO_STAGE_COMPACT_INDICATORS = 12
+};
+int urcco_session_set_timing(urcco_session* s, int32_t enable);
+int urcco_session_get_timings(urcco_session* s, double* ms /*[URCCO_N_STAGES]*/, int64_t* launches /*[URCCO_N_STAGES]*/);
 /* bytes of device scratch currently held */
 int64_t urcco_session_scratch_bytes(const urcco_session* s);
 
@@ -160,7 +181,10 @@ int urcco_dev_partition(urcco_session* s, int32_t n_items, const int64_t* work, 
  *   counts_a/counts_b     post-sampling column counts     n_users               nrow of the DRMs (N)
  *   exclude_self          1 for A'A (crossCooccurrence = false)
  * Outputs (strided, row r = item_lo + r): out_count[r] entries at out_idx/out_llr[r*k ..], sorted
- * (llr desc, col asc).  stats_dev (nullable, device int64[8]): [0] pairs, [1..4] rows per accumulator bin. */
+ * (llr desc, col asc).  stats_dev (nullable, device int64[URCCO_STATS_LEN]): [0] pairs, [1..4] rows per accumulator
+ * bin, [5..8] pairs per bin, [9..12] users (sum of cA) per bin, [13..16] emitted entries per bin (only filled while
+ * timing is enabled), [17] accumulator-table overflows (an internal invariant: must be 0). */
+#define URCCO_STATS_LEN 20
 int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a,
                        const int64_t* a_col_ptr, const int32_t* a_row_idx, const int64_t* b_row_ptr,
                        const int32_t* b_col_idx, int32_t n_cols_b, const int32_t* counts_a,

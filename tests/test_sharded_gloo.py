@@ -1,0 +1,78 @@
+"""The N > 1 path on CPU: world_size-2 and -3 `gloo` process groups drive sharded.py end to end (user-range shards,
+count all-reduces, all-gather of the down-sampled shards, work-balanced item ranges).  Compute underneath is the
+kernel sources on the TEST-ONLY host simulator; the result must equal the single-process oracle exactly the way the
+single-GPU path does -- i.e. the sharding is invisible."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, uneven, q):
+    try:
+        for p in (ROOT, HERE):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        os.environ["OMP_NUM_THREADS"] = "2"
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        from helpers import check_indicators, rand_csr, to_dev, to_params
+        from hostsim import build_sim
+        from oracle import c_oracle as O
+        from universal_recommender_amd import _lib, sharded
+        from universal_recommender_amd.device import DeviceSession
+        sess = DeviceSession(torch.device("cpu"), _lib.load(build_sim.build()))
+        rng = np.random.default_rng(77)                       # same matrices on every rank
+        n_users = 1201
+        mats = [rand_csr(rng, n_users, 300, 9, zipf_s=1.2), rand_csr(rng, n_users, 700, 14), rand_csr(rng, n_users, 11, 2, empty_frac=0.3)]
+        params = [O.DatasetParams(30, 10, None), O.DatasetParams(40, 12, None), O.DatasetParams(500, 50, 0.1)]
+        cuts = [0, 900, n_users] if (uneven and world == 2) else [n_users * r // world for r in range(world + 1)]
+        lo, hi = cuts[rank], cuts[rank + 1]
+        shards = [O.Csr(hi - lo, m.n_cols, m.row_ptr[lo:hi + 1] - m.row_ptr[lo], m.col_idx[m.row_ptr[lo]:m.row_ptr[hi]]) for m in mats]
+        res = sharded.cross_occurrence_sharded(sess, [to_dev(s, "cpu") for s in shards], to_params(params), 2024, n_users, lo)
+        sess.synchronize()
+        full = sharded.gather_indicators_to_host(res)
+        ref = O.cross_occurrence_downsampled(mats, params, 2024)
+        pairs = [int(i.stats[0]) for i in res.indicators]
+        all_pairs = [None] * world
+        dist.all_gather_object(all_pairs, pairs)
+        for d, (got, r) in enumerate(zip(full, ref)):
+            check_indicators(got, r, exact_ids=True)
+            assert sum(p[d] for p in all_pairs) == r.pairs
+            b = res.item_ranges[d]
+            assert b[0] == 0 and b[-1] == mats[0].n_cols and len(b) == world + 1
+        q.put((rank, "ok", res.item_ranges))
+        dist.destroy_process_group()
+    except Exception as e:  # surface the failure in the parent
+        import traceback
+        q.put((rank, "fail: " + traceback.format_exc(), None))
+
+
+@pytest.mark.parametrize("world,uneven", [(2, False), (2, True), (3, False)])
+def test_sharded_equals_single_process_oracle(world, uneven, sim_lib):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, uneven, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status, _ in results:
+        assert status == "ok", f"rank {rank}: {status}"
+    ranges = [r[2] for r in results]
+    assert all(r == ranges[0] for r in ranges), "ranks disagree on the item ranges"

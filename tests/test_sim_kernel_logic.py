@@ -1,0 +1,126 @@
+"""Kernel LOGIC on CPU: the unchanged HIP sources compiled against tests/hostsim and compared with the oracle.
+These are not parity claims (those are the -m gpu tests); they catch indexing / hashing / compaction / selection
+bugs before a GPU slot is spent, and they cover the C-ABI orchestration (scratch arena, stage order)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import compare_with_oracle, rand_csr, to_dev
+from oracle import c_oracle as O
+
+
+def P(max_rows=500, k=50, min_llr=None):
+    return O.DatasetParams(max_rows, k, min_llr)
+
+
+def test_small_three_events_all_modes(sim_session):
+    rng = np.random.default_rng(1)
+    mats = [rand_csr(rng, 300, 80, 6), rand_csr(rng, 300, 40, 9), rand_csr(rng, 300, 7, 2)]
+    compare_with_oracle(sim_session, mats, [P(), P(), P()], 42)
+    compare_with_oracle(sim_session, mats, [P(20, 5), P(30, 7, 0.5), P(500, 3)], 7)
+    compare_with_oracle(sim_session, mats, [P(4, 5), P(6, 7), P(2, 3)], 7, mode=1)
+    compare_with_oracle(sim_session, mats, [P(4, 5), P(6, 7), P(2, 3)], -3, mode=0)
+
+
+def test_hash_tables_and_all_bins(sim_session):
+    """Enough columns that no table covers B (hash mode), rows spread over the wave / block / CU accumulators."""
+    rng = np.random.default_rng(2)
+    a = rand_csr(rng, 4000, 20000, 12, zipf_s=1.2)
+    b = rand_csr(rng, 4000, 30000, 25, zipf_s=1.1)
+    _, _, stats = compare_with_oracle(sim_session, [a, b], [P(10000, 50), P(10000, 20)], 5)
+    bins = stats[1][0][1:5]
+    assert bins[0] > 0 and bins[1] > 0 and bins[2] > 0, bins
+
+
+def test_global_accumulator_rows(sim_session):
+    """Rows that cannot be bounded below an LDS table (w > 10240 with > 16384 columns) take the dense global path."""
+    rng = np.random.default_rng(3)
+    n_users = 1500
+    a = rand_csr(rng, n_users, 40, 6, zipf_s=1.5)
+    b = rand_csr(rng, n_users, 17000, 40, zipf_s=0.3)
+    _, _, stats = compare_with_oracle(sim_session, [a, b], [P(100000, 10), P(100000, 60)], 11)
+    assert stats[1][0][4] > 0, stats[1][0]
+
+
+def test_packed_count_overflow_goes_global(sim_session):
+    """cA[i] larger than the packed count field (many columns -> few count bits) must not use the packed table."""
+    rng = np.random.default_rng(4)
+    n_users = 3000
+    a = rand_csr(rng, n_users, 5, 2, zipf_s=2.0)            # item 0 owned by most users
+    b = rand_csr(rng, n_users, 3_000_000, 1.2, zipf_s=0.0)  # 22 key bits -> 10 count bits (max 1023)
+    _, _, stats = compare_with_oracle(sim_session, [a, b], [P(1000000, 10), P(1000000, 10)], 3)
+    assert stats[1][0][4] > 0
+
+
+def test_empty_and_ragged_inputs(sim_session):
+    rng = np.random.default_rng(5)
+    a = rand_csr(rng, 257, 33, 3, empty_frac=0.5)
+    b_empty = O.Csr(257, 9, np.zeros(258, np.int64), np.zeros(0, np.int32))
+    c = rand_csr(rng, 257, 5000, 1, empty_frac=0.9)
+    compare_with_oracle(sim_session, [a, b_empty, c], [P(), P(), P()], 1)
+    # primary with no interactions at all
+    a0 = O.Csr(10, 4, np.zeros(11, np.int64), np.zeros(0, np.int32))
+    compare_with_oracle(sim_session, [a0, rand_csr(rng, 10, 4, 2)], [P(), P()], 1)
+    # one user
+    compare_with_oracle(sim_session, [rand_csr(rng, 1, 50, 20), rand_csr(rng, 1, 50, 20)], [P(), P()], 1)
+
+
+def test_item_range_slices_concatenate(sim_session):
+    """Disjoint item ranges (the multi-GPU partition) give exactly the rows of the full run."""
+    rng = np.random.default_rng(6)
+    mats = [rand_csr(rng, 800, 300, 8), rand_csr(rng, 800, 500, 10)]
+    ps = [P(40, 10), P(40, 10)]
+    full, _, _ = compare_with_oracle(sim_session, mats, ps, 9)
+    parts = [compare_with_oracle(sim_session, mats, ps, 9, 0, lo, hi)[0] for lo, hi in [(0, 117), (117, 118), (118, 300)]]
+    for d in range(2):
+        rp, ci, llr = full[d].to_host()
+        cat_ci = np.concatenate([p[d].to_host()[1] for p in parts])
+        cat_llr = np.concatenate([p[d].to_host()[2] for p in parts])
+        assert np.array_equal(ci, cat_ci) and np.array_equal(llr, cat_llr)
+
+
+def test_downsample_row_base_matches_sharded_rows(sim_session):
+    """sampleDownAndBinarize on a row shard with row_base == the same rows of the unsharded run (RNG keyed by global row)."""
+    rng = np.random.default_rng(7)
+    m = rand_csr(rng, 1000, 60, 30, zipf_s=1.3)
+    dev = sim_session.device
+    raw = sim_session.column_counts(torch.from_numpy(m.col_idx.copy()), m.nnz, m.n_cols)
+    full, _ = sim_session.downsample(to_dev(m, dev), m.nnz, raw, 77, 25)
+    lo, hi = 333, 901
+    shard = O.Csr(hi - lo, m.n_cols, m.row_ptr[lo:hi + 1] - m.row_ptr[lo], m.col_idx[m.row_ptr[lo]:m.row_ptr[hi]])
+    part, _ = sim_session.downsample(to_dev(shard, dev), shard.nnz, raw, 77, 25, 0, lo)
+    sim_session.synchronize()
+    frp, prp = full.row_ptr.numpy(), part.row_ptr.numpy()
+    assert np.array_equal(frp[lo:hi + 1] - frp[lo], prp)
+    assert np.array_equal(full.col_idx.numpy()[frp[lo]:frp[hi]], part.col_idx.numpy()[:prp[-1]])
+    ref = O.downsample(m, O.column_counts(m), 77, 25)
+    assert np.array_equal(ref.row_ptr, frp) and np.array_equal(ref.col_idx, full.col_idx.numpy()[:frp[-1]])
+
+
+def test_unaligned_col_idx_takes_scalar_path(sim_session):
+    rng = np.random.default_rng(8)
+    m = rand_csr(rng, 500, 90, 11)
+    buf = torch.zeros(m.nnz + 8, dtype=torch.int32)
+    view = buf[1:1 + m.nnz]                      # 4-byte aligned only
+    view.copy_(torch.from_numpy(m.col_idx))
+    assert view.data_ptr() % 16 != 0
+    cnt = sim_session.column_counts(view, m.nnz, m.n_cols)
+    from universal_recommender_amd.device import DevCsr
+    out, post = sim_session.downsample(DevCsr(m.n_rows, m.n_cols, torch.from_numpy(m.row_ptr.copy()), view, m.nnz), m.nnz, cnt, 5, 7)
+    sim_session.synchronize()
+    assert np.array_equal(cnt.numpy(), O.column_counts(m))
+    ref = O.downsample(m, O.column_counts(m), 5, 7)
+    assert np.array_equal(out.row_ptr.numpy(), ref.row_ptr)
+    assert np.array_equal(out.col_idx.numpy()[:ref.nnz], ref.col_idx)
+    assert np.array_equal(post.numpy()[:m.n_cols], O.column_counts(ref))
+
+
+def test_partition_balances_work(sim_session):
+    rng = np.random.default_rng(9)
+    work = torch.from_numpy(rng.zipf(1.5, 5000).astype(np.int64))
+    bounds = sim_session.partition(work, 8)
+    assert bounds[0] == 0 and bounds[-1] == 5000 and all(a <= b for a, b in zip(bounds, bounds[1:]))
+    pref = np.concatenate([[0], np.cumsum(work.numpy())])
+    total = pref[-1]
+    for p in range(1, 8):
+        assert pref[bounds[p]] >= total * p // 8 and (bounds[p] == 0 or pref[bounds[p] - 1] < total * p // 8)

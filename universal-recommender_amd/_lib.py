@@ -16,6 +16,10 @@ DEFAULT_PATH = os.path.join(_HERE, "lib", "liburcco.so")
 OK, BAD_ARG, OOM_HOST, OOM_DEVICE, HIP_ERROR, INTERNAL, NO_DEVICE = range(7)
 ROW_RATE_MAHOUT_INT_DIV = 0
 ROW_RATE_FRACTIONAL = 1
+N_STAGES = 16
+STATS_LEN = 20
+STAGE_NAMES = ["column_counts", "downsample_flags", "downsample_scan", "downsample_compact", "transpose", "row_work", "binning",
+               "entropy", "cco_rows_wave", "cco_rows_block", "cco_rows_cu", "cco_rows_global", "compact_indicators", "", "", ""]
 
 
 class UrccoError(RuntimeError):
@@ -63,6 +67,8 @@ SYMBOLS = {
     "urcco_session_destroy": (None, [_p]),
     "urcco_session_synchronize": (C.c_int, [_p]),
     "urcco_session_scratch_bytes": (C.c_int64, [_p]),
+    "urcco_session_set_timing": (C.c_int, [_p, C.c_int32]),
+    "urcco_session_get_timings": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "urcco_dev_column_counts": (C.c_int, [_p, C.c_int64, _p, C.c_int32, _p]),
     "urcco_dev_downsample": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int64, C.c_int32, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                        _p, _p, _p]),
@@ -76,7 +82,7 @@ SYMBOLS = {
     "urcco_dev_u01": (C.c_int, [_p, C.c_int64, C.c_int32, _p, _p, _p]),
 }
 
-_lib: Optional[C.CDLL] = None
+_cache = {}
 _lib_path: Optional[str] = None
 
 
@@ -91,9 +97,20 @@ def _bind(path: str) -> C.CDLL:
 
 def use_library(path: Optional[str]) -> None:
     """Bind to an explicit shared object (test hook); None returns to the in-tree product library."""
-    global _lib, _lib_path
-    _lib = None
+    global _lib_path
     _lib_path = path
+
+
+def load(path: str) -> C.CDLL:
+    """Bind (once) the shared object at `path`."""
+    path = os.path.abspath(path)
+    if path not in _cache:
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"liburcco HIP library not found at {path}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _cache[path] = _bind(path)
+    return _cache[path]
 
 
 def library_path() -> str:
@@ -101,18 +118,11 @@ def library_path() -> str:
 
 
 def lib() -> C.CDLL:
-    global _lib
-    if _lib is None:
-        path = library_path()
-        if not os.path.exists(path):
-            raise RuntimeError(
-                f"liburcco HIP library not found at {path}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-        _lib = _bind(path)
-    return _lib
+    return load(library_path())
 
 
-def check(status: int) -> None:
+def check(status: int, library: Optional[C.CDLL] = None) -> None:
     if status != OK:
-        msg = lib().urcco_last_error()
-        raise UrccoError(status, (msg or b"").decode("utf-8", "replace") or lib().urcco_status_string(status).decode())
+        library = library or lib()
+        msg = library.urcco_last_error()
+        raise UrccoError(status, (msg or b"").decode("utf-8", "replace") or library.urcco_status_string(status).decode())

@@ -7,13 +7,15 @@
 namespace urcco {
 
 constexpr int NBINS = 4;  // accumulator classes: 0 wave-LDS (64 thr, 512 slots), 1 block-LDS (256 thr, 4096 slots),
-                          // 2 CU-LDS (1024 thr, 32768 slots), 3 global dense counters
+                          // 2 CU-LDS (1024 thr, 16384 slots), 3 global dense counters
 
 // Geometry the host side needs for scratch sizing.
 constexpr int SCAN_TILE = 2048;          // elements per scan tile (256 threads x 8)
 constexpr int DS_TILE = 4096;            // entries per down-sample tile (256 threads x 4 x 4)
 constexpr int GLOBAL_BIN_BLOCKS = 64;    // persistent blocks of the global-accumulator kernel
 constexpr int BIN_TILE = 1024;           // items per binning tile
+constexpr int BIN_COLS_HOST = 3 * NBINS + 1;  // int64 per binning tile
+constexpr int STATS_LEN = 20;            // [0] pairs, [1..4] rows/bin, [5..8] pairs/bin, [9..12] users/bin, [13..16] out entries/bin
 
 struct CcoArgs {
   // row lists per bin
@@ -42,6 +44,7 @@ struct CcoArgs {
   int32_t* out_count;
   int32_t* out_idx;
   double* out_llr;
+  unsigned long long* err;   // stats[17]: LDS table overflows (must stay 0)
   // global-accumulator scratch (bin 3)
   int32_t* g_counts;         // [GLOBAL_BIN_BLOCKS][n_cols_b] zero on entry, zero on exit
   unsigned long long* g_cand_key;  // [GLOBAL_BIN_BLOCKS][n_cols_b]
@@ -69,12 +72,14 @@ hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n,
 hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr, const int32_t* a_row_idx,
                            const int64_t* b_row_ptr, int g_log2, int64_t* work);
 
-// binning: bin_of[n] from work/cnt_a; tile_counts scratch [(ceil(n/BIN_TILE)+1) * (NBINS+1)] int64;
-// bin_off[NBINS+1] int32, bin_rows[n] int32, stats[8] int64 ([0] pairs, [1..4] rows per bin).
+// binning: tile_counts scratch [(ceil(n/BIN_TILE)+1) * BIN_COLS_HOST] int64;
+// bin_off[NBINS+1] int32, bin_rows[n] int32, stats[STATS_LEN] int64.
 hipError_t launch_binning(hipStream_t st, int32_t item_lo, int32_t n, const int64_t* work, const int32_t* cnt_a, int32_t n_cols_b,
                           int32_t count_bits, int64_t* tile_counts, int32_t* bin_off, int32_t* bin_rows, int64_t* stats);
 
-hipError_t launch_cco_rows(hipStream_t st, int n_cu, const CcoArgs& args);
+hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, int bin);
+hipError_t launch_bin_out_stats(hipStream_t st, const int32_t* bin_rows, const int32_t* bin_off, int32_t item_lo, const int32_t* out_count,
+                                int64_t* stats);
 
 hipError_t launch_compact_indicators(hipStream_t st, int32_t n_rows, int32_t k, const int32_t* count, const int32_t* idx,
                                      const double* llr, const int64_t* row_ptr, int32_t* out_idx, double* out_llr);

@@ -512,7 +512,7 @@ hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t it
 // Lists are built by a deterministic tile count / scan / scatter (a global atomic append would serialise
 // hundreds of thousands of increments on four addresses).
 // ============================================================================================
-constexpr int E0 = 512, E1 = 4096, E2 = 32768;
+constexpr int E0 = 512, E1 = 4096, E2 = 16384;
 
 __device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_cols_b, int32_t count_bits) {
   if (ca <= 0 || w <= 0) return -1;  // no users or no pairs: empty indicator row
@@ -527,7 +527,7 @@ __device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_c
 
 constexpr int BIN_THREADS = 256;
 constexpr int BIN_ITEMS = BIN_TILE / BIN_THREADS;  // 4
-constexpr int BIN_COLS = NBINS + 1;                // per tile: rows per bin, then pairs
+constexpr int BIN_COLS = 3 * NBINS + 1;            // per tile: rows per bin, pairs per bin, users per bin, total pairs
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo, int32_t n, const int64_t* __restrict__ work,
                                                                 const int32_t* __restrict__ cnt_a, int32_t n_cols_b, int32_t count_bits,
@@ -536,22 +536,33 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo,
   if (threadIdx.x < BIN_COLS) s_acc[threadIdx.x] = 0;
   __syncthreads();
   int c[NBINS] = {0, 0, 0, 0};
+  long long pw[NBINS] = {0, 0, 0, 0};
+  long long pu[NBINS] = {0, 0, 0, 0};
   long long pairs = 0;
 #pragma unroll
   for (int q = 0; q < BIN_ITEMS; ++q) {
     const int64_t t = (int64_t)blockIdx.x * BIN_TILE + (int64_t)threadIdx.x * BIN_ITEMS + q;
     if (t < n) {
       const long long w = work[t];
+      const long long ca = cnt_a[item_lo + t];
       pairs += w;
-      const int b = choose_bin(w, cnt_a[item_lo + t], n_cols_b, count_bits);
+      const int b = choose_bin(w, ca, n_cols_b, count_bits);
 #pragma unroll
-      for (int k = 0; k < NBINS; ++k) c[k] += (b == k);
+      for (int k = 0; k < NBINS; ++k) {
+        c[k] += (b == k);
+        pw[k] += (b == k) ? w : 0;
+        pu[k] += (b == k) ? ca : 0;
+      }
     }
   }
 #pragma unroll
   for (int k = 0; k < NBINS; ++k)
-    if (c[k]) atomicAdd((unsigned long long*)&s_acc[k], (unsigned long long)c[k]);
-  if (pairs) atomicAdd((unsigned long long*)&s_acc[NBINS], (unsigned long long)pairs);
+    if (c[k]) {
+      atomicAdd((unsigned long long*)&s_acc[k], (unsigned long long)c[k]);
+      atomicAdd((unsigned long long*)&s_acc[NBINS + k], (unsigned long long)pw[k]);
+      atomicAdd((unsigned long long*)&s_acc[2 * NBINS + k], (unsigned long long)pu[k]);
+    }
+  if (pairs) atomicAdd((unsigned long long*)&s_acc[3 * NBINS], (unsigned long long)pairs);
   __syncthreads();
   if (threadIdx.x < BIN_COLS) tile_counts[(int64_t)blockIdx.x * BIN_COLS + threadIdx.x] = s_acc[threadIdx.x];
 }
@@ -579,10 +590,14 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(int64_t* __restri
     for (int k = 0; k < NBINS; ++k) {
       bin_off[k] = off;
       off += (int32_t)s_tot[k];
-      if (stats) stats[1 + k] = s_tot[k];
+      if (stats) {
+        stats[1 + k] = s_tot[k];              // rows
+        stats[5 + k] = s_tot[NBINS + k];      // pairs
+        stats[9 + k] = s_tot[2 * NBINS + k];  // users (sum of cA over the bin's rows)
+      }
     }
     bin_off[NBINS] = off;
-    if (stats) stats[0] = s_tot[NBINS];
+    if (stats) stats[0] = s_tot[3 * NBINS];
   }
 }
 
@@ -613,7 +628,7 @@ hipError_t launch_binning(hipStream_t st, int32_t item_lo, int32_t n, const int6
                           int32_t count_bits, int64_t* tile_counts, int32_t* bin_off, int32_t* bin_rows, int64_t* stats) {
   if (n <= 0) {
     hipError_t e = hipMemsetAsync(bin_off, 0, sizeof(int32_t) * (NBINS + 1), st);
-    if (e == hipSuccess && stats) e = hipMemsetAsync(stats, 0, sizeof(int64_t) * 8, st);
+    if (e == hipSuccess && stats) e = hipMemsetAsync(stats, 0, sizeof(int64_t) * STATS_LEN, st);
     return e;
   }
   const int64_t n_tiles = ((int64_t)n + BIN_TILE - 1) / BIN_TILE;
@@ -646,21 +661,25 @@ __device__ __forceinline__ bool best_before(unsigned long long ka, int ca, unsig
   return ka > kb || (ka == kb && ca < cb);
 }
 
-__device__ __forceinline__ void tab_insert(unsigned* tab, unsigned key, int count_bits, unsigned mask, int hshift, bool ident) {
+// Returns false only if every slot was probed without finding the key or a free slot -- impossible while the binning
+// rule holds (the table always has room for the row's distinct columns); the bound keeps a broken invariant from
+// turning into a hung GPU and is reported through stats[17].
+__device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int count_bits, unsigned mask, int hshift, bool ident) {
   unsigned h = ident ? (key - 1u) : ((key * 0x9E3779B1u) >> hshift);
   const unsigned tagged = key << count_bits;
-  for (;;) {
+  for (unsigned probe = 0; probe <= mask; ++probe) {
     unsigned v = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (v == 0u) {
       v = atomicCAS(&tab[h], 0u, tagged | 1u);
-      if (v == 0u) return;
+      if (v == 0u) return true;
     }
     if ((v >> count_bits) == key) {
       atomicAdd(&tab[h], 1u);
-      return;
+      return true;
     }
     h = (h + 1u) & mask;
   }
+  return false;
 }
 
 template <int T, int E>
@@ -669,7 +688,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
   constexpr int TEAMS = BLOCK / T;
   constexpr int SPT = E / T;
   constexpr int NW = T / WAVE;  // waves per team
-  constexpr int LOG2E = E == 512 ? 9 : (E == 4096 ? 12 : 15);
+  constexpr int LOG2E = E == 512 ? 9 : (E == 4096 ? 12 : 14);
   static_assert((1 << LOG2E) == E, "table size");
   __shared__ unsigned s_tab[TEAMS * E];
   __shared__ unsigned long long s_pkey[2][NW > 1 ? NW : 1];
@@ -702,7 +721,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
       for (int64_t p = cs + grp; p < ce; p += ngrp) {
         const int u = a.a_row_idx[p];
         const int64_t s = a.b_row_ptr[u], e = a.b_row_ptr[u + 1];
-        for (int64_t q = s + gl; q < e; q += G) tab_insert(tab, (unsigned)a.b_col_idx[q] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident);
+        for (int64_t q = s + gl; q < e; q += G)
+          if (!tab_insert(tab, (unsigned)a.b_col_idx[q] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) atomicAdd(a.err, 1ull);
       }
     }
     __syncthreads();
@@ -904,13 +924,32 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
   }
 }
 
-hipError_t launch_cco_rows(hipStream_t st, int n_cu, const CcoArgs& args) {
+hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, int bin) {
   // Persistent grids sized to the chip; each kernel reads its own row list length from bin_off on the device,
   // so no host synchronisation sits between binning and the SpGEMM.
-  hipLaunchKernelGGL((cco_rows_kernel<64, E0>), dim3((unsigned)(n_cu * 8)), dim3(256), 0, st, args, 0);
-  hipLaunchKernelGGL((cco_rows_kernel<256, E1>), dim3((unsigned)(n_cu * 8)), dim3(256), 0, st, args, 1);
-  hipLaunchKernelGGL((cco_rows_kernel<1024, E2>), dim3((unsigned)(n_cu * 2)), dim3(1024), 0, st, args, 2);
-  hipLaunchKernelGGL(cco_rows_global_kernel, dim3(GLOBAL_BIN_BLOCKS), dim3(GB_THREADS), 0, st, args);
+  switch (bin) {
+    case 0: hipLaunchKernelGGL((cco_rows_kernel<64, E0>), dim3((unsigned)(n_cu * 8)), dim3(256), 0, st, args, 0); break;
+    case 1: hipLaunchKernelGGL((cco_rows_kernel<256, E1>), dim3((unsigned)(n_cu * 8)), dim3(256), 0, st, args, 1); break;
+    case 2: hipLaunchKernelGGL((cco_rows_kernel<1024, E2>), dim3((unsigned)(n_cu * 2)), dim3(1024), 0, st, args, 2); break;  // 64 KiB LDS: two blocks per CU
+    default: hipLaunchKernelGGL(cco_rows_global_kernel, dim3(GLOBAL_BIN_BLOCKS), dim3(GB_THREADS), 0, st, args); break;
+  }
+  return hipGetLastError();
+}
+
+// stats[13 + bin] = indicator entries emitted by the rows of each bin (profiling aid, deterministic block reduce)
+__global__ __launch_bounds__(256) void bin_out_stats_kernel(const int32_t* __restrict__ bin_rows, const int32_t* __restrict__ bin_off,
+                                                            int32_t item_lo, const int32_t* __restrict__ out_count, int64_t* __restrict__ stats) {
+  __shared__ long long s_wave[SCAN_THREADS / WAVE];
+  const int bin = blockIdx.x;
+  long long v = 0;
+  for (int t = bin_off[bin] + threadIdx.x; t < bin_off[bin + 1]; t += 256) v += out_count[bin_rows[t] - item_lo];
+  long long tot;
+  block_exclusive_scan(v, s_wave, &tot);
+  if (threadIdx.x == 0) stats[13 + bin] = tot;
+}
+hipError_t launch_bin_out_stats(hipStream_t st, const int32_t* bin_rows, const int32_t* bin_off, int32_t item_lo, const int32_t* out_count,
+                                int64_t* stats) {
+  hipLaunchKernelGGL(bin_out_stats_kernel, dim3(NBINS), dim3(256), 0, st, bin_rows, bin_off, item_lo, out_count, stats);
   return hipGetLastError();
 }
 

@@ -65,6 +65,40 @@ struct urcco_session {
   unsigned long long* g_cand_key = nullptr;
   int32_t* g_cand_col = nullptr;
   int64_t g_cols = 0;
+  // optional per-stage HIP-event timing (bench.py's roofline numbers)
+  bool timing = false;
+  struct Rec { int stage; hipEvent_t e0, e1; };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> free_events;
+  double acc_ms[URCCO_N_STAGES] = {0};
+  int64_t acc_n[URCCO_N_STAGES] = {0};
+
+  hipEvent_t get_event() {
+    if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void begin(int stage) {
+    if (!timing) return;
+    Rec r{stage, get_event(), get_event()};
+    (void)hipEventRecord(r.e0, stream);
+    recs.push_back(r);
+  }
+  void end() {
+    if (!timing) return;
+    (void)hipEventRecord(recs.back().e1, stream);
+  }
+  void collect() {
+    (void)hipStreamSynchronize(stream);
+    for (const Rec& r : recs) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { acc_ms[r.stage] += ms; acc_n[r.stage] += 1; }
+      free_events.push_back(r.e0);
+      free_events.push_back(r.e1);
+    }
+    recs.clear();
+  }
 
   int reserve(size_t bytes) {
     arena_off = 0;
@@ -158,6 +192,8 @@ void urcco_session_destroy(urcco_session* s) {
   (void)hipStreamSynchronize(s->stream);
   if (s->arena) (void)hipFree(s->arena);
   if (s->g_counts) { (void)hipFree(s->g_counts); (void)hipFree(s->g_cand_key); (void)hipFree(s->g_cand_col); }
+  s->collect();
+  for (hipEvent_t e : s->free_events) (void)hipEventDestroy(e);
   if (s->own_stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -165,6 +201,21 @@ void urcco_session_destroy(urcco_session* s) {
 int urcco_session_synchronize(urcco_session* s) {
   if (!s) return fail(URCCO_BAD_ARG, "session is NULL");
   HIPC(hipStreamSynchronize(s->stream));
+  return URCCO_OK;
+}
+
+int urcco_session_set_timing(urcco_session* s, int32_t enable) {
+  if (!s) return fail(URCCO_BAD_ARG, "session is NULL");
+  s->collect();
+  s->timing = enable != 0;
+  for (int i = 0; i < URCCO_N_STAGES; ++i) { s->acc_ms[i] = 0; s->acc_n[i] = 0; }
+  return URCCO_OK;
+}
+
+int urcco_session_get_timings(urcco_session* s, double* ms, int64_t* launches) {
+  if (!s || !ms || !launches) return fail(URCCO_BAD_ARG, "urcco_session_get_timings: bad argument");
+  s->collect();
+  for (int i = 0; i < URCCO_N_STAGES; ++i) { ms[i] = s->acc_ms[i]; launches[i] = s->acc_n[i]; }
   return URCCO_OK;
 }
 
@@ -176,7 +227,9 @@ int64_t urcco_session_scratch_bytes(const urcco_session* s) {
 int urcco_dev_column_counts(urcco_session* s, int64_t nnz, const int32_t* col_idx, int32_t n_cols, int32_t* counts) {
   if (!s || nnz < 0 || n_cols < 0 || (nnz > 0 && !col_idx) || (n_cols > 0 && !counts)) return fail(URCCO_BAD_ARG, "urcco_dev_column_counts: bad argument");
   if (n_cols == 0) return URCCO_OK;
+  s->begin(URCCO_STAGE_COLUMN_COUNTS);
   HIPC(urcco::launch_column_counts(s->stream, s->n_cu, col_idx, nnz, n_cols, counts));
+  s->end();
   return URCCO_OK;
 }
 
@@ -199,10 +252,16 @@ int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_pt
   unsigned long long* flags = s->take<unsigned long long>((size_t)n_words + 1);
   int64_t* word_prefix = s->take<int64_t>((size_t)n_words + 1);
   int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
+  s->begin(URCCO_STAGE_DOWNSAMPLE_FLAGS);
   HIPC(urcco::launch_downsample_flags(s->stream, n_rows, row_ptr, col_idx, nnz, raw_counts, (uint32_t)seed, max_elements_per_row, row_rate_mode,
                                       row_base, flags, post_counts));
+  s->end();
+  s->begin(URCCO_STAGE_DOWNSAMPLE_SCAN);
   HIPC(urcco::launch_scan_popc64(s->stream, flags, n_words, word_prefix, tile_sums));
+  s->end();
+  s->begin(URCCO_STAGE_DOWNSAMPLE_COMPACT);
   HIPC(urcco::launch_downsample_compact(s->stream, s->n_cu, n_rows, row_ptr, col_idx, nnz, flags, word_prefix, out_row_ptr, out_col_idx));
+  s->end();
   return URCCO_OK;
 }
 
@@ -214,13 +273,16 @@ int urcco_dev_transpose(urcco_session* s, int64_t n_rows, const int64_t* row_ptr
   URC(s->reserve(urcco_session::need((size_t)n_cols, 4) + urcco_session::need((size_t)n_tiles + 2, 8)));
   int32_t* cursor = s->take<int32_t>((size_t)n_cols);
   int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
+  s->begin(URCCO_STAGE_TRANSPOSE);
   HIPC(urcco::launch_scan_i32(s->stream, counts, n_cols, out_col_ptr, tile_sums));
-  if (nnz == 0 || n_rows == 0) return URCCO_OK;
-  HIPC(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)n_cols, s->stream));
-  int g = ceil_log2_i64((nnz + n_rows - 1) / n_rows);
-  if (g < 1) g = 1;
-  if (g > 6) g = 6;
-  HIPC(urcco::launch_transpose(s->stream, s->n_cu, n_rows, row_ptr, col_idx, g, out_col_ptr, cursor, out_row_idx));
+  if (nnz > 0 && n_rows > 0) {
+    HIPC(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)n_cols, s->stream));
+    int g = ceil_log2_i64((nnz + n_rows - 1) / n_rows);
+    if (g < 1) g = 1;
+    if (g > 6) g = 6;
+    HIPC(urcco::launch_transpose(s->stream, s->n_cu, n_rows, row_ptr, col_idx, g, out_col_ptr, cursor, out_row_idx));
+  }
+  s->end();
   return URCCO_OK;
 }
 
@@ -255,13 +317,13 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   if (k <= 0) return fail(URCCO_BAD_ARG, "maxInterestingElements must be positive, got %d", k);
   const int32_t n = item_hi - item_lo;
   if (n == 0) {
-    if (stats_dev) HIPC(hipMemsetAsync(stats_dev, 0, sizeof(int64_t) * 8, s->stream));
+    if (stats_dev) HIPC(hipMemsetAsync(stats_dev, 0, sizeof(int64_t) * URCCO_STATS_LEN, s->stream));
     return URCCO_OK;
   }
   if (!out_count || !out_idx || !out_llr || !counts_a || (n_cols_b > 0 && !counts_b)) return fail(URCCO_BAD_ARG, "urcco_dev_cco_rows: NULL buffer");
   HIPC(hipMemsetAsync(out_count, 0, sizeof(int32_t) * (size_t)n, s->stream));
   if (n_cols_b == 0 || n_users == 0) {
-    if (stats_dev) HIPC(hipMemsetAsync(stats_dev, 0, sizeof(int64_t) * 8, s->stream));
+    if (stats_dev) HIPC(hipMemsetAsync(stats_dev, 0, sizeof(int64_t) * URCCO_STATS_LEN, s->stream));
     return URCCO_OK;
   }
   // packed LDS entry: key = col + 1 in the high bits, count in the low bits
@@ -272,23 +334,29 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   URC(s->ensure_global_bin(n_cols_b));
   const int64_t n_tiles = ((int64_t)n + urcco::BIN_TILE - 1) / urcco::BIN_TILE;
   const bool same = (counts_a == counts_b) && (n_items_a == n_cols_b);
-  URC(s->reserve(urcco_session::need((size_t)n, 8) + urcco_session::need((size_t)(n_tiles + 1) * (urcco::NBINS + 1), 8) +
+  URC(s->reserve(urcco_session::need((size_t)n, 8) + urcco_session::need((size_t)(n_tiles + 1) * urcco::BIN_COLS_HOST, 8) +
                  urcco_session::need(urcco::NBINS + 1, 4) + urcco_session::need((size_t)n, 4) + urcco_session::need((size_t)n_items_a, 8) +
-                 urcco_session::need((size_t)n_cols_b, 8) + urcco_session::need(1, 8) + urcco_session::need(8, 8)));
+                 urcco_session::need((size_t)n_cols_b, 8) + urcco_session::need(1, 8) + urcco_session::need(URCCO_STATS_LEN, 8)));
   int64_t* work = s->take<int64_t>((size_t)n);
-  int64_t* tile_counts = s->take<int64_t>((size_t)(n_tiles + 1) * (urcco::NBINS + 1));
+  int64_t* tile_counts = s->take<int64_t>((size_t)(n_tiles + 1) * urcco::BIN_COLS_HOST);
   int32_t* bin_off = s->take<int32_t>(urcco::NBINS + 1);
   int32_t* bin_rows = s->take<int32_t>((size_t)n);
   double* ent_a = s->take<double>((size_t)n_items_a);
   double* ent_b = same ? ent_a : s->take<double>((size_t)n_cols_b);
   double* xlx_n = s->take<double>(1);
-  int64_t* stats = stats_dev ? stats_dev : s->take<int64_t>(8);
+  int64_t* stats = stats_dev ? stats_dev : s->take<int64_t>(URCCO_STATS_LEN);
 
+  s->begin(URCCO_STAGE_ROW_WORK);
   HIPC(urcco::launch_row_work(s->stream, s->n_cu, item_lo, item_hi, a_col_ptr, a_row_idx, b_row_ptr, 3, work));
-  HIPC(hipMemsetAsync(stats, 0, sizeof(int64_t) * 8, s->stream));
+  s->end();
+  s->begin(URCCO_STAGE_BINNING);
+  HIPC(hipMemsetAsync(stats, 0, sizeof(int64_t) * URCCO_STATS_LEN, s->stream));
   HIPC(urcco::launch_binning(s->stream, item_lo, n, work, counts_a, n_cols_b, count_bits, tile_counts, bin_off, bin_rows, stats));
+  s->end();
+  s->begin(URCCO_STAGE_ENTROPY);
   HIPC(urcco::launch_item_entropy(s->stream, counts_a, n_items_a, n_users, ent_a, xlx_n));
   if (!same) HIPC(urcco::launch_item_entropy(s->stream, counts_b, n_cols_b, n_users, ent_b, nullptr));
+  s->end();
 
   urcco::CcoArgs a;
   a.bin_rows = bin_rows; a.bin_off = bin_off;
@@ -298,8 +366,14 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   a.has_min_llr = has_min_llr ? 1 : 0; a.min_llr = min_llr; a.count_bits = count_bits;
   a.g_log2 = 4;  // 16 lanes stream one user's B' row: 64 B segments, matches the ~10-40 item rows the cut leaves
   a.out_count = out_count; a.out_idx = out_idx; a.out_llr = out_llr;
+  a.err = reinterpret_cast<unsigned long long*>(stats + 17);
   a.g_counts = s->g_counts; a.g_cand_key = s->g_cand_key; a.g_cand_col = s->g_cand_col;
-  HIPC(urcco::launch_cco_rows(s->stream, s->n_cu, a));
+  for (int bin = 0; bin < urcco::NBINS; ++bin) {
+    s->begin(URCCO_STAGE_CCO_BIN0 + bin);
+    HIPC(urcco::launch_cco_rows_bin(s->stream, s->n_cu, a, bin));
+    s->end();
+  }
+  if (s->timing) HIPC(urcco::launch_bin_out_stats(s->stream, bin_rows, bin_off, item_lo, out_count, stats));
   return URCCO_OK;
 }
 
@@ -310,8 +384,10 @@ int urcco_dev_compact_indicators(urcco_session* s, int32_t n_rows, int32_t k, co
   const int64_t n_tiles = ((int64_t)n_rows + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
   URC(s->reserve(urcco_session::need((size_t)n_tiles + 2, 8)));
   int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
+  s->begin(URCCO_STAGE_COMPACT_INDICATORS);
   HIPC(urcco::launch_scan_i32(s->stream, count, n_rows, out_row_ptr, tile_sums));
   HIPC(urcco::launch_compact_indicators(s->stream, n_rows, k, count, idx, llr, out_row_ptr, out_col_idx, out_llr));
+  s->end();
   return URCCO_OK;
 }
 
@@ -471,7 +547,7 @@ int build_impl(const urcco_dataset* datasets, int32_t n_datasets, int32_t seed, 
     URC(bufs.alloc(&c_rp, (size_t)n_items_a + 1));
     URC(bufs.alloc(&c_idx, strided));
     URC(bufs.alloc(&c_llr, strided));
-    URC(bufs.alloc(&d_stats, 8));
+    URC(bufs.alloc(&d_stats, URCCO_STATS_LEN));
     URC(urcco_dev_cco_rows(s, 0, n_items_a, n_items_a, a_col_ptr, a_row_idx, b.row_ptr, b.col_idx, n_cols_b, a.counts, b.counts, n_users,
                            d == 0 ? 1 : 0, k, datasets[d].has_min_llr, datasets[d].min_llr, o_count, o_idx, o_llr, d_stats));
     URC(urcco_dev_compact_indicators(s, n_items_a, k, o_count, o_idx, o_llr, c_rp, c_idx, c_llr));
@@ -482,7 +558,7 @@ int build_impl(const urcco_dataset* datasets, int32_t n_datasets, int32_t seed, 
     o.row_ptr = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_items_a + 1));
     if (!o.row_ptr) return fail(URCCO_OOM_HOST, "indicator row_ptr");
     HIPC(hipMemcpyAsync(o.row_ptr, c_rp, sizeof(int64_t) * ((size_t)n_items_a + 1), hipMemcpyDeviceToHost, s->stream));
-    int64_t h_stats[8];
+    int64_t h_stats[URCCO_STATS_LEN];
     HIPC(hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, s->stream));
     HIPC(hipStreamSynchronize(s->stream));
     o.nnz = o.row_ptr[n_items_a];

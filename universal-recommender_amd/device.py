@@ -45,7 +45,7 @@ class DevIndicators:
     row_ptr: torch.Tensor   # int64 [n + 1]
     col_idx: torch.Tensor   # int32 [n * k] (first row_ptr[-1] live)
     llr: torch.Tensor       # float64 [n * k]
-    stats: torch.Tensor     # int64 [8]: pairs, rows per accumulator bin x4
+    stats: torch.Tensor     # int64 [STATS_LEN]: pairs, then rows / pairs / users / emitted entries per accumulator bin
     sampled_row_ptr: Optional[torch.Tensor] = None  # row_ptr of the down-sampled B (its last entry = nnz')
 
     def to_host(self):
@@ -61,19 +61,22 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 class DeviceSession:
     """urcco_session bound to a torch device; launches go on torch's current stream for that device."""
 
-    def __init__(self, device: torch.device):
+    def __init__(self, device: torch.device, library=None):
         self.device = torch.device(device)
-        self.lib = _lib.lib()
+        self.lib = library if library is not None else _lib.lib()
         handle = C.c_void_p()
         if self.device.type == "cuda":
             index = self.device.index if self.device.index is not None else torch.cuda.current_device()
             self.device = torch.device("cuda", index)
             stream = torch.cuda.current_stream(self.device).cuda_stream
-            _lib.check(self.lib.urcco_session_create(index, C.c_void_p(stream), C.byref(handle)))
+            self._check(self.lib.urcco_session_create(index, C.c_void_p(stream), C.byref(handle)))
         else:
             # only meaningful when the binding points at the test-only host-simulator build
-            _lib.check(self.lib.urcco_session_create(0, None, C.byref(handle)))
+            self._check(self.lib.urcco_session_create(0, None, C.byref(handle)))
         self.handle = handle
+
+    def _check(self, status: int):
+        _lib.check(status, self.lib)
 
     def close(self):
         if self.handle:
@@ -87,7 +90,17 @@ class DeviceSession:
             pass
 
     def synchronize(self):
-        _lib.check(self.lib.urcco_session_synchronize(self.handle))
+        self._check(self.lib.urcco_session_synchronize(self.handle))
+
+    def set_timing(self, enable: bool):
+        self._check(self.lib.urcco_session_set_timing(self.handle, int(enable)))
+
+    def get_timings(self):
+        """{stage name: (summed ms, launches)} since set_timing(True); synchronises."""
+        ms = (C.c_double * _lib.N_STAGES)()
+        n = (C.c_int64 * _lib.N_STAGES)()
+        self._check(self.lib.urcco_session_get_timings(self.handle, ms, n))
+        return {_lib.STAGE_NAMES[i]: (ms[i], n[i]) for i in range(_lib.N_STAGES) if _lib.STAGE_NAMES[i]}
 
     def empty(self, n, dtype):
         return torch.empty(int(n), dtype=dtype, device=self.device)
@@ -95,7 +108,7 @@ class DeviceSession:
     # ---- stages ------------------------------------------------------------------------------------
     def column_counts(self, col_idx: torch.Tensor, nnz: int, n_cols: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         out = out if out is not None else self.empty(n_cols, torch.int32)
-        _lib.check(self.lib.urcco_dev_column_counts(self.handle, nnz, _ptr(col_idx), n_cols, _ptr(out)))
+        self._check(self.lib.urcco_dev_column_counts(self.handle, nnz, _ptr(col_idx), n_cols, _ptr(out)))
         return out
 
     def downsample(self, m: DevCsr, nnz: int, raw_counts: torch.Tensor, seed: int, max_elements_per_row: int,
@@ -103,7 +116,7 @@ class DeviceSession:
         out_rp = self.empty(m.n_rows + 1, torch.int64)
         out_ci = self.empty(max(nnz, 1), torch.int32)
         post = self.empty(max(m.n_cols, 1), torch.int32)
-        _lib.check(self.lib.urcco_dev_downsample(self.handle, m.n_rows, _ptr(m.row_ptr), _ptr(m.col_idx), nnz, m.n_cols, _ptr(raw_counts),
+        self._check(self.lib.urcco_dev_downsample(self.handle, m.n_rows, _ptr(m.row_ptr), _ptr(m.col_idx), nnz, m.n_cols, _ptr(raw_counts),
                                                  _to_i32(seed), max_elements_per_row, row_rate_mode, row_base, _ptr(out_rp), _ptr(out_ci),
                                                  _ptr(post)))
         return DevCsr(m.n_rows, m.n_cols, out_rp, out_ci, nnz), post
@@ -111,18 +124,18 @@ class DeviceSession:
     def transpose(self, m: DevCsr, counts: torch.Tensor):
         col_ptr = self.empty(m.n_cols + 1, torch.int64)
         row_idx = self.empty(max(m.nnz_bound, 1), torch.int32)
-        _lib.check(self.lib.urcco_dev_transpose(self.handle, m.n_rows, _ptr(m.row_ptr), _ptr(m.col_idx), m.nnz_bound, m.n_cols, _ptr(counts),
+        self._check(self.lib.urcco_dev_transpose(self.handle, m.n_rows, _ptr(m.row_ptr), _ptr(m.col_idx), m.nnz_bound, m.n_cols, _ptr(counts),
                                                 _ptr(col_ptr), _ptr(row_idx)))
         return col_ptr, row_idx
 
     def row_work(self, item_lo: int, item_hi: int, a_col_ptr, a_row_idx, b_row_ptr) -> torch.Tensor:
         work = self.empty(max(item_hi - item_lo, 1), torch.int64)
-        _lib.check(self.lib.urcco_dev_row_work(self.handle, item_lo, item_hi, _ptr(a_col_ptr), _ptr(a_row_idx), _ptr(b_row_ptr), _ptr(work)))
+        self._check(self.lib.urcco_dev_row_work(self.handle, item_lo, item_hi, _ptr(a_col_ptr), _ptr(a_row_idx), _ptr(b_row_ptr), _ptr(work)))
         return work[: item_hi - item_lo]
 
     def partition(self, work: torch.Tensor, n_parts: int) -> List[int]:
         bounds = (C.c_int32 * (n_parts + 1))()
-        _lib.check(self.lib.urcco_dev_partition(self.handle, work.numel(), _ptr(work), n_parts, bounds))
+        self._check(self.lib.urcco_dev_partition(self.handle, work.numel(), _ptr(work), n_parts, bounds))
         return list(bounds)
 
     def cco_rows(self, item_lo: int, item_hi: int, n_items_a: int, a_col_ptr, a_row_idx, b: DevCsr, counts_a, counts_b, n_users: int,
@@ -132,26 +145,26 @@ class DeviceSession:
         o_count = self.empty(max(n, 1), torch.int32)
         o_idx = self.empty(max(n * k, 1), torch.int32)
         o_llr = self.empty(max(n * k, 1), torch.float64)
-        stats = self.empty(8, torch.int64)
-        _lib.check(self.lib.urcco_dev_cco_rows(self.handle, item_lo, item_hi, n_items_a, _ptr(a_col_ptr), _ptr(a_row_idx), _ptr(b.row_ptr),
+        stats = self.empty(_lib.STATS_LEN, torch.int64)
+        self._check(self.lib.urcco_dev_cco_rows(self.handle, item_lo, item_hi, n_items_a, _ptr(a_col_ptr), _ptr(a_row_idx), _ptr(b.row_ptr),
                                                _ptr(b.col_idx), b.n_cols, _ptr(counts_a), _ptr(counts_b), n_users, int(exclude_self), k,
                                                int(p.min_llr is not None), float(p.min_llr) if p.min_llr is not None else 0.0,
                                                _ptr(o_count), _ptr(o_idx), _ptr(o_llr), _ptr(stats)))
         c_rp = self.empty(n + 1, torch.int64)
         c_idx = self.empty(max(n * k, 1), torch.int32)
         c_llr = self.empty(max(n * k, 1), torch.float64)
-        _lib.check(self.lib.urcco_dev_compact_indicators(self.handle, n, k, _ptr(o_count), _ptr(o_idx), _ptr(o_llr), _ptr(c_rp), _ptr(c_idx),
+        self._check(self.lib.urcco_dev_compact_indicators(self.handle, n, k, _ptr(o_count), _ptr(o_idx), _ptr(o_llr), _ptr(c_rp), _ptr(c_idx),
                                                          _ptr(c_llr)))
         return DevIndicators(item_lo, item_hi, b.n_cols, k, c_rp, c_idx, c_llr, stats, b.row_ptr)
 
     def llr(self, with_a, with_b, with_ab, n_users) -> torch.Tensor:
         out = self.empty(with_a.numel(), torch.float64)
-        _lib.check(self.lib.urcco_dev_llr(self.handle, with_a.numel(), _ptr(with_a), _ptr(with_b), _ptr(with_ab), _ptr(n_users), _ptr(out)))
+        self._check(self.lib.urcco_dev_llr(self.handle, with_a.numel(), _ptr(with_a), _ptr(with_b), _ptr(with_ab), _ptr(n_users), _ptr(out)))
         return out
 
     def u01(self, seed: int, row, col) -> torch.Tensor:
         out = self.empty(row.numel(), torch.float64)
-        _lib.check(self.lib.urcco_dev_u01(self.handle, row.numel(), _to_i32(seed), _ptr(row), _ptr(col), _ptr(out)))
+        self._check(self.lib.urcco_dev_u01(self.handle, row.numel(), _to_i32(seed), _ptr(row), _ptr(col), _ptr(out)))
         return out
 
 

@@ -1,0 +1,71 @@
+"""Host-side mirror of Preparator.prepare (reference src/main/scala/Preparator.scala:44-87 and the two
+`object IndexedDatasetSpark.apply` overloads at :102-158, :160-214): one binary user x item matrix per event type,
+all sharing one user dictionary; `minEventsPerUser` filters users on their RAW primary-event count."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .data_source import TrainingData
+from .indexed_dataset import BiDictionary, IndexedDataset
+
+
+@dataclass
+class PreparedData:
+    """Preparator.scala:91-93."""
+    actions: List[Tuple[str, IndexedDataset]]
+    fields: Dict[str, Dict[str, object]]
+
+
+def _first_appearance(keys: Sequence[str]) -> List[str]:
+    return list(dict.fromkeys(keys))
+
+
+def _indexed_dataset(elements: Sequence[Tuple[str, str]], existing_row_ids: Optional[BiDictionary]) -> IndexedDataset:
+    """IndexedDatasetSpark.apply(elements, existingRowIDs) Preparator.scala:160-214."""
+    if existing_row_ids is None:
+        row_ids = BiDictionary(_first_appearance([u for u, _ in elements]))            # :170
+        filtered = elements
+    else:
+        row_ids = existing_row_ids                                                      # :173-179, never extended
+        filtered = [(u, i) for (u, i) in elements if u in row_ids]
+    column_ids = BiDictionary(_first_appearance([i for _, i in filtered]))              # :184-186
+    n_rows, n_cols = row_ids.size, column_ids.size
+    if filtered:
+        r = np.fromiter((row_ids.get(u) for u, _ in filtered), np.int64, count=len(filtered))
+        c = np.fromiter((column_ids.get(i) for _, i in filtered), np.int64, count=len(filtered))
+        key = np.unique(r * max(n_cols, 1) + c)        # setQuick(col, 1.0): duplicates collapse (:205); sorted by (row, col)
+        rr = key // max(n_cols, 1)
+        cc = (key - rr * max(n_cols, 1)).astype(np.int32)
+    else:
+        rr = np.zeros(0, np.int64)
+        cc = np.zeros(0, np.int32)
+    row_ptr = np.zeros(n_rows + 1, np.int64)
+    np.cumsum(np.bincount(rr, minlength=n_rows), out=row_ptr[1:])
+    return IndexedDataset(row_ptr, cc, row_ids, column_ids)
+
+
+def _min_events_row_ids(elements: Sequence[Tuple[str, str]], min_events: int) -> BiDictionary:
+    """IndexedDatasetSpark.apply(elements, minEventsPerUser): only its rowIDs are used (Preparator.scala:57-62).
+    groupByKey ... items.size counts RAW events, duplicates included (:129-132)."""
+    counts: Dict[str, int] = {}
+    for u, _ in elements:
+        counts[u] = counts.get(u, 0) + 1
+    return BiDictionary([u for u, c in counts.items() if c >= min_events])
+
+
+class Preparator:
+    def prepare(self, trainingData: TrainingData) -> PreparedData:
+        user_dictionary: Optional[BiDictionary] = None
+        out: List[Tuple[str, IndexedDataset]] = []
+        for pos, (event_name, elements) in enumerate(trainingData.actions):
+            if pos == 0 and trainingData.minEventsPerUser is not None:
+                d_row_ids = _min_events_row_ids(elements, trainingData.minEventsPerUser)     # :57
+                ids = _indexed_dataset(elements, d_row_ids)                                  # :62
+            else:
+                ids = _indexed_dataset(elements, user_dictionary)                            # :71
+            user_dictionary = ids.rowIDs                                                     # :63, :72
+            out.append((event_name, ids))
+        return PreparedData(out, trainingData.fields)

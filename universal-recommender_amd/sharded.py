@@ -1,0 +1,136 @@
+"""Multi-GPU CCO model build: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The path shards with ONE exchange step:
+
+  input phase   -- users are range-sharded: rank r holds rows [row_base, row_base + n_local) of every raw matrix,
+                   computes local column counts (all-reduce -> the raw counts sampleDownAndBinarize needs), down-samples
+                   its rows (the RNG is keyed by the GLOBAL row, so the result does not depend on the sharding) and
+                   all-reduces the post-sampling column counts;
+  exchange      -- all-gather of the down-sampled CSR shards (variable length: padded to the largest shard, then
+                   compacted), after which every rank holds A' and each B'_i whole;
+  compute phase -- items of A are split into world_size contiguous ranges of equal summed row work (not equal count:
+                   Zipf skew) and each rank emits the indicator rows of its range -- disjoint rows, no further traffic.
+
+Collectives per event type: 2 small all-reduces (int32[n_items]) + 1 all-gather of row lengths + 1 all-gather of
+column indices.  Mahout does the same job with Spark broadcasts of the count vectors and a shuffle inside `A.t %*% B`
+(reference call sites URAlgorithm.scala:323-346).  With world_size == 1 nothing is exchanged.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .device import DatasetParams, DevCsr, DevIndicators, DeviceSession
+
+
+@dataclass
+class ShardedResult:
+    indicators: List[DevIndicators]       # this rank's rows, one entry per event type
+    item_ranges: List[List[int]]          # per event type: world_size + 1 bounds
+    nnz_sampled: List[int]                # global nnz after down-sampling, per event type
+
+
+def _all_reduce_sum(t: torch.Tensor, group) -> None:
+    if dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+
+def _gather_sampled(sess: DeviceSession, local: DevCsr, n_rows_global: int, group) -> DevCsr:
+    """All-gather a down-sampled row shard into the whole matrix (rows in rank order)."""
+    world = dist.get_world_size(group)
+    dev = local.row_ptr.device
+    # per-rank (rows, nnz): one tiny all-gather, the only host sync of the exchange (sizes the receive buffers)
+    mine = torch.stack([torch.tensor(local.n_rows, dtype=torch.int64, device=dev), local.row_ptr[-1]])
+    sizes = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, mine, group=group)
+    sizes = sizes.cpu().view(world, 2)
+    rows = [int(x) for x in sizes[:, 0]]
+    nnzs = [int(x) for x in sizes[:, 1]]
+    if sum(rows) != n_rows_global:
+        raise ValueError(f"row shards sum to {sum(rows)} rows, expected {n_rows_global}")
+    max_rows, max_nnz = max(rows), max(max(nnzs), 1)
+    # row lengths (int32) and column indices, padded to the largest shard
+    deg = torch.zeros(max_rows, dtype=torch.int32, device=dev)
+    deg[: local.n_rows] = (local.row_ptr[1:] - local.row_ptr[:-1]).to(torch.int32)
+    all_deg = torch.empty(world * max_rows, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(all_deg, deg, group=group)
+    ci = torch.zeros(max_nnz, dtype=torch.int32, device=dev)
+    rank = dist.get_rank(group)
+    ci[: nnzs[rank]] = local.col_idx[: nnzs[rank]]
+    all_ci = torch.empty(world * max_nnz, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(all_ci, ci, group=group)
+    deg_cat = torch.cat([all_deg[r * max_rows: r * max_rows + rows[r]] for r in range(world)])
+    row_ptr = torch.zeros(n_rows_global + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(deg_cat, 0, out=row_ptr[1:])
+    col_idx = torch.cat([all_ci[r * max_nnz: r * max_nnz + nnzs[r]] for r in range(world)])
+    total = sum(nnzs)
+    if total == 0:
+        col_idx = torch.zeros(1, dtype=torch.int32, device=dev)
+    return DevCsr(n_rows_global, local.n_cols, row_ptr, col_idx, total)
+
+
+def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], params: Sequence[DatasetParams], seed: int,
+                             n_rows_global: int, row_base: int, row_rate_mode: int = _lib.ROW_RATE_MAHOUT_INT_DIV,
+                             group=None) -> ShardedResult:
+    """SimilarityAnalysis.crossOccurrenceDownsampled over world_size GPUs.  shards[d] = this rank's user rows of
+    event type d (shards[0] = primary)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if len(shards) == 0 or len(shards) != len(params):
+        raise ValueError("need one DatasetParams per matrix and at least the primary matrix")
+
+    def sample(m: DevCsr, p: DatasetParams):
+        raw = sess.column_counts(m.col_idx, m.nnz_bound, m.n_cols)
+        if world > 1:
+            _all_reduce_sum(raw, group)
+        local, post = sess.downsample(m, m.nnz_bound, raw, seed, p.max_elements_per_row, row_rate_mode, row_base)
+        if world == 1:
+            return local, post, None
+        _all_reduce_sum(post, group)
+        whole = _gather_sampled(sess, local, n_rows_global, group)
+        return whole, post, whole.nnz_bound
+
+    a, cnt_a, nnz_a = sample(shards[0], params[0])
+    a_col_ptr, a_row_idx = sess.transpose(a, cnt_a)
+    n_items_a = a.n_cols
+    out: List[DevIndicators] = []
+    ranges: List[List[int]] = []
+    nnzs: List[int] = []
+    for d, (m, p) in enumerate(zip(shards, params)):
+        if d == 0:
+            b, cnt_b, nnz_b = a, cnt_a, nnz_a
+        else:
+            b, cnt_b, nnz_b = sample(m, p)
+        if world > 1:
+            work = sess.row_work(0, n_items_a, a_col_ptr, a_row_idx, b.row_ptr)
+            bounds = sess.partition(work, world)   # same inputs on every rank -> same bounds, no communication
+        else:
+            bounds = [0, n_items_a]
+        out.append(sess.cco_rows(bounds[rank], bounds[rank + 1], n_items_a, a_col_ptr, a_row_idx, b, cnt_a, cnt_b, n_rows_global, d == 0, p))
+        ranges.append(bounds)
+        nnzs.append(-1 if nnz_b is None else nnz_b)
+    return ShardedResult(out, ranges, nnzs)
+
+
+def gather_indicators_to_host(res: ShardedResult, group=None):
+    """Concatenate every rank's indicator rows on every rank (host numpy): list of (row_ptr, col_idx, llr).
+    Not part of the timed model build (the reference hands the rows to URModel.save per partition)."""
+    import numpy as np
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    out = []
+    for ind in res.indicators:
+        rp, ci, llr = ind.to_host()
+        if world == 1:
+            out.append((rp, ci, llr))
+            continue
+        parts = [None] * world
+        dist.all_gather_object(parts, (np.diff(rp), ci, llr), group=group)
+        lens = np.concatenate([p[0] for p in parts])
+        full_rp = np.zeros(lens.size + 1, np.int64)
+        np.cumsum(lens, out=full_rp[1:])
+        out.append((full_rp, np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])))
+    return out
