@@ -168,8 +168,8 @@ int urcco_dev_transpose(urcco_session* s, int64_t n_rows, const int64_t* row_ptr
 
 /* Upper-bound work per item row of A'B: work[i - item_lo] = sum over users u of item i of d_B(u)
  * (= the cooccurrence pairs row i forms).  Used for accumulator binning and for work-balanced item ranges. */
-int urcco_dev_row_work(urcco_session* s, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr,
-                       const int32_t* a_row_idx, const int64_t* b_row_ptr, int64_t* work);
+int urcco_dev_row_work(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a, const int64_t* a_col_ptr,
+                       const int32_t* a_row_idx, int64_t nnz_a_bound, const int64_t* b_row_ptr, int64_t* work);
 
 /* Splits items [0, n_items) into n_parts contiguous ranges of ~equal summed work.  bounds_host[n_parts+1]
  * (host memory).  Synchronises. */
@@ -177,7 +177,8 @@ int urcco_dev_partition(urcco_session* s, int32_t n_items, const int64_t* work, 
                         int32_t* bounds_host);
 
 /* Rows [item_lo, item_hi) of A'B, LLR scored, cut to the top k (computeSimilarities fused onto the SpGEMM).
- *   a_col_ptr/a_row_idx   CSC of down-sampled A          b_row_ptr/b_col_idx   CSR of down-sampled B
+ *   a_col_ptr/a_row_idx   CSC of down-sampled A (nnz_a_bound >= its nnz: sizes scratch, no host sync needed)
+ *   b_row_ptr/b_col_idx   CSR of down-sampled B
  *   counts_a/counts_b     post-sampling column counts     n_users               nrow of the DRMs (N)
  *   exclude_self          1 for A'A (crossCooccurrence = false)
  * Outputs (strided, row r = item_lo + r): out_count[r] entries at out_idx/out_llr[r*k ..], sorted
@@ -186,8 +187,8 @@ int urcco_dev_partition(urcco_session* s, int32_t n_items, const int64_t* work, 
  * timing is enabled), [17] accumulator-table overflows (an internal invariant: must be 0). */
 #define URCCO_STATS_LEN 20
 int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a,
-                       const int64_t* a_col_ptr, const int32_t* a_row_idx, const int64_t* b_row_ptr,
-                       const int32_t* b_col_idx, int32_t n_cols_b, const int32_t* counts_a,
+                       const int64_t* a_col_ptr, const int32_t* a_row_idx, int64_t nnz_a_bound,
+                       const int64_t* b_row_ptr, const int32_t* b_col_idx, int32_t n_cols_b, const int32_t* counts_a,
                        const int32_t* counts_b, int64_t n_users, int32_t exclude_self, int32_t k,
                        int32_t has_min_llr, double min_llr, int32_t* out_count, int32_t* out_idx,
                        double* out_llr, int64_t* stats_dev);

@@ -173,6 +173,8 @@ template <typename T> static inline T atomicMin(T* p, T v) {
 static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __builtin_amdgcn_s_sleep(int) {}
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+__attribute__((noinline)) static void __builtin_amdgcn_wave_barrier() { hipsim::wave_op(hipsim::OP_BALLOT, 0, 0, __builtin_return_address(0)); }
 
 // ---- runtime API ---------------------------------------------------------------------------
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess(sim)" : "hipError(sim)"; }

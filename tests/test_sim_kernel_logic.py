@@ -84,43 +84,45 @@ def test_downsample_row_base_matches_sharded_rows(sim_session):
     rng = np.random.default_rng(7)
     m = rand_csr(rng, 1000, 60, 30, zipf_s=1.3)
     dev = sim_session.device
-    raw = sim_session.column_counts(torch.from_numpy(m.col_idx.copy()), m.nnz, m.n_cols)
+    raw = sim_session.column_counts(torch.from_numpy(m.col_idx.copy()).to(dev), m.nnz, m.n_cols)
     full, _ = sim_session.downsample(to_dev(m, dev), m.nnz, raw, 77, 25)
     lo, hi = 333, 901
     shard = O.Csr(hi - lo, m.n_cols, m.row_ptr[lo:hi + 1] - m.row_ptr[lo], m.col_idx[m.row_ptr[lo]:m.row_ptr[hi]])
     part, _ = sim_session.downsample(to_dev(shard, dev), shard.nnz, raw, 77, 25, 0, lo)
     sim_session.synchronize()
-    frp, prp = full.row_ptr.numpy(), part.row_ptr.numpy()
+    frp, prp = full.row_ptr.cpu().numpy(), part.row_ptr.cpu().numpy()
+    fci, pci = full.col_idx.cpu().numpy(), part.col_idx.cpu().numpy()
     assert np.array_equal(frp[lo:hi + 1] - frp[lo], prp)
-    assert np.array_equal(full.col_idx.numpy()[frp[lo]:frp[hi]], part.col_idx.numpy()[:prp[-1]])
+    assert np.array_equal(fci[frp[lo]:frp[hi]], pci[:prp[-1]])
     ref = O.downsample(m, O.column_counts(m), 77, 25)
-    assert np.array_equal(ref.row_ptr, frp) and np.array_equal(ref.col_idx, full.col_idx.numpy()[:frp[-1]])
+    assert np.array_equal(ref.row_ptr, frp) and np.array_equal(ref.col_idx, fci[:frp[-1]])
 
 
 def test_unaligned_col_idx_takes_scalar_path(sim_session):
     rng = np.random.default_rng(8)
     m = rand_csr(rng, 500, 90, 11)
-    buf = torch.zeros(m.nnz + 8, dtype=torch.int32)
+    dev = sim_session.device
+    buf = torch.zeros(m.nnz + 8, dtype=torch.int32, device=dev)
     view = buf[1:1 + m.nnz]                      # 4-byte aligned only
     view.copy_(torch.from_numpy(m.col_idx))
     assert view.data_ptr() % 16 != 0
     cnt = sim_session.column_counts(view, m.nnz, m.n_cols)
     from universal_recommender_amd.device import DevCsr
-    out, post = sim_session.downsample(DevCsr(m.n_rows, m.n_cols, torch.from_numpy(m.row_ptr.copy()), view, m.nnz), m.nnz, cnt, 5, 7)
+    out, post = sim_session.downsample(DevCsr(m.n_rows, m.n_cols, torch.from_numpy(m.row_ptr.copy()).to(dev), view, m.nnz), m.nnz, cnt, 5, 7)
     sim_session.synchronize()
-    assert np.array_equal(cnt.numpy(), O.column_counts(m))
+    assert np.array_equal(cnt.cpu().numpy(), O.column_counts(m))
     ref = O.downsample(m, O.column_counts(m), 5, 7)
-    assert np.array_equal(out.row_ptr.numpy(), ref.row_ptr)
-    assert np.array_equal(out.col_idx.numpy()[:ref.nnz], ref.col_idx)
-    assert np.array_equal(post.numpy()[:m.n_cols], O.column_counts(ref))
+    assert np.array_equal(out.row_ptr.cpu().numpy(), ref.row_ptr)
+    assert np.array_equal(out.col_idx.cpu().numpy()[:ref.nnz], ref.col_idx)
+    assert np.array_equal(post.cpu().numpy()[:m.n_cols], O.column_counts(ref))
 
 
 def test_partition_balances_work(sim_session):
     rng = np.random.default_rng(9)
-    work = torch.from_numpy(rng.zipf(1.5, 5000).astype(np.int64))
+    work = torch.from_numpy(rng.zipf(1.5, 5000).astype(np.int64)).to(sim_session.device)
     bounds = sim_session.partition(work, 8)
     assert bounds[0] == 0 and bounds[-1] == 5000 and all(a <= b for a, b in zip(bounds, bounds[1:]))
-    pref = np.concatenate([[0], np.cumsum(work.numpy())])
+    pref = np.concatenate([[0], np.cumsum(work.cpu().numpy())])
     total = pref[-1]
     for p in range(1, 8):
         assert pref[bounds[p]] >= total * p // 8 and (bounds[p] == 0 or pref[bounds[p] - 1] < total * p // 8)

@@ -73,9 +73,9 @@ SYMBOLS = {
     "urcco_dev_downsample": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int64, C.c_int32, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                        _p, _p, _p]),
     "urcco_dev_transpose": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int64, C.c_int32, _p, _p, _p]),
-    "urcco_dev_row_work": (C.c_int, [_p, C.c_int32, C.c_int32, _p, _p, _p, _p]),
+    "urcco_dev_row_work": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, C.c_int64, _p, _p]),
     "urcco_dev_partition": (C.c_int, [_p, C.c_int32, _p, C.c_int32, C.POINTER(C.c_int32)]),
-    "urcco_dev_cco_rows": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, _p, _p, C.c_int32, _p, _p, C.c_int64, C.c_int32,
+    "urcco_dev_cco_rows": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, C.c_int64, _p, _p, C.c_int32, _p, _p, C.c_int64, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_double, _p, _p, _p, _p]),
     "urcco_dev_compact_indicators": (C.c_int, [_p, C.c_int32, C.c_int32, _p, _p, _p, _p, _p, _p]),
     "urcco_dev_llr": (C.c_int, [_p, C.c_int64, _p, _p, _p, _p, _p]),
@@ -87,6 +87,12 @@ _lib_path: Optional[str] = None
 
 
 def _bind(path: str) -> C.CDLL:
+    # PyTorch ships its own HIP runtime; when both live in one process the runtime torch initialised must be the one
+    # liburcco resolves (same devices, streams and allocations), so torch is imported before the dlopen.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol

@@ -6,8 +6,8 @@
 
 namespace urcco {
 
-constexpr int NBINS = 4;  // accumulator classes: 0 wave-LDS (64 thr, 512 slots), 1 block-LDS (256 thr, 4096 slots),
-                          // 2 CU-LDS (1024 thr, 16384 slots), 3 global dense counters
+constexpr int NBINS = 4;  // accumulator classes: 0 wave-LDS (64 thr, 1024 words), 1 block-LDS (256 thr, 8192 words),
+                          // 2 CU-LDS (1024 thr, 32768 words), 3 global dense counters
 
 // Geometry the host side needs for scratch sizing.
 constexpr int SCAN_TILE = 2048;          // elements per scan tile (256 threads x 8)
@@ -22,9 +22,9 @@ struct CcoArgs {
   const int32_t* bin_rows;   // item ids grouped by bin
   const int32_t* bin_off;    // [NBINS+1] offsets into bin_rows
   // matrices
-  const int64_t* a_col_ptr;
-  const int32_t* a_row_idx;
-  const int64_t* b_row_ptr;
+  const int64_t* a_col_ptr;  // CSC of A': users of item i are entries [a_col_ptr[i], a_col_ptr[i+1])
+  const int64_t* pstart;     // per CSC entry: start of that user's B' row in b_col_idx
+  const int64_t* wp;         // per CSC entry (+1): exclusive prefix of B' row lengths over the CSC
   const int32_t* b_col_idx;
   const int32_t* cnt_a;
   const int32_t* cnt_b;
@@ -69,8 +69,10 @@ hipError_t launch_transpose(hipStream_t st, int n_cu, int64_t n_rows, const int6
 
 hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, double* xlx_n);
 
-hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr, const int32_t* a_row_idx,
-                           const int64_t* b_row_ptr, int g_log2, int64_t* work);
+// pstart[cap], plen[cap] (scratch), wp[cap + 1]; cap >= nnz(A'); tile_sums scratch as for scans over cap elements
+hipError_t launch_expand_prepare(hipStream_t st, int n_cu, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx,
+                                 const int64_t* b_row_ptr, int64_t cap, int64_t* pstart, int32_t* plen, int64_t* wp, int64_t* tile_sums);
+hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr, const int64_t* wp, int64_t* work);
 
 // binning: tile_counts scratch [(ceil(n/BIN_TILE)+1) * BIN_COLS_HOST] int64;
 // bin_off[NBINS+1] int32, bin_rows[n] int32, stats[STATS_LEN] int64.

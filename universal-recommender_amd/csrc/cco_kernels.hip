@@ -465,62 +465,79 @@ hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n,
 }
 
 // ============================================================================================
-// Row work: w_i = sum over users u of item i of d_B(u) -- exactly the cooccurrence pairs row i forms and an
-// upper bound on its distinct columns.  Drives accumulator binning and work-balanced item ranges.
+// Expand preparation.  For every entry p of the CSC of A' (user u of some item) it records where u's B' row starts
+// and how long it is, then prefix-sums the lengths over the whole CSC:
+//     pstart[p] = b_row_ptr[u_p]            wp[p] = sum_{q < p} d_B(u_q)
+// One flat, fully parallel gather replaces the per-row pointer chase: inside the SpGEMM the row pointers of B are never
+// touched again -- item i's work is the contiguous slice wp[cp[i]] .. wp[cp[i+1]], its upper-bound work
+// w_i = wp[cp[i+1]] - wp[cp[i]] (exactly the cooccurrence pairs row i forms) drives binning and work-balanced item
+// ranges, and lanes find "their" pairs by searching that slice.
 // ============================================================================================
-__global__ __launch_bounds__(256) void row_work_kernel(int32_t item_lo, int32_t item_hi, const int64_t* __restrict__ a_cp,
-                                                       const int32_t* __restrict__ a_ri, const int64_t* __restrict__ b_rp, int g_log2,
-                                                       int64_t* __restrict__ work) {
-  const int G = 1 << g_log2;
-  const int gl = threadIdx.x & (G - 1);
-  const int64_t gpb = 256 >> g_log2;
-  const int64_t n = (int64_t)item_hi - item_lo;
-  const int64_t stride = (int64_t)gridDim.x * gpb;
-  const int64_t n_round = ((n + stride - 1) / stride) * stride;  // grid-uniform trip count for the shuffles below
-  for (int64_t t = (int64_t)blockIdx.x * gpb + (threadIdx.x >> g_log2); t < n_round; t += stride) {
-    long long w = 0;
-    if (t < n) {
-      const int64_t i = item_lo + t;
-      const int64_t s = a_cp[i], e = a_cp[i + 1];
-      for (int64_t p = s + gl; p < e; p += G) {
-        const int u = a_ri[p];
-        w += b_rp[u + 1] - b_rp[u];
-      }
+__global__ __launch_bounds__(256) void expand_prepare_kernel(const int64_t* __restrict__ a_cp, int32_t n_items_a, const int32_t* __restrict__ a_ri,
+                                                             const int64_t* __restrict__ b_rp, int64_t cap, int64_t* __restrict__ pstart,
+                                                             int32_t* __restrict__ plen) {
+  const int64_t nnz = a_cp[n_items_a];
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < cap; p += (int64_t)gridDim.x * 256) {
+    int32_t len = 0;
+    int64_t s = 0;
+    if (p < nnz) {
+      const int u = a_ri[p];
+      s = b_rp[u];
+      len = (int32_t)(b_rp[u + 1] - s);
     }
-    for (int m = 1; m < G; m <<= 1) w += (long long)shfl_xor_u64((unsigned long long)w, m);
-    if (gl == 0 && t < n) work[t] = w;
+    pstart[p] = s;
+    plen[p] = len;
   }
 }
 
-hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr, const int32_t* a_row_idx,
-                           const int64_t* b_row_ptr, int g_log2, int64_t* work) {
+hipError_t launch_expand_prepare(hipStream_t st, int n_cu, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx,
+                                 const int64_t* b_row_ptr, int64_t cap, int64_t* pstart, int32_t* plen, int64_t* wp, int64_t* tile_sums) {
+  if (cap > 0) {
+    int64_t blocks = (cap + 255) / 256;
+    const int64_t lim = (int64_t)n_cu * 16;
+    if (blocks > lim) blocks = lim;
+    hipLaunchKernelGGL(expand_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, cap, pstart, plen);
+  }
+  return launch_scan_i32(st, plen, cap, wp, tile_sums);
+}
+
+__global__ __launch_bounds__(256) void row_work_kernel(int32_t item_lo, int32_t item_hi, const int64_t* __restrict__ a_cp,
+                                                       const int64_t* __restrict__ wp, int64_t* __restrict__ work) {
+  const int64_t n = (int64_t)item_hi - item_lo;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+    const int64_t i = item_lo + t;
+    work[t] = wp[a_cp[i + 1]] - wp[a_cp[i]];
+  }
+}
+
+hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr, const int64_t* wp, int64_t* work) {
   const int64_t n = (int64_t)item_hi - item_lo;
   if (n <= 0) return hipSuccess;
-  const int64_t gpb = 256 >> g_log2;
-  int64_t blocks = (n + gpb - 1) / gpb;
+  int64_t blocks = (n + 255) / 256;
   const int64_t cap = (int64_t)n_cu * 8;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(row_work_kernel, dim3((unsigned)blocks), dim3(256), 0, st, item_lo, item_hi, a_col_ptr, a_row_idx, b_row_ptr, g_log2, work);
+  hipLaunchKernelGGL(row_work_kernel, dim3((unsigned)blocks), dim3(256), 0, st, item_lo, item_hi, a_col_ptr, wp, work);
   return hipGetLastError();
 }
 
 // ============================================================================================
 // Binning (row-tile partitioning of the SpGEMM).  A row goes to the smallest accumulator class that
-// (a) is guaranteed to hold its distinct columns: w <= 5/8 of the table, or the table covers every column of B
-//     (then slots are addressed by column and never collide), and packed counts cannot overflow;
+// (a) is guaranteed to hold its distinct columns AND their 64-bit LLR keys: 3 w < table words, or 3 n_cols_b < table
+//     words (then slots are addressed by column and never collide), and packed counts cannot overflow;
 // (b) gives it enough lanes: <= 512 pairs -> one wave, <= 8192 -> 256 threads, else 1024 threads.
 // Lists are built by a deterministic tile count / scan / scatter (a global atomic append would serialise
 // hundreds of thousands of increments on four addresses).
 // ============================================================================================
-constexpr int E0 = 512, E1 = 4096, E2 = 16384;
+constexpr int E0 = 1024, E1 = 8192, E2 = 32768;
 
 __device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_cols_b, int32_t count_bits) {
   if (ca <= 0 || w <= 0) return -1;  // no users or no pairs: empty indicator row
   if (count_bits < 31 && ca > ((1ll << count_bits) - 1)) return 3;
   int cap_bin = 3;
-  if (n_cols_b <= E0 || w * 8 <= (long long)E0 * 5) cap_bin = 0;
-  else if (n_cols_b <= E1 || w * 8 <= (long long)E1 * 5) cap_bin = 1;
-  else if (n_cols_b <= E2 || w * 8 <= (long long)E2 * 5) cap_bin = 2;
+  // a table of E words must hold D packed counts + D 64-bit keys: 3 D + 1 <= E, with D <= min(w, n_cols_b)
+  if ((long long)n_cols_b * 3 < E0 || w * 3 < E0) cap_bin = 0;
+  else if ((long long)n_cols_b * 3 < E1 || w * 3 < E1) cap_bin = 1;
+  else if ((long long)n_cols_b * 3 < E2 || w * 3 < E2) cap_bin = 2;
   const int work_bin = w <= 512 ? 0 : (w <= 8192 ? 1 : 2);
   return cap_bin > work_bin ? cap_bin : work_bin;
 }
@@ -642,16 +659,21 @@ hipError_t launch_binning(hipStream_t st, int32_t item_lo, int32_t n, const int6
 // ============================================================================================
 // K4+K5  A'B rows (Gustavson over rows of A') with LDS hash accumulators, fused LLR + top-k.
 //
-// A team of T threads owns one item row i at a time:
+// A team of T threads (one wave, 256 or 1024 threads) owns one item row i at a time:
 //   1. zero its table of E packed 32-bit entries  ((col+1) << count_bits) | count
-//   2. for every user u of item i (CSC of A'), 2^g lanes stream u's B' row (coalesced 4 B/lane segments) and
-//      insert each column: relaxed LDS read, CAS to claim an empty slot, LDS atomic add to count
-//   3. every thread scores its E/T slots: k11 = count, LLR from the per-item entropies + 4 logs (fp64),
-//      drops self pairs (A'A), zeros and llr < minLLR; keys stay in registers
-//   4. top-k by repeated argmax over (llr desc, col asc): wave shuffles (+ one LDS hop for T > 64); the
-//      winners come out already in output order.
-// Counts never leave the CU.  Hash = Fibonacci multiplicative; when the table covers all of B's columns
-// slots are addressed by column (no probing).
+//   2. EXPAND: row i's work is the slice wp[cp[i]] .. wp[cp[i+1]] of the prepared prefix (see expand_prepare).  Users are
+//      taken T at a time (coalesced reads of pstart / wp into LDS); the chunk's pairs are dealt out evenly, each lane
+//      binary-searches the LDS prefix once for its first pair and then walks B' column indices -- every lane busy, all
+//      gathers of a chunk in flight together -- inserting each column: relaxed LDS read, CAS to claim an empty slot,
+//      LDS atomic add to count
+//   3. COMPACT: occupied slots are packed to the front of the table (registers -> scan -> same LDS), so that
+//   4. SCORE runs dense: candidate t gets k11 = count, LLR from the per-item entropies + 4 logs (fp64); self pairs
+//      (A'A), zeros and llr < minLLR are dropped; keys and columns stay in registers
+//   5. TOP-K: one wave with <= 64 candidates ranks them by counting (shuffle broadcast) and writes each straight to its
+//      output position; otherwise repeated argmax over (llr desc, col asc) -- wave shuffles + one LDS hop for T > 64.
+// Counts never leave the CU.  Hash = Fibonacci multiplicative; when the table covers all of B's columns slots are
+// addressed by column (no probing).  One-wave teams synchronise with wave-level barriers only, so the four teams of a
+// block run independent row loops.
 // ============================================================================================
 struct Best {
   unsigned long long key;  // llr bits (positive doubles order like unsigned integers); 0 = none
@@ -682,138 +704,243 @@ __device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int coun
   return false;
 }
 
+// LDS hand-off inside ONE wave: DS operations of a wave execute in program order, so a compiler-level fence is all that
+// is needed between a lane's write and another lane's read.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int T>
+__device__ __forceinline__ void team_sync() {
+  if (T == WAVE) wave_sync(); else __syncthreads();
+}
+
+// exclusive scan of one unsigned per thread across a team of T threads; *total = team sum.  Every thread must call.
+template <int T>
+__device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_wsum /*[T / WAVE]*/, unsigned* total) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  unsigned inc = v;
+#pragma unroll
+  for (int d = 1; d < WAVE; d <<= 1) {
+    const unsigned o = __shfl_up(inc, d);
+    if (lane >= d) inc += o;
+  }
+  if (T == WAVE) {
+    *total = __shfl(inc, WAVE - 1);
+    return inc - v;
+  }
+  const int wave = (threadIdx.x % T) / WAVE;
+  if (lane == WAVE - 1) s_wsum[wave] = inc;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < T / WAVE; ++w) {
+    const unsigned sw = s_wsum[w];
+    if (w < wave) base += sw;
+    tot += sw;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
 template <int T, int E>
 __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a, int bin) {
   constexpr int BLOCK = T < 256 ? 256 : T;
   constexpr int TEAMS = BLOCK / T;
   constexpr int SPT = E / T;
   constexpr int NW = T / WAVE;  // waves per team
-  constexpr int LOG2E = E == 512 ? 9 : (E == 4096 ? 12 : 14);
+  constexpr int LOG2E = E == 1024 ? 10 : (E == 8192 ? 13 : 15);
   static_assert((1 << LOG2E) == E, "table size");
   __shared__ unsigned s_tab[TEAMS * E];
-  __shared__ unsigned long long s_pkey[2][NW > 1 ? NW : 1];
-  __shared__ int s_pcol[2][NW > 1 ? NW : 1];
+  __shared__ long long s_ustart[TEAMS * T];
+  __shared__ unsigned s_uoff[TEAMS * (T + 1)];
+  __shared__ unsigned s_wsum[NW];
+  __shared__ unsigned long long s_pkey[2][NW];
+  __shared__ int s_pcol[2][NW];
 
   const int team = threadIdx.x / T;
   const int tl = threadIdx.x % T;
   const int lane = threadIdx.x & (WAVE - 1);
   unsigned* tab = s_tab + team * E;
+  long long* ustart = s_ustart + team * T;
+  unsigned* uoff = s_uoff + team * (T + 1);
   const int list_start = a.bin_off[bin];
   const int list_n = a.bin_off[bin + 1] - list_start;
   const int total_teams = gridDim.x * TEAMS;
-  const int iters = (list_n + total_teams - 1) / total_teams;  // grid-uniform: barriers below are legal
-  const bool ident = a.n_cols_b <= E;
+  const bool ident = (long long)a.n_cols_b * 3 < E;  // same rule as choose_bin: slots addressed by column
   const int cb = a.count_bits;
   const unsigned cmask = (1u << cb) - 1u;
-  const int G = 1 << a.g_log2;
-  const int grp = tl >> a.g_log2, gl = tl & (G - 1), ngrp = T >> a.g_log2;
   const double xlx_n = *a.xlx_n;
 
-  for (int it = 0; it < iters; ++it) {
-    const int li = it * total_teams + blockIdx.x * TEAMS + team;
-    const bool active = li < list_n;
-    const int i = active ? a.bin_rows[list_start + li] : 0;
+  // T == 64: teams are independent waves (wave-level sync only).  T > 64: one team per block, loop is block-uniform.
+  for (int li = blockIdx.x * TEAMS + team; li < list_n; li += total_teams) {
+    const int i = a.bin_rows[list_start + li];
 #pragma unroll
     for (int q = 0; q < SPT; ++q) tab[tl + q * T] = 0u;
-    __syncthreads();
-    if (active) {
-      const int64_t cs = a.a_col_ptr[i], ce = a.a_col_ptr[i + 1];
-      for (int64_t p = cs + grp; p < ce; p += ngrp) {
-        const int u = a.a_row_idx[p];
-        const int64_t s = a.b_row_ptr[u], e = a.b_row_ptr[u + 1];
-        for (int64_t q = s + gl; q < e; q += G)
-          if (!tab_insert(tab, (unsigned)a.b_col_idx[q] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) atomicAdd(a.err, 1ull);
+    team_sync<T>();
+    // ---- 2. expand + accumulate
+    const int64_t cs = a.a_col_ptr[i], ce = a.a_col_ptr[i + 1];
+    for (int64_t c0 = cs; c0 < ce; c0 += T) {  // team-uniform
+      const int64_t c1 = c0 + T < ce ? c0 + T : ce;
+      const int64_t w0 = a.wp[c0];
+      const unsigned total = (unsigned)(a.wp[c1] - w0);
+      const int64_t p = c0 + tl;
+      if (p < c1) {
+        ustart[tl] = a.pstart[p];
+        uoff[tl] = (unsigned)(a.wp[p] - w0);
+      } else {
+        uoff[tl] = total;
       }
-    }
-    __syncthreads();
-    // ---- score this thread's slots
-    unsigned long long key[SPT];
-    Best best;
-    best.key = 0ull;
-    best.col = 0x7fffffff;
-    if (active) {
-      const long long ca = a.cnt_a[i];
-      const double row_entropy = a.ent_a[i];
-#pragma unroll
-      for (int q = 0; q < SPT; ++q) {
-        const unsigned v = tab[tl + q * T];
-        key[q] = 0ull;
-        if (v != 0u) {
-          const int j = (int)(v >> cb) - 1;
-          const long long k11 = (long long)(v & cmask);
-          if (!(a.exclude_self && j == i)) {
-            const long long cbj = a.cnt_b[j];
-            const double llr = llr_from_entropies(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11);
-            if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
-              key[q] = (unsigned long long)__double_as_longlong(llr);
-              if (best_before(key[q], j, best.key, best.col)) {
-                best.key = key[q];
-                best.col = j;
-              }
+      if (tl == 0) uoff[T] = total;
+      team_sync<T>();
+      if (total > 0u) {
+        const unsigned per = (total + T - 1) / T;
+        const unsigned first = (unsigned)tl * per;
+        if (first < total) {
+          const unsigned last = first + per < total ? first + per : total;
+          int lo = 1, hi = T;  // first idx in [1, T] with uoff[idx] > first (uoff[T] = total > first)
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (uoff[mid] > first) hi = mid; else lo = mid + 1;
+          }
+          int o = lo - 1;
+          int64_t pos = ustart[o] + (first - uoff[o]);
+          unsigned uend = uoff[o + 1];
+          unsigned t = first;
+          while (t < last) {
+            const unsigned stop = last < uend ? last : uend;
+            for (; t < stop; ++t, ++pos)
+              if (!tab_insert(tab, (unsigned)a.b_col_idx[pos] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) atomicAdd(a.err, 1ull);
+            if (t < last) {  // next user with a non-empty B' row
+              do { ++o; } while (uoff[o + 1] <= t);
+              pos = ustart[o];
+              uend = uoff[o + 1];
             }
           }
         }
       }
-    } else {
-#pragma unroll
-      for (int q = 0; q < SPT; ++q) key[q] = 0ull;
+      team_sync<T>();  // before the next chunk overwrites ustart / uoff
     }
-    // ---- top-k by repeated argmax; loop bounds are team-uniform (every lane sees the same winner)
-    int emitted = 0;
-    const int64_t obase = active ? ((int64_t)(i - a.item_lo)) * a.k : 0;
-    for (int r = 0; r < a.k; ++r) {
-      unsigned long long wk = best.key;
-      int wc = best.col;
+    // ---- 3. compact the occupied slots to tab[0 .. D); candidate keys will live behind them in the same LDS:
+    //         words [kb, kb + 2 D) with kb = D rounded up to even.  The binning rule keeps 3 D + 1 <= E.
+    unsigned D;
+    {
+      unsigned v[SPT];
+      unsigned occ = 0;
 #pragma unroll
-      for (int m = WAVE / 2; m >= 1; m >>= 1) {
-        const unsigned long long ok = shfl_xor_u64(wk, m);
-        const int oc = __shfl_xor(wc, m);
-        if (best_before(ok, oc, wk, wc)) {
-          wk = ok;
-          wc = oc;
-        }
+      for (int q = 0; q < SPT; ++q) {
+        v[q] = tab[tl + q * T];
+        occ += v[q] != 0u;
       }
-      if (NW > 1) {
-        const int wv = tl / WAVE;
-        if (lane == 0) {
-          s_pkey[r & 1][wv] = wk;
-          s_pcol[r & 1][wv] = wc;
-        }
-        __syncthreads();
+      unsigned wpos = team_exclusive_scan<T>(occ, s_wsum, &D);
+      team_sync<T>();  // every read of the table precedes every write below
 #pragma unroll
-        for (int w2 = 0; w2 < NW; ++w2) {
-          const unsigned long long ok = s_pkey[r & 1][w2];
-          const int oc = s_pcol[r & 1][w2];
+      for (int q = 0; q < SPT; ++q)
+        if (v[q] != 0u) tab[wpos++] = v[q];
+    }
+    team_sync<T>();
+    unsigned long long* kk = reinterpret_cast<unsigned long long*>(tab + ((D + 1u) & ~1u));
+    // ---- 4. score candidates tl, tl + T, ... (dense); keys to LDS, each thread remembers its best
+    Best best;
+    best.key = 0ull;
+    best.col = 0x7fffffff;
+    unsigned best_t = 0;
+    const long long ca = a.cnt_a[i];
+    const double row_entropy = a.ent_a[i];
+    for (unsigned t = (unsigned)tl; t < D; t += T) {
+      const unsigned vv = tab[t];
+      const int j = (int)(vv >> cb) - 1;
+      const long long k11 = (long long)(vv & cmask);
+      unsigned long long key = 0ull;
+      if (!(a.exclude_self && j == i)) {
+        const long long cbj = a.cnt_b[j];
+        const double llr = llr_from_entropies(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11);
+        if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
+      }
+      kk[t] = key;
+      if (key != 0ull && best_before(key, j, best.key, best.col)) {
+        best.key = key;
+        best.col = j;
+        best_t = t;
+      }
+    }
+    // ---- 5. top-k
+    const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
+    int emitted = 0;
+    if (T == WAVE && D <= (unsigned)WAVE) {
+      // at most one candidate per lane: rank by counting, write straight to the output position
+      const unsigned long long mk = best.key;
+      const int mc = best.col;
+      int rank = 0;
+      for (unsigned l = 0; l < D; ++l) {  // wave-uniform bound
+        const unsigned long long ok = ((unsigned long long)__shfl((unsigned)(mk >> 32), (int)l) << 32) | __shfl((unsigned)mk, (int)l);
+        const int oc = __shfl(mc, (int)l);
+        rank += best_before(ok, oc, mk, mc) ? 1 : 0;
+      }
+      const int n_valid = __popcll(__ballot(mk != 0ull));
+      if (mk != 0ull && rank < a.k) {
+        a.out_idx[obase + rank] = mc;
+        a.out_llr[obase + rank] = __longlong_as_double((long long)mk);
+      }
+      emitted = n_valid < a.k ? n_valid : a.k;
+    } else {
+      for (int r = 0; r < a.k; ++r) {  // team-uniform: every thread sees the same winner
+        unsigned long long wk = best.key;
+        int wc = best.col;
+#pragma unroll
+        for (int m = WAVE / 2; m >= 1; m >>= 1) {
+          const unsigned long long ok = shfl_xor_u64(wk, m);
+          const int oc = __shfl_xor(wc, m);
           if (best_before(ok, oc, wk, wc)) {
             wk = ok;
             wc = oc;
           }
         }
-      }
-      if (wk == 0ull) break;  // no candidate left (team-uniform; for TEAMS == 1 block-uniform)
-      if (tl == 0) {
-        a.out_idx[obase + r] = wc;
-        a.out_llr[obase + r] = __longlong_as_double((long long)wk);
-      }
-      ++emitted;
-      if (best.key == wk && best.col == wc) {  // the owner retires it and rescans its slots
-        best.key = 0ull;
-        best.col = 0x7fffffff;
+        if (NW > 1) {
+          const int wv = tl / WAVE;
+          if (lane == 0) {
+            s_pkey[r & 1][wv] = wk;
+            s_pcol[r & 1][wv] = wc;
+          }
+          __syncthreads();
 #pragma unroll
-        for (int q = 0; q < SPT; ++q) {
-          if (key[q] != 0ull) {
-            const int j = (int)(tab[tl + q * T] >> cb) - 1;
-            if (key[q] == wk && j == wc) key[q] = 0ull;
-            else if (best_before(key[q], j, best.key, best.col)) {
-              best.key = key[q];
-              best.col = j;
+          for (int w2 = 0; w2 < NW; ++w2) {
+            const unsigned long long ok = s_pkey[r & 1][w2];
+            const int oc = s_pcol[r & 1][w2];
+            if (best_before(ok, oc, wk, wc)) {
+              wk = ok;
+              wc = oc;
+            }
+          }
+        }
+        if (wk == 0ull) break;  // no candidate left
+        if (tl == 0) {
+          a.out_idx[obase + r] = wc;
+          a.out_llr[obase + r] = __longlong_as_double((long long)wk);
+        }
+        ++emitted;
+        if (best.key == wk && best.col == wc) {  // the owner retires it and rescans its own candidates (only it reads them)
+          kk[best_t] = 0ull;
+          best.key = 0ull;
+          best.col = 0x7fffffff;
+          for (unsigned t = (unsigned)tl; t < D; t += T) {
+            const unsigned long long key = kk[t];
+            if (key != 0ull) {
+              const int j = (int)(tab[t] >> cb) - 1;
+              if (best_before(key, j, best.key, best.col)) {
+                best.key = key;
+                best.col = j;
+                best_t = t;
+              }
             }
           }
         }
       }
     }
-    if (active && tl == 0) a.out_count[i - a.item_lo] = emitted;
-    __syncthreads();  // table is re-zeroed next iteration
+    if (tl == 0) a.out_count[i - a.item_lo] = emitted;
+    team_sync<T>();  // the table is re-zeroed by the next row
   }
 }
 
@@ -845,16 +972,14 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
     const int64_t cs = a.a_col_ptr[i], ce = a.a_col_ptr[i + 1];
     if (threadIdx.x == 0) s_ncand = 0;
     for (int64_t p = cs + grp; p < ce; p += ngrp) {
-      const int u = a.a_row_idx[p];
-      const int64_t s = a.b_row_ptr[u], e = a.b_row_ptr[u + 1];
+      const int64_t s = a.pstart[p], e = s + (a.wp[p + 1] - a.wp[p]);
       for (int64_t q = s + gl; q < e; q += G) atomicAdd(&cnt[a.b_col_idx[q]], 1);
     }
     __syncthreads();
     const long long ca = a.cnt_a[i];
     const double row_entropy = a.ent_a[i];
     for (int64_t p = cs + grp; p < ce; p += ngrp) {
-      const int u = a.a_row_idx[p];
-      const int64_t s = a.b_row_ptr[u], e = a.b_row_ptr[u + 1];
+      const int64_t s = a.pstart[p], e = s + (a.wp[p + 1] - a.wp[p]);
       for (int64_t q = s + gl; q < e; q += G) {
         const int j = a.b_col_idx[q];
         const long long k11 = atomicExch(&cnt[j], 0);  // exactly one lane claims (and clears) each column
@@ -930,7 +1055,7 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
   switch (bin) {
     case 0: hipLaunchKernelGGL((cco_rows_kernel<64, E0>), dim3((unsigned)(n_cu * 8)), dim3(256), 0, st, args, 0); break;
     case 1: hipLaunchKernelGGL((cco_rows_kernel<256, E1>), dim3((unsigned)(n_cu * 8)), dim3(256), 0, st, args, 1); break;
-    case 2: hipLaunchKernelGGL((cco_rows_kernel<1024, E2>), dim3((unsigned)(n_cu * 2)), dim3(1024), 0, st, args, 2); break;  // 64 KiB LDS: two blocks per CU
+    case 2: hipLaunchKernelGGL((cco_rows_kernel<1024, E2>), dim3((unsigned)n_cu), dim3(1024), 0, st, args, 2); break;  // 128 KiB table: one block per CU
     default: hipLaunchKernelGGL(cco_rows_global_kernel, dim3(GLOBAL_BIN_BLOCKS), dim3(GB_THREADS), 0, st, args); break;
   }
   return hipGetLastError();

@@ -286,11 +286,22 @@ int urcco_dev_transpose(urcco_session* s, int64_t n_rows, const int64_t* row_ptr
   return URCCO_OK;
 }
 
-int urcco_dev_row_work(urcco_session* s, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr, const int32_t* a_row_idx,
-                       const int64_t* b_row_ptr, int64_t* work) {
-  if (!s || item_lo < 0 || item_hi < item_lo || !a_col_ptr || !b_row_ptr || (item_hi > item_lo && !work))
+int urcco_dev_row_work(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a, const int64_t* a_col_ptr, const int32_t* a_row_idx,
+                       int64_t nnz_a_bound, const int64_t* b_row_ptr, int64_t* work) {
+  if (!s || item_lo < 0 || item_hi < item_lo || item_hi > n_items_a || nnz_a_bound < 0 || !a_col_ptr || !b_row_ptr || (item_hi > item_lo && !work))
     return fail(URCCO_BAD_ARG, "urcco_dev_row_work: bad argument");
-  HIPC(urcco::launch_row_work(s->stream, s->n_cu, item_lo, item_hi, a_col_ptr, a_row_idx, b_row_ptr, 3, work));
+  const int64_t cap = nnz_a_bound;
+  const int64_t n_tiles = (cap + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
+  URC(s->reserve(urcco_session::need((size_t)cap, 8) + urcco_session::need((size_t)cap, 4) + urcco_session::need((size_t)cap + 1, 8) +
+                 urcco_session::need((size_t)n_tiles + 2, 8)));
+  int64_t* pstart = s->take<int64_t>((size_t)cap);
+  int32_t* plen = s->take<int32_t>((size_t)cap);
+  int64_t* wp = s->take<int64_t>((size_t)cap + 1);
+  int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
+  s->begin(URCCO_STAGE_ROW_WORK);
+  HIPC(urcco::launch_expand_prepare(s->stream, s->n_cu, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, cap, pstart, plen, wp, tile_sums));
+  HIPC(urcco::launch_row_work(s->stream, s->n_cu, item_lo, item_hi, a_col_ptr, wp, work));
+  s->end();
   return URCCO_OK;
 }
 
@@ -309,10 +320,10 @@ int urcco_dev_partition(urcco_session* s, int32_t n_items, const int64_t* work, 
 }
 
 int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a, const int64_t* a_col_ptr,
-                       const int32_t* a_row_idx, const int64_t* b_row_ptr, const int32_t* b_col_idx, int32_t n_cols_b,
+                       const int32_t* a_row_idx, int64_t nnz_a_bound, const int64_t* b_row_ptr, const int32_t* b_col_idx, int32_t n_cols_b,
                        const int32_t* counts_a, const int32_t* counts_b, int64_t n_users, int32_t exclude_self, int32_t k,
                        int32_t has_min_llr, double min_llr, int32_t* out_count, int32_t* out_idx, double* out_llr, int64_t* stats_dev) {
-  if (!s || item_lo < 0 || item_hi < item_lo || item_hi > n_items_a || n_cols_b < 0 || n_users < 0 || !a_col_ptr || !b_row_ptr)
+  if (!s || item_lo < 0 || item_hi < item_lo || item_hi > n_items_a || n_cols_b < 0 || n_users < 0 || nnz_a_bound < 0 || !a_col_ptr || !b_row_ptr)
     return fail(URCCO_BAD_ARG, "urcco_dev_cco_rows: bad argument");
   if (k <= 0) return fail(URCCO_BAD_ARG, "maxInterestingElements must be positive, got %d", k);
   const int32_t n = item_hi - item_lo;
@@ -334,9 +345,17 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   URC(s->ensure_global_bin(n_cols_b));
   const int64_t n_tiles = ((int64_t)n + urcco::BIN_TILE - 1) / urcco::BIN_TILE;
   const bool same = (counts_a == counts_b) && (n_items_a == n_cols_b);
-  URC(s->reserve(urcco_session::need((size_t)n, 8) + urcco_session::need((size_t)(n_tiles + 1) * urcco::BIN_COLS_HOST, 8) +
+  const int64_t cap = nnz_a_bound;
+  const int64_t p_tiles = (cap + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
+  URC(s->reserve(urcco_session::need((size_t)cap, 8) + urcco_session::need((size_t)cap, 4) + urcco_session::need((size_t)cap + 1, 8) +
+                 urcco_session::need((size_t)p_tiles + 2, 8) +
+                 urcco_session::need((size_t)n, 8) + urcco_session::need((size_t)(n_tiles + 1) * urcco::BIN_COLS_HOST, 8) +
                  urcco_session::need(urcco::NBINS + 1, 4) + urcco_session::need((size_t)n, 4) + urcco_session::need((size_t)n_items_a, 8) +
                  urcco_session::need((size_t)n_cols_b, 8) + urcco_session::need(1, 8) + urcco_session::need(URCCO_STATS_LEN, 8)));
+  int64_t* pstart = s->take<int64_t>((size_t)cap);
+  int32_t* plen = s->take<int32_t>((size_t)cap);
+  int64_t* wp = s->take<int64_t>((size_t)cap + 1);
+  int64_t* p_tile_sums = s->take<int64_t>((size_t)p_tiles + 2);
   int64_t* work = s->take<int64_t>((size_t)n);
   int64_t* tile_counts = s->take<int64_t>((size_t)(n_tiles + 1) * urcco::BIN_COLS_HOST);
   int32_t* bin_off = s->take<int32_t>(urcco::NBINS + 1);
@@ -347,7 +366,8 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   int64_t* stats = stats_dev ? stats_dev : s->take<int64_t>(URCCO_STATS_LEN);
 
   s->begin(URCCO_STAGE_ROW_WORK);
-  HIPC(urcco::launch_row_work(s->stream, s->n_cu, item_lo, item_hi, a_col_ptr, a_row_idx, b_row_ptr, 3, work));
+  HIPC(urcco::launch_expand_prepare(s->stream, s->n_cu, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, cap, pstart, plen, wp, p_tile_sums));
+  HIPC(urcco::launch_row_work(s->stream, s->n_cu, item_lo, item_hi, a_col_ptr, wp, work));
   s->end();
   s->begin(URCCO_STAGE_BINNING);
   HIPC(hipMemsetAsync(stats, 0, sizeof(int64_t) * URCCO_STATS_LEN, s->stream));
@@ -360,7 +380,7 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
 
   urcco::CcoArgs a;
   a.bin_rows = bin_rows; a.bin_off = bin_off;
-  a.a_col_ptr = a_col_ptr; a.a_row_idx = a_row_idx; a.b_row_ptr = b_row_ptr; a.b_col_idx = b_col_idx;
+  a.a_col_ptr = a_col_ptr; a.pstart = pstart; a.wp = wp; a.b_col_idx = b_col_idx;
   a.cnt_a = counts_a; a.cnt_b = counts_b; a.ent_a = ent_a; a.ent_b = ent_b; a.xlx_n = xlx_n;
   a.n_users = n_users; a.n_cols_b = n_cols_b; a.item_lo = item_lo; a.exclude_self = exclude_self ? 1 : 0; a.k = k;
   a.has_min_llr = has_min_llr ? 1 : 0; a.min_llr = min_llr; a.count_bits = count_bits;
@@ -548,7 +568,7 @@ int build_impl(const urcco_dataset* datasets, int32_t n_datasets, int32_t seed, 
     URC(bufs.alloc(&c_idx, strided));
     URC(bufs.alloc(&c_llr, strided));
     URC(bufs.alloc(&d_stats, URCCO_STATS_LEN));
-    URC(urcco_dev_cco_rows(s, 0, n_items_a, n_items_a, a_col_ptr, a_row_idx, b.row_ptr, b.col_idx, n_cols_b, a.counts, b.counts, n_users,
+    URC(urcco_dev_cco_rows(s, 0, n_items_a, n_items_a, a_col_ptr, a_row_idx, a.nnz, b.row_ptr, b.col_idx, n_cols_b, a.counts, b.counts, n_users,
                            d == 0 ? 1 : 0, k, datasets[d].has_min_llr, datasets[d].min_llr, o_count, o_idx, o_llr, d_stats));
     URC(urcco_dev_compact_indicators(s, n_items_a, k, o_count, o_idx, o_llr, c_rp, c_idx, c_llr));
     HIPC(hipEventRecord(ev1, s->stream));

@@ -128,9 +128,10 @@ class DeviceSession:
                                                 _ptr(col_ptr), _ptr(row_idx)))
         return col_ptr, row_idx
 
-    def row_work(self, item_lo: int, item_hi: int, a_col_ptr, a_row_idx, b_row_ptr) -> torch.Tensor:
+    def row_work(self, item_lo: int, item_hi: int, n_items_a: int, a_col_ptr, a_row_idx, nnz_a_bound: int, b_row_ptr) -> torch.Tensor:
         work = self.empty(max(item_hi - item_lo, 1), torch.int64)
-        self._check(self.lib.urcco_dev_row_work(self.handle, item_lo, item_hi, _ptr(a_col_ptr), _ptr(a_row_idx), _ptr(b_row_ptr), _ptr(work)))
+        self._check(self.lib.urcco_dev_row_work(self.handle, item_lo, item_hi, n_items_a, _ptr(a_col_ptr), _ptr(a_row_idx), nnz_a_bound,
+                                                _ptr(b_row_ptr), _ptr(work)))
         return work[: item_hi - item_lo]
 
     def partition(self, work: torch.Tensor, n_parts: int) -> List[int]:
@@ -138,15 +139,15 @@ class DeviceSession:
         self._check(self.lib.urcco_dev_partition(self.handle, work.numel(), _ptr(work), n_parts, bounds))
         return list(bounds)
 
-    def cco_rows(self, item_lo: int, item_hi: int, n_items_a: int, a_col_ptr, a_row_idx, b: DevCsr, counts_a, counts_b, n_users: int,
-                 exclude_self: bool, p: DatasetParams) -> DevIndicators:
+    def cco_rows(self, item_lo: int, item_hi: int, n_items_a: int, a_col_ptr, a_row_idx, nnz_a_bound: int, b: DevCsr, counts_a, counts_b,
+                 n_users: int, exclude_self: bool, p: DatasetParams) -> DevIndicators:
         n = item_hi - item_lo
         k = p.max_interesting_elements
         o_count = self.empty(max(n, 1), torch.int32)
         o_idx = self.empty(max(n * k, 1), torch.int32)
         o_llr = self.empty(max(n * k, 1), torch.float64)
         stats = self.empty(_lib.STATS_LEN, torch.int64)
-        self._check(self.lib.urcco_dev_cco_rows(self.handle, item_lo, item_hi, n_items_a, _ptr(a_col_ptr), _ptr(a_row_idx), _ptr(b.row_ptr),
+        self._check(self.lib.urcco_dev_cco_rows(self.handle, item_lo, item_hi, n_items_a, _ptr(a_col_ptr), _ptr(a_row_idx), nnz_a_bound, _ptr(b.row_ptr),
                                                _ptr(b.col_idx), b.n_cols, _ptr(counts_a), _ptr(counts_b), n_users, int(exclude_self), k,
                                                int(p.min_llr is not None), float(p.min_llr) if p.min_llr is not None else 0.0,
                                                _ptr(o_count), _ptr(o_idx), _ptr(o_llr), _ptr(stats)))
@@ -197,5 +198,5 @@ def cross_occurrence_device(sess: DeviceSession, mats: Sequence[DevCsr], params:
         else:
             raw_b = sess.column_counts(m.col_idx, m.nnz_bound, m.n_cols)
             b, cnt_b = sess.downsample(m, m.nnz_bound, raw_b, seed, p.max_elements_per_row, row_rate_mode)
-        out.append(sess.cco_rows(item_lo, item_hi, a_raw.n_cols, a_col_ptr, a_row_idx, b, cnt_a, cnt_b, a_raw.n_rows, d == 0, p))
+        out.append(sess.cco_rows(item_lo, item_hi, a_raw.n_cols, a_col_ptr, a_row_idx, a.nnz_bound, b, cnt_a, cnt_b, a_raw.n_rows, d == 0, p))
     return out

@@ -106,11 +106,11 @@ def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], para
         else:
             b, cnt_b, nnz_b = sample(m, p)
         if world > 1:
-            work = sess.row_work(0, n_items_a, a_col_ptr, a_row_idx, b.row_ptr)
+            work = sess.row_work(0, n_items_a, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b.row_ptr)
             bounds = sess.partition(work, world)   # same inputs on every rank -> same bounds, no communication
         else:
             bounds = [0, n_items_a]
-        out.append(sess.cco_rows(bounds[rank], bounds[rank + 1], n_items_a, a_col_ptr, a_row_idx, b, cnt_a, cnt_b, n_rows_global, d == 0, p))
+        out.append(sess.cco_rows(bounds[rank], bounds[rank + 1], n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b, cnt_a, cnt_b, n_rows_global, d == 0, p))
         ranges.append(bounds)
         nnzs.append(-1 if nnz_b is None else nnz_b)
     return ShardedResult(out, ranges, nnzs)
