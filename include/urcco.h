@@ -142,6 +142,9 @@ enum {
   URCCO_STAGE_COMPACT_INDICATORS = 12
 };
 int urcco_session_set_timing(urcco_session* s, int32_t enable);
+/* Profiling aid: kernel ablation switches (1 = gather only, 2 = no LLR, 4 = no top-k); results are meaningless when
+ * non-zero.  0 in production. */
+int urcco_session_set_debug(urcco_session* s, int32_t flags);
 int urcco_session_get_timings(urcco_session* s, double* ms /*[URCCO_N_STAGES]*/, int64_t* launches /*[URCCO_N_STAGES]*/);
 /* bytes of device scratch currently held */
 int64_t urcco_session_scratch_bytes(const urcco_session* s);

@@ -204,6 +204,7 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   p->totalGlobalMem = (size_t)8 << 30;
   return hipSuccess;
 }
+template <typename F> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 2; return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipsimEvent(); return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Profiling aid: per-stage HIP-event timings of the config-3 model build with kernel phases switched off
+(urcco_session_set_debug: 1 = gather only, 2 = no LLR, 4 = no top-k).  Results of ablated runs are meaningless."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from universal_recommender_amd import _lib, synth  # noqa: E402
+from universal_recommender_amd.device import DatasetParams, DevCsr, DeviceSession, cross_occurrence_device  # noqa: E402
+
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+flags = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 4, 6, 7]
+dev = torch.device("cuda", 0)
+cfg = synth.config3(scale)
+data = synth.generate(cfg)
+mats = [DevCsr(cfg.n_users, nc, torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), int(rp[-1])) for (_, nc, rp, ci) in data]
+params = [DatasetParams(500, 50, None) for _ in mats]
+sess = DeviceSession(dev, _lib.load(_lib.DEFAULT_PATH))
+for f in flags:
+    sess.set_debug(f)
+    for _ in range(2):
+        cross_occurrence_device(sess, mats, params, 1)
+    torch.cuda.synchronize()
+    sess.set_timing(True)
+    t0 = time.perf_counter()
+    steps = 3
+    for _ in range(steps):
+        cross_occurrence_device(sess, mats, params, 1)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    tm = sess.get_timings()
+    sess.set_timing(False)
+    print(f"debug={f} wall {wall:.3f} ms/step | " + " ".join(f"{k}={v[0] / steps:.3f}" for k, v in tm.items() if v[1]))
+sess.set_debug(0)

@@ -68,6 +68,7 @@ SYMBOLS = {
     "urcco_session_synchronize": (C.c_int, [_p]),
     "urcco_session_scratch_bytes": (C.c_int64, [_p]),
     "urcco_session_set_timing": (C.c_int, [_p, C.c_int32]),
+    "urcco_session_set_debug": (C.c_int, [_p, C.c_int32]),
     "urcco_session_get_timings": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "urcco_dev_column_counts": (C.c_int, [_p, C.c_int64, _p, C.c_int32, _p]),
     "urcco_dev_downsample": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int64, C.c_int32, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,

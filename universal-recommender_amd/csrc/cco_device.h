@@ -64,6 +64,22 @@ __device__ __forceinline__ double x_log_x(long long x) { return x == 0 ? 0.0 : (
 // LogLikelihood.entropy(a, b) = xLogX(a+b) - xLogX(a) - xLogX(b), left to right.
 __device__ __forceinline__ double entropy2(long long a, long long b) { return (x_log_x(a + b) - x_log_x(a)) - x_log_x(b); }
 
+// xLogX through a table for small arguments.  xlx_tab[x] = x_log_x(x) was produced by the same device function, so the
+// value is bit-identical to evaluating it in place.  After the interaction cut k11, k12 and k21 are almost always
+// below the table size, which leaves one real logarithm (k22) per candidate.
+constexpr int XLX_TABLE = 4096;
+__device__ __forceinline__ double x_log_x_tab(long long x, const double* __restrict__ xlx_tab) {
+  return x < (long long)XLX_TABLE ? xlx_tab[x] : (double)x * log_pos((double)x);
+}
+__device__ __forceinline__ double llr_from_entropies_tab(double row_entropy, double column_entropy, double xlx_n, long long k11, long long k12,
+                                                         long long k21, long long k22, const double* __restrict__ xlx_tab) {
+  const double matrix_entropy =
+      (((xlx_n - x_log_x_tab(k11, xlx_tab)) - x_log_x_tab(k12, xlx_tab)) - x_log_x_tab(k21, xlx_tab)) - x_log_x_tab(k22, xlx_tab);
+  const double s = row_entropy + column_entropy;
+  if (s < matrix_entropy) return 0.0; /* round off error */
+  return 2.0 * (s - matrix_entropy);
+}
+
 // LogLikelihood.logLikelihoodRatio with the row / column entropies supplied (they are per-item constants:
 // rowEntropy = entropy(cA[i], N - cA[i]), columnEntropy = entropy(cB[j], N - cB[j])); xlx_n = xLogX(N).
 // Same operations in the same order as the Java, so the value equals the un-hoisted formula bit for bit.

@@ -14,6 +14,7 @@ constexpr int SCAN_TILE = 2048;          // elements per scan tile (256 threads 
 constexpr int DS_TILE = 4096;            // entries per down-sample tile (256 threads x 4 x 4)
 constexpr int GLOBAL_BIN_BLOCKS = 64;    // persistent blocks of the global-accumulator kernel
 constexpr int BIN_TILE = 1024;           // items per binning tile
+constexpr int XLX_TABLE_HOST = 4096;     // entries of the small-integer xLogX table (== XLX_TABLE in cco_device.h)
 constexpr int BIN_COLS_HOST = 3 * NBINS + 1;  // int64 per binning tile
 constexpr int STATS_LEN = 20;            // [0] pairs, [1..4] rows/bin, [5..8] pairs/bin, [9..12] users/bin, [13..16] out entries/bin
 
@@ -31,6 +32,8 @@ struct CcoArgs {
   const double* ent_a;       // rowEntropy per item of A
   const double* ent_b;       // columnEntropy per item of B
   const double* xlx_n;       // [1] xLogX(N)
+  const double* xlx_tab;     // [XLX_TABLE_HOST] xLogX of small integers
+  int32_t debug;             // ablation switches for profiling (0 in production): 1 = gather only, 2 = no LLR, 4 = no top-k
   long long n_users;
   int32_t n_cols_b;
   int32_t item_lo;
@@ -67,6 +70,7 @@ hipError_t launch_downsample_compact(hipStream_t st, int n_cu, int64_t n_rows, c
 hipError_t launch_transpose(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int g_log2,
                             const int64_t* col_ptr, int32_t* cursor, int32_t* out_row_idx);
 
+hipError_t launch_xlx_table(hipStream_t st, double* tab);
 hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, double* xlx_n);
 
 // pstart[cap], plen[cap] (scratch), wp[cap + 1]; cap >= nnz(A'); tile_sums scratch as for scans over cap elements
@@ -77,7 +81,7 @@ hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t it
 // binning: tile_counts scratch [(ceil(n/BIN_TILE)+1) * BIN_COLS_HOST] int64;
 // bin_off[NBINS+1] int32, bin_rows[n] int32, stats[STATS_LEN] int64.
 hipError_t launch_binning(hipStream_t st, int32_t item_lo, int32_t n, const int64_t* work, const int32_t* cnt_a, int32_t n_cols_b,
-                          int32_t count_bits, int64_t* tile_counts, int32_t* bin_off, int32_t* bin_rows, int64_t* stats);
+                          int32_t count_bits, int32_t k, int64_t* tile_counts, int32_t* bin_off, int32_t* bin_rows, int64_t* stats);
 
 hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, int bin);
 hipError_t launch_bin_out_stats(hipStream_t st, const int32_t* bin_rows, const int32_t* bin_off, int32_t item_lo, const int32_t* out_count,

@@ -464,6 +464,15 @@ hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n,
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void xlx_table_kernel(double* __restrict__ tab) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x < XLX_TABLE) tab[x] = x_log_x((long long)x);
+}
+hipError_t launch_xlx_table(hipStream_t st, double* tab) {
+  hipLaunchKernelGGL(xlx_table_kernel, dim3(XLX_TABLE / 256), dim3(256), 0, st, tab);
+  return hipGetLastError();
+}
+
 // ============================================================================================
 // Expand preparation.  For every entry p of the CSC of A' (user u of some item) it records where u's B' row starts
 // and how long it is, then prefix-sums the lengths over the whole CSC:
@@ -530,14 +539,16 @@ hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t it
 // ============================================================================================
 constexpr int E0 = 1024, E1 = 8192, E2 = 32768;
 
-__device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_cols_b, int32_t count_bits) {
+__device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_cols_b, int32_t count_bits, int32_t k) {
   if (ca <= 0 || w <= 0) return -1;  // no users or no pairs: empty indicator row
   if (count_bits < 31 && ca > ((1ll << count_bits) - 1)) return 3;
   int cap_bin = 3;
-  // a table of E words must hold D packed counts + D 64-bit keys: 3 D + 1 <= E, with D <= min(w, n_cols_b)
-  if ((long long)n_cols_b * 3 < E0 || w * 3 < E0) cap_bin = 0;
-  else if ((long long)n_cols_b * 3 < E1 || w * 3 < E1) cap_bin = 1;
-  else if ((long long)n_cols_b * 3 < E2 || w * 3 < E2) cap_bin = 2;
+  // a table of E words must hold D packed counts + D 64-bit keys + the k selected (key, col): 3 D + 3 k + 1 <= E,
+  // with D <= min(w, n_cols_b)
+  const long long dmax = (w < (long long)n_cols_b ? w : (long long)n_cols_b) * 3 + (long long)k * 3 + 2;
+  if (dmax <= E0) cap_bin = 0;
+  else if (dmax <= E1) cap_bin = 1;
+  else if (dmax <= E2) cap_bin = 2;
   const int work_bin = w <= 512 ? 0 : (w <= 8192 ? 1 : 2);
   return cap_bin > work_bin ? cap_bin : work_bin;
 }
@@ -547,7 +558,7 @@ constexpr int BIN_ITEMS = BIN_TILE / BIN_THREADS;  // 4
 constexpr int BIN_COLS = 3 * NBINS + 1;            // per tile: rows per bin, pairs per bin, users per bin, total pairs
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo, int32_t n, const int64_t* __restrict__ work,
-                                                                const int32_t* __restrict__ cnt_a, int32_t n_cols_b, int32_t count_bits,
+                                                                const int32_t* __restrict__ cnt_a, int32_t n_cols_b, int32_t count_bits, int32_t k,
                                                                 int64_t* __restrict__ tile_counts) {
   __shared__ long long s_acc[BIN_COLS];
   if (threadIdx.x < BIN_COLS) s_acc[threadIdx.x] = 0;
@@ -563,7 +574,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo,
       const long long w = work[t];
       const long long ca = cnt_a[item_lo + t];
       pairs += w;
-      const int b = choose_bin(w, ca, n_cols_b, count_bits);
+      const int b = choose_bin(w, ca, n_cols_b, count_bits, k);
 #pragma unroll
       for (int k = 0; k < NBINS; ++k) {
         c[k] += (b == k);
@@ -619,7 +630,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(int64_t* __restri
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int32_t item_lo, int32_t n, const int64_t* __restrict__ work,
-                                                                  const int32_t* __restrict__ cnt_a, int32_t n_cols_b, int32_t count_bits,
+                                                                  const int32_t* __restrict__ cnt_a, int32_t n_cols_b, int32_t count_bits, int32_t k,
                                                                   const int64_t* __restrict__ tile_counts, const int32_t* __restrict__ bin_off,
                                                                   int32_t* __restrict__ bin_rows) {
   __shared__ long long s_wave[SCAN_THREADS / WAVE];
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int32_t item_l
 #pragma unroll
   for (int q = 0; q < BIN_ITEMS; ++q) {
     const int64_t t = (int64_t)blockIdx.x * BIN_TILE + (int64_t)threadIdx.x * BIN_ITEMS + q;
-    b[q] = t < n ? choose_bin(work[t], cnt_a[item_lo + t], n_cols_b, count_bits) : -1;
+    b[q] = t < n ? choose_bin(work[t], cnt_a[item_lo + t], n_cols_b, count_bits, k) : -1;
   }
   for (int k = 0; k < NBINS; ++k) {  // block-uniform: one block scan per bin
     int c = 0;
@@ -642,16 +653,16 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int32_t item_l
 }
 
 hipError_t launch_binning(hipStream_t st, int32_t item_lo, int32_t n, const int64_t* work, const int32_t* cnt_a, int32_t n_cols_b,
-                          int32_t count_bits, int64_t* tile_counts, int32_t* bin_off, int32_t* bin_rows, int64_t* stats) {
+                          int32_t count_bits, int32_t k, int64_t* tile_counts, int32_t* bin_off, int32_t* bin_rows, int64_t* stats) {
   if (n <= 0) {
     hipError_t e = hipMemsetAsync(bin_off, 0, sizeof(int32_t) * (NBINS + 1), st);
     if (e == hipSuccess && stats) e = hipMemsetAsync(stats, 0, sizeof(int64_t) * STATS_LEN, st);
     return e;
   }
   const int64_t n_tiles = ((int64_t)n + BIN_TILE - 1) / BIN_TILE;
-  hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)n_tiles), dim3(BIN_THREADS), 0, st, item_lo, n, work, cnt_a, n_cols_b, count_bits, tile_counts);
+  hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)n_tiles), dim3(BIN_THREADS), 0, st, item_lo, n, work, cnt_a, n_cols_b, count_bits, k, tile_counts);
   hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(BIN_THREADS), 0, st, tile_counts, n_tiles, bin_off, stats);
-  hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)n_tiles), dim3(BIN_THREADS), 0, st, item_lo, n, work, cnt_a, n_cols_b, count_bits,
+  hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)n_tiles), dim3(BIN_THREADS), 0, st, item_lo, n, work, cnt_a, n_cols_b, count_bits, k,
                      tile_counts, bin_off, bin_rows);
   return hipGetLastError();
 }
@@ -757,8 +768,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
   __shared__ long long s_ustart[TEAMS * T];
   __shared__ unsigned s_uoff[TEAMS * (T + 1)];
   __shared__ unsigned s_wsum[NW];
-  __shared__ unsigned long long s_pkey[2][NW];
-  __shared__ int s_pcol[2][NW];
+  __shared__ unsigned s_hist[TEAMS * 256];
+  __shared__ unsigned s_selres[TEAMS * 4];
 
   const int team = threadIdx.x / T;
   const int tl = threadIdx.x % T;
@@ -766,10 +777,13 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
   unsigned* tab = s_tab + team * E;
   long long* ustart = s_ustart + team * T;
   unsigned* uoff = s_uoff + team * (T + 1);
+  unsigned* hist = s_hist + team * 256;
+  unsigned* sel_res = s_selres + team * 4;
+  unsigned* nsel = sel_res + 3;
   const int list_start = a.bin_off[bin];
   const int list_n = a.bin_off[bin + 1] - list_start;
   const int total_teams = gridDim.x * TEAMS;
-  const bool ident = (long long)a.n_cols_b * 3 < E;  // same rule as choose_bin: slots addressed by column
+  const bool ident = (long long)a.n_cols_b * 3 + (long long)a.k * 3 + 2 <= E;  // the table spans every column of B: slots addressed by column
   const int cb = a.count_bits;
   const unsigned cmask = (1u << cb) - 1u;
   const double xlx_n = *a.xlx_n;
@@ -811,8 +825,14 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
           unsigned t = first;
           while (t < last) {
             const unsigned stop = last < uend ? last : uend;
-            for (; t < stop; ++t, ++pos)
-              if (!tab_insert(tab, (unsigned)a.b_col_idx[pos] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) atomicAdd(a.err, 1ull);
+            for (; t < stop; ++t, ++pos) {
+              const unsigned jj = (unsigned)a.b_col_idx[pos];
+              if (a.debug & 1) {  // ablation: gather only
+                if (jj == 0xffffffffu) tab[0] = 1u;
+              } else if (!tab_insert(tab, jj + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) {
+                atomicAdd(a.err, 1ull);
+              }
+            }
             if (t < last) {  // next user with a non-empty B' row
               do { ++o; } while (uoff[o + 1] <= t);
               pos = ustart[o];
@@ -842,104 +862,118 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
     }
     team_sync<T>();
     unsigned long long* kk = reinterpret_cast<unsigned long long*>(tab + ((D + 1u) & ~1u));
-    // ---- 4. score candidates tl, tl + T, ... (dense); keys to LDS, each thread remembers its best
-    Best best;
-    best.key = 0ull;
-    best.col = 0x7fffffff;
-    unsigned best_t = 0;
-    const long long ca = a.cnt_a[i];
-    const double row_entropy = a.ent_a[i];
-    for (unsigned t = (unsigned)tl; t < D; t += T) {
-      const unsigned vv = tab[t];
-      const int j = (int)(vv >> cb) - 1;
-      const long long k11 = (long long)(vv & cmask);
-      unsigned long long key = 0ull;
-      if (!(a.exclude_self && j == i)) {
-        const long long cbj = a.cnt_b[j];
-        const double llr = llr_from_entropies(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11);
-        if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
-      }
-      kk[t] = key;
-      if (key != 0ull && best_before(key, j, best.key, best.col)) {
-        best.key = key;
-        best.col = j;
-        best_t = t;
+    // ---- 4. score candidates tl, tl + T, ... (dense); keys go to LDS behind the packed counts
+    unsigned n_valid = 0;
+    {
+      const long long ca = a.cnt_a[i];
+      const double row_entropy = a.ent_a[i];
+      for (unsigned t = (unsigned)tl; t < D; t += T) {
+        const unsigned vv = tab[t];
+        const int j = (int)(vv >> cb) - 1;
+        const long long k11 = (long long)(vv & cmask);
+        unsigned long long key = 0ull;
+        if (!(a.exclude_self && j == i)) {
+          const long long cbj = a.cnt_b[j];
+          const double llr = (a.debug & 2) ? (double)k11
+                                           : llr_from_entropies_tab(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11,
+                                                                    a.n_users - ca - cbj + k11, a.xlx_tab);
+          if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
+        }
+        kk[t] = key;
+        n_valid += key != 0ull;
       }
     }
-    // ---- 5. top-k
+    unsigned C;
+    team_exclusive_scan<T>(n_valid, s_wsum, &C);
+    team_sync<T>();
+    // ---- 5. top-k.  Order: key desc, then column asc == (key, ~col) desc as one 96-bit composite.
+    //   a. C > k: MSB-first radix select (8-bit digits, LDS histogram) of the k-th composite; stops as soon as the digit
+    //      bin that straddles the cut is wanted whole;   b. the <= k survivors are gathered;   c. each is ranked by
+    //      counting and written straight to its output position (already in output order).
     const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
-    int emitted = 0;
-    if (T == WAVE && D <= (unsigned)WAVE) {
-      // at most one candidate per lane: rank by counting, write straight to the output position
-      const unsigned long long mk = best.key;
-      const int mc = best.col;
-      int rank = 0;
-      for (unsigned l = 0; l < D; ++l) {  // wave-uniform bound
-        const unsigned long long ok = ((unsigned long long)__shfl((unsigned)(mk >> 32), (int)l) << 32) | __shfl((unsigned)mk, (int)l);
-        const int oc = __shfl(mc, (int)l);
-        rank += best_before(ok, oc, mk, mc) ? 1 : 0;
+    unsigned long long thr_key = 0ull;
+    unsigned thr_ncol = 0u;
+    if (!(a.debug & 4)) {
+      if (C > (unsigned)a.k) {  // team-uniform
+        unsigned need = (unsigned)a.k;
+        for (int p = 0; p < 12; ++p) {  // team-uniform trip count (break below is on broadcast values)
+          for (int b = tl; b < 256; b += T) hist[b] = 0u;
+          team_sync<T>();
+          for (unsigned t = (unsigned)tl; t < D; t += T) {
+            const unsigned long long key = kk[t];
+            if (key == 0ull) continue;
+            const unsigned ncol = ~(unsigned)((int)(tab[t] >> cb) - 1);
+            bool match;
+            unsigned dig;
+            if (p < 8) {
+              const int sh = 56 - 8 * p;
+              match = p == 0 || (key >> (sh + 8)) == (thr_key >> (sh + 8));
+              dig = (unsigned)(key >> sh) & 255u;
+            } else {
+              const int sh = 24 - 8 * (p - 8);
+              match = key == thr_key && (p == 8 || (ncol >> (sh + 8)) == (thr_ncol >> (sh + 8)));
+              dig = (ncol >> sh) & 255u;
+            }
+            if (match) atomicAdd(&hist[dig], 1u);
+          }
+          team_sync<T>();
+          if (tl < WAVE) {  // first wave of the team: locate the digit that holds the cut
+            const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            const unsigned v4 = h0 + h1 + h2 + h3;
+            unsigned S = v4;  // inclusive suffix sum over lanes (higher lanes = higher digits)
+#pragma unroll
+            for (int dd = 1; dd < WAVE; dd <<= 1) {
+              const unsigned o = __shfl_down(S, dd);
+              if (lane + dd < WAVE) S += o;
+            }
+            const unsigned long long ge = __ballot(S >= need);
+            const int L = 63 - __clzll((long long)ge);
+            if (lane == L) {
+              unsigned above = S - v4;
+              unsigned d, cnt;
+              if (above + h3 >= need) { d = 3; cnt = h3; }
+              else if (above + h3 + h2 >= need) { d = 2; cnt = h2; above += h3; }
+              else if (above + h3 + h2 + h1 >= need) { d = 1; cnt = h1; above += h3 + h2; }
+              else { d = 0; cnt = h0; above += h3 + h2 + h1; }
+              sel_res[0] = 4u * (unsigned)lane + d;
+              sel_res[1] = above;
+              sel_res[2] = cnt;
+            }
+          }
+          team_sync<T>();
+          const unsigned d = sel_res[0], above = sel_res[1], cnt = sel_res[2];
+          need -= above;
+          if (p < 8) thr_key |= (unsigned long long)d << (56 - 8 * p);
+          else thr_ncol |= d << (24 - 8 * (p - 8));
+          if (cnt == need) break;  // the whole bin is wanted: every composite >= the prefix (low bits zero) is selected
+        }
       }
-      const int n_valid = __popcll(__ballot(mk != 0ull));
-      if (mk != 0ull && rank < a.k) {
+      if (tl == 0) *nsel = 0u;
+      team_sync<T>();
+      unsigned long long* selk = kk + D;                                  // [k]
+      unsigned* selc = reinterpret_cast<unsigned*>(selk + a.k);          // [k]
+      for (unsigned t = (unsigned)tl; t < D; t += T) {
+        const unsigned long long key = kk[t];
+        if (key == 0ull) continue;
+        const unsigned col = (unsigned)((int)(tab[t] >> cb) - 1);
+        if (key > thr_key || (key == thr_key && ~col >= thr_ncol)) {
+          const unsigned pos = atomicAdd(nsel, 1u);
+          selk[pos] = key;
+          selc[pos] = col;
+        }
+      }
+      team_sync<T>();
+      const unsigned n = *nsel;
+      for (unsigned t = (unsigned)tl; t < n; t += T) {
+        const unsigned long long mk = selk[t];
+        const int mc = (int)selc[t];
+        unsigned rank = 0;
+        for (unsigned u = 0; u < n; ++u) rank += best_before(selk[u], (int)selc[u], mk, mc) ? 1u : 0u;
         a.out_idx[obase + rank] = mc;
         a.out_llr[obase + rank] = __longlong_as_double((long long)mk);
       }
-      emitted = n_valid < a.k ? n_valid : a.k;
-    } else {
-      for (int r = 0; r < a.k; ++r) {  // team-uniform: every thread sees the same winner
-        unsigned long long wk = best.key;
-        int wc = best.col;
-#pragma unroll
-        for (int m = WAVE / 2; m >= 1; m >>= 1) {
-          const unsigned long long ok = shfl_xor_u64(wk, m);
-          const int oc = __shfl_xor(wc, m);
-          if (best_before(ok, oc, wk, wc)) {
-            wk = ok;
-            wc = oc;
-          }
-        }
-        if (NW > 1) {
-          const int wv = tl / WAVE;
-          if (lane == 0) {
-            s_pkey[r & 1][wv] = wk;
-            s_pcol[r & 1][wv] = wc;
-          }
-          __syncthreads();
-#pragma unroll
-          for (int w2 = 0; w2 < NW; ++w2) {
-            const unsigned long long ok = s_pkey[r & 1][w2];
-            const int oc = s_pcol[r & 1][w2];
-            if (best_before(ok, oc, wk, wc)) {
-              wk = ok;
-              wc = oc;
-            }
-          }
-        }
-        if (wk == 0ull) break;  // no candidate left
-        if (tl == 0) {
-          a.out_idx[obase + r] = wc;
-          a.out_llr[obase + r] = __longlong_as_double((long long)wk);
-        }
-        ++emitted;
-        if (best.key == wk && best.col == wc) {  // the owner retires it and rescans its own candidates (only it reads them)
-          kk[best_t] = 0ull;
-          best.key = 0ull;
-          best.col = 0x7fffffff;
-          for (unsigned t = (unsigned)tl; t < D; t += T) {
-            const unsigned long long key = kk[t];
-            if (key != 0ull) {
-              const int j = (int)(tab[t] >> cb) - 1;
-              if (best_before(key, j, best.key, best.col)) {
-                best.key = key;
-                best.col = j;
-                best_t = t;
-              }
-            }
-          }
-        }
-      }
+      if (tl == 0) a.out_count[i - a.item_lo] = (int)n;
     }
-    if (tl == 0) a.out_count[i - a.item_lo] = emitted;
     team_sync<T>();  // the table is re-zeroed by the next row
   }
 }
@@ -985,7 +1019,7 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
         const long long k11 = atomicExch(&cnt[j], 0);  // exactly one lane claims (and clears) each column
         if (k11 > 0 && !(a.exclude_self && j == i)) {
           const long long cbj = a.cnt_b[j];
-          const double llr = llr_from_entropies(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11);
+          const double llr = llr_from_entropies_tab(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11, a.xlx_tab);
           if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
             const int pos = atomicAdd(&s_ncand, 1);
             ckey[pos] = (unsigned long long)__double_as_longlong(llr);
@@ -1049,13 +1083,28 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
   }
 }
 
+// resident blocks per CU of each LDS-accumulator kernel (registers / LDS decide), so that the persistent grids fill
+// the chip exactly once
+static int blocks_per_cu(int bin) {
+  static int cache[3] = {0, 0, 0};
+  if (cache[bin] == 0) {
+    int n = 0;
+    hipError_t e = hipErrorUnknown;
+    if (bin == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<64, E0>, 256, 0);
+    if (bin == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1>, 256, 0);
+    if (bin == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2>, 1024, 0);
+    cache[bin] = (e == hipSuccess && n > 0) ? n : 1;
+  }
+  return cache[bin];
+}
+
 hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, int bin) {
   // Persistent grids sized to the chip; each kernel reads its own row list length from bin_off on the device,
   // so no host synchronisation sits between binning and the SpGEMM.
   switch (bin) {
-    case 0: hipLaunchKernelGGL((cco_rows_kernel<64, E0>), dim3((unsigned)(n_cu * 8)), dim3(256), 0, st, args, 0); break;
-    case 1: hipLaunchKernelGGL((cco_rows_kernel<256, E1>), dim3((unsigned)(n_cu * 8)), dim3(256), 0, st, args, 1); break;
-    case 2: hipLaunchKernelGGL((cco_rows_kernel<1024, E2>), dim3((unsigned)n_cu), dim3(1024), 0, st, args, 2); break;  // 128 KiB table: one block per CU
+    case 0: hipLaunchKernelGGL((cco_rows_kernel<64, E0>), dim3((unsigned)(n_cu * blocks_per_cu(0))), dim3(256), 0, st, args, 0); break;
+    case 1: hipLaunchKernelGGL((cco_rows_kernel<256, E1>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1); break;
+    case 2: hipLaunchKernelGGL((cco_rows_kernel<1024, E2>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(1024), 0, st, args, 2); break;
     default: hipLaunchKernelGGL(cco_rows_global_kernel, dim3(GLOBAL_BIN_BLOCKS), dim3(GB_THREADS), 0, st, args); break;
   }
   return hipGetLastError();
@@ -1067,14 +1116,14 @@ __global__ __launch_bounds__(256) void bin_out_stats_kernel(const int32_t* __res
   __shared__ long long s_wave[SCAN_THREADS / WAVE];
   const int bin = blockIdx.x;
   long long v = 0;
-  for (int t = bin_off[bin] + threadIdx.x; t < bin_off[bin + 1]; t += 256) v += out_count[bin_rows[t] - item_lo];
+  for (int t = bin_off[bin] + blockIdx.y * 256 + threadIdx.x; t < bin_off[bin + 1]; t += 256 * gridDim.y) v += out_count[bin_rows[t] - item_lo];
   long long tot;
   block_exclusive_scan(v, s_wave, &tot);
-  if (threadIdx.x == 0) stats[13 + bin] = tot;
+  if (threadIdx.x == 0 && tot) atomicAdd((unsigned long long*)&stats[13 + bin], (unsigned long long)tot);
 }
 hipError_t launch_bin_out_stats(hipStream_t st, const int32_t* bin_rows, const int32_t* bin_off, int32_t item_lo, const int32_t* out_count,
                                 int64_t* stats) {
-  hipLaunchKernelGGL(bin_out_stats_kernel, dim3(NBINS), dim3(256), 0, st, bin_rows, bin_off, item_lo, out_count, stats);
+  hipLaunchKernelGGL(bin_out_stats_kernel, dim3(NBINS, 128), dim3(256), 0, st, bin_rows, bin_off, item_lo, out_count, stats);
   return hipGetLastError();
 }
 

@@ -65,6 +65,8 @@ struct urcco_session {
   unsigned long long* g_cand_key = nullptr;
   int32_t* g_cand_col = nullptr;
   int64_t g_cols = 0;
+  double* xlx_tab = nullptr;  // xLogX of small integers (N-independent), filled once
+  int debug = 0;              // kernel ablation switches (profiling only)
   // optional per-stage HIP-event timing (bench.py's roofline numbers)
   bool timing = false;
   struct Rec { int stage; hipEvent_t e0, e1; };
@@ -191,6 +193,7 @@ void urcco_session_destroy(urcco_session* s) {
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
   if (s->arena) (void)hipFree(s->arena);
+  if (s->xlx_tab) (void)hipFree(s->xlx_tab);
   if (s->g_counts) { (void)hipFree(s->g_counts); (void)hipFree(s->g_cand_key); (void)hipFree(s->g_cand_col); }
   s->collect();
   for (hipEvent_t e : s->free_events) (void)hipEventDestroy(e);
@@ -201,6 +204,12 @@ void urcco_session_destroy(urcco_session* s) {
 int urcco_session_synchronize(urcco_session* s) {
   if (!s) return fail(URCCO_BAD_ARG, "session is NULL");
   HIPC(hipStreamSynchronize(s->stream));
+  return URCCO_OK;
+}
+
+int urcco_session_set_debug(urcco_session* s, int32_t flags) {
+  if (!s) return fail(URCCO_BAD_ARG, "session is NULL");
+  s->debug = flags;
   return URCCO_OK;
 }
 
@@ -343,6 +352,10 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   const int count_bits = 32 - key_bits;
   if (count_bits < 1) return fail(URCCO_BAD_ARG, "n_cols_b %d too large for the packed accumulator", n_cols_b);
   URC(s->ensure_global_bin(n_cols_b));
+  if (!s->xlx_tab) {
+    HIPC(hipMalloc((void**)&s->xlx_tab, sizeof(double) * urcco::XLX_TABLE_HOST));
+    HIPC(urcco::launch_xlx_table(s->stream, s->xlx_tab));
+  }
   const int64_t n_tiles = ((int64_t)n + urcco::BIN_TILE - 1) / urcco::BIN_TILE;
   const bool same = (counts_a == counts_b) && (n_items_a == n_cols_b);
   const int64_t cap = nnz_a_bound;
@@ -371,7 +384,7 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   s->end();
   s->begin(URCCO_STAGE_BINNING);
   HIPC(hipMemsetAsync(stats, 0, sizeof(int64_t) * URCCO_STATS_LEN, s->stream));
-  HIPC(urcco::launch_binning(s->stream, item_lo, n, work, counts_a, n_cols_b, count_bits, tile_counts, bin_off, bin_rows, stats));
+  HIPC(urcco::launch_binning(s->stream, item_lo, n, work, counts_a, n_cols_b, count_bits, k, tile_counts, bin_off, bin_rows, stats));
   s->end();
   s->begin(URCCO_STAGE_ENTROPY);
   HIPC(urcco::launch_item_entropy(s->stream, counts_a, n_items_a, n_users, ent_a, xlx_n));
@@ -381,7 +394,7 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   urcco::CcoArgs a;
   a.bin_rows = bin_rows; a.bin_off = bin_off;
   a.a_col_ptr = a_col_ptr; a.pstart = pstart; a.wp = wp; a.b_col_idx = b_col_idx;
-  a.cnt_a = counts_a; a.cnt_b = counts_b; a.ent_a = ent_a; a.ent_b = ent_b; a.xlx_n = xlx_n;
+  a.cnt_a = counts_a; a.cnt_b = counts_b; a.ent_a = ent_a; a.ent_b = ent_b; a.xlx_n = xlx_n; a.xlx_tab = s->xlx_tab; a.debug = s->debug;
   a.n_users = n_users; a.n_cols_b = n_cols_b; a.item_lo = item_lo; a.exclude_self = exclude_self ? 1 : 0; a.k = k;
   a.has_min_llr = has_min_llr ? 1 : 0; a.min_llr = min_llr; a.count_bits = count_bits;
   a.g_log2 = 4;  // 16 lanes stream one user's B' row: 64 B segments, matches the ~10-40 item rows the cut leaves

@@ -95,6 +95,9 @@ class DeviceSession:
     def set_timing(self, enable: bool):
         self._check(self.lib.urcco_session_set_timing(self.handle, int(enable)))
 
+    def set_debug(self, flags: int):
+        self._check(self.lib.urcco_session_set_debug(self.handle, int(flags)))
+
     def get_timings(self):
         """{stage name: (summed ms, launches)} since set_timing(True); synchronises."""
         ms = (C.c_double * _lib.N_STAGES)()
