@@ -9,14 +9,17 @@ namespace urcco {
 
 // Stateless down-sampling RNG (decision D10): uniform [0,1) double keyed by (seed,row,col).
 // splitmix64 finaliser over the packed key; top 53 bits.
-__device__ __forceinline__ double u01_hash(uint32_t seed, uint32_t row, uint32_t col) {
+__device__ __forceinline__ unsigned long long hash53(uint32_t seed, uint32_t row, uint32_t col) {
   unsigned long long x = ((unsigned long long)row << 32) | (unsigned long long)col;
   x ^= (unsigned long long)seed * 0x9E3779B97F4A7C15ull;
   x += 0x9E3779B97F4A7C15ull;
   x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
   x ^= x >> 27; x *= 0x94D049BB133111EBull;
   x ^= x >> 31;
-  return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+  return x >> 11;
+}
+__device__ __forceinline__ double u01_hash(uint32_t seed, uint32_t row, uint32_t col) {
+  return (double)hash53(seed, row, col) * (1.0 / 9007199254740992.0);
 }
 
 // Natural log of a positive, normal double (the path only ever feeds it positive integers < 2^53).

@@ -42,6 +42,7 @@ struct CcoArgs {
   int32_t has_min_llr;
   double min_llr;
   int32_t count_bits;        // packed LDS entry = ((col+1) << count_bits) | count
+  int32_t col_bytes;         // bytes needed for a column index of B (1..4): digits of the top-k tie break
   int32_t g_log2;            // lanes cooperating on one user's B row = 1 << g_log2
   // outputs (strided by k)
   int32_t* out_count;
@@ -60,9 +61,10 @@ hipError_t launch_column_counts(hipStream_t st, int n_cu, const int32_t* col_idx
 hipError_t launch_scan_i32(hipStream_t st, const int32_t* in, int64_t n, int64_t* out, int64_t* tile_sums);
 hipError_t launch_scan_popc64(hipStream_t st, const unsigned long long* in, int64_t n, int64_t* out, int64_t* tile_sums);
 
-hipError_t launch_downsample_flags(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
-                                   const int32_t* raw_counts, uint32_t seed, int32_t max_n, int row_rate_mode, int64_t row_base,
-                                   unsigned long long* flags, int32_t* post_counts);
+// thresholds: scratch [n_cols] u64 (per-column sample-rate thresholds, filled here)
+hipError_t launch_downsample_flags(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
+                                   const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n, int row_rate_mode,
+                                   int64_t row_base, unsigned long long* flags, int32_t* post_counts);
 hipError_t launch_downsample_compact(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
                                      const unsigned long long* flags, const int64_t* word_prefix, int64_t* out_row_ptr,
                                      int32_t* out_col_idx);

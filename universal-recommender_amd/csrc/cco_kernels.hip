@@ -112,17 +112,54 @@ hipError_t launch_column_counts(hipStream_t st, int n_cu, const int32_t* col_idx
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = SCAN_TILE / SCAN_THREADS;  // 8
 
+// load8: 8 consecutive elements starting at a multiple of 8 -- 16-byte vector loads when the array is 16-byte aligned,
+// so that a wave's reads cover one contiguous span (a scalar loop would touch every cache line 8 times).
 struct LoadI32 {
   const int32_t* p;
   __device__ __forceinline__ long long operator()(int64_t i) const { return p[i]; }
+  __device__ __forceinline__ void load8(int64_t i, long long* x) const {
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+      const int4 a = *reinterpret_cast<const int4*>(p + i), b = *reinterpret_cast<const int4*>(p + i + 4);
+      x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = p[i + q];
+    }
+  }
 };
 struct LoadI64 {
   const int64_t* p;
   __device__ __forceinline__ long long operator()(int64_t i) const { return p[i]; }
+  __device__ __forceinline__ void load8(int64_t i, long long* x) const {
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int4 a = *reinterpret_cast<const int4*>(p + i + 2 * q);
+        x[2 * q] = (long long)(((unsigned long long)(unsigned)a.y << 32) | (unsigned)a.x);
+        x[2 * q + 1] = (long long)(((unsigned long long)(unsigned)a.w << 32) | (unsigned)a.z);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = p[i + q];
+    }
+  }
 };
 struct LoadPopc64 {
   const unsigned long long* p;
   __device__ __forceinline__ long long operator()(int64_t i) const { return __popcll(p[i]); }
+  __device__ __forceinline__ void load8(int64_t i, long long* x) const {
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int4 a = *reinterpret_cast<const int4*>(p + i + 2 * q);
+        x[2 * q] = __popc((unsigned)a.x) + __popc((unsigned)a.y);
+        x[2 * q + 1] = __popc((unsigned)a.z) + __popc((unsigned)a.w);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = __popcll(p[i + q]);
+    }
+  }
 };
 
 // inclusive scan of one value per thread over the block; returns the exclusive prefix, *total = block sum.
@@ -185,21 +222,37 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(Load ld, i
   __shared__ long long s_wave[SCAN_THREADS / WAVE];
   // thread t owns SCAN_ITEMS consecutive elements so that the scan order is the element order
   const int64_t first = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  static_assert(SCAN_ITEMS == 8, "load8");
   long long x[SCAN_ITEMS];
   long long v = 0;
+  const bool interior = first + SCAN_ITEMS <= n;
+  if (interior) {
+    ld.load8(first, x);
+  } else {
 #pragma unroll
-  for (int q = 0; q < SCAN_ITEMS; ++q) {
-    const int64_t i = first + q;
-    x[q] = i < n ? ld(i) : 0;
-    v += x[q];
+    for (int q = 0; q < SCAN_ITEMS; ++q) x[q] = first + q < n ? ld(first + q) : 0;
   }
+#pragma unroll
+  for (int q = 0; q < SCAN_ITEMS; ++q) v += x[q];
   long long tot;
   long long run = block_exclusive_scan(v, s_wave, &tot) + tile_sums[blockIdx.x];
+  if (interior && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {  // four 16-byte stores per thread
 #pragma unroll
-  for (int q = 0; q < SCAN_ITEMS; ++q) {
-    const int64_t i = first + q;
-    if (i < n) out[i] = run;
-    run += x[q];
+    for (int q = 0; q < SCAN_ITEMS; q += 2) {
+      const long long e0 = run, e1 = run + x[q];
+      run = e1 + x[q + 1];
+      int4 w;
+      w.x = (int)(unsigned)e0; w.y = (int)(unsigned)((unsigned long long)e0 >> 32);
+      w.z = (int)(unsigned)e1; w.w = (int)(unsigned)((unsigned long long)e1 >> 32);
+      *reinterpret_cast<int4*>(out + first + q) = w;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS; ++q) {
+      const int64_t i = first + q;
+      if (i < n) out[i] = run;
+      run += x[q];
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_sums[n_tiles];
 }
@@ -236,6 +289,18 @@ constexpr int DS_THREADS = 256;
 constexpr int DS_ITERS = DS_TILE / (DS_THREADS * 4);  // 4
 constexpr int DS_SLICE = DS_TILE + 2;                 // row_ptr entries staged per tile
 
+constexpr unsigned long long RATE_ONE = 1ull << 53;  // threshold of a sample rate of 1.0 (every 53-bit hash passes)
+
+// perThingSampleRate = min(max, n) / n of sampleDownAndBinarize, as the integer threshold floor(rate * 2^53)
+__global__ __launch_bounds__(256) void sample_threshold_kernel(const int32_t* __restrict__ raw_counts, int32_t n_cols, int32_t max_n,
+                                                               unsigned long long* __restrict__ thresholds) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_cols) return;
+  const double n_thing = (double)raw_counts[j];
+  const double dmax = (double)max_n;
+  thresholds[j] = n_thing <= dmax ? RATE_ONE : (unsigned long long)((dmax / n_thing) * 9007199254740992.0);
+}
+
 // first idx in [lo, hi] with rp[idx] > e   (rp[hi] > e guaranteed by the caller)
 __device__ __forceinline__ int64_t upper_bound_i64(const int64_t* __restrict__ rp, int64_t lo, int64_t hi, int64_t e) {
   while (lo < hi) {
@@ -247,7 +312,7 @@ __device__ __forceinline__ int64_t upper_bound_i64(const int64_t* __restrict__ r
 
 __global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_rows, const int64_t* __restrict__ rp,
                                                                       const int32_t* __restrict__ ci, int64_t nnz,
-                                                                      const int32_t* __restrict__ raw_counts, uint32_t seed,
+                                                                      const unsigned long long* __restrict__ thresholds, uint32_t seed,
                                                                       int32_t max_n, int row_rate_mode, int64_t row_base,
                                                                       unsigned long long* __restrict__ flags,
                                                                       int32_t* __restrict__ post_counts, int vec_ok) {
@@ -304,14 +369,17 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_
             r_beg = r_end;
             r_end = in_lds ? s_rp[r + 1 - r_first] : rp[r + 1];
           }
+          // u01 = m * 2^-53 with integer m < 2^53, so  u01 <= rate  <=>  m <= floor(rate * 2^53)  (the scaling is exact):
+          // the per-column threshold is precomputed (one division per column, not per interaction) and entries whose
+          // rate is 1.0 are kept without evaluating the hash.
           const int64_t n_row = r_end - r_beg;
-          const int64_t capped = n_row < (int64_t)max_n ? n_row : (int64_t)max_n;
-          const double per_row = row_rate_mode == 0 ? (double)(capped / n_row) : (double)capped / (double)n_row;
+          unsigned long long thr_row = RATE_ONE;
+          if (n_row > (int64_t)max_n)
+            thr_row = row_rate_mode == 0 ? 0ull /* Int / Int = 0 */ : (unsigned long long)((dmax / (double)n_row) * 9007199254740992.0);
           const int j = cols[q];
-          const double n_thing = (double)raw_counts[j];
-          const double per_thing = (n_thing < dmax ? n_thing : dmax) / n_thing;
-          const double rate = per_row < per_thing ? per_row : per_thing;
-          if (u01_hash(seed, (uint32_t)(row_base + r), (uint32_t)j) <= rate) {
+          const unsigned long long thr_col = thresholds[j];
+          const unsigned long long thr = thr_row < thr_col ? thr_row : thr_col;
+          if (thr == RATE_ONE || hash53(seed, (uint32_t)(row_base + r), (uint32_t)j) <= thr) {
             nib |= 1u << q;
             if (post_counts) atomicAdd(&post_counts[j], 1);
           }
@@ -376,13 +444,14 @@ __global__ __launch_bounds__(256) void downsample_rowptr_kernel(int64_t n_rows, 
   }
 }
 
-hipError_t launch_downsample_flags(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
-                                   const int32_t* raw_counts, uint32_t seed, int32_t max_n, int row_rate_mode, int64_t row_base,
-                                   unsigned long long* flags, int32_t* post_counts) {
+hipError_t launch_downsample_flags(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
+                                   const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n, int row_rate_mode,
+                                   int64_t row_base, unsigned long long* flags, int32_t* post_counts) {
   if (nnz == 0) return hipSuccess;
+  hipLaunchKernelGGL(sample_threshold_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, raw_counts, n_cols, max_n, thresholds);
   const int64_t tiles = (nnz + DS_TILE - 1) / DS_TILE;
   const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
-  hipLaunchKernelGGL(downsample_flags_kernel, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, raw_counts,
+  hipLaunchKernelGGL(downsample_flags_kernel, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, thresholds,
                      seed, max_n, row_rate_mode, row_base, flags, post_counts, vec_ok);
   return hipGetLastError();
 }
@@ -768,7 +837,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
   __shared__ long long s_ustart[TEAMS * T];
   __shared__ unsigned s_uoff[TEAMS * (T + 1)];
   __shared__ unsigned s_wsum[NW];
-  __shared__ unsigned s_hist[TEAMS * 256];
+  __shared__ unsigned s_hist[TEAMS * 3 * 256];
   __shared__ unsigned s_selres[TEAMS * 4];
 
   const int team = threadIdx.x / T;
@@ -777,7 +846,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
   unsigned* tab = s_tab + team * E;
   long long* ustart = s_ustart + team * T;
   unsigned* uoff = s_uoff + team * (T + 1);
-  unsigned* hist = s_hist + team * 256;
+  unsigned* hist = s_hist + team * 3 * 256;
   unsigned* sel_res = s_selres + team * 4;
   unsigned* nsel = sel_res + 3;
   const int list_start = a.bin_off[bin];
@@ -789,13 +858,26 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
   const double xlx_n = *a.xlx_n;
 
   // T == 64: teams are independent waves (wave-level sync only).  T > 64: one team per block, loop is block-uniform.
-  for (int li = blockIdx.x * TEAMS + team; li < list_n; li += total_teams) {
-    const int i = a.bin_rows[list_start + li];
+  int li = blockIdx.x * TEAMS + team;
+  int i_nx = 0;
+  int64_t cs_nx = 0, ce_nx = 0;
+  if (li < list_n) {
+    i_nx = a.bin_rows[list_start + li];
+    cs_nx = a.a_col_ptr[i_nx];
+    ce_nx = a.a_col_ptr[i_nx + 1];
+  }
+  for (; li < list_n; li += total_teams) {
+    const int i = i_nx;
+    const int64_t cs = cs_nx, ce = ce_nx;
+    if (li + total_teams < list_n) {  // the next row's row id and CSC bounds travel while this row is processed
+      i_nx = a.bin_rows[list_start + li + total_teams];
+      cs_nx = a.a_col_ptr[i_nx];
+      ce_nx = a.a_col_ptr[i_nx + 1];
+    }
 #pragma unroll
     for (int q = 0; q < SPT; ++q) tab[tl + q * T] = 0u;
     team_sync<T>();
     // ---- 2. expand + accumulate
-    const int64_t cs = a.a_col_ptr[i], ce = a.a_col_ptr[i + 1];
     for (int64_t c0 = cs; c0 < ce; c0 += T) {  // team-uniform
       const int64_t c1 = c0 + T < ce ? c0 + T : ce;
       const int64_t w0 = a.wp[c0];
@@ -895,10 +977,16 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
     unsigned thr_ncol = 0u;
     if (!(a.debug & 4)) {
       if (C > (unsigned)a.k) {  // team-uniform
+        // MSB-first radix select.  Three rotating 256-bin histograms (pass p counts into H[p % 3] while H[(p + 2) % 3]
+        // is being cleared) and a digit search that every wave repeats for itself leave ONE team barrier per pass.
         unsigned need = (unsigned)a.k;
-        for (int p = 0; p < 12; ++p) {  // team-uniform trip count (break below is on broadcast values)
-          for (int b = tl; b < 256; b += T) hist[b] = 0u;
-          team_sync<T>();
+        if (a.col_bytes < 4) thr_ncol = 0xffffffffu << (8 * a.col_bytes);  // digits of ~col above the highest used byte are all ones
+        for (int b = tl; b < 3 * 256; b += T) hist[b] = 0u;
+        team_sync<T>();
+        const int first_col_pass = 8 + (3 - (a.col_bytes - 1));  // column digits above the highest used byte are constant: skip
+        for (int p = 0; p < 12; ++p) {  // team-uniform trip count (the break below is on values every thread agrees on)
+          if (p >= 8 && p < first_col_pass) continue;
+          unsigned* H = hist + (p % 3) * 256;
           for (unsigned t = (unsigned)tl; t < D; t += T) {
             const unsigned long long key = kk[t];
             if (key == 0ull) continue;
@@ -911,16 +999,18 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
               dig = (unsigned)(key >> sh) & 255u;
             } else {
               const int sh = 24 - 8 * (p - 8);
-              match = key == thr_key && (p == 8 || (ncol >> (sh + 8)) == (thr_ncol >> (sh + 8)));
+              match = key == thr_key && (p == first_col_pass || (ncol >> (sh + 8)) == (thr_ncol >> (sh + 8)));
               dig = (ncol >> sh) & 255u;
             }
-            if (match) atomicAdd(&hist[dig], 1u);
+            if (match) atomicAdd(&H[dig], 1u);
           }
           team_sync<T>();
-          if (tl < WAVE) {  // first wave of the team: locate the digit that holds the cut
-            const unsigned h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+          {  // every wave locates the digit that holds the cut (lanes own 4 bins each, higher lanes = higher digits)
+            unsigned* Hz = hist + ((p + 2) % 3) * 256;
+            for (int b = tl; b < 256; b += T) Hz[b] = 0u;  // last read two passes ago
+            const unsigned h0 = H[4 * lane], h1 = H[4 * lane + 1], h2 = H[4 * lane + 2], h3 = H[4 * lane + 3];
             const unsigned v4 = h0 + h1 + h2 + h3;
-            unsigned S = v4;  // inclusive suffix sum over lanes (higher lanes = higher digits)
+            unsigned S = v4;  // inclusive suffix sum over lanes
 #pragma unroll
             for (int dd = 1; dd < WAVE; dd <<= 1) {
               const unsigned o = __shfl_down(S, dd);
@@ -928,24 +1018,20 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
             }
             const unsigned long long ge = __ballot(S >= need);
             const int L = 63 - __clzll((long long)ge);
-            if (lane == L) {
-              unsigned above = S - v4;
-              unsigned d, cnt;
-              if (above + h3 >= need) { d = 3; cnt = h3; }
-              else if (above + h3 + h2 >= need) { d = 2; cnt = h2; above += h3; }
-              else if (above + h3 + h2 + h1 >= need) { d = 1; cnt = h1; above += h3 + h2; }
-              else { d = 0; cnt = h0; above += h3 + h2 + h1; }
-              sel_res[0] = 4u * (unsigned)lane + d;
-              sel_res[1] = above;
-              sel_res[2] = cnt;
-            }
+            unsigned above = S - v4;
+            unsigned d, cnt;
+            if (above + h3 >= need) { d = 3; cnt = h3; }
+            else if (above + h3 + h2 >= need) { d = 2; cnt = h2; above += h3; }
+            else if (above + h3 + h2 + h1 >= need) { d = 1; cnt = h1; above += h3 + h2; }
+            else { d = 0; cnt = h0; above += h3 + h2 + h1; }
+            d = (unsigned)__shfl((int)(4u * (unsigned)lane + d), L);
+            cnt = (unsigned)__shfl((int)cnt, L);
+            above = (unsigned)__shfl((int)above, L);
+            need -= above;
+            if (p < 8) thr_key |= (unsigned long long)d << (56 - 8 * p);
+            else thr_ncol |= d << (24 - 8 * (p - 8));
+            if (cnt == need) break;  // the whole bin is wanted: every composite >= the prefix (low bits zero) is selected
           }
-          team_sync<T>();
-          const unsigned d = sel_res[0], above = sel_res[1], cnt = sel_res[2];
-          need -= above;
-          if (p < 8) thr_key |= (unsigned long long)d << (56 - 8 * p);
-          else thr_ncol |= d << (24 - 8 * (p - 8));
-          if (cnt == need) break;  // the whole bin is wanted: every composite >= the prefix (low bits zero) is selected
         }
       }
       if (tl == 0) *nsel = 0u;

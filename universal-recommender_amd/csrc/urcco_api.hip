@@ -257,13 +257,14 @@ int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_pt
   }
   const int64_t n_words = (nnz + 63) >> 6;
   const int64_t n_tiles = (n_words + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
-  URC(s->reserve(urcco_session::need((size_t)n_words + 1, 8) * 2 + urcco_session::need((size_t)n_tiles + 2, 8)));
+  URC(s->reserve(urcco_session::need((size_t)n_words + 1, 8) * 2 + urcco_session::need((size_t)n_tiles + 2, 8) + urcco_session::need((size_t)n_cols, 8)));
+  unsigned long long* thresholds = s->take<unsigned long long>((size_t)n_cols);
   unsigned long long* flags = s->take<unsigned long long>((size_t)n_words + 1);
   int64_t* word_prefix = s->take<int64_t>((size_t)n_words + 1);
   int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
   s->begin(URCCO_STAGE_DOWNSAMPLE_FLAGS);
-  HIPC(urcco::launch_downsample_flags(s->stream, n_rows, row_ptr, col_idx, nnz, raw_counts, (uint32_t)seed, max_elements_per_row, row_rate_mode,
-                                      row_base, flags, post_counts));
+  HIPC(urcco::launch_downsample_flags(s->stream, n_rows, row_ptr, col_idx, nnz, n_cols, raw_counts, thresholds, (uint32_t)seed, max_elements_per_row,
+                                      row_rate_mode, row_base, flags, post_counts));
   s->end();
   s->begin(URCCO_STAGE_DOWNSAMPLE_SCAN);
   HIPC(urcco::launch_scan_popc64(s->stream, flags, n_words, word_prefix, tile_sums));
@@ -397,6 +398,7 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   a.cnt_a = counts_a; a.cnt_b = counts_b; a.ent_a = ent_a; a.ent_b = ent_b; a.xlx_n = xlx_n; a.xlx_tab = s->xlx_tab; a.debug = s->debug;
   a.n_users = n_users; a.n_cols_b = n_cols_b; a.item_lo = item_lo; a.exclude_self = exclude_self ? 1 : 0; a.k = k;
   a.has_min_llr = has_min_llr ? 1 : 0; a.min_llr = min_llr; a.count_bits = count_bits;
+  a.col_bytes = n_cols_b <= (1 << 8) ? 1 : (n_cols_b <= (1 << 16) ? 2 : (n_cols_b <= (1 << 24) ? 3 : 4));
   a.g_log2 = 4;  // 16 lanes stream one user's B' row: 64 B segments, matches the ~10-40 item rows the cut leaves
   a.out_count = out_count; a.out_idx = out_idx; a.out_llr = out_llr;
   a.err = reinterpret_cast<unsigned long long*>(stats + 17);
