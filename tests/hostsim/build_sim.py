@@ -20,7 +20,7 @@ def build(force: bool = False) -> str:
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-fno-strict-aliasing",
+    cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-fno-strict-aliasing", "-ldl",
            "-I", os.path.join(HERE, "include"), "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas", "-Wno-unused-variable"]
     for s in SOURCES:
         cmd += ["-x", "c++", s]

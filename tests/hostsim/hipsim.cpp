@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <dlfcn.h>
 
 #if !defined(__x86_64__)
 #error "hostsim context switch is written for x86-64"
@@ -102,7 +103,12 @@ void resolve_wave(BlockCtx* c, int w0, int w1) {
     if (f.state != AT_WAVE) continue;
     if (!any) { site = f.site; op = f.op; any = true; }
     else if (f.site != site || f.op != op) {
-      fprintf(stderr, "hipsim: lanes of one wave sit at different wave ops (divergent __shfl/__ballot) in block (%u)\n", bIdx.x);
+      fprintf(stderr, "hipsim: lanes of one wave sit at different wave ops (divergent __shfl/__ballot) in block (%u) of %u threads, grid %u: lane %d at %p (op %d) vs %p (op %d)\n",
+              bIdx.x, bDim.x, gDim.x, t - w0, f.site, f.op, site, op);
+      for (int q = w0; q < w1; ++q) fprintf(stderr, " %d:%d:%p", q - w0, c->fibers[(size_t)q].state, c->fibers[(size_t)q].state == AT_WAVE ? c->fibers[(size_t)q].site : nullptr);
+      Dl_info di;
+      if (dladdr(site, &di)) fprintf(stderr, "\n offsets: %lx %lx in %s", (unsigned long)((const char*)site - (const char*)di.dli_fbase), (unsigned long)((const char*)f.site - (const char*)di.dli_fbase), di.dli_fname);
+      fprintf(stderr, "\n");
       abort();
     }
   }

@@ -75,57 +75,66 @@ int lane_id();
 
 static inline void __syncthreads() { hipsim::sync_threads(); }
 
-__attribute__((noinline)) static unsigned long long __ballot(int pred) {
-  return hipsim::wave_op(hipsim::OP_BALLOT, pred ? 1 : 0, 0, __builtin_return_address(0));
+// Wave ops are identified by their SOURCE LINE (g++ may duplicate a call site by jump threading / loop unswitching,
+// so a return address would not identify the source-level operation).
+#define HIPSIM_SITE(line) (reinterpret_cast<const void*>(static_cast<uintptr_t>(line)))
+static inline unsigned long long hipsim_ballot(int line, int pred) {
+  return hipsim::wave_op(hipsim::OP_BALLOT, pred ? 1 : 0, 0, HIPSIM_SITE(line));
 }
+#define __ballot(...) hipsim_ballot(__LINE__, __VA_ARGS__)
 template <typename T>
-__attribute__((noinline)) static T __shfl(T v, int src, int width = 64) {
+static inline T hipsim_shfl(int line, T v, int src, int width = 64) {
   static_assert(sizeof(T) <= 8, "shfl payload");
   uint64_t p = 0;
   memcpy(&p, &v, sizeof(T));
   int lane = hipsim::lane_id();
   int s = (lane & ~(width - 1)) | (src & (width - 1));
-  uint64_t r = hipsim::wave_op(hipsim::OP_SHFL, p, s, __builtin_return_address(0));
+  uint64_t r = hipsim::wave_op(hipsim::OP_SHFL, p, s, HIPSIM_SITE(line));
   T out;
   memcpy(&out, &r, sizeof(T));
   return out;
 }
 template <typename T>
-__attribute__((noinline)) static T __shfl_xor(T v, int mask, int width = 64) {
+static inline T hipsim_shfl_xor(int line, T v, int mask, int width = 64) {
   uint64_t p = 0;
   memcpy(&p, &v, sizeof(T));
   int lane = hipsim::lane_id();
   int s = lane ^ mask;
   if ((s & ~(width - 1)) != (lane & ~(width - 1))) s = lane;
-  uint64_t r = hipsim::wave_op(hipsim::OP_SHFL, p, s, __builtin_return_address(0));
+  uint64_t r = hipsim::wave_op(hipsim::OP_SHFL, p, s, HIPSIM_SITE(line));
   T out;
   memcpy(&out, &r, sizeof(T));
   return out;
 }
 template <typename T>
-__attribute__((noinline)) static T __shfl_down(T v, unsigned delta, int width = 64) {
+static inline T hipsim_shfl_down(int line, T v, unsigned delta, int width = 64) {
   uint64_t p = 0;
   memcpy(&p, &v, sizeof(T));
   int lane = hipsim::lane_id();
   int s = lane + (int)delta;
   if ((s & ~(width - 1)) != (lane & ~(width - 1))) s = lane;
-  uint64_t r = hipsim::wave_op(hipsim::OP_SHFL, p, s, __builtin_return_address(0));
+  uint64_t r = hipsim::wave_op(hipsim::OP_SHFL, p, s, HIPSIM_SITE(line));
   T out;
   memcpy(&out, &r, sizeof(T));
   return out;
 }
 template <typename T>
-__attribute__((noinline)) static T __shfl_up(T v, unsigned delta, int width = 64) {
+static inline T hipsim_shfl_up(int line, T v, unsigned delta, int width = 64) {
   uint64_t p = 0;
   memcpy(&p, &v, sizeof(T));
   int lane = hipsim::lane_id();
   int s = lane - (int)delta;
   if (s < 0 || (s & ~(width - 1)) != (lane & ~(width - 1))) s = lane;
-  uint64_t r = hipsim::wave_op(hipsim::OP_SHFL, p, s, __builtin_return_address(0));
+  uint64_t r = hipsim::wave_op(hipsim::OP_SHFL, p, s, HIPSIM_SITE(line));
   T out;
   memcpy(&out, &r, sizeof(T));
   return out;
 }
+
+#define __shfl(...) hipsim_shfl(__LINE__, __VA_ARGS__)
+#define __shfl_xor(...) hipsim_shfl_xor(__LINE__, __VA_ARGS__)
+#define __shfl_down(...) hipsim_shfl_down(__LINE__, __VA_ARGS__)
+#define __shfl_up(...) hipsim_shfl_up(__LINE__, __VA_ARGS__)
 
 static inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
@@ -174,7 +183,8 @@ static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline void __builtin_amdgcn_s_sleep(int) {}
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
-__attribute__((noinline)) static void __builtin_amdgcn_wave_barrier() { hipsim::wave_op(hipsim::OP_BALLOT, 0, 0, __builtin_return_address(0)); }
+static inline void hipsim_wave_barrier(int line) { hipsim::wave_op(hipsim::OP_BALLOT, 0, 0, HIPSIM_SITE(line)); }
+#define __builtin_amdgcn_wave_barrier() hipsim_wave_barrier(__LINE__)
 
 // ---- runtime API ---------------------------------------------------------------------------
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess(sim)" : "hipError(sim)"; }

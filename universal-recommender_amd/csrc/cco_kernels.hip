@@ -987,20 +987,36 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
         for (int p = 0; p < 12; ++p) {  // team-uniform trip count (the break below is on values every thread agrees on)
           if (p >= 8 && p < first_col_pass) continue;
           unsigned* H = hist + (p % 3) * 256;
-          for (unsigned t = (unsigned)tl; t < D; t += T) {
-            const unsigned long long key = kk[t];
-            if (key == 0ull) continue;
-            const unsigned ncol = ~(unsigned)((int)(tab[t] >> cb) - 1);
-            bool match;
-            unsigned dig;
-            if (p < 8) {
-              const int sh = 56 - 8 * p;
-              match = p == 0 || (key >> (sh + 8)) == (thr_key >> (sh + 8));
-              dig = (unsigned)(key >> sh) & 255u;
-            } else {
-              const int sh = 24 - 8 * (p - 8);
-              match = key == thr_key && (p == first_col_pass || (ncol >> (sh + 8)) == (thr_ncol >> (sh + 8)));
-              dig = (ncol >> sh) & 255u;
+          for (unsigned base = 0; base < D; base += T) {  // wave-uniform trip count (wave ops below)
+            const unsigned t = base + (unsigned)tl;
+            bool match = false;
+            unsigned dig = 0;
+            if (t < D) {
+              const unsigned long long key = kk[t];
+              if (key != 0ull) {
+                if (p < 8) {
+                  const int sh = 56 - 8 * p;
+                  match = p == 0 || (key >> (sh + 8)) == (thr_key >> (sh + 8));
+                  dig = (unsigned)(key >> sh) & 255u;
+                } else {
+                  const unsigned ncol = ~(unsigned)((int)(tab[t] >> cb) - 1);
+                  const int sh = 24 - 8 * (p - 8);
+                  match = key == thr_key && (p == first_col_pass || (ncol >> (sh + 8)) == (thr_ncol >> (sh + 8)));
+                  dig = (ncol >> sh) & 255u;
+                }
+              }
+            }
+            // LLRs of one row share their leading digits, so a plain histogram would serialise thousands of LDS atomics on
+            // one bin: the two most common digits of each wave are counted with one ballot + one atomic each.
+            unsigned long long active = __ballot(match);
+#pragma unroll 1
+            for (int round = 0; round < 2 && active != 0ull; ++round) {  // wave-uniform
+              const int leader = __ffsll(active) - 1;
+              const unsigned ld = (unsigned)__shfl((int)dig, leader);
+              const unsigned long long same = __ballot(match && dig == ld);
+              if (lane == leader) atomicAdd(&H[ld], (unsigned)__popcll(same));
+              match = match && dig != ld;
+              active &= ~same;
             }
             if (match) atomicAdd(&H[dig], 1u);
           }
