@@ -839,6 +839,11 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
   __shared__ unsigned s_wsum[NW];
   __shared__ unsigned s_hist[TEAMS * 3 * 256];
   __shared__ unsigned s_selres[TEAMS * 4];
+  constexpr int SEL_CAP = T == WAVE ? 384 : (T == 256 ? 1024 : 2048);  // explicit survivor list (indices)
+  constexpr int SEL_M = T == WAVE ? 64 : 128;                           // ambiguous set ranked directly
+  __shared__ unsigned s_lst[TEAMS * SEL_CAP];
+  __shared__ unsigned s_amb[TEAMS * SEL_M];
+  __shared__ unsigned long long s_selthr[TEAMS * 2];
 
   const int team = threadIdx.x / T;
   const int tl = threadIdx.x % T;
@@ -849,6 +854,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
   unsigned* hist = s_hist + team * 3 * 256;
   unsigned* sel_res = s_selres + team * 4;
   unsigned* nsel = sel_res + 3;
+  unsigned* lst = s_lst + team * SEL_CAP;
+  unsigned* amb = s_amb + team * SEL_M;
+  unsigned long long* sel_thr = s_selthr + team * 2;
   const int list_start = a.bin_off[bin];
   const int list_n = a.bin_off[bin + 1] - list_start;
   const int total_teams = gridDim.x * TEAMS;
@@ -976,51 +984,56 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
     unsigned long long thr_key = 0ull;
     unsigned thr_ncol = 0u;
     if (!(a.debug & 4)) {
-      if (C > (unsigned)a.k) {  // team-uniform
-        // MSB-first radix select.  Three rotating 256-bin histograms (pass p counts into H[p % 3] while H[(p + 2) % 3]
-        // is being cleared) and a digit search that every wave repeats for itself leave ONE team barrier per pass.
+      if (a.debug & 8) {  // ablation: no select (nothing passes)
+        if (C > (unsigned)a.k) thr_key = ~0ull;
+      } else if (C > (unsigned)a.k) {  // team-uniform
+        // MSB-first radix select of the k-th composite, 8-bit digits, LDS histograms (three rotating 256-bin arrays:
+        // pass p counts into H[p % 3] while H[(p + 2) % 3] is cleared; every wave repeats the digit search for itself,
+        // so a pass costs ONE team barrier).  Two shortcuts keep it to ~3 sweeps of the candidates:
+        //  * once the bin that straddles the cut is small enough its members are copied to an explicit index list and
+        //    later passes sweep only that list;
+        //  * once it holds <= SEL_M members they are ranked against each other (full composite, so ties by column are
+        //    exact) and the need-th best becomes the threshold.
         unsigned need = (unsigned)a.k;
         if (a.col_bytes < 4) thr_ncol = 0xffffffffu << (8 * a.col_bytes);  // digits of ~col above the highest used byte are all ones
         for (int b = tl; b < 3 * 256; b += T) hist[b] = 0u;
+        if (tl == 0) { sel_res[0] = 0u; sel_res[1] = 0u; }  // list length, ambiguous-set length
         team_sync<T>();
         const int first_col_pass = 8 + (3 - (a.col_bytes - 1));  // column digits above the highest used byte are constant: skip
-        for (int p = 0; p < 12; ++p) {  // team-uniform trip count (the break below is on values every thread agrees on)
+        bool have_list = false;
+        unsigned list_n = 0, prev_cnt = C;
+        bool first_pass = true;
+        for (int p = 0; p < 12; ++p) {  // team-uniform trip count (the breaks below are on values every thread agrees on)
           if (p >= 8 && p < first_col_pass) continue;
           unsigned* H = hist + (p % 3) * 256;
-          for (unsigned base = 0; base < D; base += T) {  // wave-uniform trip count (wave ops below)
-            const unsigned t = base + (unsigned)tl;
-            bool match = false;
-            unsigned dig = 0;
-            if (t < D) {
-              const unsigned long long key = kk[t];
-              if (key != 0ull) {
-                if (p < 8) {
-                  const int sh = 56 - 8 * p;
-                  match = p == 0 || (key >> (sh + 8)) == (thr_key >> (sh + 8));
-                  dig = (unsigned)(key >> sh) & 255u;
-                } else {
-                  const unsigned ncol = ~(unsigned)((int)(tab[t] >> cb) - 1);
-                  const int sh = 24 - 8 * (p - 8);
-                  match = key == thr_key && (p == first_col_pass || (ncol >> (sh + 8)) == (thr_ncol >> (sh + 8)));
-                  dig = (ncol >> sh) & 255u;
-                }
-              }
+          const bool build = !have_list && !first_pass && prev_cnt <= (unsigned)SEL_CAP;  // this sweep also records the survivors
+          const unsigned n_scan = have_list ? list_n : D;
+          const int shk = p < 8 ? 56 - 8 * p : 0, shc = p < 8 ? 0 : 24 - 8 * (p - 8);
+          for (unsigned idx = (unsigned)tl; idx < n_scan; idx += T) {
+            const unsigned t = have_list ? lst[idx] : idx;
+            const unsigned long long key = kk[t];
+            if (key == 0ull) continue;
+            bool match;
+            unsigned dig;
+            if (p < 8) {
+              match = first_pass || (key >> (shk + 8)) == (thr_key >> (shk + 8));
+              dig = (unsigned)(key >> shk) & 255u;
+            } else {
+              const unsigned ncol = ~(unsigned)((int)(tab[t] >> cb) - 1);
+              match = key == thr_key && (p == first_col_pass || (ncol >> (shc + 8)) == (thr_ncol >> (shc + 8)));
+              dig = (ncol >> shc) & 255u;
             }
-            // LLRs of one row share their leading digits, so a plain histogram would serialise thousands of LDS atomics on
-            // one bin: the two most common digits of each wave are counted with one ballot + one atomic each.
-            unsigned long long active = __ballot(match);
-#pragma unroll 1
-            for (int round = 0; round < 2 && active != 0ull; ++round) {  // wave-uniform
-              const int leader = __ffsll(active) - 1;
-              const unsigned ld = (unsigned)__shfl((int)dig, leader);
-              const unsigned long long same = __ballot(match && dig == ld);
-              if (lane == leader) atomicAdd(&H[ld], (unsigned)__popcll(same));
-              match = match && dig != ld;
-              active &= ~same;
+            if (match) {
+              atomicAdd(&H[dig], 1u);
+              if (build) lst[atomicAdd(&sel_res[0], 1u)] = t;
             }
-            if (match) atomicAdd(&H[dig], 1u);
           }
           team_sync<T>();
+          if (build) {
+            have_list = true;
+            list_n = sel_res[0];
+          }
+          first_pass = false;
           {  // every wave locates the digit that holds the cut (lanes own 4 bins each, higher lanes = higher digits)
             unsigned* Hz = hist + ((p + 2) % 3) * 256;
             for (int b = tl; b < 256; b += T) Hz[b] = 0u;  // last read two passes ago
@@ -1044,9 +1057,48 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
             cnt = (unsigned)__shfl((int)cnt, L);
             above = (unsigned)__shfl((int)above, L);
             need -= above;
-            if (p < 8) thr_key |= (unsigned long long)d << (56 - 8 * p);
-            else thr_ncol |= d << (24 - 8 * (p - 8));
+            if (p < 8) thr_key |= (unsigned long long)d << shk;
+            else thr_ncol |= d << shc;
+            prev_cnt = cnt;
             if (cnt == need) break;  // the whole bin is wanted: every composite >= the prefix (low bits zero) is selected
+          }
+          if (prev_cnt <= (unsigned)SEL_M) {
+            // finish: gather the members of the cut bin (they match the prefix through digit p) ...
+            const unsigned n_scan2 = have_list ? list_n : D;
+            for (unsigned idx = (unsigned)tl; idx < n_scan2; idx += T) {
+              const unsigned t = have_list ? lst[idx] : idx;
+              const unsigned long long key = kk[t];
+              if (key == 0ull) continue;
+              bool match;
+              if (p < 8) {
+                match = (key >> shk) == (thr_key >> shk);
+              } else {
+                const unsigned ncol = ~(unsigned)((int)(tab[t] >> cb) - 1);
+                match = key == thr_key && (ncol >> shc) == (thr_ncol >> shc);
+              }
+              if (match) amb[atomicAdd(&sel_res[1], 1u)] = t;
+            }
+            team_sync<T>();
+            // ... rank them by counting; the need-th best composite is the exact threshold
+            const unsigned m = sel_res[1];
+            for (unsigned x = (unsigned)tl; x < m; x += T) {
+              const unsigned t = amb[x];
+              const unsigned long long mk = kk[t];
+              const int mc = (int)(tab[t] >> cb) - 1;
+              unsigned rank = 0;
+              for (unsigned u = 0; u < m; ++u) {
+                const unsigned t2 = amb[u];
+                rank += best_before(kk[t2], (int)(tab[t2] >> cb) - 1, mk, mc) ? 1u : 0u;
+              }
+              if (rank + 1u == need) {
+                sel_thr[0] = mk;
+                sel_thr[1] = (unsigned long long)(~(unsigned)mc);
+              }
+            }
+            team_sync<T>();
+            thr_key = sel_thr[0];
+            thr_ncol = (unsigned)sel_thr[1];
+            break;
           }
         }
       }
@@ -1065,7 +1117,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
         }
       }
       team_sync<T>();
-      const unsigned n = *nsel;
+      const unsigned n = (a.debug & 16) ? 0u : *nsel;  // ablation 16: no ranking / output
       for (unsigned t = (unsigned)tl; t < n; t += T) {
         const unsigned long long mk = selk[t];
         const int mc = (int)selc[t];
