@@ -837,12 +837,13 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
   __shared__ long long s_ustart[TEAMS * T];
   __shared__ unsigned s_uoff[TEAMS * (T + 1)];
   __shared__ unsigned s_wsum[NW];
-  __shared__ unsigned s_hist[TEAMS * 3 * 256];
+  __shared__ unsigned s_hist[TEAMS * 3 * 128];  // 256 bins of 16-bit counters, two per word
   __shared__ unsigned s_selres[TEAMS * 4];
-  constexpr int SEL_CAP = T == WAVE ? 384 : (T == 256 ? 1024 : 2048);  // explicit survivor list (indices)
-  constexpr int SEL_M = T == WAVE ? 64 : 128;                           // ambiguous set ranked directly
-  __shared__ unsigned s_lst[TEAMS * SEL_CAP];
-  __shared__ unsigned s_amb[TEAMS * SEL_M];
+  constexpr int SEL_CAP = T == WAVE ? 0 : (T == 256 ? 512 : 2048);  // explicit survivor list (16-bit indices); a wave sweeps its <= 341 candidates directly
+  constexpr int SEL_M = T == WAVE ? 64 : 128;                        // ambiguous set ranked directly
+  __shared__ unsigned short s_lst[TEAMS * (SEL_CAP > 0 ? SEL_CAP : 1)];
+  __shared__ unsigned long long s_ambkey[TEAMS * SEL_M];
+  __shared__ unsigned s_ambcol[TEAMS * SEL_M];
   __shared__ unsigned long long s_selthr[TEAMS * 2];
 
   const int team = threadIdx.x / T;
@@ -851,11 +852,12 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
   unsigned* tab = s_tab + team * E;
   long long* ustart = s_ustart + team * T;
   unsigned* uoff = s_uoff + team * (T + 1);
-  unsigned* hist = s_hist + team * 3 * 256;
+  unsigned* hist = s_hist + team * 3 * 128;
   unsigned* sel_res = s_selres + team * 4;
   unsigned* nsel = sel_res + 3;
-  unsigned* lst = s_lst + team * SEL_CAP;
-  unsigned* amb = s_amb + team * SEL_M;
+  unsigned short* lst = s_lst + team * (SEL_CAP > 0 ? SEL_CAP : 1);
+  unsigned long long* amb_key = s_ambkey + team * SEL_M;
+  unsigned* amb_col = s_ambcol + team * SEL_M;
   unsigned long long* sel_thr = s_selthr + team * 2;
   const int list_start = a.bin_off[bin];
   const int list_n = a.bin_off[bin + 1] - list_start;
@@ -987,16 +989,16 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
       if (a.debug & 8) {  // ablation: no select (nothing passes)
         if (C > (unsigned)a.k) thr_key = ~0ull;
       } else if (C > (unsigned)a.k) {  // team-uniform
-        // MSB-first radix select of the k-th composite, 8-bit digits, LDS histograms (three rotating 256-bin arrays:
-        // pass p counts into H[p % 3] while H[(p + 2) % 3] is cleared; every wave repeats the digit search for itself,
-        // so a pass costs ONE team barrier).  Two shortcuts keep it to ~3 sweeps of the candidates:
+        // MSB-first radix select of the k-th composite, 8-bit digits, LDS histograms (three rotating 256-bin arrays of
+        // 16-bit counters, two per word: pass p counts into H[p % 3] while H[(p + 2) % 3] is cleared; every wave repeats
+        // the digit search for itself, so a pass costs ONE team barrier).  Two shortcuts keep it to ~3 sweeps:
         //  * once the bin that straddles the cut is small enough its members are copied to an explicit index list and
-        //    later passes sweep only that list;
-        //  * once it holds <= SEL_M members they are ranked against each other (full composite, so ties by column are
-        //    exact) and the need-th best becomes the threshold.
+        //    later passes sweep only that list (teams larger than a wave);
+        //  * once it holds <= SEL_M members their (key, col) are copied out and ranked against each other (full
+        //    composite, so ties by column are exact); the need-th best becomes the threshold.
         unsigned need = (unsigned)a.k;
         if (a.col_bytes < 4) thr_ncol = 0xffffffffu << (8 * a.col_bytes);  // digits of ~col above the highest used byte are all ones
-        for (int b = tl; b < 3 * 256; b += T) hist[b] = 0u;
+        for (int b = tl; b < 3 * 128; b += T) hist[b] = 0u;
         if (tl == 0) { sel_res[0] = 0u; sel_res[1] = 0u; }  // list length, ambiguous-set length
         team_sync<T>();
         const int first_col_pass = 8 + (3 - (a.col_bytes - 1));  // column digits above the highest used byte are constant: skip
@@ -1005,12 +1007,12 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
         bool first_pass = true;
         for (int p = 0; p < 12; ++p) {  // team-uniform trip count (the breaks below are on values every thread agrees on)
           if (p >= 8 && p < first_col_pass) continue;
-          unsigned* H = hist + (p % 3) * 256;
-          const bool build = !have_list && !first_pass && prev_cnt <= (unsigned)SEL_CAP;  // this sweep also records the survivors
+          unsigned* H = hist + (p % 3) * 128;
+          const bool build = SEL_CAP > 0 && !have_list && !first_pass && prev_cnt <= (unsigned)SEL_CAP;  // this sweep also records the survivors
           const unsigned n_scan = have_list ? list_n : D;
           const int shk = p < 8 ? 56 - 8 * p : 0, shc = p < 8 ? 0 : 24 - 8 * (p - 8);
           for (unsigned idx = (unsigned)tl; idx < n_scan; idx += T) {
-            const unsigned t = have_list ? lst[idx] : idx;
+            const unsigned t = have_list ? (unsigned)lst[idx] : idx;
             const unsigned long long key = kk[t];
             if (key == 0ull) continue;
             bool match;
@@ -1024,8 +1026,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
               dig = (ncol >> shc) & 255u;
             }
             if (match) {
-              atomicAdd(&H[dig], 1u);
-              if (build) lst[atomicAdd(&sel_res[0], 1u)] = t;
+              atomicAdd(&H[dig >> 1], 1u << (16 * (dig & 1u)));  // counts < 2^16: D is bounded by the table size
+              if (build) lst[atomicAdd(&sel_res[0], 1u)] = (unsigned short)t;
             }
           }
           team_sync<T>();
@@ -1035,9 +1037,10 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
           }
           first_pass = false;
           {  // every wave locates the digit that holds the cut (lanes own 4 bins each, higher lanes = higher digits)
-            unsigned* Hz = hist + ((p + 2) % 3) * 256;
-            for (int b = tl; b < 256; b += T) Hz[b] = 0u;  // last read two passes ago
-            const unsigned h0 = H[4 * lane], h1 = H[4 * lane + 1], h2 = H[4 * lane + 2], h3 = H[4 * lane + 3];
+            unsigned* Hz = hist + ((p + 2) % 3) * 128;
+            for (int b = tl; b < 128; b += T) Hz[b] = 0u;  // last read two passes ago
+            const unsigned w01 = H[2 * lane], w23 = H[2 * lane + 1];
+            const unsigned h0 = w01 & 0xffffu, h1 = w01 >> 16, h2 = w23 & 0xffffu, h3 = w23 >> 16;
             const unsigned v4 = h0 + h1 + h2 + h3;
             unsigned S = v4;  // inclusive suffix sum over lanes
 #pragma unroll
@@ -1053,9 +1056,10 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
             else if (above + h3 + h2 >= need) { d = 2; cnt = h2; above += h3; }
             else if (above + h3 + h2 + h1 >= need) { d = 1; cnt = h1; above += h3 + h2; }
             else { d = 0; cnt = h0; above += h3 + h2 + h1; }
-            d = (unsigned)__shfl((int)(4u * (unsigned)lane + d), L);
-            cnt = (unsigned)__shfl((int)cnt, L);
+            const unsigned packed = (unsigned)__shfl((int)(((4u * (unsigned)lane + d) << 16) | cnt), L);  // cnt < 2^16
             above = (unsigned)__shfl((int)above, L);
+            d = packed >> 16;
+            cnt = packed & 0xffffu;
             need -= above;
             if (p < 8) thr_key |= (unsigned long long)d << shk;
             else thr_ncol |= d << shc;
@@ -1063,33 +1067,29 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
             if (cnt == need) break;  // the whole bin is wanted: every composite >= the prefix (low bits zero) is selected
           }
           if (prev_cnt <= (unsigned)SEL_M) {
-            // finish: gather the members of the cut bin (they match the prefix through digit p) ...
+            // finish: copy out the members of the cut bin (they match the prefix through digit p) ...
             const unsigned n_scan2 = have_list ? list_n : D;
             for (unsigned idx = (unsigned)tl; idx < n_scan2; idx += T) {
-              const unsigned t = have_list ? lst[idx] : idx;
+              const unsigned t = have_list ? (unsigned)lst[idx] : idx;
               const unsigned long long key = kk[t];
               if (key == 0ull) continue;
-              bool match;
-              if (p < 8) {
-                match = (key >> shk) == (thr_key >> shk);
-              } else {
-                const unsigned ncol = ~(unsigned)((int)(tab[t] >> cb) - 1);
-                match = key == thr_key && (ncol >> shc) == (thr_ncol >> shc);
+              const unsigned col = (unsigned)((int)(tab[t] >> cb) - 1);
+              const bool match = p < 8 ? (key >> shk) == (thr_key >> shk) : (key == thr_key && (~col >> shc) == (thr_ncol >> shc));
+              if (match) {
+                const unsigned pos = atomicAdd(&sel_res[1], 1u);
+                amb_key[pos] = key;
+                amb_col[pos] = col;
               }
-              if (match) amb[atomicAdd(&sel_res[1], 1u)] = t;
             }
             team_sync<T>();
-            // ... rank them by counting; the need-th best composite is the exact threshold
+            // ... and rank them by counting; the need-th best composite is the exact threshold
             const unsigned m = sel_res[1];
             for (unsigned x = (unsigned)tl; x < m; x += T) {
-              const unsigned t = amb[x];
-              const unsigned long long mk = kk[t];
-              const int mc = (int)(tab[t] >> cb) - 1;
+              const unsigned long long mk = amb_key[x];
+              const int mc = (int)amb_col[x];
               unsigned rank = 0;
-              for (unsigned u = 0; u < m; ++u) {
-                const unsigned t2 = amb[u];
-                rank += best_before(kk[t2], (int)(tab[t2] >> cb) - 1, mk, mc) ? 1u : 0u;
-              }
+#pragma unroll 4
+              for (unsigned u = 0; u < m; ++u) rank += best_before(amb_key[u], (int)amb_col[u], mk, mc) ? 1u : 0u;
               if (rank + 1u == need) {
                 sel_thr[0] = mk;
                 sel_thr[1] = (unsigned long long)(~(unsigned)mc);
