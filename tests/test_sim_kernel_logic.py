@@ -126,3 +126,28 @@ def test_partition_balances_work(sim_session):
     total = pref[-1]
     for p in range(1, 8):
         assert pref[bounds[p]] >= total * p // 8 and (bounds[p] == 0 or pref[bounds[p] - 1] < total * p // 8)
+
+
+def test_partitioned_column_counts_large_matrix(sim_session):
+    """>= 2^20 interactions take the atomic-free partition/dense-LDS histogram (raw counts and, after compaction, the
+    post-sampling counts whose length only the device knows)."""
+    rng = np.random.default_rng(10)
+    m = rand_csr(rng, 70000, 100_000, 18, zipf_s=1.0)
+    assert m.nnz >= (1 << 20)
+    dev = sim_session.device
+    d = to_dev(m, dev)
+    cnt = sim_session.column_counts(d.col_idx, m.nnz, m.n_cols)
+    out, post = sim_session.downsample(d, m.nnz, cnt, 11, 40)
+    sim_session.synchronize()
+    assert np.array_equal(cnt.cpu().numpy(), O.column_counts(m))
+    ref = O.downsample(m, O.column_counts(m), 11, 40)
+    assert np.array_equal(out.row_ptr.cpu().numpy(), ref.row_ptr)
+    assert np.array_equal(out.col_idx.cpu().numpy()[:ref.nnz], ref.col_idx)
+    assert np.array_equal(post.cpu().numpy()[:m.n_cols], O.column_counts(ref))
+    # unaligned view + a column count that is not a multiple of the bucket size
+    buf = torch.zeros(m.nnz + 8, dtype=torch.int32, device=dev)
+    view = buf[3:3 + m.nnz]
+    view.copy_(d.col_idx[:m.nnz])
+    cnt2 = sim_session.column_counts(view, m.nnz, m.n_cols)
+    sim_session.synchronize()
+    assert np.array_equal(cnt2.cpu().numpy(), O.column_counts(m))

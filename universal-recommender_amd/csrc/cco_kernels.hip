@@ -277,6 +277,182 @@ hipError_t launch_scan_popc64(hipStream_t st, const unsigned long long* in, int6
 }
 
 // ============================================================================================
+// K1b  column counts without global atomics (matrices large enough to repay six launches).
+// A global atomic per interaction caps the histogram at ~20-40 G updates/s; here the interactions are first
+// partitioned by column range (PH_BUCKET = 8192 columns, so one bucket's counters fit 32 KiB of LDS) and then counted
+// densely in LDS:
+//   count    per part of 16384 interactions: how many fall in each bucket (LDS atomics)
+//   scan     bucket-major exclusive prefix -> where every (bucket, part) slice starts
+//   scatter  interactions -> 16-bit in-bucket column ids, grouped by bucket
+//   blockmap buckets -> histogram blocks of 32768 interactions each
+//   hist     one block per slice: dense LDS counters, written out as a partial histogram (plain coalesced stores)
+//   reduce   counts[col] = sum of its bucket's partials
+// Every pass streams; traffic is ~3.5x the column-index array however many columns there are.
+// `nnz_dev` (nullable) overrides nnz with a device-side value <= nnz (no host sync after compaction).
+// ============================================================================================
+constexpr int PH_BITS = 13;
+constexpr int PH_BUCKET = 1 << PH_BITS;
+constexpr int PH_PART = 16384;
+constexpr int PH_CHUNK = 32768;
+constexpr int PH_MAX_BUCKETS = 1024;
+
+__global__ __launch_bounds__(256) void ph_count_kernel(const int32_t* __restrict__ ci, int64_t nnz_host, const int64_t* __restrict__ nnz_dev,
+                                                       int n_buckets, int64_t n_parts, int32_t* __restrict__ part_counts, int vec_ok) {
+  __shared__ int s_cnt[PH_MAX_BUCKETS];
+  const int64_t nnz = nnz_dev ? *nnz_dev : nnz_host;
+  for (int b = threadIdx.x; b < n_buckets; b += 256) s_cnt[b] = 0;
+  __syncthreads();
+  const int64_t e0 = (int64_t)blockIdx.x * PH_PART;
+  const int64_t e1 = e0 + PH_PART < nnz ? e0 + PH_PART : nnz;
+  for (int64_t e = e0 + (int64_t)threadIdx.x * 4; e < e1; e += 256 * 4) {
+    if (vec_ok && e + 3 < e1) {
+      const int4 x = *reinterpret_cast<const int4*>(ci + e);
+      atomicAdd(&s_cnt[x.x >> PH_BITS], 1);
+      atomicAdd(&s_cnt[x.y >> PH_BITS], 1);
+      atomicAdd(&s_cnt[x.z >> PH_BITS], 1);
+      atomicAdd(&s_cnt[x.w >> PH_BITS], 1);
+    } else {
+      for (int q = 0; q < 4 && e + q < e1; ++q) atomicAdd(&s_cnt[ci[e + q] >> PH_BITS], 1);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < n_buckets; b += 256) part_counts[(int64_t)b * n_parts + blockIdx.x] = s_cnt[b];
+}
+
+__global__ __launch_bounds__(256) void ph_scatter_kernel(const int32_t* __restrict__ ci, int64_t nnz_host, const int64_t* __restrict__ nnz_dev,
+                                                         int n_buckets, int64_t n_parts, const int64_t* __restrict__ offsets,
+                                                         unsigned short* __restrict__ bucketed, int vec_ok) {
+  __shared__ long long s_base[PH_MAX_BUCKETS];
+  __shared__ int s_cur[PH_MAX_BUCKETS];
+  const int64_t nnz = nnz_dev ? *nnz_dev : nnz_host;
+  for (int b = threadIdx.x; b < n_buckets; b += 256) {
+    s_base[b] = offsets[(int64_t)b * n_parts + blockIdx.x];
+    s_cur[b] = 0;
+  }
+  __syncthreads();
+  const int64_t e0 = (int64_t)blockIdx.x * PH_PART;
+  const int64_t e1 = e0 + PH_PART < nnz ? e0 + PH_PART : nnz;
+  for (int64_t e = e0 + (int64_t)threadIdx.x * 4; e < e1; e += 256 * 4) {
+    int cols[4];
+    int n = 4;
+    if (vec_ok && e + 3 < e1) {
+      const int4 x = *reinterpret_cast<const int4*>(ci + e);
+      cols[0] = x.x; cols[1] = x.y; cols[2] = x.z; cols[3] = x.w;
+    } else {
+      n = (int)(e1 - e < 4 ? e1 - e : 4);
+      for (int q = 0; q < n; ++q) cols[q] = ci[e + q];
+    }
+    for (int q = 0; q < n; ++q) {
+      const int b = cols[q] >> PH_BITS;
+      const int r = atomicAdd(&s_cur[b], 1);
+      bucketed[s_base[b] + r] = (unsigned short)(cols[q] & (PH_BUCKET - 1));
+    }
+  }
+}
+
+// single block: blk_prefix[b] = first histogram block of bucket b, blk_prefix[n_buckets] = number of blocks
+__global__ __launch_bounds__(SCAN_THREADS) void ph_blockmap_kernel(const int64_t* __restrict__ offsets, int n_buckets, int64_t n_parts,
+                                                                  int32_t* __restrict__ blk_prefix) {
+  __shared__ long long s_wave[SCAN_THREADS / WAVE];
+  long long carry = 0;
+  for (int base = 0; base < n_buckets; base += SCAN_THREADS) {  // block-uniform
+    const int b = base + threadIdx.x;
+    long long v = 0;
+    if (b < n_buckets) {
+      const long long size = offsets[(int64_t)(b + 1) * n_parts] - offsets[(int64_t)b * n_parts];
+      v = (size + PH_CHUNK - 1) / PH_CHUNK;
+    }
+    long long tot;
+    const long long ex = block_exclusive_scan(v, s_wave, &tot);
+    if (b < n_buckets) blk_prefix[b] = (int32_t)(carry + ex);
+    carry += tot;
+  }
+  if (threadIdx.x == 0) blk_prefix[n_buckets] = (int32_t)carry;
+}
+
+__global__ __launch_bounds__(256) void ph_hist_kernel(const unsigned short* __restrict__ bucketed, const int64_t* __restrict__ offsets,
+                                                      int n_buckets, int64_t n_parts, const int32_t* __restrict__ blk_prefix,
+                                                      unsigned* __restrict__ partial) {
+  __shared__ unsigned s_cnt[PH_BUCKET];
+  const int blk = blockIdx.x;
+  if (blk >= blk_prefix[n_buckets]) return;  // block-uniform
+  int lo = 0, hi = n_buckets;  // last b with blk_prefix[b] <= blk
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (blk_prefix[mid] <= blk) lo = mid; else hi = mid;
+  }
+  const int b = lo;
+  for (int c = threadIdx.x; c < PH_BUCKET; c += 256) s_cnt[c] = 0u;
+  __syncthreads();
+  const int64_t bs = offsets[(int64_t)b * n_parts], be = offsets[(int64_t)(b + 1) * n_parts];
+  const int64_t e0 = bs + (int64_t)(blk - blk_prefix[b]) * PH_CHUNK;
+  const int64_t e1 = e0 + PH_CHUNK < be ? e0 + PH_CHUNK : be;
+  // 16-byte loads of eight 16-bit ids where aligned
+  int64_t e = e0 + threadIdx.x;
+  const int64_t a0 = (e0 + 7) & ~(int64_t)7;
+  for (; e < e1 && e < a0; e += 256) atomicAdd(&s_cnt[bucketed[e]], 1u);  // unaligned head (< 8 entries: first iteration only)
+  for (int64_t v = a0 + (int64_t)threadIdx.x * 8; v + 7 < e1; v += 256 * 8) {
+    const uint4 x = *reinterpret_cast<const uint4*>(bucketed + v);
+    atomicAdd(&s_cnt[x.x & 0xffffu], 1u); atomicAdd(&s_cnt[x.x >> 16], 1u);
+    atomicAdd(&s_cnt[x.y & 0xffffu], 1u); atomicAdd(&s_cnt[x.y >> 16], 1u);
+    atomicAdd(&s_cnt[x.z & 0xffffu], 1u); atomicAdd(&s_cnt[x.z >> 16], 1u);
+    atomicAdd(&s_cnt[x.w & 0xffffu], 1u); atomicAdd(&s_cnt[x.w >> 16], 1u);
+  }
+  {
+    const int64_t n_vec = e1 > a0 ? (e1 - a0) / 8 : 0;
+    for (int64_t t = a0 + n_vec * 8 + threadIdx.x; t < e1; t += 256) atomicAdd(&s_cnt[bucketed[t]], 1u);  // tail
+  }
+  __syncthreads();
+  unsigned* out = partial + (int64_t)blk * PH_BUCKET;
+  for (int c = threadIdx.x; c < PH_BUCKET; c += 256) out[c] = s_cnt[c];
+}
+
+__global__ __launch_bounds__(256) void ph_reduce_kernel(const unsigned* __restrict__ partial, const int32_t* __restrict__ blk_prefix, int32_t n_cols,
+                                                        int32_t* __restrict__ counts) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_cols) return;
+  const int b = (int)(j >> PH_BITS);
+  const int c = (int)(j & (PH_BUCKET - 1));
+  unsigned sum = 0;
+  for (int blk = blk_prefix[b]; blk < blk_prefix[b + 1]; ++blk) sum += partial[(int64_t)blk * PH_BUCKET + c];
+  counts[j] = (int32_t)sum;
+}
+
+int64_t column_counts_scratch_bytes(int64_t nnz, int32_t n_cols) {
+  if (nnz < PH_MIN_NNZ || (((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS) > PH_MAX_BUCKETS) return 0;
+  const int64_t n_buckets = ((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS;
+  const int64_t n_parts = (nnz + PH_PART - 1) / PH_PART;
+  const int64_t m = n_buckets * n_parts;
+  const int64_t max_blocks = n_buckets + (nnz + PH_CHUNK - 1) / PH_CHUNK;
+  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  return al(m * 4) + al((m + 1) * 8) + al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8) + al(nnz * 2 + 16) + al((n_buckets + 1) * 4) + al(max_blocks * PH_BUCKET * 4);
+}
+
+hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_idx, int64_t nnz, const int64_t* nnz_dev, int32_t n_cols,
+                                            int32_t* counts, char* scratch) {
+  const int n_buckets = (int)(((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS);
+  const int64_t n_parts = (nnz + PH_PART - 1) / PH_PART;
+  const int64_t m = (int64_t)n_buckets * n_parts;
+  const int64_t max_blocks = n_buckets + (nnz + PH_CHUNK - 1) / PH_CHUNK;
+  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  int32_t* part_counts = reinterpret_cast<int32_t*>(scratch); scratch += al(m * 4);
+  int64_t* offsets = reinterpret_cast<int64_t*>(scratch); scratch += al((m + 1) * 8);
+  int64_t* tile_sums = reinterpret_cast<int64_t*>(scratch); scratch += al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8);
+  unsigned short* bucketed = reinterpret_cast<unsigned short*>(scratch); scratch += al(nnz * 2 + 16);
+  int32_t* blk_prefix = reinterpret_cast<int32_t*>(scratch); scratch += al(((int64_t)n_buckets + 1) * 4);
+  unsigned* partial = reinterpret_cast<unsigned*>(scratch);
+  const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
+  hipLaunchKernelGGL(ph_count_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, part_counts, vec_ok);
+  hipError_t e = launch_scan_i32(st, part_counts, m, offsets, tile_sums);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(ph_scatter_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, offsets, bucketed, vec_ok);
+  hipLaunchKernelGGL(ph_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, offsets, n_buckets, n_parts, blk_prefix);
+  hipLaunchKernelGGL(ph_hist_kernel, dim3((unsigned)max_blocks), dim3(256), 0, st, bucketed, offsets, n_buckets, n_parts, blk_prefix, partial);
+  hipLaunchKernelGGL(ph_reduce_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, partial, blk_prefix, n_cols, counts);
+  return hipGetLastError();
+}
+
+// ============================================================================================
 // K2  sampleDownAndBinarize -- the CSR row scan
 // Pass A (flags): flat over the nnz array, 16 B per lane, the block's row_ptr slice staged in LDS for the
 //   entry -> row lookup; keep decision per entry = u01(seed,row,col) <= min(perRowRate, perThingRate);

@@ -236,8 +236,13 @@ int64_t urcco_session_scratch_bytes(const urcco_session* s) {
 int urcco_dev_column_counts(urcco_session* s, int64_t nnz, const int32_t* col_idx, int32_t n_cols, int32_t* counts) {
   if (!s || nnz < 0 || n_cols < 0 || (nnz > 0 && !col_idx) || (n_cols > 0 && !counts)) return fail(URCCO_BAD_ARG, "urcco_dev_column_counts: bad argument");
   if (n_cols == 0) return URCCO_OK;
+  const int64_t ph_bytes = urcco::column_counts_scratch_bytes(nnz, n_cols);
+  if (ph_bytes > 0) URC(s->reserve((size_t)ph_bytes));
   s->begin(URCCO_STAGE_COLUMN_COUNTS);
-  HIPC(urcco::launch_column_counts(s->stream, s->n_cu, col_idx, nnz, n_cols, counts));
+  if (ph_bytes > 0)
+    HIPC(urcco::launch_column_counts_partitioned(s->stream, col_idx, nnz, nullptr, n_cols, counts, s->take<char>((size_t)ph_bytes)));
+  else
+    HIPC(urcco::launch_column_counts(s->stream, s->n_cu, col_idx, nnz, n_cols, counts));
   s->end();
   return URCCO_OK;
 }
@@ -257,14 +262,18 @@ int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_pt
   }
   const int64_t n_words = (nnz + 63) >> 6;
   const int64_t n_tiles = (n_words + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
-  URC(s->reserve(urcco_session::need((size_t)n_words + 1, 8) * 2 + urcco_session::need((size_t)n_tiles + 2, 8) + urcco_session::need((size_t)n_cols, 8)));
+  // post-sampling column counts: large matrices are counted after compaction by the atomic-free partitioned histogram
+  // (its length is read on the device: out_row_ptr[n_rows]); small ones by L2 atomics inside the flags kernel
+  const int64_t ph_bytes = post_counts ? urcco::column_counts_scratch_bytes(nnz, n_cols) : 0;
+  URC(s->reserve(urcco_session::need((size_t)n_words + 1, 8) * 2 + urcco_session::need((size_t)n_tiles + 2, 8) + urcco_session::need((size_t)n_cols, 8) +
+                 (size_t)ph_bytes + 256));
   unsigned long long* thresholds = s->take<unsigned long long>((size_t)n_cols);
   unsigned long long* flags = s->take<unsigned long long>((size_t)n_words + 1);
   int64_t* word_prefix = s->take<int64_t>((size_t)n_words + 1);
   int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
   s->begin(URCCO_STAGE_DOWNSAMPLE_FLAGS);
   HIPC(urcco::launch_downsample_flags(s->stream, n_rows, row_ptr, col_idx, nnz, n_cols, raw_counts, thresholds, (uint32_t)seed, max_elements_per_row,
-                                      row_rate_mode, row_base, flags, post_counts));
+                                      row_rate_mode, row_base, flags, ph_bytes > 0 ? nullptr : post_counts));
   s->end();
   s->begin(URCCO_STAGE_DOWNSAMPLE_SCAN);
   HIPC(urcco::launch_scan_popc64(s->stream, flags, n_words, word_prefix, tile_sums));
@@ -272,6 +281,11 @@ int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_pt
   s->begin(URCCO_STAGE_DOWNSAMPLE_COMPACT);
   HIPC(urcco::launch_downsample_compact(s->stream, s->n_cu, n_rows, row_ptr, col_idx, nnz, flags, word_prefix, out_row_ptr, out_col_idx));
   s->end();
+  if (ph_bytes > 0) {
+    s->begin(URCCO_STAGE_COLUMN_COUNTS);
+    HIPC(urcco::launch_column_counts_partitioned(s->stream, out_col_idx, nnz, out_row_ptr + n_rows, n_cols, post_counts, s->take<char>((size_t)ph_bytes)));
+    s->end();
+  }
   return URCCO_OK;
 }
 
