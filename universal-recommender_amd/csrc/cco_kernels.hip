@@ -1052,10 +1052,22 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
     cs_nx = a.a_col_ptr[i_nx];
     ce_nx = a.a_col_ptr[i_nx + 1];
   }
+  // first-chunk operands of the row about to be processed (loaded one row ahead, see the end of step 4)
+  int64_t pf_w0 = 0, pf_w1 = 0, pf_wp = 0, pf_start = 0;
+  if (li < list_n) {
+    const int64_t c1 = cs_nx + T < ce_nx ? cs_nx + T : ce_nx;
+    pf_w0 = a.wp[cs_nx];
+    pf_w1 = a.wp[c1];
+    if (cs_nx + tl < c1) {
+      pf_wp = a.wp[cs_nx + tl];
+      pf_start = a.pstart[cs_nx + tl];
+    }
+  }
   for (; li < list_n; li += total_teams) {
     const int i = i_nx;
     const int64_t cs = cs_nx, ce = ce_nx;
-    if (li + total_teams < list_n) {  // the next row's row id and CSC bounds travel while this row is processed
+    const bool has_next = li + total_teams < list_n;
+    if (has_next) {  // the next row's row id and CSC bounds travel while this row is processed
       i_nx = a.bin_rows[list_start + li + total_teams];
       cs_nx = a.a_col_ptr[i_nx];
       ce_nx = a.a_col_ptr[i_nx + 1];
@@ -1066,12 +1078,13 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
     // ---- 2. expand + accumulate
     for (int64_t c0 = cs; c0 < ce; c0 += T) {  // team-uniform
       const int64_t c1 = c0 + T < ce ? c0 + T : ce;
-      const int64_t w0 = a.wp[c0];
-      const unsigned total = (unsigned)(a.wp[c1] - w0);
+      const bool pre = c0 == cs;  // the first chunk's operands were prefetched
+      const int64_t w0 = pre ? pf_w0 : a.wp[c0];
+      const unsigned total = (unsigned)((pre ? pf_w1 : a.wp[c1]) - w0);
       const int64_t p = c0 + tl;
       if (p < c1) {
-        ustart[tl] = a.pstart[p];
-        uoff[tl] = (unsigned)(a.wp[p] - w0);
+        ustart[tl] = pre ? pf_start : a.pstart[p];
+        uoff[tl] = (unsigned)((pre ? pf_wp : a.wp[p]) - w0);
       } else {
         uoff[tl] = total;
       }
@@ -1149,6 +1162,15 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
         }
         kk[t] = key;
         n_valid += key != 0ull;
+      }
+    }
+    if (has_next) {  // the next row's first-chunk operands travel while this row is ranked
+      const int64_t c1 = cs_nx + T < ce_nx ? cs_nx + T : ce_nx;
+      pf_w0 = a.wp[cs_nx];
+      pf_w1 = a.wp[c1];
+      if (cs_nx + tl < c1) {
+        pf_wp = a.wp[cs_nx + tl];
+        pf_start = a.pstart[cs_nx + tl];
       }
     }
     unsigned C;
