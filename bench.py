@@ -182,8 +182,18 @@ def main():
     dominant = max(timed, key=lambda k: timed[k]["ms_per_step"])
     dk = timed[dominant]
     launches = max(dk["launches_per_step"], 1)
+    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot wrap the process it runs in)
+    traffic, traffic_src = None, None
+    stage_to_kernel = {"cco_rows_wave": "cco_rows_kernel<64, 1024>", "cco_rows_block": "cco_rows_kernel<256, 8192>",
+                       "cco_rows_cu": "cco_rows_kernel<1024, 32768>", "downsample_flags": "downsample_flags_kernel",
+                       "transpose": "transpose_kernel"}
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
+    if world == 1 and args.scale == 1.0 and os.path.exists(tpath) and dominant in stage_to_kernel:
+        tk = json.load(open(tpath))["kernels"].get(stage_to_kernel[dominant])
+        if tk:
+            traffic, traffic_src = tk["hbm_bytes_per_launch"], "profiles/r01_hbm_traffic_pmc.json (2*FETCH_SIZE + WRITE_SIZE, KB -> bytes)"
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(dk["GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(dk["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "bytes_per_launch": round(dk["alg_MB_per_step"] * 1e6 / launches), "avg_launch_ms": round(dk["ms_per_step"] / launches, 4)}
     llr_ms = sum(kernels[n]["ms_per_step"] for n in ("cco_rows_wave", "cco_rows_block", "cco_rows_cu", "cco_rows_global", "compact_indicators", "row_work") if n in kernels)
 
