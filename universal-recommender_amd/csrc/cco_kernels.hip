@@ -186,10 +186,17 @@ __device__ __forceinline__ long long block_exclusive_scan(long long v, long long
   return base + inc - v;
 }
 
+// n_live (nullable, device): elements at index >= *n_live are known to be zero -- their tiles are skipped (the caller
+// sized the launch for an upper bound of a device-side length)
 template <typename Load>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(Load ld, int64_t n, int64_t* __restrict__ tile_sums) {
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(Load ld, int64_t n, int64_t* __restrict__ tile_sums,
+                                                                   const int64_t* __restrict__ n_live) {
   __shared__ long long s_wave[SCAN_THREADS / WAVE];
   const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+  if (n_live && base >= *n_live) {  // block-uniform
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = 0;
+    return;
+  }
   long long v = 0;
 #pragma unroll
   for (int q = 0; q < SCAN_ITEMS; ++q) {
@@ -218,8 +225,10 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_tiles_kernel(int64_t* __res
 
 template <typename Load>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(Load ld, int64_t n, const int64_t* __restrict__ tile_sums,
-                                                                      int64_t n_tiles, int64_t* __restrict__ out) {
+                                                                      int64_t n_tiles, int64_t* __restrict__ out,
+                                                                      const int64_t* __restrict__ n_live) {
   __shared__ long long s_wave[SCAN_THREADS / WAVE];
+  if (n_live && (int64_t)blockIdx.x * SCAN_TILE > *n_live) return;  // block-uniform; out[] beyond *n_live is never read
   // thread t owns SCAN_ITEMS consecutive elements so that the scan order is the element order
   const int64_t first = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
   static_assert(SCAN_ITEMS == 8, "load8");
@@ -258,12 +267,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(Load ld, i
 }
 
 template <typename Load>
-static hipError_t launch_scan(hipStream_t st, Load ld, int64_t n, int64_t* out, int64_t* tile_sums) {
+static hipError_t launch_scan(hipStream_t st, Load ld, int64_t n, int64_t* out, int64_t* tile_sums, const int64_t* n_live = nullptr) {
   if (n <= 0) return hipMemsetAsync(out, 0, sizeof(int64_t), st);
   const int64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-  hipLaunchKernelGGL((scan_reduce_kernel<Load>), dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, st, ld, n, tile_sums);
+  hipLaunchKernelGGL((scan_reduce_kernel<Load>), dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, st, ld, n, tile_sums, n_live);
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, tile_sums, n_tiles);
-  hipLaunchKernelGGL((scan_downsweep_kernel<Load>), dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, st, ld, n, tile_sums, n_tiles, out);
+  hipLaunchKernelGGL((scan_downsweep_kernel<Load>), dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, st, ld, n, tile_sums, n_tiles, out, n_live);
   return hipGetLastError();
 }
 hipError_t launch_scan_i32(hipStream_t st, const int32_t* in, int64_t n, int64_t* out, int64_t* tile_sums) {
@@ -492,10 +501,23 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_
                                                                       int32_t max_n, int row_rate_mode, int64_t row_base,
                                                                       unsigned long long* __restrict__ flags,
                                                                       int32_t* __restrict__ post_counts, int vec_ok) {
-  __shared__ long long s_rp[DS_SLICE];
+  __shared__ int s_rel[DS_SLICE];  // row_ptr slice of the tile, relative to the tile start (a row has < 2^31 entries)
   __shared__ long long s_rows[2];
   const int64_t e0 = (int64_t)blockIdx.x * DS_TILE;
   const int64_t e1 = (e0 + DS_TILE < nnz) ? e0 + DS_TILE : nnz;
+  // all four 16-byte column vectors of this thread are requested before anything else (independent of the row lookup)
+  int cols[DS_ITERS][4];
+#pragma unroll
+  for (int it = 0; it < DS_ITERS; ++it) {
+    const int64_t e = e0 + ((int64_t)it * DS_THREADS + threadIdx.x) * 4;
+    if (vec_ok && e + 3 < nnz) {
+      const int4 x = *reinterpret_cast<const int4*>(ci + e);
+      cols[it][0] = x.x; cols[it][1] = x.y; cols[it][2] = x.z; cols[it][3] = x.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cols[it][q] = (e + q < nnz) ? ci[e + q] : 0;
+    }
+  }
   if (threadIdx.x < 2) {
     const int64_t e = threadIdx.x == 0 ? e0 : e1 - 1;
     s_rows[threadIdx.x] = upper_bound_i64(rp, 0, n_rows, e) - 1;  // row holding entry e
@@ -505,45 +527,44 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_
   const int64_t n_slice = r_last - r_first + 2;  // rp[r_first .. r_last+1]
   const bool in_lds = n_slice <= DS_SLICE;
   if (in_lds)
-    for (int64_t t = threadIdx.x; t < n_slice; t += DS_THREADS) s_rp[t] = rp[r_first + t];
+    for (int64_t t = threadIdx.x; t < n_slice; t += DS_THREADS) s_rel[t] = (int)(rp[r_first + t] - e0);
   __syncthreads();
   const double dmax = (double)max_n;
   const int lane = threadIdx.x & (WAVE - 1);
-#pragma unroll 1
+#pragma unroll
   for (int it = 0; it < DS_ITERS; ++it) {  // block-uniform trip count: wave ops below are legal
     const int64_t e = e0 + ((int64_t)it * DS_THREADS + threadIdx.x) * 4;
     unsigned nib = 0;
     if (e < e1) {
-      int cols[4];
-      if (vec_ok && e + 3 < nnz) {
-        const int4 x = *reinterpret_cast<const int4*>(ci + e);
-        cols[0] = x.x; cols[1] = x.y; cols[2] = x.z; cols[3] = x.w;
-      } else {
+      unsigned long long thr_col[4];  // the four threshold gathers travel together
 #pragma unroll
-        for (int q = 0; q < 4; ++q) cols[q] = (e + q < nnz) ? ci[e + q] : 0;
-      }
+      for (int q = 0; q < 4; ++q) thr_col[q] = thresholds[cols[it][q]];
       // row of the first entry
+      const int el = (int)(e - e0);
       int64_t r;
+      int64_t r_beg, r_end;  // relative to e0
       if (in_lds) {
-        int lo = 0, hi = (int)n_slice - 1;  // s_rp[hi] = rp[r_last+1] > e
+        int lo = 0, hi = (int)n_slice - 1;  // s_rel[hi] = rp[r_last+1] - e0 > el
         while (lo < hi) {
           const int mid = (lo + hi) >> 1;
-          if (s_rp[mid] > e) hi = mid; else lo = mid + 1;
+          if (s_rel[mid] > el) hi = mid; else lo = mid + 1;
         }
         r = r_first + lo - 1;
+        r_beg = s_rel[lo - 1];
+        r_end = s_rel[lo];
       } else {
         r = upper_bound_i64(rp, r_first, r_last + 1, e) - 1;
+        r_beg = rp[r] - e0;
+        r_end = rp[r + 1] - e0;
       }
-      int64_t r_end = in_lds ? s_rp[r + 1 - r_first] : rp[r + 1];
-      int64_t r_beg = in_lds ? s_rp[r - r_first] : rp[r];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int64_t ee = e + q;
-        if (ee < e1) {
-          while (ee >= r_end) {  // next non-empty row
+        const int64_t rel = el + q;
+        if (e + q < e1) {
+          while (rel >= r_end) {  // next non-empty row
             ++r;
             r_beg = r_end;
-            r_end = in_lds ? s_rp[r + 1 - r_first] : rp[r + 1];
+            r_end = in_lds ? (int64_t)s_rel[r + 1 - r_first] : rp[r + 1] - e0;
           }
           // u01 = m * 2^-53 with integer m < 2^53, so  u01 <= rate  <=>  m <= floor(rate * 2^53)  (the scaling is exact):
           // the per-column threshold is precomputed (one division per column, not per interaction) and entries whose
@@ -552,9 +573,8 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_
           unsigned long long thr_row = RATE_ONE;
           if (n_row > (int64_t)max_n)
             thr_row = row_rate_mode == 0 ? 0ull /* Int / Int = 0 */ : (unsigned long long)((dmax / (double)n_row) * 9007199254740992.0);
-          const int j = cols[q];
-          const unsigned long long thr_col = thresholds[j];
-          const unsigned long long thr = thr_row < thr_col ? thr_row : thr_col;
+          const int j = cols[it][q];
+          const unsigned long long thr = thr_row < thr_col[q] ? thr_row : thr_col[q];
           if (thr == RATE_ONE || hash53(seed, (uint32_t)(row_base + r), (uint32_t)j) <= thr) {
             nib |= 1u << q;
             if (post_counts) atomicAdd(&post_counts[j], 1);
@@ -731,7 +751,9 @@ __global__ __launch_bounds__(256) void expand_prepare_kernel(const int64_t* __re
                                                              const int64_t* __restrict__ b_rp, int64_t cap, int64_t* __restrict__ pstart,
                                                              int32_t* __restrict__ plen) {
   const int64_t nnz = a_cp[n_items_a];
-  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < cap; p += (int64_t)gridDim.x * 256) {
+  int64_t lim = (nnz / SCAN_TILE + 1) * SCAN_TILE;  // the scan skips tiles that start at or beyond nnz
+  if (lim > cap) lim = cap;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < lim; p += (int64_t)gridDim.x * 256) {
     int32_t len = 0;
     int64_t s = 0;
     if (p < nnz) {
@@ -752,7 +774,7 @@ hipError_t launch_expand_prepare(hipStream_t st, int n_cu, const int64_t* a_col_
     if (blocks > lim) blocks = lim;
     hipLaunchKernelGGL(expand_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, cap, pstart, plen);
   }
-  return launch_scan_i32(st, plen, cap, wp, tile_sums);
+  return launch_scan(st, LoadI32{plen}, cap, wp, tile_sums, a_col_ptr + n_items_a);
 }
 
 __global__ __launch_bounds__(256) void row_work_kernel(int32_t item_lo, int32_t item_hi, const int64_t* __restrict__ a_cp,
