@@ -18,13 +18,6 @@ constexpr int XLX_TABLE_HOST = 4096;     // entries of the small-integer xLogX t
 constexpr int BIN_COLS_HOST = 3 * NBINS + 1;  // int64 per binning tile
 constexpr int STATS_LEN = 20;            // [0] pairs, [1..4] rows/bin, [5..8] pairs/bin, [9..12] users/bin, [13..16] out entries/bin
 
-// per item of B: columnEntropy and interaction count, one 16-byte gather per candidate
-struct alignas(16) ColInfo {
-  double ent;
-  int32_t cnt;
-  int32_t pad;
-};
-
 struct CcoArgs {
   // row lists per bin
   const int32_t* bin_rows;   // item ids grouped by bin
@@ -35,8 +28,9 @@ struct CcoArgs {
   const int64_t* wp;         // per CSC entry (+1): exclusive prefix of B' row lengths over the CSC
   const int32_t* b_col_idx;
   const int32_t* cnt_a;
+  const int32_t* cnt_b;
   const double* ent_a;       // rowEntropy per item of A
-  const ColInfo* info_b;     // columnEntropy + count per item of B
+  const double* ent_b;       // columnEntropy per item of B
   const double* xlx_n;       // [1] xLogX(N)
   const double* xlx_tab;     // [XLX_TABLE_HOST] xLogX of small integers
   int32_t debug;             // ablation switches for profiling (0 in production): 1 = gather only, 2 = no LLR, 4 = no top-k
@@ -85,7 +79,7 @@ hipError_t launch_transpose(hipStream_t st, int n_cu, int64_t n_rows, const int6
                             const int64_t* col_ptr, int32_t* cursor, int32_t* out_row_idx);
 
 hipError_t launch_xlx_table(hipStream_t st, double* tab);
-hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, ColInfo* info, double* xlx_n);
+hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, double* xlx_n);
 
 // pstart[cap], plen[cap] (scratch), wp[cap + 1]; cap >= nnz(A'); tile_sums scratch as for scans over cap elements
 hipError_t launch_expand_prepare(hipStream_t st, int n_cu, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx,

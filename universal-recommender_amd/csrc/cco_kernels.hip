@@ -714,26 +714,18 @@ hipError_t launch_transpose(hipStream_t st, int n_cu, int64_t n_rows, const int6
 // item's interaction count and N only, so they are evaluated once per item, not once per cooccurrence.
 // ============================================================================================
 __global__ __launch_bounds__(256) void item_entropy_kernel(const int32_t* __restrict__ counts, int32_t n, long long n_users,
-                                                           double* __restrict__ ent, ColInfo* __restrict__ info, double* __restrict__ xlx_n) {
+                                                           double* __restrict__ ent, double* __restrict__ xlx_n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) {
     const long long c = counts[i];
-    const double e = entropy2(c, n_users - c);
-    if (ent) ent[i] = e;
-    if (info) {
-      ColInfo ci;
-      ci.ent = e;
-      ci.cnt = (int)c;
-      ci.pad = 0;
-      info[i] = ci;
-    }
+    ent[i] = entropy2(c, n_users - c);
   }
   if (i == 0 && xlx_n) *xlx_n = x_log_x(n_users);
 }
 
-hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, ColInfo* info, double* xlx_n) {
+hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, double* xlx_n) {
   const int blocks = n > 0 ? (n + 255) / 256 : 1;
-  hipLaunchKernelGGL(item_entropy_kernel, dim3(blocks), dim3(256), 0, st, counts, n, n_users, ent, info, xlx_n);
+  hipLaunchKernelGGL(item_entropy_kernel, dim3(blocks), dim3(256), 0, st, counts, n, n_users, ent, xlx_n);
   return hipGetLastError();
 }
 
@@ -1136,23 +1128,13 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
           unsigned t = first;
           while (t < last) {
             const unsigned stop = last < uend ? last : uend;
-            while (t < stop) {  // four column gathers in flight before the first insert
-              const unsigned nb = stop - t < 4u ? stop - t : 4u;
-              unsigned jj[4];
-#pragma unroll
-              for (int x = 0; x < 4; ++x) jj[x] = (unsigned)x < nb ? (unsigned)a.b_col_idx[pos + x] : 0u;
-#pragma unroll
-              for (int x = 0; x < 4; ++x) {
-                if ((unsigned)x < nb) {
-                  if (a.debug & 1) {  // ablation: gather only
-                    if (jj[x] == 0xffffffffu) tab[0] = 1u;
-                  } else if (!tab_insert(tab, jj[x] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) {
-                    atomicAdd(a.err, 1ull);
-                  }
-                }
+            for (; t < stop; ++t, ++pos) {
+              const unsigned jj = (unsigned)a.b_col_idx[pos];
+              if (a.debug & 1) {  // ablation: gather only
+                if (jj == 0xffffffffu) tab[0] = 1u;
+              } else if (!tab_insert(tab, jj + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) {
+                atomicAdd(a.err, 1ull);
               }
-              t += nb;
-              pos += nb;
             }
             if (t < last) {  // next user with a non-empty B' row
               do { ++o; } while (uoff[o + 1] <= t);
@@ -1188,33 +1170,20 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
     {
       const long long ca = a.cnt_a[i];
       const double row_entropy = a.ent_a[i];
-      for (unsigned t0 = (unsigned)tl; t0 < D; t0 += 2 * T) {  // two candidates per trip: both column-info gathers travel together
-        unsigned vv[2];
-        ColInfo cinfo[2];
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-          const unsigned t = t0 + (unsigned)x * T;
-          vv[x] = t < D ? tab[t] : 0u;
-          if (vv[x] != 0u) cinfo[x] = a.info_b[(int)(vv[x] >> cb) - 1];
+      for (unsigned t = (unsigned)tl; t < D; t += T) {
+        const unsigned vv = tab[t];
+        const int j = (int)(vv >> cb) - 1;
+        const long long k11 = (long long)(vv & cmask);
+        unsigned long long key = 0ull;
+        if (!(a.exclude_self && j == i)) {
+          const long long cbj = a.cnt_b[j];
+          const double llr = (a.debug & 2) ? (double)k11
+                                           : llr_from_entropies_tab(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11,
+                                                                    a.n_users - ca - cbj + k11, a.xlx_tab);
+          if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
         }
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-          const unsigned t = t0 + (unsigned)x * T;
-          if (t < D) {
-            const int j = (int)(vv[x] >> cb) - 1;
-            const long long k11 = (long long)(vv[x] & cmask);
-            unsigned long long key = 0ull;
-            if (!(a.exclude_self && j == i)) {
-              const long long cbj = cinfo[x].cnt;
-              const double llr = (a.debug & 2) ? (double)k11
-                                               : llr_from_entropies_tab(row_entropy, cinfo[x].ent, xlx_n, k11, ca - k11, cbj - k11,
-                                                                        a.n_users - ca - cbj + k11, a.xlx_tab);
-              if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
-            }
-            kk[t] = key;
-            n_valid += key != 0ull;
-          }
-        }
+        kk[t] = key;
+        n_valid += key != 0ull;
       }
     }
     if (has_next) {  // the next row's first-chunk operands travel while this row is ranked
@@ -1423,9 +1392,8 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
         const int j = a.b_col_idx[q];
         const long long k11 = atomicExch(&cnt[j], 0);  // exactly one lane claims (and clears) each column
         if (k11 > 0 && !(a.exclude_self && j == i)) {
-          const ColInfo cinfo = a.info_b[j];
-          const long long cbj = cinfo.cnt;
-          const double llr = llr_from_entropies_tab(row_entropy, cinfo.ent, xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11, a.xlx_tab);
+          const long long cbj = a.cnt_b[j];
+          const double llr = llr_from_entropies_tab(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11, a.xlx_tab);
           if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
             const int pos = atomicAdd(&s_ncand, 1);
             ckey[pos] = (unsigned long long)__double_as_longlong(llr);
