@@ -1094,6 +1094,92 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
       cs_nx = a.a_col_ptr[i_nx];
       ce_nx = a.a_col_ptr[i_nx + 1];
     }
+    if (T == WAVE && !(a.debug & 32) && ce - cs <= (int64_t)WAVE && pf_w1 - pf_w0 <= (int64_t)WAVE) {
+      // ---- micro row (one wave, <= 64 users, <= 64 pairs): one pair per lane, a 256-word corner of the table, compaction
+      //      by ballots, one candidate per lane ranked by counting -- no scans, no chunk loop, no selection passes.
+      //      Layout inside the team's table: [0,256) accumulator, [256,320) packed candidates, [384,512) their keys.
+      const unsigned total = (unsigned)(pf_w1 - pf_w0);
+      const bool owns_user = cs + tl < ce;
+      const int64_t my_start = pf_start;
+      const unsigned my_off = owns_user ? (unsigned)(pf_wp - pf_w0) : total;
+      const int row_i = i;
+      const int64_t obase_m = ((int64_t)(row_i - a.item_lo)) * a.k;
+      const long long ca_m = a.cnt_a[row_i];
+      const double row_entropy_m = a.ent_a[row_i];
+      if (has_next) {  // next row's first-chunk operands (the normal path issues these after scoring)
+        const int64_t c1 = cs_nx + T < ce_nx ? cs_nx + T : ce_nx;
+        pf_w0 = a.wp[cs_nx];
+        pf_w1 = a.wp[c1];
+        if (cs_nx + tl < c1) {
+          pf_wp = a.wp[cs_nx + tl];
+          pf_start = a.pstart[cs_nx + tl];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tab[tl + q * WAVE] = 0u;
+      ustart[tl] = my_start;
+      uoff[tl] = my_off;
+      if (tl == 0) uoff[WAVE] = total;
+      wave_sync();
+      const bool ident_m = a.n_cols_b <= 256;
+      if ((unsigned)tl < total) {
+        int lo = 1, hi = WAVE;  // first idx in [1, 64] with uoff[idx] > tl
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (uoff[mid] > (unsigned)tl) hi = mid; else lo = mid + 1;
+        }
+        const int o = lo - 1;
+        const unsigned jj = (unsigned)a.b_col_idx[ustart[o] + ((unsigned)tl - uoff[o])];
+        if (!tab_insert(tab, jj + 1u, cb, 255u, 24, ident_m)) atomicAdd(a.err, 1ull);
+      }
+      wave_sync();
+      unsigned* cand = tab + 256;
+      unsigned long long* kkm = reinterpret_cast<unsigned long long*>(tab + 384);
+      unsigned Dm = 0;
+      const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned v = tab[tl + q * WAVE];
+        const unsigned long long m = __ballot(v != 0u);
+        if (v != 0u) cand[Dm + (unsigned)__popcll(m & lt)] = v;
+        Dm += (unsigned)__popcll(m);
+      }
+      wave_sync();
+      unsigned long long mk = 0ull;
+      int mc = 0x7fffffff;
+      if ((unsigned)tl < Dm) {
+        const unsigned vv = cand[tl];
+        const int j = (int)(vv >> cb) - 1;
+        const long long k11 = (long long)(vv & cmask);
+        if (!(a.exclude_self && j == row_i)) {
+          const long long cbj = a.cnt_b[j];
+          const double llr = (a.debug & 2) ? (double)k11
+                                           : llr_from_entropies_tab(row_entropy_m, a.ent_b[j], xlx_n, k11, ca_m - k11, cbj - k11,
+                                                                    a.n_users - ca_m - cbj + k11, a.xlx_tab);
+          if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
+            mk = (unsigned long long)__double_as_longlong(llr);
+            mc = j;
+          }
+        }
+        kkm[tl] = mk;
+      }
+      wave_sync();
+      const int n_valid_m = __popcll(__ballot(mk != 0ull));
+      if (!(a.debug & 4)) {
+        unsigned rank = 0;
+        for (unsigned u = 0; u < Dm; ++u) {  // broadcast LDS reads
+          const unsigned long long ok = kkm[u];
+          rank += (ok != 0ull && best_before(ok, (int)(cand[u] >> cb) - 1, mk, mc)) ? 1u : 0u;
+        }
+        if (mk != 0ull && rank < (unsigned)a.k) {
+          a.out_idx[obase_m + rank] = mc;
+          a.out_llr[obase_m + rank] = __longlong_as_double((long long)mk);
+        }
+        if (tl == 0) a.out_count[row_i - a.item_lo] = n_valid_m < a.k ? n_valid_m : a.k;
+      }
+      wave_sync();
+      continue;
+    }
 #pragma unroll
     for (int q = 0; q < SPT; ++q) tab[tl + q * T] = 0u;
     team_sync<T>();
