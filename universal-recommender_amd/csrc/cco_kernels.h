@@ -6,8 +6,8 @@
 
 namespace urcco {
 
-constexpr int NBINS = 4;  // accumulator classes: 0 wave-LDS (64 thr, 1024 words), 1 block-LDS (256 thr, 8192 words),
-                          // 2 CU-LDS (1024 thr, 32768 words), 3 global dense counters
+constexpr int NBINS = 5;  // accumulator classes: 0 micro (one wave, <= 64 pairs), 1 wave-LDS (64 thr, 1024 words),
+                          // 2 block-LDS (256 thr, 8192 words), 3 CU-LDS (1024 thr, 32768 words), 4 global dense counters
 
 // Geometry the host side needs for scratch sizing.
 constexpr int SCAN_TILE = 2048;          // elements per scan tile (256 threads x 8)
@@ -16,7 +16,7 @@ constexpr int GLOBAL_BIN_BLOCKS = 64;    // persistent blocks of the global-accu
 constexpr int BIN_TILE = 1024;           // items per binning tile
 constexpr int XLX_TABLE_HOST = 4096;     // entries of the small-integer xLogX table (== XLX_TABLE in cco_device.h)
 constexpr int BIN_COLS_HOST = 3 * NBINS + 1;  // int64 per binning tile
-constexpr int STATS_LEN = 20;            // [0] pairs, [1..4] rows/bin, [5..8] pairs/bin, [9..12] users/bin, [13..16] out entries/bin
+constexpr int STATS_LEN = 24;            // [0] pairs, then NBINS each of rows / pairs / users / out entries per bin, [1 + 4 NBINS] table overflows
 
 struct CcoArgs {
   // row lists per bin
@@ -48,7 +48,7 @@ struct CcoArgs {
   int32_t* out_count;
   int32_t* out_idx;
   double* out_llr;
-  unsigned long long* err;   // stats[17]: LDS table overflows (must stay 0)
+  unsigned long long* err;   // stats[1 + 4 * NBINS]: LDS table overflows (must stay 0)
   // global-accumulator scratch (bin 3)
   int32_t* g_counts;         // [GLOBAL_BIN_BLOCKS][n_cols_b] zero on entry, zero on exit
   unsigned long long* g_cand_key;  // [GLOBAL_BIN_BLOCKS][n_cols_b]

@@ -800,7 +800,8 @@ hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t it
 // Binning (row-tile partitioning of the SpGEMM).  A row goes to the smallest accumulator class that
 // (a) is guaranteed to hold its distinct columns AND their 64-bit LLR keys: 3 w < table words, or 3 n_cols_b < table
 //     words (then slots are addressed by column and never collide), and packed counts cannot overflow;
-// (b) gives it enough lanes: <= 512 pairs -> one wave, <= 8192 -> 256 threads, else 1024 threads.
+// (b) gives it enough lanes: <= 64 pairs and users -> the micro kernel (one pair per lane), <= 512 pairs -> one wave,
+//     <= 8192 -> 256 threads, else 1024 threads.
 // Lists are built by a deterministic tile count / scan / scatter (a global atomic append would serialise
 // hundreds of thousands of increments on four addresses).
 // ============================================================================================
@@ -808,15 +809,16 @@ constexpr int E0 = 1024, E1 = 8192, E2 = 32768;
 
 __device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_cols_b, int32_t count_bits, int32_t k) {
   if (ca <= 0 || w <= 0) return -1;  // no users or no pairs: empty indicator row
-  if (count_bits < 31 && ca > ((1ll << count_bits) - 1)) return 3;
-  int cap_bin = 3;
+  if (count_bits < 31 && ca > ((1ll << count_bits) - 1)) return NBINS - 1;
+  if (w <= 64 && ca <= 64) return 0;  // micro: one pair per lane
+  int cap_bin = NBINS - 1;
   // a table of E words must hold D packed counts + D 64-bit keys + the k selected (key, col): 3 D + 3 k + 1 <= E,
   // with D <= min(w, n_cols_b)
   const long long dmax = (w < (long long)n_cols_b ? w : (long long)n_cols_b) * 3 + (long long)k * 3 + 2;
-  if (dmax <= E0) cap_bin = 0;
-  else if (dmax <= E1) cap_bin = 1;
-  else if (dmax <= E2) cap_bin = 2;
-  const int work_bin = w <= 512 ? 0 : (w <= 8192 ? 1 : 2);
+  if (dmax <= E0) cap_bin = 1;
+  else if (dmax <= E1) cap_bin = 2;
+  else if (dmax <= E2) cap_bin = 3;
+  const int work_bin = w <= 512 ? 1 : (w <= 8192 ? 2 : 3);
   return cap_bin > work_bin ? cap_bin : work_bin;
 }
 
@@ -830,9 +832,10 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo,
   __shared__ long long s_acc[BIN_COLS];
   if (threadIdx.x < BIN_COLS) s_acc[threadIdx.x] = 0;
   __syncthreads();
-  int c[NBINS] = {0, 0, 0, 0};
-  long long pw[NBINS] = {0, 0, 0, 0};
-  long long pu[NBINS] = {0, 0, 0, 0};
+  int c[NBINS];
+  long long pw[NBINS], pu[NBINS];
+#pragma unroll
+  for (int k = 0; k < NBINS; ++k) { c[k] = 0; pw[k] = 0; pu[k] = 0; }
   long long pairs = 0;
 #pragma unroll
   for (int q = 0; q < BIN_ITEMS; ++q) {
@@ -886,9 +889,9 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(int64_t* __restri
       bin_off[k] = off;
       off += (int32_t)s_tot[k];
       if (stats) {
-        stats[1 + k] = s_tot[k];              // rows
-        stats[5 + k] = s_tot[NBINS + k];      // pairs
-        stats[9 + k] = s_tot[2 * NBINS + k];  // users (sum of cA over the bin's rows)
+        stats[1 + k] = s_tot[k];                          // rows
+        stats[1 + NBINS + k] = s_tot[NBINS + k];          // pairs
+        stats[1 + 2 * NBINS + k] = s_tot[2 * NBINS + k];  // users (sum of cA over the bin's rows)
       }
     }
     bin_off[NBINS] = off;
@@ -1093,92 +1096,6 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
       i_nx = a.bin_rows[list_start + li + total_teams];
       cs_nx = a.a_col_ptr[i_nx];
       ce_nx = a.a_col_ptr[i_nx + 1];
-    }
-    if (T == WAVE && !(a.debug & 32) && ce - cs <= (int64_t)WAVE && pf_w1 - pf_w0 <= (int64_t)WAVE) {
-      // ---- micro row (one wave, <= 64 users, <= 64 pairs): one pair per lane, a 256-word corner of the table, compaction
-      //      by ballots, one candidate per lane ranked by counting -- no scans, no chunk loop, no selection passes.
-      //      Layout inside the team's table: [0,256) accumulator, [256,320) packed candidates, [384,512) their keys.
-      const unsigned total = (unsigned)(pf_w1 - pf_w0);
-      const bool owns_user = cs + tl < ce;
-      const int64_t my_start = pf_start;
-      const unsigned my_off = owns_user ? (unsigned)(pf_wp - pf_w0) : total;
-      const int row_i = i;
-      const int64_t obase_m = ((int64_t)(row_i - a.item_lo)) * a.k;
-      const long long ca_m = a.cnt_a[row_i];
-      const double row_entropy_m = a.ent_a[row_i];
-      if (has_next) {  // next row's first-chunk operands (the normal path issues these after scoring)
-        const int64_t c1 = cs_nx + T < ce_nx ? cs_nx + T : ce_nx;
-        pf_w0 = a.wp[cs_nx];
-        pf_w1 = a.wp[c1];
-        if (cs_nx + tl < c1) {
-          pf_wp = a.wp[cs_nx + tl];
-          pf_start = a.pstart[cs_nx + tl];
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) tab[tl + q * WAVE] = 0u;
-      ustart[tl] = my_start;
-      uoff[tl] = my_off;
-      if (tl == 0) uoff[WAVE] = total;
-      wave_sync();
-      const bool ident_m = a.n_cols_b <= 256;
-      if ((unsigned)tl < total) {
-        int lo = 1, hi = WAVE;  // first idx in [1, 64] with uoff[idx] > tl
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (uoff[mid] > (unsigned)tl) hi = mid; else lo = mid + 1;
-        }
-        const int o = lo - 1;
-        const unsigned jj = (unsigned)a.b_col_idx[ustart[o] + ((unsigned)tl - uoff[o])];
-        if (!tab_insert(tab, jj + 1u, cb, 255u, 24, ident_m)) atomicAdd(a.err, 1ull);
-      }
-      wave_sync();
-      unsigned* cand = tab + 256;
-      unsigned long long* kkm = reinterpret_cast<unsigned long long*>(tab + 384);
-      unsigned Dm = 0;
-      const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const unsigned v = tab[tl + q * WAVE];
-        const unsigned long long m = __ballot(v != 0u);
-        if (v != 0u) cand[Dm + (unsigned)__popcll(m & lt)] = v;
-        Dm += (unsigned)__popcll(m);
-      }
-      wave_sync();
-      unsigned long long mk = 0ull;
-      int mc = 0x7fffffff;
-      if ((unsigned)tl < Dm) {
-        const unsigned vv = cand[tl];
-        const int j = (int)(vv >> cb) - 1;
-        const long long k11 = (long long)(vv & cmask);
-        if (!(a.exclude_self && j == row_i)) {
-          const long long cbj = a.cnt_b[j];
-          const double llr = (a.debug & 2) ? (double)k11
-                                           : llr_from_entropies_tab(row_entropy_m, a.ent_b[j], xlx_n, k11, ca_m - k11, cbj - k11,
-                                                                    a.n_users - ca_m - cbj + k11, a.xlx_tab);
-          if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
-            mk = (unsigned long long)__double_as_longlong(llr);
-            mc = j;
-          }
-        }
-        kkm[tl] = mk;
-      }
-      wave_sync();
-      const int n_valid_m = __popcll(__ballot(mk != 0ull));
-      if (!(a.debug & 4)) {
-        unsigned rank = 0;
-        for (unsigned u = 0; u < Dm; ++u) {  // broadcast LDS reads
-          const unsigned long long ok = kkm[u];
-          rank += (ok != 0ull && best_before(ok, (int)(cand[u] >> cb) - 1, mk, mc)) ? 1u : 0u;
-        }
-        if (mk != 0ull && rank < (unsigned)a.k) {
-          a.out_idx[obase_m + rank] = mc;
-          a.out_llr[obase_m + rank] = __longlong_as_double((long long)mk);
-        }
-        if (tl == 0) a.out_count[row_i - a.item_lo] = n_valid_m < a.k ? n_valid_m : a.k;
-      }
-      wave_sync();
-      continue;
     }
 #pragma unroll
     for (int q = 0; q < SPT; ++q) tab[tl + q * T] = 0u;
@@ -1439,7 +1356,119 @@ __global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a
 }
 
 // --------------------------------------------------------------------------------------------
-// Global-accumulator variant (bin 3): rows whose distinct columns cannot be bounded below an LDS table or
+// Micro rows (bin 0): <= 64 users and <= 64 cooccurrence pairs -- more than half of all item rows under a Zipf
+// catalogue.  One wave per row, one pair per lane, a 256-word accumulator, compaction by ballots, at most one
+// candidate per lane ranked by counting: no scans, no chunk loop, no selection passes, few registers (8 waves/SIMD).
+// Team LDS layout (words): [0,256) accumulator, [256,320) packed candidates, [320,448) their 64-bit keys.
+// --------------------------------------------------------------------------------------------
+constexpr int MICRO_WORDS = 448;
+
+__global__ __launch_bounds__(256) void cco_rows_micro_kernel(CcoArgs a) {
+  constexpr int TEAMS = 256 / WAVE;
+  __shared__ unsigned s_tab[TEAMS * MICRO_WORDS];
+  __shared__ long long s_ustart[TEAMS * WAVE];
+  __shared__ unsigned s_uoff[TEAMS * (WAVE + 1)];
+  const int team = threadIdx.x / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1);
+  unsigned* tab = s_tab + team * MICRO_WORDS;
+  unsigned* cand = tab + 256;
+  unsigned long long* kkm = reinterpret_cast<unsigned long long*>(tab + 320);
+  long long* ustart = s_ustart + team * WAVE;
+  unsigned* uoff = s_uoff + team * (WAVE + 1);
+  const int list_start = a.bin_off[0];
+  const int list_n = a.bin_off[1] - list_start;
+  const int total_teams = gridDim.x * TEAMS;
+  const bool ident = a.n_cols_b <= 256;
+  const int cb = a.count_bits;
+  const unsigned cmask = (1u << cb) - 1u;
+  const double xlx_n = *a.xlx_n;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+
+  int li = blockIdx.x * TEAMS + team;
+  int i_nx = 0;
+  int64_t cs_nx = 0, ce_nx = 0;
+  if (li < list_n) {
+    i_nx = a.bin_rows[list_start + li];
+    cs_nx = a.a_col_ptr[i_nx];
+    ce_nx = a.a_col_ptr[i_nx + 1];
+  }
+  for (; li < list_n; li += total_teams) {  // each wave runs its own row loop: wave-level sync only
+    const int i = i_nx;
+    const int64_t cs = cs_nx, ce = ce_nx;
+    if (li + total_teams < list_n) {  // the next row's id and CSC bounds travel while this row is processed
+      i_nx = a.bin_rows[list_start + li + total_teams];
+      cs_nx = a.a_col_ptr[i_nx];
+      ce_nx = a.a_col_ptr[i_nx + 1];
+    }
+    const int64_t w0 = a.wp[cs];
+    const unsigned total = (unsigned)(a.wp[ce] - w0);  // <= 64 by the binning rule
+    const bool owns_user = cs + lane < ce;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tab[lane + q * WAVE] = 0u;
+    ustart[lane] = owns_user ? a.pstart[cs + lane] : 0;
+    uoff[lane] = owns_user ? (unsigned)(a.wp[cs + lane] - w0) : total;
+    if (lane == 0) uoff[WAVE] = total;
+    wave_sync();
+    if ((unsigned)lane < total) {
+      int lo = 1, hi = WAVE;  // first idx in [1, 64] with uoff[idx] > lane
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (uoff[mid] > (unsigned)lane) hi = mid; else lo = mid + 1;
+      }
+      const int o = lo - 1;
+      const unsigned jj = (unsigned)a.b_col_idx[ustart[o] + ((unsigned)lane - uoff[o])];
+      if (!(a.debug & 1) && !tab_insert(tab, jj + 1u, cb, 255u, 24, ident)) atomicAdd(a.err, 1ull);
+    }
+    wave_sync();
+    unsigned D = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned v = tab[lane + q * WAVE];
+      const unsigned long long m = __ballot(v != 0u);
+      if (v != 0u) cand[D + (unsigned)__popcll(m & lt)] = v;
+      D += (unsigned)__popcll(m);
+    }
+    wave_sync();
+    unsigned long long mk = 0ull;
+    int mc = 0x7fffffff;
+    if ((unsigned)lane < D) {
+      const unsigned vv = cand[lane];
+      const int j = (int)(vv >> cb) - 1;
+      const long long k11 = (long long)(vv & cmask);
+      if (!(a.exclude_self && j == i)) {
+        const long long ca = a.cnt_a[i];
+        const long long cbj = a.cnt_b[j];
+        const double llr = (a.debug & 2) ? (double)k11
+                                         : llr_from_entropies_tab(a.ent_a[i], a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11,
+                                                                  a.xlx_tab);
+        if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
+          mk = (unsigned long long)__double_as_longlong(llr);
+          mc = j;
+        }
+      }
+      kkm[lane] = mk;
+    }
+    wave_sync();
+    const int n_valid = __popcll(__ballot(mk != 0ull));
+    if (!(a.debug & 4)) {
+      const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
+      unsigned rank = 0;
+      for (unsigned u = 0; u < D; ++u) {  // broadcast LDS reads
+        const unsigned long long ok = kkm[u];
+        rank += (ok != 0ull && best_before(ok, (int)(cand[u] >> cb) - 1, mk, mc)) ? 1u : 0u;
+      }
+      if (mk != 0ull && rank < (unsigned)a.k) {
+        a.out_idx[obase + rank] = mc;
+        a.out_llr[obase + rank] = __longlong_as_double((long long)mk);
+      }
+      if (lane == 0) a.out_count[i - a.item_lo] = n_valid < a.k ? n_valid : a.k;
+    }
+    wave_sync();
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// Global-accumulator variant (bin 4): rows whose distinct columns cannot be bounded below an LDS table or
 // whose counts overflow the packed entry.  One 1024-thread block per row; a dense int32 counter array per
 // resident block (zero on entry, restored to zero by the claim walk), candidates spilled to global scratch,
 // top-k by k strictly-descending argmax sweeps.  Correct for any row; only meant for the rare heavy ones.
@@ -1451,7 +1480,7 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
   __shared__ unsigned long long s_pkey[2][NW];
   __shared__ int s_pcol[2][NW];
   __shared__ int s_ncand;
-  const int bin = 3;
+  const int bin = NBINS - 1;
   const int list_start = a.bin_off[bin];
   const int list_n = a.bin_off[bin + 1] - list_start;
   int32_t* cnt = a.g_counts + (int64_t)blockIdx.x * a.n_cols_b;
@@ -1546,13 +1575,14 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
 // resident blocks per CU of each LDS-accumulator kernel (registers / LDS decide), so that the persistent grids fill
 // the chip exactly once
 static int blocks_per_cu(int bin) {
-  static int cache[3] = {0, 0, 0};
+  static int cache[4] = {0, 0, 0, 0};
   if (cache[bin] == 0) {
     int n = 0;
     hipError_t e = hipErrorUnknown;
-    if (bin == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<64, E0>, 256, 0);
-    if (bin == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1>, 256, 0);
-    if (bin == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2>, 1024, 0);
+    if (bin == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_micro_kernel, 256, 0);
+    if (bin == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<64, E0>, 256, 0);
+    if (bin == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1>, 256, 0);
+    if (bin == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2>, 1024, 0);
     cache[bin] = (e == hipSuccess && n > 0) ? n : 1;
   }
   return cache[bin];
@@ -1562,15 +1592,16 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
   // Persistent grids sized to the chip; each kernel reads its own row list length from bin_off on the device,
   // so no host synchronisation sits between binning and the SpGEMM.
   switch (bin) {
-    case 0: hipLaunchKernelGGL((cco_rows_kernel<64, E0>), dim3((unsigned)(n_cu * blocks_per_cu(0))), dim3(256), 0, st, args, 0); break;
-    case 1: hipLaunchKernelGGL((cco_rows_kernel<256, E1>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1); break;
-    case 2: hipLaunchKernelGGL((cco_rows_kernel<1024, E2>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(1024), 0, st, args, 2); break;
+    case 0: hipLaunchKernelGGL(cco_rows_micro_kernel, dim3((unsigned)(n_cu * blocks_per_cu(0))), dim3(256), 0, st, args); break;
+    case 1: hipLaunchKernelGGL((cco_rows_kernel<64, E0>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1); break;
+    case 2: hipLaunchKernelGGL((cco_rows_kernel<256, E1>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(256), 0, st, args, 2); break;
+    case 3: hipLaunchKernelGGL((cco_rows_kernel<1024, E2>), dim3((unsigned)(n_cu * blocks_per_cu(3))), dim3(1024), 0, st, args, 3); break;
     default: hipLaunchKernelGGL(cco_rows_global_kernel, dim3(GLOBAL_BIN_BLOCKS), dim3(GB_THREADS), 0, st, args); break;
   }
   return hipGetLastError();
 }
 
-// stats[13 + bin] = indicator entries emitted by the rows of each bin (profiling aid, deterministic block reduce)
+// stats[1 + 3 * NBINS + bin] = indicator entries emitted by the rows of each bin (profiling aid, deterministic block reduce)
 __global__ __launch_bounds__(256) void bin_out_stats_kernel(const int32_t* __restrict__ bin_rows, const int32_t* __restrict__ bin_off,
                                                             int32_t item_lo, const int32_t* __restrict__ out_count, int64_t* __restrict__ stats) {
   __shared__ long long s_wave[SCAN_THREADS / WAVE];
@@ -1579,7 +1610,7 @@ __global__ __launch_bounds__(256) void bin_out_stats_kernel(const int32_t* __res
   for (int t = bin_off[bin] + blockIdx.y * 256 + threadIdx.x; t < bin_off[bin + 1]; t += 256 * gridDim.y) v += out_count[bin_rows[t] - item_lo];
   long long tot;
   block_exclusive_scan(v, s_wave, &tot);
-  if (threadIdx.x == 0 && tot) atomicAdd((unsigned long long*)&stats[13 + bin], (unsigned long long)tot);
+  if (threadIdx.x == 0 && tot) atomicAdd((unsigned long long*)&stats[1 + 3 * NBINS + bin], (unsigned long long)tot);
 }
 hipError_t launch_bin_out_stats(hipStream_t st, const int32_t* bin_rows, const int32_t* bin_off, int32_t item_lo, const int32_t* out_count,
                                 int64_t* stats) {

@@ -415,7 +415,7 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   a.col_bytes = n_cols_b <= (1 << 8) ? 1 : (n_cols_b <= (1 << 16) ? 2 : (n_cols_b <= (1 << 24) ? 3 : 4));
   a.g_log2 = 4;  // 16 lanes stream one user's B' row: 64 B segments, matches the ~10-40 item rows the cut leaves
   a.out_count = out_count; a.out_idx = out_idx; a.out_llr = out_llr;
-  a.err = reinterpret_cast<unsigned long long*>(stats + 17);
+  a.err = reinterpret_cast<unsigned long long*>(stats + 1 + 4 * urcco::NBINS);
   a.g_counts = s->g_counts; a.g_cand_key = s->g_cand_key; a.g_cand_col = s->g_cand_col;
   for (int bin = 0; bin < urcco::NBINS; ++bin) {
     s->begin(URCCO_STAGE_CCO_BIN0 + bin);
@@ -624,7 +624,7 @@ int build_impl(const urcco_dataset* datasets, int32_t n_datasets, int32_t seed, 
       (void)hipEventElapsedTime(&ms, ev0, ev1);
       stats[d].ms_total = ms;
       stats[d].pairs = h_stats[0];
-      for (int b2 = 0; b2 < 4; ++b2) stats[d].rows_by_bin[b2] = h_stats[1 + b2];
+      for (int b2 = 0; b2 < URCCO_N_BINS; ++b2) stats[d].rows_by_bin[b2] = h_stats[1 + b2];
       stats[d].nnz_out = o.nnz;
     }
     bufs.release(o_count); bufs.release(o_idx); bufs.release(o_llr); bufs.release(c_rp); bufs.release(c_idx); bufs.release(c_llr);
