@@ -1392,21 +1392,38 @@ __global__ __launch_bounds__(256) void cco_rows_micro_kernel(CcoArgs a) {
     cs_nx = a.a_col_ptr[i_nx];
     ce_nx = a.a_col_ptr[i_nx + 1];
   }
+  // operands of the row about to be processed, loaded one row ahead (the row loop is a chain of dependent gathers)
+  int64_t pf_w0 = 0, pf_w1 = 0, pf_wp = 0, pf_start = 0;
+  long long pf_ca = 0;
+  double pf_ent = 0.0;
+  if (li < list_n) {
+    pf_w0 = a.wp[cs_nx];
+    pf_w1 = a.wp[ce_nx];
+    if (cs_nx + lane < ce_nx) {
+      pf_wp = a.wp[cs_nx + lane];
+      pf_start = a.pstart[cs_nx + lane];
+    }
+    pf_ca = a.cnt_a[i_nx];
+    pf_ent = a.ent_a[i_nx];
+  }
   for (; li < list_n; li += total_teams) {  // each wave runs its own row loop: wave-level sync only
     const int i = i_nx;
     const int64_t cs = cs_nx, ce = ce_nx;
-    if (li + total_teams < list_n) {  // the next row's id and CSC bounds travel while this row is processed
+    const bool has_next = li + total_teams < list_n;
+    if (has_next) {  // the next row's id and CSC bounds travel while this row is processed
       i_nx = a.bin_rows[list_start + li + total_teams];
       cs_nx = a.a_col_ptr[i_nx];
       ce_nx = a.a_col_ptr[i_nx + 1];
     }
-    const int64_t w0 = a.wp[cs];
-    const unsigned total = (unsigned)(a.wp[ce] - w0);  // <= 64 by the binning rule
+    const int64_t w0 = pf_w0;
+    const unsigned total = (unsigned)(pf_w1 - w0);  // <= 64 by the binning rule
     const bool owns_user = cs + lane < ce;
+    const long long ca = pf_ca;
+    const double row_entropy = pf_ent;
 #pragma unroll
     for (int q = 0; q < 4; ++q) tab[lane + q * WAVE] = 0u;
-    ustart[lane] = owns_user ? a.pstart[cs + lane] : 0;
-    uoff[lane] = owns_user ? (unsigned)(a.wp[cs + lane] - w0) : total;
+    ustart[lane] = owns_user ? pf_start : 0;
+    uoff[lane] = owns_user ? (unsigned)(pf_wp - w0) : total;
     if (lane == 0) uoff[WAVE] = total;
     wave_sync();
     if ((unsigned)lane < total) {
@@ -1420,6 +1437,16 @@ __global__ __launch_bounds__(256) void cco_rows_micro_kernel(CcoArgs a) {
       if (!(a.debug & 1) && !tab_insert(tab, jj + 1u, cb, 255u, 24, ident)) atomicAdd(a.err, 1ull);
     }
     wave_sync();
+    if (has_next) {  // next row's operands (its CSC bounds arrived during the insert phase)
+      pf_w0 = a.wp[cs_nx];
+      pf_w1 = a.wp[ce_nx];
+      if (cs_nx + lane < ce_nx) {
+        pf_wp = a.wp[cs_nx + lane];
+        pf_start = a.pstart[cs_nx + lane];
+      }
+      pf_ca = a.cnt_a[i_nx];
+      pf_ent = a.ent_a[i_nx];
+    }
     unsigned D = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1436,10 +1463,9 @@ __global__ __launch_bounds__(256) void cco_rows_micro_kernel(CcoArgs a) {
       const int j = (int)(vv >> cb) - 1;
       const long long k11 = (long long)(vv & cmask);
       if (!(a.exclude_self && j == i)) {
-        const long long ca = a.cnt_a[i];
         const long long cbj = a.cnt_b[j];
         const double llr = (a.debug & 2) ? (double)k11
-                                         : llr_from_entropies_tab(a.ent_a[i], a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11,
+                                         : llr_from_entropies_tab(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11,
                                                                   a.xlx_tab);
         if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
           mk = (unsigned long long)__double_as_longlong(llr);
