@@ -1483,11 +1483,21 @@ __global__ __launch_bounds__(256) void cco_rows_micro_kernel(CcoArgs a) {
         const unsigned long long ok = kkm[u];
         rank += (ok != 0ull && best_before(ok, (int)(cand[u] >> cb) - 1, mk, mc)) ? 1u : 0u;
       }
-      if (mk != 0ull && rank < (unsigned)a.k) {
-        a.out_idx[obase + rank] = mc;
-        a.out_llr[obase + rank] = __longlong_as_double((long long)mk);
+      // the row is put in order in LDS (the accumulator words are free again) and leaves as contiguous stores
+      wave_sync();
+      unsigned* srt_col = tab;                                                    // [64]
+      unsigned long long* srt_key = reinterpret_cast<unsigned long long*>(tab + 64);  // [64]
+      const unsigned n_out = (unsigned)(n_valid < a.k ? n_valid : a.k);
+      if (mk != 0ull && rank < n_out) {
+        srt_col[rank] = (unsigned)mc;
+        srt_key[rank] = mk;
       }
-      if (lane == 0) a.out_count[i - a.item_lo] = n_valid < a.k ? n_valid : a.k;
+      wave_sync();
+      if ((unsigned)lane < n_out) {
+        a.out_idx[obase + lane] = (int)srt_col[lane];
+        a.out_llr[obase + lane] = __longlong_as_double((long long)srt_key[lane]);
+      }
+      if (lane == 0) a.out_count[i - a.item_lo] = (int)n_out;
     }
     wave_sync();
   }
