@@ -166,15 +166,23 @@ int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_pt
                          int64_t* out_row_ptr, int32_t* out_col_idx, int32_t* post_counts);
 
 /* CSR -> CSC of a (down-sampled) matrix.  counts[n_cols] = its column counts.  out_col_ptr[n_cols+1],
- * out_row_idx[nnz]; order inside a column is unspecified (only integer sums are formed from it). */
+ * out_row_idx[nnz]; order inside a column is unspecified (only integer sums are formed from it).  Only columns in
+ * [col_lo, col_hi) are materialised (the others get empty CSC columns): a rank of a multi-GPU job transposes just the
+ * item range it owns. */
 int urcco_dev_transpose(urcco_session* s, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx,
-                        int64_t nnz, int32_t n_cols, const int32_t* counts, int64_t* out_col_ptr,
-                        int32_t* out_row_idx);
+                        int64_t nnz, int32_t n_cols, const int32_t* counts, int32_t col_lo, int32_t col_hi,
+                        int64_t* out_col_ptr, int32_t* out_row_idx);
 
 /* Upper-bound work per item row of A'B: work[i - item_lo] = sum over users u of item i of d_B(u)
  * (= the cooccurrence pairs row i forms).  Used for accumulator binning and for work-balanced item ranges. */
 int urcco_dev_row_work(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a, const int64_t* a_col_ptr,
                        const int32_t* a_row_idx, int64_t nnz_a_bound, const int64_t* b_row_ptr, int64_t* work);
+
+/* The same per-item work from a USER shard, before any rank holds the whole matrix: work[i] = sum over the shard's
+ * users u that hold item i (rows of a_*) of d_B(u) (rows of b_row_ptr, same users).  Summed over the ranks it equals
+ * urcco_dev_row_work's result.  work[n_items_a] is overwritten. */
+int urcco_dev_row_work_csr(urcco_session* s, int64_t n_rows, const int64_t* a_row_ptr, const int32_t* a_col_idx,
+                           int64_t nnz_a, const int64_t* b_row_ptr, int32_t n_items_a, int64_t* work);
 
 /* Splits items [0, n_items) into n_parts contiguous ranges of ~equal summed work.  bounds_host[n_parts+1]
  * (host memory).  Synchronises. */

@@ -74,7 +74,8 @@ SYMBOLS = {
     "urcco_dev_column_counts": (C.c_int, [_p, C.c_int64, _p, C.c_int32, _p]),
     "urcco_dev_downsample": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int64, C.c_int32, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                        _p, _p, _p]),
-    "urcco_dev_transpose": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int64, C.c_int32, _p, _p, _p]),
+    "urcco_dev_transpose": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int64, C.c_int32, _p, C.c_int32, C.c_int32, _p, _p]),
+    "urcco_dev_row_work_csr": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int64, _p, C.c_int32, _p]),
     "urcco_dev_row_work": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, C.c_int64, _p, _p]),
     "urcco_dev_partition": (C.c_int, [_p, C.c_int32, _p, C.c_int32, C.POINTER(C.c_int32)]),
     "urcco_dev_cco_rows": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, C.c_int64, _p, _p, C.c_int32, _p, _p, C.c_int64, C.c_int32,

@@ -75,8 +75,12 @@ hipError_t launch_downsample_compact(hipStream_t st, int n_cu, int64_t n_rows, c
                                      const unsigned long long* flags, const int64_t* word_prefix, int64_t* out_row_ptr,
                                      int32_t* out_col_idx);
 
+// only columns in [col_lo, col_hi) are transposed (col_ptr must come from launch_scan_i32_range with the same range)
+hipError_t launch_scan_i32_range(hipStream_t st, const int32_t* in, int64_t n, int32_t lo, int32_t hi, int64_t* out, int64_t* tile_sums);
 hipError_t launch_transpose(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int g_log2,
-                            const int64_t* col_ptr, int32_t* cursor, int32_t* out_row_idx);
+                            const int64_t* col_ptr, int32_t* cursor, int32_t* out_row_idx, int32_t col_lo, int32_t col_hi);
+hipError_t launch_row_work_csr(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* a_row_ptr, const int32_t* a_col_idx,
+                               const int64_t* b_row_ptr, int g_log2, int32_t n_items_a, int64_t* work);
 
 hipError_t launch_xlx_table(hipStream_t st, double* tab);
 hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, double* xlx_n);

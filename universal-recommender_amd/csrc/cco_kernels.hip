@@ -683,7 +683,7 @@ hipError_t launch_downsample_compact(hipStream_t st, int n_cu, int64_t n_rows, c
 // ============================================================================================
 __global__ __launch_bounds__(256) void transpose_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
                                                         int g_log2, const int64_t* __restrict__ col_ptr, int32_t* __restrict__ cursor,
-                                                        int32_t* __restrict__ out_rows) {
+                                                        int32_t* __restrict__ out_rows, int32_t col_lo, int32_t col_hi) {
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
   const int64_t groups_per_block = 256 >> g_log2;
@@ -692,20 +692,67 @@ __global__ __launch_bounds__(256) void transpose_kernel(int64_t n_rows, const in
     const int64_t s = rp[r], e = rp[r + 1];
     for (int64_t p = s + gl; p < e; p += G) {
       const int j = ci[p];
+      if (j < col_lo || j >= col_hi) continue;  // a rank only transposes the item range it owns
       const int pos = atomicAdd(&cursor[j], 1);
       out_rows[col_ptr[j] + pos] = (int32_t)r;
     }
   }
 }
 
+struct LoadI32Range {  // counts masked to [lo, hi): columns outside the range get empty CSC columns
+  const int32_t* p;
+  int32_t lo, hi;
+  __device__ __forceinline__ long long operator()(int64_t i) const { return (i >= lo && i < hi) ? p[i] : 0; }
+  __device__ __forceinline__ void load8(int64_t i, long long* x) const {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = (*this)(i + q);
+  }
+};
+hipError_t launch_scan_i32_range(hipStream_t st, const int32_t* in, int64_t n, int32_t lo, int32_t hi, int64_t* out, int64_t* tile_sums) {
+  return launch_scan(st, LoadI32Range{in, lo, hi}, n, out, tile_sums);
+}
+
 hipError_t launch_transpose(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int g_log2,
-                            const int64_t* col_ptr, int32_t* cursor, int32_t* out_row_idx) {
+                            const int64_t* col_ptr, int32_t* cursor, int32_t* out_row_idx, int32_t col_lo, int32_t col_hi) {
   if (n_rows == 0) return hipSuccess;
   const int64_t gpb = 256 >> g_log2;
   int64_t blocks = (n_rows + gpb - 1) / gpb;
   const int64_t cap = (int64_t)n_cu * 8;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, row_ptr, col_idx, g_log2, col_ptr, cursor, out_row_idx);
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, row_ptr, col_idx, g_log2, col_ptr, cursor, out_row_idx, col_lo,
+                     col_hi);
+  return hipGetLastError();
+}
+
+// ============================================================================================
+// Row work from a USER shard (multi-GPU input phase): work[i] += d_B(u) for every local user u holding item i.
+// Summed over the ranks (all-reduce) this is the same w_i the expand prefix yields, but available before any rank
+// holds the whole matrix, so the work-balanced item ranges can be fixed first and every rank transposes only its own
+// range.  L2 atomics; after the interaction cut a column receives <= ~max of them.
+// ============================================================================================
+__global__ __launch_bounds__(256) void row_work_csr_kernel(int64_t n_rows, const int64_t* __restrict__ a_rp, const int32_t* __restrict__ a_ci,
+                                                           const int64_t* __restrict__ b_rp, int g_log2, unsigned long long* __restrict__ work) {
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t groups_per_block = 256 >> g_log2;
+  for (int64_t r = (int64_t)blockIdx.x * groups_per_block + (threadIdx.x >> g_log2); r < n_rows;
+       r += (int64_t)gridDim.x * groups_per_block) {
+    const unsigned long long d = (unsigned long long)(b_rp[r + 1] - b_rp[r]);
+    if (d == 0ull) continue;
+    const int64_t s = a_rp[r], e = a_rp[r + 1];
+    for (int64_t p = s + gl; p < e; p += G) atomicAdd(&work[a_ci[p]], d);
+  }
+}
+hipError_t launch_row_work_csr(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* a_row_ptr, const int32_t* a_col_idx,
+                               const int64_t* b_row_ptr, int g_log2, int32_t n_items_a, int64_t* work) {
+  hipError_t e = hipMemsetAsync(work, 0, sizeof(int64_t) * (size_t)n_items_a, st);
+  if (e != hipSuccess || n_rows == 0) return e;
+  const int64_t gpb = 256 >> g_log2;
+  int64_t blocks = (n_rows + gpb - 1) / gpb;
+  const int64_t cap = (int64_t)n_cu * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(row_work_csr_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, a_row_ptr, a_col_idx, b_row_ptr, g_log2,
+                     reinterpret_cast<unsigned long long*>(work));
   return hipGetLastError();
 }
 

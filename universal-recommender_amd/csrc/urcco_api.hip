@@ -290,22 +290,36 @@ int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_pt
 }
 
 int urcco_dev_transpose(urcco_session* s, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
-                        const int32_t* counts, int64_t* out_col_ptr, int32_t* out_row_idx) {
-  if (!s || n_rows < 0 || nnz < 0 || n_cols < 0 || !row_ptr || !out_col_ptr || (n_cols > 0 && !counts) || (nnz > 0 && (!col_idx || !out_row_idx)))
+                        const int32_t* counts, int32_t col_lo, int32_t col_hi, int64_t* out_col_ptr, int32_t* out_row_idx) {
+  if (!s || n_rows < 0 || nnz < 0 || n_cols < 0 || !row_ptr || !out_col_ptr || (n_cols > 0 && !counts) || (nnz > 0 && (!col_idx || !out_row_idx)) ||
+      col_lo < 0 || col_hi < col_lo || col_hi > n_cols)
     return fail(URCCO_BAD_ARG, "urcco_dev_transpose: bad argument");
   const int64_t n_tiles = ((int64_t)n_cols + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
   URC(s->reserve(urcco_session::need((size_t)n_cols, 4) + urcco_session::need((size_t)n_tiles + 2, 8)));
   int32_t* cursor = s->take<int32_t>((size_t)n_cols);
   int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
   s->begin(URCCO_STAGE_TRANSPOSE);
-  HIPC(urcco::launch_scan_i32(s->stream, counts, n_cols, out_col_ptr, tile_sums));
+  HIPC(urcco::launch_scan_i32_range(s->stream, counts, n_cols, col_lo, col_hi, out_col_ptr, tile_sums));
   if (nnz > 0 && n_rows > 0) {
     HIPC(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)n_cols, s->stream));
     int g = ceil_log2_i64((nnz + n_rows - 1) / n_rows);
     if (g < 1) g = 1;
     if (g > 6) g = 6;
-    HIPC(urcco::launch_transpose(s->stream, s->n_cu, n_rows, row_ptr, col_idx, g, out_col_ptr, cursor, out_row_idx));
+    HIPC(urcco::launch_transpose(s->stream, s->n_cu, n_rows, row_ptr, col_idx, g, out_col_ptr, cursor, out_row_idx, col_lo, col_hi));
   }
+  s->end();
+  return URCCO_OK;
+}
+
+int urcco_dev_row_work_csr(urcco_session* s, int64_t n_rows, const int64_t* a_row_ptr, const int32_t* a_col_idx, int64_t nnz_a, const int64_t* b_row_ptr,
+                           int32_t n_items_a, int64_t* work) {
+  if (!s || n_rows < 0 || nnz_a < 0 || n_items_a < 0 || !a_row_ptr || !b_row_ptr || (nnz_a > 0 && !a_col_idx) || (n_items_a > 0 && !work))
+    return fail(URCCO_BAD_ARG, "urcco_dev_row_work_csr: bad argument");
+  int g = n_rows > 0 ? ceil_log2_i64((nnz_a + n_rows - 1) / n_rows) : 1;
+  if (g < 1) g = 1;
+  if (g > 6) g = 6;
+  s->begin(URCCO_STAGE_ROW_WORK);
+  HIPC(urcco::launch_row_work_csr(s->stream, s->n_cu, n_rows, a_row_ptr, a_col_idx, b_row_ptr, g, n_items_a, work));
   s->end();
   return URCCO_OK;
 }
@@ -572,7 +586,7 @@ int build_impl(const urcco_dataset* datasets, int32_t n_datasets, int32_t seed, 
   int32_t* a_row_idx = nullptr;
   URC(bufs.alloc(&a_col_ptr, (size_t)n_items_a + 1));
   URC(bufs.alloc(&a_row_idx, (size_t)a.nnz));
-  URC(urcco_dev_transpose(s, n_users, a.row_ptr, a.col_idx, a.nnz, n_items_a, a.counts, a_col_ptr, a_row_idx));
+  URC(urcco_dev_transpose(s, n_users, a.row_ptr, a.col_idx, a.nnz, n_items_a, a.counts, 0, n_items_a, a_col_ptr, a_row_idx));
 
   for (int d = 0; d < n_datasets; ++d) {
     SampledMatrix b = a;

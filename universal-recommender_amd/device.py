@@ -124,12 +124,21 @@ class DeviceSession:
                                                  _ptr(post)))
         return DevCsr(m.n_rows, m.n_cols, out_rp, out_ci, nnz), post
 
-    def transpose(self, m: DevCsr, counts: torch.Tensor):
+    def transpose(self, m: DevCsr, counts: torch.Tensor, col_lo: int = 0, col_hi: Optional[int] = None):
+        """CSC of m; only columns in [col_lo, col_hi) are materialised (the others are empty)."""
+        col_hi = m.n_cols if col_hi is None else col_hi
         col_ptr = self.empty(m.n_cols + 1, torch.int64)
         row_idx = self.empty(max(m.nnz_bound, 1), torch.int32)
         self._check(self.lib.urcco_dev_transpose(self.handle, m.n_rows, _ptr(m.row_ptr), _ptr(m.col_idx), m.nnz_bound, m.n_cols, _ptr(counts),
-                                                _ptr(col_ptr), _ptr(row_idx)))
+                                                col_lo, col_hi, _ptr(col_ptr), _ptr(row_idx)))
         return col_ptr, row_idx
+
+    def row_work_csr(self, a: DevCsr, b_row_ptr: torch.Tensor) -> torch.Tensor:
+        """Per-item work contributed by this user shard (sum over ranks = row_work)."""
+        work = self.empty(max(a.n_cols, 1), torch.int64)
+        self._check(self.lib.urcco_dev_row_work_csr(self.handle, a.n_rows, _ptr(a.row_ptr), _ptr(a.col_idx), a.nnz_bound, _ptr(b_row_ptr), a.n_cols,
+                                                   _ptr(work)))
+        return work[: a.n_cols]
 
     def row_work(self, item_lo: int, item_hi: int, n_items_a: int, a_col_ptr, a_row_idx, nnz_a_bound: int, b_row_ptr) -> torch.Tensor:
         work = self.empty(max(item_hi - item_lo, 1), torch.int64)

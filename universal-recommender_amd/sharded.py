@@ -9,10 +9,12 @@ The path shards with ONE exchange step:
   exchange      -- all-gather of the down-sampled CSR shards (variable length: padded to the largest shard, then
                    compacted), after which every rank holds A' and each B'_i whole;
   compute phase -- items of A are split into world_size contiguous ranges of equal summed row work (not equal count:
-                   Zipf skew) and each rank emits the indicator rows of its range -- disjoint rows, no further traffic.
+                   Zipf skew; the per-item work is summed from the user shards by one all-reduce, so the ranges are known
+                   before any whole-matrix work), each rank transposes and expands ONLY its item range of A' and emits
+                   the indicator rows of that range -- disjoint rows, no further traffic.
 
-Collectives per event type: 2 small all-reduces (int32[n_items]) + 1 all-gather of row lengths + 1 all-gather of
-column indices.  Mahout does the same job with Spark broadcasts of the count vectors and a shuffle inside `A.t %*% B`
+Collectives per event type: 2 small all-reduces (int32[n_items]) + 1 all-reduce of the row work (int64[n_items]) +
+1 all-gather of row lengths + 1 all-gather of column indices.  Mahout does the same job with Spark broadcasts of the count vectors and a shuffle inside `A.t %*% B`
 (reference call sites URAlgorithm.scala:323-346).  With world_size == 1 nothing is exchanged.
 """
 from __future__ import annotations
@@ -84,35 +86,42 @@ def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], para
         raise ValueError("need one DatasetParams per matrix and at least the primary matrix")
 
     def sample(m: DevCsr, p: DatasetParams):
+        """-> (local down-sampled shard, whole down-sampled matrix, global post-sampling column counts)"""
         raw = sess.column_counts(m.col_idx, m.nnz_bound, m.n_cols)
         if world > 1:
             _all_reduce_sum(raw, group)
         local, post = sess.downsample(m, m.nnz_bound, raw, seed, p.max_elements_per_row, row_rate_mode, row_base)
         if world == 1:
-            return local, post, None
+            return local, local, post
         _all_reduce_sum(post, group)
-        whole = _gather_sampled(sess, local, n_rows_global, group)
-        return whole, post, whole.nnz_bound
+        return local, _gather_sampled(sess, local, n_rows_global, group), post
 
-    a, cnt_a, nnz_a = sample(shards[0], params[0])
-    a_col_ptr, a_row_idx = sess.transpose(a, cnt_a)
+    a_loc, a, cnt_a = sample(shards[0], params[0])
     n_items_a = a.n_cols
+    if world == 1:
+        a_col_ptr, a_row_idx = sess.transpose(a, cnt_a)
     out: List[DevIndicators] = []
     ranges: List[List[int]] = []
     nnzs: List[int] = []
     for d, (m, p) in enumerate(zip(shards, params)):
         if d == 0:
-            b, cnt_b, nnz_b = a, cnt_a, nnz_a
+            b_loc, b, cnt_b = a_loc, a, cnt_a
         else:
-            b, cnt_b, nnz_b = sample(m, p)
+            b_loc, b, cnt_b = sample(m, p)
         if world > 1:
-            work = sess.row_work(0, n_items_a, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b.row_ptr)
-            bounds = sess.partition(work, world)   # same inputs on every rank -> same bounds, no communication
+            # work-balanced item ranges BEFORE any whole-matrix work: every rank adds up the row work its own users
+            # contribute, one all-reduce makes it global, the same prefix split runs on every rank (same bounds, no
+            # further communication).  Then a rank transposes and expands only the item range it owns.
+            work = sess.row_work_csr(a_loc, b_loc.row_ptr)
+            _all_reduce_sum(work, group)
+            bounds = sess.partition(work, world)
+            a_col_ptr, a_row_idx = sess.transpose(a, cnt_a, bounds[rank], bounds[rank + 1])
         else:
             bounds = [0, n_items_a]
-        out.append(sess.cco_rows(bounds[rank], bounds[rank + 1], n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b, cnt_a, cnt_b, n_rows_global, d == 0, p))
+        out.append(sess.cco_rows(bounds[rank], bounds[rank + 1], n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b, cnt_a, cnt_b, n_rows_global,
+                                 d == 0, p))
         ranges.append(bounds)
-        nnzs.append(-1 if nnz_b is None else nnz_b)
+        nnzs.append(b.nnz_bound if world > 1 else -1)
     return ShardedResult(out, ranges, nnzs)
 
 
