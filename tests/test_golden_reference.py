@@ -126,3 +126,31 @@ def test_host_mirror_builds_the_same_model_as_the_oracle(sim_lib):
                 model.setdefault(item, {}).update(m)
         ref, _ = _oracle_model(doc, by_event)
         assert model == ref
+
+
+def test_model_documents_match_the_oracle_and_the_reference_document_shape(sim_lib, tmp_path):
+    """URModel.save's per-item documents (URModel.scala:57-75): {id, <event>: [ids strongest first], ...props}."""
+    from universal_recommender_amd.data_source import DataSource, DataSourceParams
+    from universal_recommender_amd.preparator import Preparator
+    from universal_recommender_amd.ur_algorithm import URAlgorithm, URAlgorithmParams
+    from universal_recommender_amd.ur_model import URModel
+    doc, by_event, _, items = _load("handmade.json")
+    lines = [",".join(e) for e in doc["events"]] + [f"{i},$set,{p}" for i, p in doc["sets"]]
+    engine = {"datasource": {"params": doc["datasource_params"]}, "algorithms": [{"name": "ur", "params": doc["algorithm_params"]}]}
+    td = DataSource(DataSourceParams.from_engine_json(engine)).readTraining(lines)
+    ap = URAlgorithmParams.from_engine_json(engine)
+    ap.seed = 1
+    model = URModel(URAlgorithm(ap, library=sim_lib).train(Preparator().prepare(td)), [td.fields])
+    docs = {d["id"]: d for d in model.documents()}
+    ref, _ = _oracle_model(doc, by_event)
+    props = item_properties(doc["sets"])
+    assert set(docs) == set(ref) | set(props)                       # full outer join of indicators and properties
+    for item, d in docs.items():
+        for ev in ("purchase", "view", "category-pref"):
+            assert d.get(ev) == ref.get(item, {}).get(ev)
+        for name, values in props.get(item, {}).items():
+            assert d[name] == values
+    assert docs["Iphone 4"]["view"] == ["Soap", "Tablets"] and "purchase" not in docs["Galaxy"]
+    n = model.save(str(tmp_path / "model.ndjson"))
+    out = [json.loads(l) for l in open(tmp_path / "model.ndjson")]
+    assert n == len(docs) and len(out) == 2 * n and out[0]["index"]["_id"] == out[1]["id"]
