@@ -182,3 +182,19 @@ def test_hardware_execution_equals_simulated_logic(gpu_session, sim_session):
     for a, b in zip(g, s):
         for x, y in zip(a.to_host(), b.to_host()):
             assert np.array_equal(x, y)
+
+
+def test_exchange_path_over_rccl_on_one_gpu():
+    """The N > 1 exchange path (RCCL all-reduce / all-gather, work-balanced ranges, per-range transpose) in a one-rank
+    `nccl` group on the real GPU, launched exactly as the driver launches bench.py (torch.distributed.run)."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(here, "dist_one_gpu.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "EXCHANGE_PATH_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

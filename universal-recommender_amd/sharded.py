@@ -37,8 +37,7 @@ class ShardedResult:
 
 
 def _all_reduce_sum(t: torch.Tensor, group) -> None:
-    if dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
 def _gather_sampled(sess: DeviceSession, local: DevCsr, n_rows_global: int, group) -> DevCsr:
@@ -77,11 +76,13 @@ def _gather_sampled(sess: DeviceSession, local: DevCsr, n_rows_global: int, grou
 
 def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], params: Sequence[DatasetParams], seed: int,
                              n_rows_global: int, row_base: int, row_rate_mode: int = _lib.ROW_RATE_MAHOUT_INT_DIV,
-                             group=None) -> ShardedResult:
+                             group=None, force_exchange: bool = False) -> ShardedResult:
     """SimilarityAnalysis.crossOccurrenceDownsampled over world_size GPUs.  shards[d] = this rank's user rows of
-    event type d (shards[0] = primary)."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    event type d (shards[0] = primary).  force_exchange runs the collectives and the range logic even in a one-rank
+    group (used to exercise the RCCL path on a single GPU)."""
+    n_ranks = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = 2 if (force_exchange and n_ranks == 1 and dist.is_initialized()) else n_ranks  # > 1 selects the exchange path
     if len(shards) == 0 or len(shards) != len(params):
         raise ValueError("need one DatasetParams per matrix and at least the primary matrix")
 
@@ -114,7 +115,7 @@ def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], para
             # further communication).  Then a rank transposes and expands only the item range it owns.
             work = sess.row_work_csr(a_loc, b_loc.row_ptr)
             _all_reduce_sum(work, group)
-            bounds = sess.partition(work, world)
+            bounds = sess.partition(work, n_ranks)
             a_col_ptr, a_row_idx = sess.transpose(a, cnt_a, bounds[rank], bounds[rank + 1])
         else:
             bounds = [0, n_items_a]
