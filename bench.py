@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; the reported config says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="debug: run the N > 1 code path (RCCL collectives, range-restricted transpose) in a one-rank group")
     ap.add_argument("--seed", type=int, default=20260925)
     args = ap.parse_args()
 
@@ -80,8 +82,12 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the CCO path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = world > 1 or args.force_exchange
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from universal_recommender_amd import _lib, sharded, synth
@@ -106,10 +112,10 @@ def main():
     sess = DeviceSession(dev, _lib.load(_lib.DEFAULT_PATH))
 
     def step():
-        return sharded.cross_occurrence_sharded(sess, shards, params, args.seed, cfg.n_users, lo)
+        return sharded.cross_occurrence_sharded(sess, shards, params, args.seed, cfg.n_users, lo, force_exchange=args.force_exchange)
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -124,7 +130,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timings = sess.get_timings()
     sess.set_timing(False)
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -132,7 +138,7 @@ def main():
     # ---- facts about the last step (identical every step: the build is a pure function of inputs + seed) ----
     stats = torch.stack([ind.stats for ind in res.indicators]).clone()
     nnz_out = torch.tensor([int(ind.row_ptr[-1]) for ind in res.indicators], dtype=torch.int64, device=dev)
-    if world > 1:
+    if distributed:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         dist.all_reduce(nnz_out, op=dist.ReduceOp.SUM)
     stats = stats.cpu().numpy()
@@ -145,8 +151,7 @@ def main():
     value = pairs / (elapsed / args.steps)
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     # ---- per-kernel table + roofline of the dominant kernel (rank 0's HIP-event timings) ----------------
@@ -234,7 +239,7 @@ def main():
         "host_generation_s": round(gen_s, 1),
     }
     print(json.dumps(line))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 
