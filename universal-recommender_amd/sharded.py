@@ -40,17 +40,25 @@ def _all_reduce_sum(t: torch.Tensor, group) -> None:
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
-def _gather_sampled(sess: DeviceSession, local: DevCsr, n_rows_global: int, group) -> DevCsr:
-    """All-gather a down-sampled row shard into the whole matrix (rows in rank order)."""
+def _exchange_sizes(locals_: Sequence[DevCsr], group) -> List[List[List[int]]]:
+    """(rows, nnz) of every rank's down-sampled shard for ALL event types in one tiny all-gather: the first of the two
+    host syncs of a multi-GPU build (it sizes the receive buffers of the exchange)."""
     world = dist.get_world_size(group)
-    dev = local.row_ptr.device
-    # per-rank (rows, nnz): one tiny all-gather, the only host sync of the exchange (sizes the receive buffers)
-    mine = torch.stack([torch.tensor(local.n_rows, dtype=torch.int64, device=dev), local.row_ptr[-1]])
-    sizes = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    dev = locals_[0].row_ptr.device
+    mine = torch.stack([v for m in locals_ for v in (torch.tensor(m.n_rows, dtype=torch.int64, device=dev), m.row_ptr[-1])])
+    sizes = torch.empty(world * mine.numel(), dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(sizes, mine, group=group)
-    sizes = sizes.cpu().view(world, 2)
-    rows = [int(x) for x in sizes[:, 0]]
-    nnzs = [int(x) for x in sizes[:, 1]]
+    sizes = sizes.cpu().view(world, len(locals_), 2)
+    return [[[int(sizes[r, d, 0]), int(sizes[r, d, 1])] for r in range(world)] for d in range(len(locals_))]
+
+
+def _gather_sampled(local: DevCsr, sizes: List[List[int]], n_rows_global: int, group) -> DevCsr:
+    """All-gather a down-sampled row shard into the whole matrix (rows in rank order).  sizes[r] = (rows, nnz) of rank r."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = local.row_ptr.device
+    rows = [s[0] for s in sizes]
+    nnzs = [s[1] for s in sizes]
     if sum(rows) != n_rows_global:
         raise ValueError(f"row shards sum to {sum(rows)} rows, expected {n_rows_global}")
     max_rows, max_nnz = max(rows), max(max(nnzs), 1)
@@ -60,14 +68,16 @@ def _gather_sampled(sess: DeviceSession, local: DevCsr, n_rows_global: int, grou
     all_deg = torch.empty(world * max_rows, dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(all_deg, deg, group=group)
     ci = torch.zeros(max_nnz, dtype=torch.int32, device=dev)
-    rank = dist.get_rank(group)
     ci[: nnzs[rank]] = local.col_idx[: nnzs[rank]]
     all_ci = torch.empty(world * max_nnz, dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(all_ci, ci, group=group)
-    deg_cat = torch.cat([all_deg[r * max_rows: r * max_rows + rows[r]] for r in range(world)])
+    if world == 1:
+        deg_cat, col_idx = all_deg[: rows[0]], all_ci[: max(nnzs[0], 1)]
+    else:
+        deg_cat = torch.cat([all_deg[r * max_rows: r * max_rows + rows[r]] for r in range(world)])
+        col_idx = torch.cat([all_ci[r * max_nnz: r * max_nnz + nnzs[r]] for r in range(world)])
     row_ptr = torch.zeros(n_rows_global + 1, dtype=torch.int64, device=dev)
     torch.cumsum(deg_cat, 0, out=row_ptr[1:])
-    col_idx = torch.cat([all_ci[r * max_nnz: r * max_nnz + nnzs[r]] for r in range(world)])
     total = sum(nnzs)
     if total == 0:
         col_idx = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -82,48 +92,52 @@ def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], para
     group (used to exercise the RCCL path on a single GPU)."""
     n_ranks = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    world = 2 if (force_exchange and n_ranks == 1 and dist.is_initialized()) else n_ranks  # > 1 selects the exchange path
+    exchange = n_ranks > 1 or (force_exchange and dist.is_initialized())
     if len(shards) == 0 or len(shards) != len(params):
         raise ValueError("need one DatasetParams per matrix and at least the primary matrix")
+    n_items_a = shards[0].n_cols
+    n_ds = len(shards)
 
-    def sample(m: DevCsr, p: DatasetParams):
-        """-> (local down-sampled shard, whole down-sampled matrix, global post-sampling column counts)"""
+    # ---- input phase: every event type's shard is down-sampled (nothing here waits for the host)
+    locals_: List[DevCsr] = []
+    counts: List[torch.Tensor] = []
+    for m, p in zip(shards, params):
         raw = sess.column_counts(m.col_idx, m.nnz_bound, m.n_cols)
-        if world > 1:
+        if exchange:
             _all_reduce_sum(raw, group)
         local, post = sess.downsample(m, m.nnz_bound, raw, seed, p.max_elements_per_row, row_rate_mode, row_base)
-        if world == 1:
-            return local, local, post
-        _all_reduce_sum(post, group)
-        return local, _gather_sampled(sess, local, n_rows_global, group), post
+        if exchange:
+            _all_reduce_sum(post, group)
+        locals_.append(local)
+        counts.append(post)
 
-    a_loc, a, cnt_a = sample(shards[0], params[0])
-    n_items_a = a.n_cols
-    if world == 1:
-        a_col_ptr, a_row_idx = sess.transpose(a, cnt_a)
+    if not exchange:
+        a = locals_[0]
+        a_col_ptr, a_row_idx = sess.transpose(a, counts[0])
+        out = [sess.cco_rows(0, n_items_a, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, locals_[d], counts[0], counts[d], n_rows_global, d == 0,
+                             params[d]) for d in range(n_ds)]
+        return ShardedResult(out, [[0, n_items_a]] * n_ds, [-1] * n_ds)
+
+    # ---- work-balanced item ranges, fixed BEFORE any whole-matrix work: every rank adds up the row work its own users
+    #      contribute (per event type), one all-reduce makes it global, the same prefix split runs on every rank.
+    works = []
+    for d in range(n_ds):
+        w = sess.row_work_csr(locals_[0], locals_[d].row_ptr)
+        _all_reduce_sum(w, group)
+        works.append(w)
+    # ---- exchange: sizes of all shards in one tiny all-gather (host sync #1), then the all-gathers
+    sizes = _exchange_sizes(locals_, group)
+    wholes = [_gather_sampled(locals_[d], sizes[d], n_rows_global, group) for d in range(n_ds)]
+    bounds_all = [sess.partition(works[d], n_ranks) for d in range(n_ds)]   # host sync #2 (one small D2H per event type, GPU idle-free: queued behind the gathers)
+    # ---- compute phase: a rank transposes and expands only the item range it owns
+    a = wholes[0]
     out: List[DevIndicators] = []
-    ranges: List[List[int]] = []
-    nnzs: List[int] = []
-    for d, (m, p) in enumerate(zip(shards, params)):
-        if d == 0:
-            b_loc, b, cnt_b = a_loc, a, cnt_a
-        else:
-            b_loc, b, cnt_b = sample(m, p)
-        if world > 1:
-            # work-balanced item ranges BEFORE any whole-matrix work: every rank adds up the row work its own users
-            # contribute, one all-reduce makes it global, the same prefix split runs on every rank (same bounds, no
-            # further communication).  Then a rank transposes and expands only the item range it owns.
-            work = sess.row_work_csr(a_loc, b_loc.row_ptr)
-            _all_reduce_sum(work, group)
-            bounds = sess.partition(work, n_ranks)
-            a_col_ptr, a_row_idx = sess.transpose(a, cnt_a, bounds[rank], bounds[rank + 1])
-        else:
-            bounds = [0, n_items_a]
-        out.append(sess.cco_rows(bounds[rank], bounds[rank + 1], n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b, cnt_a, cnt_b, n_rows_global,
-                                 d == 0, p))
-        ranges.append(bounds)
-        nnzs.append(b.nnz_bound if world > 1 else -1)
-    return ShardedResult(out, ranges, nnzs)
+    for d in range(n_ds):
+        bounds = bounds_all[d]
+        a_col_ptr, a_row_idx = sess.transpose(a, counts[0], bounds[rank], bounds[rank + 1])
+        out.append(sess.cco_rows(bounds[rank], bounds[rank + 1], n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, wholes[d], counts[0], counts[d],
+                                 n_rows_global, d == 0, params[d]))
+    return ShardedResult(out, bounds_all, [w.nnz_bound for w in wholes])
 
 
 def gather_indicators_to_host(res: ShardedResult, group=None):
