@@ -92,6 +92,12 @@ def main():
 
     from universal_recommender_amd import _lib, sharded, synth
     from universal_recommender_amd.device import DatasetParams, DevCsr, DeviceSession
+    if not os.path.exists(_lib.DEFAULT_PATH):   # the in-tree HIP library normally travels with the repo; build it otherwise
+        if local_rank == 0:
+            import __graft_entry__
+            __graft_entry__.build_hip()
+        if distributed:
+            dist.barrier()
 
     # ---- workload -------------------------------------------------------------------------------------
     base = synth.config3(args.scale)

@@ -38,6 +38,8 @@ def gpu_session():
     from universal_recommender_amd import _lib
     from universal_recommender_amd.device import DeviceSession
     assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    import __graft_entry__
+    __graft_entry__.build_hip()   # no-op when the in-tree liburcco.so is newer than its sources
     s = DeviceSession(torch.device("cuda", 0), _lib.load(_lib.DEFAULT_PATH))
     yield s
     s.close()
