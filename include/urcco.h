@@ -84,13 +84,13 @@ typedef struct urcco_indicators {
   double* llr;
 } urcco_indicators;
 
-#define URCCO_N_BINS 5
+#define URCCO_N_BINS 6
 typedef struct urcco_dataset_stats {
   int64_t nnz_raw;     /* interactions before down-sampling */
   int64_t nnz_sampled; /* after sampleDownAndBinarize */
   int64_t pairs;       /* cooccurrence pairs formed: sum_u d_A'(u) * d_B'(u) (the metric's unit) */
   int64_t nnz_out;     /* indicator entries emitted */
-  int64_t rows_by_bin[5]; /* item rows per accumulator class: micro, wave-LDS, block-LDS, CU-LDS, global (URCCO_N_BINS) */
+  int64_t rows_by_bin[6]; /* item rows per accumulator class: micro, wave, small block, block, CU, global (URCCO_N_BINS) */
   double ms_total;     /* device time of this dataset's stages (HIP events) */
 } urcco_dataset_stats;
 
@@ -138,10 +138,11 @@ enum {
   URCCO_STAGE_ENTROPY = 7,
   URCCO_STAGE_CCO_BIN0 = 8,  /* micro rows (<= 64 pairs)    */
   URCCO_STAGE_CCO_BIN1 = 9,  /* wave-LDS accumulator rows   */
-  URCCO_STAGE_CCO_BIN2 = 10, /* block-LDS accumulator rows  */
-  URCCO_STAGE_CCO_BIN3 = 11, /* CU-LDS accumulator rows     */
-  URCCO_STAGE_CCO_BIN4 = 12, /* global accumulator rows     */
-  URCCO_STAGE_COMPACT_INDICATORS = 13
+  URCCO_STAGE_CCO_BIN2 = 10, /* small block-LDS rows        */
+  URCCO_STAGE_CCO_BIN3 = 11, /* block-LDS accumulator rows  */
+  URCCO_STAGE_CCO_BIN4 = 12, /* CU-LDS accumulator rows     */
+  URCCO_STAGE_CCO_BIN5 = 13, /* global accumulator rows     */
+  URCCO_STAGE_COMPACT_INDICATORS = 14
 };
 int urcco_session_set_timing(urcco_session* s, int32_t enable);
 /* Profiling aid: kernel ablation switches (1 = gather only, 2 = no LLR, 4 = no top-k); results are meaningless when
@@ -198,7 +199,7 @@ int urcco_dev_partition(urcco_session* s, int32_t n_items, const int64_t* work, 
  * (llr desc, col asc).  stats_dev (nullable, device int64[URCCO_STATS_LEN]): [0] pairs, then URCCO_N_BINS entries each
  * of rows / pairs / users (sum of cA) / emitted entries per accumulator bin (the last group only while timing is
  * enabled), then [1 + 4 * URCCO_N_BINS] accumulator-table overflows (an internal invariant: must be 0). */
-#define URCCO_STATS_LEN 24
+#define URCCO_STATS_LEN 32
 int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a,
                        const int64_t* a_col_ptr, const int32_t* a_row_idx, int64_t nnz_a_bound,
                        const int64_t* b_row_ptr, const int32_t* b_col_idx, int32_t n_cols_b, const int32_t* counts_a,

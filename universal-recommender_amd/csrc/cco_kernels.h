@@ -6,8 +6,9 @@
 
 namespace urcco {
 
-constexpr int NBINS = 5;  // accumulator classes: 0 micro (one wave, <= 64 pairs), 1 wave-LDS (64 thr, 1024 words),
-                          // 2 block-LDS (256 thr, 8192 words), 3 CU-LDS (1024 thr, 32768 words), 4 global dense counters
+constexpr int NBINS = 6;  // accumulator classes: 0 micro (one wave, <= 64 pairs), 1 wave-LDS (64 thr, 1024 words),
+                          // 2 small-block-LDS (256 thr, 4096 words), 3 block-LDS (256 thr, 8192 words),
+                          // 4 CU-LDS (1024 thr, 32768 words), 5 global dense counters
 
 // Geometry the host side needs for scratch sizing.
 constexpr int SCAN_TILE = 2048;          // elements per scan tile (256 threads x 8)
@@ -16,7 +17,7 @@ constexpr int GLOBAL_BIN_BLOCKS = 64;    // persistent blocks of the global-accu
 constexpr int BIN_TILE = 1024;           // items per binning tile
 constexpr int XLX_TABLE_HOST = 4096;     // entries of the small-integer xLogX table (== XLX_TABLE in cco_device.h)
 constexpr int BIN_COLS_HOST = 3 * NBINS + 1;  // int64 per binning tile
-constexpr int STATS_LEN = 24;            // [0] pairs, then NBINS each of rows / pairs / users / out entries per bin, [1 + 4 NBINS] table overflows
+constexpr int STATS_LEN = 32;            // [0] pairs, then NBINS each of rows / pairs / users / out entries per bin, [1 + 4 NBINS] table overflows
 
 struct CcoArgs {
   // row lists per bin
