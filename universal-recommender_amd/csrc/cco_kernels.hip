@@ -1075,7 +1075,7 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 }
 
 template <int T, int E>
-__global__ __launch_bounds__((T < 256 ? 256 : T)) void cco_rows_kernel(CcoArgs a, int bin) {
+__global__ __launch_bounds__((T < 256 ? 256 : T), (T == 256 && E == 4096 ? 6 : 1)) void cco_rows_kernel(CcoArgs a, int bin) {
   constexpr int BLOCK = T < 256 ? 256 : T;
   constexpr int TEAMS = BLOCK / T;
   constexpr int SPT = E / T;
