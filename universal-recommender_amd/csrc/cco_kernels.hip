@@ -1075,7 +1075,7 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 }
 
 template <int T, int E>
-__global__ __launch_bounds__((T < 256 ? 256 : T), (T == 256 && E == 4096 ? 6 : 1)) void cco_rows_kernel(CcoArgs a, int bin) {
+__global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T == 64 ? 6 : 1)) void cco_rows_kernel(CcoArgs a, int bin) {
   constexpr int BLOCK = T < 256 ? 256 : T;
   constexpr int TEAMS = BLOCK / T;
   constexpr int SPT = E / T;
@@ -1086,7 +1086,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 256 && E == 4096 ? 6 : 1
   __shared__ long long s_ustart[TEAMS * T];
   __shared__ unsigned s_uoff[TEAMS * (T + 1)];
   __shared__ unsigned s_wsum[NW];
-  __shared__ unsigned s_hist[TEAMS * 3 * 128];  // 256 bins of 16-bit counters, two per word
+  constexpr int NH = T == WAVE ? 2 : 3;  // rotating histograms (a one-wave team can afford the extra wave-level sync of two)
+  __shared__ unsigned s_hist[TEAMS * NH * 128];  // 256 bins of 16-bit counters, two per word
   __shared__ unsigned s_selres[TEAMS * 4];
   constexpr int SEL_CAP = T == WAVE ? 0 : (T == 256 ? 512 : 2048);  // explicit survivor list (16-bit indices); a wave sweeps its <= 341 candidates directly
   constexpr int SEL_M = T == WAVE ? 64 : 128;                        // ambiguous set ranked directly
@@ -1101,7 +1102,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 256 && E == 4096 ? 6 : 1
   unsigned* tab = s_tab + team * E;
   long long* ustart = s_ustart + team * T;
   unsigned* uoff = s_uoff + team * (T + 1);
-  unsigned* hist = s_hist + team * 3 * 128;
+  unsigned* hist = s_hist + team * NH * 128;
   unsigned* sel_res = s_selres + team * 4;
   unsigned* nsel = sel_res + 3;
   unsigned short* lst = s_lst + team * (SEL_CAP > 0 ? SEL_CAP : 1);
@@ -1269,7 +1270,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 256 && E == 4096 ? 6 : 1
         //    composite, so ties by column are exact); the need-th best becomes the threshold.
         unsigned need = (unsigned)a.k;
         if (a.col_bytes < 4) thr_ncol = 0xffffffffu << (8 * a.col_bytes);  // digits of ~col above the highest used byte are all ones
-        for (int b = tl; b < 3 * 128; b += T) hist[b] = 0u;
+        for (int b = tl; b < NH * 128; b += T) hist[b] = 0u;
         if (tl == 0) { sel_res[0] = 0u; sel_res[1] = 0u; }  // list length, ambiguous-set length
         team_sync<T>();
         const int first_col_pass = 8 + (3 - (a.col_bytes - 1));  // column digits above the highest used byte are constant: skip
@@ -1278,7 +1279,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 256 && E == 4096 ? 6 : 1
         bool first_pass = true;
         for (int p = 0; p < 12; ++p) {  // team-uniform trip count (the breaks below are on values every thread agrees on)
           if (p >= 8 && p < first_col_pass) continue;
-          unsigned* H = hist + (p % 3) * 128;
+          unsigned* H = hist + (p % NH) * 128;
           const bool build = SEL_CAP > 0 && !have_list && !first_pass && prev_cnt <= (unsigned)SEL_CAP;  // this sweep also records the survivors
           const unsigned n_scan = have_list ? list_n : D;
           const int shk = p < 8 ? 56 - 8 * p : 0, shc = p < 8 ? 0 : 24 - 8 * (p - 8);
@@ -1308,7 +1309,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 256 && E == 4096 ? 6 : 1
           }
           first_pass = false;
           {  // every wave locates the digit that holds the cut (lanes own 4 bins each, higher lanes = higher digits)
-            unsigned* Hz = hist + ((p + 2) % 3) * 128;
+            unsigned* Hz = hist + ((p + NH - 1) % NH) * 128;
             for (int b = tl; b < 128; b += T) Hz[b] = 0u;  // last read two passes ago
             const unsigned w01 = H[2 * lane], w23 = H[2 * lane + 1];
             const unsigned h0 = w01 & 0xffffu, h1 = w01 >> 16, h2 = w23 & 0xffffu, h3 = w23 >> 16;
@@ -1336,6 +1337,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 256 && E == 4096 ? 6 : 1
             else thr_ncol |= d << shc;
             prev_cnt = cnt;
             if (cnt == need) break;  // the whole bin is wanted: every composite >= the prefix (low bits zero) is selected
+            if (NH == 2) team_sync<T>();  // the buffer just cleared is the next pass's target
           }
           if (prev_cnt <= (unsigned)SEL_M) {
             // finish: copy out the members of the cut bin (they match the prefix through digit p) ...
@@ -1411,7 +1413,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 256 && E == 4096 ? 6 : 1
 // --------------------------------------------------------------------------------------------
 constexpr int MICRO_WORDS = 448;
 
-__global__ __launch_bounds__(256) void cco_rows_micro_kernel(CcoArgs a) {
+__global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
   constexpr int TEAMS = 256 / WAVE;
   __shared__ unsigned s_tab[TEAMS * MICRO_WORDS];
   __shared__ long long s_ustart[TEAMS * WAVE];
