@@ -51,7 +51,7 @@ def algorithmic_bytes(stage: str, f: dict) -> float:
     if stage == "row_work":
         return 4.0 * f["nnz_a"] + 8.0 * (IA + 1) + 16.0 * f["nnz_a"] + 8.0 * IA
     if stage.startswith("cco_rows"):     # SURVEY 8d K4 + K5 restricted to the bin's rows
-        b = {"cco_rows_micro": 0, "cco_rows_wave": 1, "cco_rows_block_small": 2, "cco_rows_block": 3, "cco_rows_cu": 4, "cco_rows_global": 5}[stage]
+        b = {"cco_rows_micro": 0, "cco_rows_wave": 1, "cco_rows_block_small": 2, "cco_rows_block": 3, "cco_rows_cu_half": 4, "cco_rows_cu": 5, "cco_rows_global": 6}[stage]
         rows, pairs, users, outs = f["bin_rows"][b], f["bin_pairs"][b], f["bin_users"][b], f["bin_out"][b]
         return 4.0 * rows + 16.0 * rows + 4.0 * users + 16.0 * users + 4.0 * pairs + 12.0 * outs + 4.0 * rows
     if stage == "compact_indicators":
@@ -172,7 +172,7 @@ def main():
                           bin_users=[int(x) for x in st[1 + 2 * NB:1 + 3 * NB]], bin_out=[int(x) for x in st[1 + 3 * NB:1 + 4 * NB]],
                           nnz_out=int(res.indicators[d].row_ptr[-1])))
     per_event_stages = ["column_counts", "downsample_flags", "downsample_scan", "downsample_compact", "row_work", "cco_rows_micro",
-                        "cco_rows_wave", "cco_rows_block_small", "cco_rows_block", "cco_rows_cu", "cco_rows_global", "compact_indicators"]
+                        "cco_rows_wave", "cco_rows_block_small", "cco_rows_block", "cco_rows_cu_half", "cco_rows_cu", "cco_rows_global", "compact_indicators"]
     kernels = {}
     for name, (ms, n) in timings.items():
         if n == 0:
@@ -199,7 +199,7 @@ def main():
     traffic, traffic_src = None, None
     stage_to_kernel = {"cco_rows_micro": "cco_rows_micro_kernel", "cco_rows_wave": "cco_rows_kernel<64, 1024>",
                        "cco_rows_block_small": "cco_rows_kernel<256, 4096>", "cco_rows_block": "cco_rows_kernel<256, 8192>",
-                       "cco_rows_cu": "cco_rows_kernel<1024, 32768>", "downsample_flags": "downsample_flags_kernel",
+                       "cco_rows_cu_half": "cco_rows_kernel<512, 16384>", "cco_rows_cu": "cco_rows_kernel<1024, 32768>", "downsample_flags": "downsample_flags_kernel",
                        "transpose": "transpose_kernel"}
     tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
     if world == 1 and args.scale == 1.0 and os.path.exists(tpath) and dominant in stage_to_kernel:
@@ -209,7 +209,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(dk["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "bytes_per_launch": round(dk["alg_MB_per_step"] * 1e6 / launches), "avg_launch_ms": round(dk["ms_per_step"] / launches, 4)}
-    llr_ms = sum(kernels[n]["ms_per_step"] for n in ("cco_rows_micro", "cco_rows_wave", "cco_rows_block_small", "cco_rows_block", "cco_rows_cu", "cco_rows_global",
+    llr_ms = sum(kernels[n]["ms_per_step"] for n in ("cco_rows_micro", "cco_rows_wave", "cco_rows_block_small", "cco_rows_block", "cco_rows_cu_half", "cco_rows_cu", "cco_rows_global",
                                                       "compact_indicators", "row_work") if n in kernels)
 
     # ---- CPU baseline: the C oracle (a restatement of the Mahout algorithm -- Mahout/Spark itself cannot run here:
@@ -240,7 +240,7 @@ def main():
                    "parallelism": f"items range-partitioned over {world} GPU(s)" + (", RCCL all-reduce + all-gather per event type" if world > 1 else "")},
         "pairs_per_step": pairs, "items_per_sec": round(items / (llr_ms / 1e3), 1) if llr_ms > 0 else None,
         "items_per_sec_note": "sum over event types of nItems(A) / time of the SpGEMM+LLR+top-k stages",
-        "indicator_entries": int(nnz_out.sum()), "rows_by_accumulator": dict(zip(["micro", "wave", "block_small", "block", "cu", "global"], [int(sum(s[1 + b] for s in stats)) for b in range(_lib.N_BINS)])),
+        "indicator_entries": int(nnz_out.sum()), "rows_by_accumulator": dict(zip(["micro", "wave", "block_small", "block", "cu_half", "cu", "global"], [int(sum(s[1 + b] for s in stats)) for b in range(_lib.N_BINS)])),
         "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu_baseline,
         "gpu_over_cpu": round(value / cpu_baseline["value"], 1) if cpu_baseline else None,
         "host_generation_s": round(gen_s, 1),

@@ -84,13 +84,13 @@ typedef struct urcco_indicators {
   double* llr;
 } urcco_indicators;
 
-#define URCCO_N_BINS 6
+#define URCCO_N_BINS 7
 typedef struct urcco_dataset_stats {
   int64_t nnz_raw;     /* interactions before down-sampling */
   int64_t nnz_sampled; /* after sampleDownAndBinarize */
   int64_t pairs;       /* cooccurrence pairs formed: sum_u d_A'(u) * d_B'(u) (the metric's unit) */
   int64_t nnz_out;     /* indicator entries emitted */
-  int64_t rows_by_bin[6]; /* item rows per accumulator class: micro, wave, small block, block, CU, global (URCCO_N_BINS) */
+  int64_t rows_by_bin[7]; /* item rows per accumulator class: micro, wave, small block, block, half CU, CU, global (URCCO_N_BINS) */
   double ms_total;     /* device time of this dataset's stages (HIP events) */
 } urcco_dataset_stats;
 
@@ -140,9 +140,10 @@ enum {
   URCCO_STAGE_CCO_BIN1 = 9,  /* wave-LDS accumulator rows   */
   URCCO_STAGE_CCO_BIN2 = 10, /* small block-LDS rows        */
   URCCO_STAGE_CCO_BIN3 = 11, /* block-LDS accumulator rows  */
-  URCCO_STAGE_CCO_BIN4 = 12, /* CU-LDS accumulator rows     */
-  URCCO_STAGE_CCO_BIN5 = 13, /* global accumulator rows     */
-  URCCO_STAGE_COMPACT_INDICATORS = 14
+  URCCO_STAGE_CCO_BIN4 = 12, /* half-CU-LDS rows            */
+  URCCO_STAGE_CCO_BIN5 = 13, /* CU-LDS accumulator rows     */
+  URCCO_STAGE_CCO_BIN6 = 14, /* global accumulator rows     */
+  URCCO_STAGE_COMPACT_INDICATORS = 15
 };
 int urcco_session_set_timing(urcco_session* s, int32_t enable);
 /* Profiling aid: kernel ablation switches (1 = gather only, 2 = no LLR, 4 = no top-k); results are meaningless when

@@ -86,7 +86,7 @@ def compare_with_oracle(sess, mats, params, seed, mode=0, item_lo=0, item_hi=Non
     for o, r in zip(out, ref):
         st = o.stats.cpu().numpy()
         assert int(st[0]) == r.pairs, f"pairs {int(st[0])} vs oracle {r.pairs}"
-        assert int(st[25]) == 0, "LDS accumulator overflow reported"
+        assert int(st[1 + 4 * 7]) == 0, "LDS accumulator overflow reported"
         n, ties = check_indicators(o.to_host(), r, exact_ids=exact_ids)
         stats.append((st.copy(), n, ties))
     return out, ref, stats

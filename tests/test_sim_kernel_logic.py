@@ -28,8 +28,8 @@ def test_hash_tables_and_all_bins(sim_session):
     a = rand_csr(rng, 4000, 20000, 12, zipf_s=1.2)
     b = rand_csr(rng, 4000, 30000, 25, zipf_s=1.1)
     _, _, stats = compare_with_oracle(sim_session, [a, b], [P(10000, 50), P(10000, 20)], 5)
-    bins = stats[1][0][1:7]          # micro, wave, small block, block, CU, global
-    assert bins[1] > 0 and bins[2] + bins[3] > 0 and bins[4] > 0, bins
+    bins = stats[1][0][1:8]          # micro, wave, small block, block, half CU, CU, global
+    assert bins[1] > 0 and bins[2] + bins[3] > 0 and bins[4] + bins[5] > 0, bins
 
 
 def test_global_accumulator_rows(sim_session):
@@ -39,7 +39,7 @@ def test_global_accumulator_rows(sim_session):
     a = rand_csr(rng, n_users, 40, 6, zipf_s=1.5)
     b = rand_csr(rng, n_users, 17000, 40, zipf_s=0.3)
     _, _, stats = compare_with_oracle(sim_session, [a, b], [P(100000, 10), P(100000, 60)], 11)
-    assert stats[1][0][6] > 0, stats[1][0]
+    assert stats[1][0][7] > 0, stats[1][0]
 
 
 def test_packed_count_overflow_goes_global(sim_session):
@@ -49,7 +49,7 @@ def test_packed_count_overflow_goes_global(sim_session):
     a = rand_csr(rng, n_users, 5, 2, zipf_s=2.0)            # item 0 owned by most users
     b = rand_csr(rng, n_users, 3_000_000, 1.2, zipf_s=0.0)  # 22 key bits -> 10 count bits (max 1023)
     _, _, stats = compare_with_oracle(sim_session, [a, b], [P(1000000, 10), P(1000000, 10)], 3)
-    assert stats[1][0][6] > 0
+    assert stats[1][0][7] > 0
 
 
 def test_empty_and_ragged_inputs(sim_session):

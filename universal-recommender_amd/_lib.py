@@ -17,10 +17,10 @@ OK, BAD_ARG, OOM_HOST, OOM_DEVICE, HIP_ERROR, INTERNAL, NO_DEVICE = range(7)
 ROW_RATE_MAHOUT_INT_DIV = 0
 ROW_RATE_FRACTIONAL = 1
 N_STAGES = 16
-N_BINS = 6
+N_BINS = 7
 STATS_LEN = 32
 STAGE_NAMES = ["column_counts", "downsample_flags", "downsample_scan", "downsample_compact", "transpose", "row_work", "binning",
-               "entropy", "cco_rows_micro", "cco_rows_wave", "cco_rows_block_small", "cco_rows_block", "cco_rows_cu", "cco_rows_global", "compact_indicators", ""]
+               "entropy", "cco_rows_micro", "cco_rows_wave", "cco_rows_block_small", "cco_rows_block", "cco_rows_cu_half", "cco_rows_cu", "cco_rows_global", "compact_indicators"]
 
 
 class UrccoError(RuntimeError):
@@ -49,7 +49,7 @@ class Indicators(C.Structure):
 
 class DatasetStats(C.Structure):
     _fields_ = [("nnz_raw", C.c_int64), ("nnz_sampled", C.c_int64), ("pairs", C.c_int64), ("nnz_out", C.c_int64),
-                ("rows_by_bin", C.c_int64 * 6), ("ms_total", C.c_double)]
+                ("rows_by_bin", C.c_int64 * 7), ("ms_total", C.c_double)]
 
 
 # every symbol include/urcco.h declares: (restype, argtypes)

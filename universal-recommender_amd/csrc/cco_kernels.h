@@ -6,9 +6,9 @@
 
 namespace urcco {
 
-constexpr int NBINS = 6;  // accumulator classes: 0 micro (one wave, <= 64 pairs), 1 wave-LDS (64 thr, 1024 words),
+constexpr int NBINS = 7;  // accumulator classes: 0 micro (one wave, <= 64 pairs), 1 wave-LDS (64 thr, 1024 words),
                           // 2 small-block-LDS (256 thr, 4096 words), 3 block-LDS (256 thr, 8192 words),
-                          // 4 CU-LDS (1024 thr, 32768 words), 5 global dense counters
+                          // 4 half-CU-LDS (512 thr, 16384 words), 5 CU-LDS (1024 thr, 32768 words), 6 global dense counters
 
 // Geometry the host side needs for scratch sizing.
 constexpr int SCAN_TILE = 2048;          // elements per scan tile (256 threads x 8)

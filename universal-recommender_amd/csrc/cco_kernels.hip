@@ -852,7 +852,7 @@ hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t it
 // Lists are built by a deterministic tile count / scan / scatter (a global atomic append would serialise
 // hundreds of thousands of increments on four addresses).
 // ============================================================================================
-constexpr int E0 = 1024, E1S = 4096, E1 = 8192, E2 = 32768;  // LDS table words of the wave / small-block / block / CU classes
+constexpr int E0 = 1024, E1S = 4096, E1 = 8192, E2S = 16384, E2 = 32768;  // LDS table words: wave / small block / block / half CU / CU
 
 __device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_cols_b, int32_t count_bits, int32_t k) {
   if (ca <= 0 || w <= 0) return -1;  // no users or no pairs: empty indicator row
@@ -865,7 +865,8 @@ __device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_c
   if (dmax <= E0) cap_bin = 1;
   else if (dmax <= E1S) cap_bin = 2;
   else if (dmax <= E1) cap_bin = 3;
-  else if (dmax <= E2) cap_bin = 4;
+  else if (dmax <= E2S) cap_bin = 4;
+  else if (dmax <= E2) cap_bin = 5;
   const int work_bin = w <= 512 ? 1 : (w <= 8192 ? 2 : 4);
   return cap_bin > work_bin ? cap_bin : work_bin;
 }
@@ -1080,7 +1081,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
   constexpr int TEAMS = BLOCK / T;
   constexpr int SPT = E / T;
   constexpr int NW = T / WAVE;  // waves per team
-  constexpr int LOG2E = E == 1024 ? 10 : (E == 4096 ? 12 : (E == 8192 ? 13 : 15));
+  constexpr int LOG2E = E == 1024 ? 10 : (E == 4096 ? 12 : (E == 8192 ? 13 : (E == 16384 ? 14 : 15)));
   static_assert((1 << LOG2E) == E, "table size");
   __shared__ unsigned s_tab[TEAMS * E];
   __shared__ long long s_ustart[TEAMS * T];
@@ -1661,7 +1662,7 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
 // resident blocks per CU of each LDS-accumulator kernel (registers / LDS decide), so that the persistent grids fill
 // the chip exactly once
 static int blocks_per_cu(int bin) {
-  static int cache[5] = {0, 0, 0, 0, 0};
+  static int cache[6] = {0, 0, 0, 0, 0, 0};
   if (cache[bin] == 0) {
     int n = 0;
     hipError_t e = hipErrorUnknown;
@@ -1669,7 +1670,8 @@ static int blocks_per_cu(int bin) {
     if (bin == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<64, E0>, 256, 0);
     if (bin == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1S>, 256, 0);
     if (bin == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1>, 256, 0);
-    if (bin == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2>, 1024, 0);
+    if (bin == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<512, E2S>, 512, 0);
+    if (bin == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2>, 1024, 0);
     cache[bin] = (e == hipSuccess && n > 0) ? n : 1;
   }
   return cache[bin];
@@ -1683,7 +1685,8 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
     case 1: hipLaunchKernelGGL((cco_rows_kernel<64, E0>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1); break;
     case 2: hipLaunchKernelGGL((cco_rows_kernel<256, E1S>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(256), 0, st, args, 2); break;
     case 3: hipLaunchKernelGGL((cco_rows_kernel<256, E1>), dim3((unsigned)(n_cu * blocks_per_cu(3))), dim3(256), 0, st, args, 3); break;
-    case 4: hipLaunchKernelGGL((cco_rows_kernel<1024, E2>), dim3((unsigned)(n_cu * blocks_per_cu(4))), dim3(1024), 0, st, args, 4); break;
+    case 4: hipLaunchKernelGGL((cco_rows_kernel<512, E2S>), dim3((unsigned)(n_cu * blocks_per_cu(4))), dim3(512), 0, st, args, 4); break;
+    case 5: hipLaunchKernelGGL((cco_rows_kernel<1024, E2>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5); break;
     default: hipLaunchKernelGGL(cco_rows_global_kernel, dim3(GLOBAL_BIN_BLOCKS), dim3(GB_THREADS), 0, st, args); break;
   }
   return hipGetLastError();
