@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; the reported config says so)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true", help="N = 1: run the event types back to back on one HIP stream")
     ap.add_argument("--force-exchange", action="store_true",
                     help="debug: run the N > 1 code path (RCCL collectives, range-restricted transpose) in a one-rank group")
     ap.add_argument("--seed", type=int, default=20260925)
@@ -115,10 +116,17 @@ def main():
     gen_s = time.time() - t0
     params = [DatasetParams(500, 50, None) for _ in data]   # engine.json defaults: maxEventsPerEventType 500, maxCorrelatorsPerEventType 50
     shards = [DevCsr(hi - lo, nc, torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), int(rp[-1])) for (_, nc, rp, ci) in data]
-    sess = DeviceSession(dev, _lib.load(_lib.DEFAULT_PATH))
+    from universal_recommender_amd.device import SessionPool, cross_occurrence_streams
+    library = _lib.load(_lib.DEFAULT_PATH)
+    if distributed:
+        sess = DeviceSession(dev, library)
+    else:
+        sess = SessionPool(dev, 1 if args.single_stream else len(shards), library)   # one HIP stream per event type
 
     def step():
-        return sharded.cross_occurrence_sharded(sess, shards, params, args.seed, cfg.n_users, lo, force_exchange=args.force_exchange)
+        if distributed:
+            return sharded.cross_occurrence_sharded(sess, shards, params, args.seed, cfg.n_users, lo, force_exchange=args.force_exchange)
+        return sharded.ShardedResult(cross_occurrence_streams(sess, shards, params, args.seed), [[0, shards[0].n_cols]] * len(shards), [-1] * len(shards))
 
     def barrier():
         if distributed:

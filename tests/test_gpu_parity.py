@@ -198,3 +198,24 @@ def test_exchange_path_over_rccl_on_one_gpu():
            "--master-port", str(port), os.path.join(here, "dist_one_gpu.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "EXCHANGE_PATH_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_stream_per_event_type_is_bit_identical(gpu_session):
+    """device.cross_occurrence_streams (one HIP stream + scratch arena per event type) == the single-stream pipeline."""
+    from universal_recommender_amd import _lib
+    from universal_recommender_amd.device import SessionPool, cross_occurrence_streams
+    from helpers import to_params
+    rng = np.random.default_rng(41)
+    mats = [rand_csr(rng, 30000, 4000, 10, zipf_s=1.1), rand_csr(rng, 30000, 6000, 16), rand_csr(rng, 30000, 50, 2)]
+    ps = [P(80, 20), P(80, 20), P(500, 50)]
+    dev = gpu_session.device
+    ref = run_device(gpu_session, mats, ps, 17)
+    pool = SessionPool(dev, 3, _lib.load(_lib.DEFAULT_PATH))
+    for _ in range(3):
+        out = cross_occurrence_streams(pool, [to_dev(m, dev) for m in mats], to_params(ps), 17)
+    torch.cuda.synchronize()
+    for a, b in zip(out, ref):
+        for x, y in zip(a.to_host(), b.to_host()):
+            assert np.array_equal(x, y)
+        assert torch.equal(a.stats[:1].cpu(), b.stats[:1].cpu())
+    pool.close()

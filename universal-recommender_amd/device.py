@@ -61,15 +61,16 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 class DeviceSession:
     """urcco_session bound to a torch device; launches go on torch's current stream for that device."""
 
-    def __init__(self, device: torch.device, library=None):
+    def __init__(self, device: torch.device, library=None, stream: Optional["torch.cuda.Stream"] = None):
         self.device = torch.device(device)
         self.lib = library if library is not None else _lib.lib()
+        self.torch_stream = None
         handle = C.c_void_p()
         if self.device.type == "cuda":
             index = self.device.index if self.device.index is not None else torch.cuda.current_device()
             self.device = torch.device("cuda", index)
-            stream = torch.cuda.current_stream(self.device).cuda_stream
-            self._check(self.lib.urcco_session_create(index, C.c_void_p(stream), C.byref(handle)))
+            self.torch_stream = stream if stream is not None else torch.cuda.current_stream(self.device)
+            self._check(self.lib.urcco_session_create(index, C.c_void_p(self.torch_stream.cuda_stream), C.byref(handle)))
         else:
             # only meaningful when the binding points at the test-only host-simulator build
             self._check(self.lib.urcco_session_create(0, None, C.byref(handle)))
@@ -185,6 +186,92 @@ def _to_i32(seed: int) -> int:
     """Scala `Long.toInt` (URAlgorithm.scala:240,325,345)."""
     s = int(seed) & 0xFFFFFFFF
     return s - (1 << 32) if s >= (1 << 31) else s
+
+
+class SessionPool:
+    """One urcco_session (own HIP stream + scratch arena) per event type, so that the per-event pipelines -- dozens of
+    short kernels and persistent SpGEMM grids with ragged tails -- overlap on the GPU.  pool[0] runs the primary matrix."""
+
+    def __init__(self, device: torch.device, n: int, library=None):
+        self.device = torch.device(device)
+        if self.device.type == "cuda":
+            self.sessions = [DeviceSession(self.device, library, torch.cuda.Stream(self.device)) for _ in range(n)]
+        else:
+            self.sessions = [DeviceSession(self.device, library) for _ in range(n)]
+
+    def __len__(self):
+        return len(self.sessions)
+
+    def __getitem__(self, i) -> DeviceSession:
+        return self.sessions[i % len(self.sessions)]
+
+    def close(self):
+        for s in self.sessions:
+            s.close()
+
+    def synchronize(self):
+        for s in self.sessions:
+            s.synchronize()
+
+    def set_timing(self, enable: bool):
+        for s in self.sessions:
+            s.set_timing(enable)
+
+    def get_timings(self):
+        out = {}
+        for s in self.sessions:
+            for k, (ms, n) in s.get_timings().items():
+                a, b = out.get(k, (0.0, 0))
+                out[k] = (a + ms, b + n)
+        return out
+
+
+def cross_occurrence_streams(pool: SessionPool, mats: Sequence[DevCsr], params: Sequence[DatasetParams], seed: int,
+                             row_rate_mode: int = _lib.ROW_RATE_MAHOUT_INT_DIV) -> List[DevIndicators]:
+    """cross_occurrence_device with one HIP stream per event type: B_i is sampled on its own stream while A is sampled and
+    transposed on stream 0; every A'B_i then runs on stream i behind an event on A's CSC.  Same results, bit for bit."""
+    if len(mats) == 0 or len(mats) != len(params):
+        raise ValueError("need one DatasetParams per matrix and at least the primary matrix")
+    a_raw = mats[0]
+    for m in mats:
+        if m.n_rows != a_raw.n_rows:
+            raise ValueError("all matrices share the user dictionary: row counts differ")
+    n_items_a = a_raw.n_cols
+    if pool.device.type != "cuda":   # host-simulator sessions have no streams: plain sequential pipeline
+        return cross_occurrence_device(pool[0], mats, params, seed, row_rate_mode)
+    main = torch.cuda.current_stream(pool.device)
+    streams = [pool[d].torch_stream for d in range(len(mats))]
+    for st in set(streams):
+        st.wait_stream(main)                       # inputs were produced on the caller's stream
+    sampled = [None] * len(mats)
+    with torch.cuda.stream(streams[0]):
+        s0 = pool[0]
+        raw = s0.column_counts(a_raw.col_idx, a_raw.nnz_bound, a_raw.n_cols)
+        a, cnt_a = s0.downsample(a_raw, a_raw.nnz_bound, raw, seed, params[0].max_elements_per_row, row_rate_mode)
+        a_col_ptr, a_row_idx = s0.transpose(a, cnt_a)
+        a_ready = torch.cuda.Event()
+        a_ready.record(streams[0])
+        sampled[0] = (a, cnt_a)
+    for d in range(1, len(mats)):
+        with torch.cuda.stream(streams[d]):
+            sd, m, p = pool[d], mats[d], params[d]
+            raw_b = sd.column_counts(m.col_idx, m.nnz_bound, m.n_cols)
+            sampled[d] = sd.downsample(m, m.nnz_bound, raw_b, seed, p.max_elements_per_row, row_rate_mode)
+    out = []
+    for d in range(len(mats)):
+        with torch.cuda.stream(streams[d]):
+            if streams[d] is not streams[0]:
+                streams[d].wait_event(a_ready)
+                for t in (a_col_ptr, a_row_idx, cnt_a, a.row_ptr, a.col_idx):
+                    t.record_stream(streams[d])   # produced on stream 0, read here
+            b, cnt_b = sampled[d]
+            ind = pool[d].cco_rows(0, n_items_a, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b, cnt_a, cnt_b, a_raw.n_rows, d == 0, params[d])
+            for t in (ind.row_ptr, ind.col_idx, ind.llr, ind.stats, b.row_ptr):
+                t.record_stream(main)             # consumed by the caller on its stream
+            out.append(ind)
+    for st in set(streams):
+        main.wait_stream(st)
+    return out
 
 
 def cross_occurrence_device(sess: DeviceSession, mats: Sequence[DevCsr], params: Sequence[DatasetParams], seed: int,

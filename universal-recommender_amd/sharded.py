@@ -111,7 +111,7 @@ def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], para
         locals_.append(local)
         counts.append(post)
 
-    if not exchange:
+    if not exchange:  # (kept for callers that pass a plain session; bench.py uses device.cross_occurrence_streams at N = 1)
         a = locals_[0]
         a_col_ptr, a_row_idx = sess.transpose(a, counts[0])
         out = [sess.cco_rows(0, n_items_a, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, locals_[d], counts[0], counts[d], n_rows_global, d == 0,
