@@ -144,6 +144,26 @@ def main():
     elapsed = time.perf_counter() - t0
     timings = sess.get_timings()
     sess.set_timing(False)
+    kernel_timing_mode = "timed region (one stream)"
+    if not distributed and not args.single_stream and len(sess) > 1:
+        # The timed region overlaps the event types on separate HIP streams, so a kernel's event-bracketed duration there
+        # includes time it shared the GPU with other kernels.  Per-kernel durations (roofline) are therefore taken from a
+        # second pass of the same steps with the event types serialised on one stream (== `bench.py --single-stream`,
+        # the command the rocprofv3 summary in profiles/ is taken from).
+        from universal_recommender_amd.device import cross_occurrence_device
+        one = sess[0]
+        with torch.cuda.stream(one.torch_stream):
+            for _ in range(args.warmup):
+                cross_occurrence_device(one, shards, params, args.seed)
+            torch.cuda.synchronize(dev)
+            one.set_timing(True)
+            for _ in range(args.steps):
+                res1 = cross_occurrence_device(one, shards, params, args.seed)
+            torch.cuda.synchronize(dev)
+            timings = one.get_timings()
+            one.set_timing(False)
+        res = sharded.ShardedResult(res1, res.item_ranges, res.nnz_sampled)   # carries the per-bin emitted-entry stats
+        kernel_timing_mode = "separate single-stream pass of the same steps (the timed region overlaps event types on 3 HIP streams)"
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -245,11 +265,12 @@ def main():
                    "n_users": cfg.n_users, "n_items": [ev.n_items for ev in cfg.events], "events": [ev.name for ev in cfg.events],
                    "nnz_raw": [s.nnz_bound for s in shards] if world == 1 else None, "nnz_sampled": nnz_sampled,
                    "pairs_per_event": pairs_per_event, "maxEventsPerEventType": 500, "maxCorrelatorsPerEventType": 50, "seed": args.seed,
-                   "parallelism": f"items range-partitioned over {world} GPU(s)" + (", RCCL all-reduce + all-gather per event type" if world > 1 else "")},
+                   "parallelism": f"items range-partitioned over {world} GPU(s)" + (", RCCL all-reduce + all-gather per event type" if world > 1 else
+                                                                                      ("" if args.single_stream else ", one HIP stream per event type"))},
         "pairs_per_step": pairs, "items_per_sec": round(items / (llr_ms / 1e3), 1) if llr_ms > 0 else None,
         "items_per_sec_note": "sum over event types of nItems(A) / time of the SpGEMM+LLR+top-k stages",
         "indicator_entries": int(nnz_out.sum()), "rows_by_accumulator": dict(zip(["micro", "wave", "block_small", "block", "cu_half", "cu", "global"], [int(sum(s[1 + b] for s in stats)) for b in range(_lib.N_BINS)])),
-        "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu_baseline,
+        "roofline": roofline, "kernels": kernels, "kernel_timing": kernel_timing_mode, "cpu_baseline": cpu_baseline,
         "gpu_over_cpu": round(value / cpu_baseline["value"], 1) if cpu_baseline else None,
         "host_generation_s": round(gen_s, 1),
     }
