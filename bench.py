@@ -136,16 +136,18 @@ def main():
     for _ in range(args.warmup):
         res = step()
     barrier()
-    sess.set_timing(True)
+    serial_pass = not distributed and not args.single_stream and len(sess) > 1
+    if not serial_pass:
+        sess.set_timing(True)   # HIP events around every launch group, on the launching stream
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    timings = sess.get_timings()
+    timings = sess.get_timings() if not serial_pass else {}
     sess.set_timing(False)
     kernel_timing_mode = "timed region (one stream)"
-    if not distributed and not args.single_stream and len(sess) > 1:
+    if serial_pass:
         # The timed region overlaps the event types on separate HIP streams, so a kernel's event-bracketed duration there
         # includes time it shared the GPU with other kernels.  Per-kernel durations (roofline) are therefore taken from a
         # second pass of the same steps with the event types serialised on one stream (== `bench.py --single-stream`,
