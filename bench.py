@@ -122,8 +122,6 @@ def main():
         sess = DeviceSession(dev, library)
     else:
         sess = SessionPool(dev, 1 if args.single_stream else len(shards), library)   # one HIP stream per event type
-        if args.single_stream:
-            sess[0].set_debug(64)   # ... and no forking of the accumulator-class kernels either: every kernel runs alone
 
     def step():
         if distributed:
@@ -156,7 +154,6 @@ def main():
         # the command the rocprofv3 summary in profiles/ is taken from).
         from universal_recommender_amd.device import cross_occurrence_device
         one = sess[0]
-        one.set_debug(64)   # also serialise the accumulator-class kernels inside one A'B
         with torch.cuda.stream(one.torch_stream):
             for _ in range(args.warmup):
                 cross_occurrence_device(one, shards, params, args.seed)
@@ -167,7 +164,6 @@ def main():
             torch.cuda.synchronize(dev)
             timings = one.get_timings()
             one.set_timing(False)
-        one.set_debug(0)
         res = sharded.ShardedResult(res1, res.item_ranges, res.nnz_sampled)   # carries the per-bin emitted-entry stats
         kernel_timing_mode = "separate single-stream pass of the same steps (the timed region overlaps event types on 3 HIP streams)"
     if distributed:

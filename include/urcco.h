@@ -146,9 +146,8 @@ enum {
   URCCO_STAGE_COMPACT_INDICATORS = 15
 };
 int urcco_session_set_timing(urcco_session* s, int32_t enable);
-/* Profiling aid: kernel ablation switches (1 = gather only, 2 = no LLR, 4 = no top-k, 8 = no selection, 16 = no ranking:
- * results are meaningless) and 64 = run the accumulator-class kernels one after the other instead of forking them onto
- * side streams (results unchanged; gives clean per-kernel durations).  0 in production. */
+/* Profiling aid: kernel ablation switches (1 = gather only, 2 = no LLR, 4 = no top-k); results are meaningless when
+ * non-zero.  0 in production. */
 int urcco_session_set_debug(urcco_session* s, int32_t flags);
 int urcco_session_get_timings(urcco_session* s, double* ms /*[URCCO_N_STAGES]*/, int64_t* launches /*[URCCO_N_STAGES]*/);
 /* bytes of device scratch currently held */

@@ -81,30 +81,15 @@ struct urcco_session {
     (void)hipEventCreate(&e);
     return e;
   }
-  void begin(int stage, hipStream_t on = nullptr) {
+  void begin(int stage) {
     if (!timing) return;
     Rec r{stage, get_event(), get_event()};
-    (void)hipEventRecord(r.e0, on ? on : stream);
+    (void)hipEventRecord(r.e0, stream);
     recs.push_back(r);
   }
-  void end(hipStream_t on = nullptr) {
+  void end() {
     if (!timing) return;
-    (void)hipEventRecord(recs.back().e1, on ? on : stream);
-  }
-  // side streams: the accumulator-class kernels of one A'B are independent (disjoint row lists), so they are forked onto
-  // a few extra streams behind an event and joined again -- the ragged tail of one persistent grid fills with the next.
-  static constexpr int N_SIDE = 3;
-  hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr};
-  hipEvent_t fork_ev = nullptr;
-  hipEvent_t join_ev[N_SIDE] = {nullptr, nullptr, nullptr};
-  int ensure_side() {
-    if (side[0]) return URCCO_OK;
-    for (int i = 0; i < N_SIDE; ++i) {
-      HIPC(hipStreamCreate(&side[i]));
-      HIPC(hipEventCreate(&join_ev[i]));
-    }
-    HIPC(hipEventCreate(&fork_ev));
-    return URCCO_OK;
+    (void)hipEventRecord(recs.back().e1, stream);
   }
   void collect() {
     (void)hipStreamSynchronize(stream);
@@ -209,10 +194,6 @@ void urcco_session_destroy(urcco_session* s) {
   (void)hipStreamSynchronize(s->stream);
   if (s->arena) (void)hipFree(s->arena);
   if (s->xlx_tab) (void)hipFree(s->xlx_tab);
-  for (int i = 0; i < urcco_session::N_SIDE; ++i) {
-    if (s->side[i]) { (void)hipStreamSynchronize(s->side[i]); (void)hipStreamDestroy(s->side[i]); (void)hipEventDestroy(s->join_ev[i]); }
-  }
-  if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
   if (s->g_counts) { (void)hipFree(s->g_counts); (void)hipFree(s->g_cand_key); (void)hipFree(s->g_cand_col); }
   s->collect();
   for (hipEvent_t e : s->free_events) (void)hipEventDestroy(e);
@@ -450,25 +431,11 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   a.out_count = out_count; a.out_idx = out_idx; a.out_llr = out_llr;
   a.err = reinterpret_cast<unsigned long long*>(stats + 1 + 4 * urcco::NBINS);
   a.g_counts = s->g_counts; a.g_cand_key = s->g_cand_key; a.g_cand_col = s->g_cand_col;
-  const bool fork = !(s->debug & 64);  // debug 64: one class kernel after the other on the session stream (clean per-kernel timing)
-  if (fork) {
-    URC(s->ensure_side());
-    HIPC(hipEventRecord(s->fork_ev, s->stream));
-    for (int i = 0; i < urcco_session::N_SIDE; ++i) HIPC(hipStreamWaitEvent(s->side[i], s->fork_ev, 0));
+  for (int bin = 0; bin < urcco::NBINS; ++bin) {
+    s->begin(URCCO_STAGE_CCO_BIN0 + bin);
+    HIPC(urcco::launch_cco_rows_bin(s->stream, s->n_cu, a, bin));
+    s->end();
   }
-  static const int order[urcco::NBINS] = {1, 2, 0, 3, 4, 5, 6};  // heaviest classes first, spread over the side streams
-  for (int q = 0; q < urcco::NBINS; ++q) {
-    const int bin = order[q];
-    hipStream_t on = fork ? s->side[q % urcco_session::N_SIDE] : s->stream;
-    s->begin(URCCO_STAGE_CCO_BIN0 + bin, on);
-    HIPC(urcco::launch_cco_rows_bin(on, s->n_cu, a, bin));
-    s->end(on);
-  }
-  if (fork)
-    for (int i = 0; i < urcco_session::N_SIDE; ++i) {
-      HIPC(hipEventRecord(s->join_ev[i], s->side[i]));
-      HIPC(hipStreamWaitEvent(s->stream, s->join_ev[i], 0));
-    }
   if (s->timing) HIPC(urcco::launch_bin_out_stats(s->stream, bin_rows, bin_off, item_lo, out_count, stats));
   return URCCO_OK;
 }
