@@ -192,10 +192,11 @@ class SessionPool:
     """One urcco_session (own HIP stream + scratch arena) per event type, so that the per-event pipelines -- dozens of
     short kernels and persistent SpGEMM grids with ragged tails -- overlap on the GPU.  pool[0] runs the primary matrix."""
 
-    def __init__(self, device: torch.device, n: int, library=None):
+    def __init__(self, device: torch.device, n: int, library=None, priorities: Optional[Sequence[int]] = None):
         self.device = torch.device(device)
         if self.device.type == "cuda":
-            self.sessions = [DeviceSession(self.device, library, torch.cuda.Stream(self.device)) for _ in range(n)]
+            pr = list(priorities) if priorities is not None else [0] * n
+            self.sessions = [DeviceSession(self.device, library, torch.cuda.Stream(self.device, priority=pr[i])) for i in range(n)]
         else:
             self.sessions = [DeviceSession(self.device, library) for _ in range(n)]
 
@@ -257,8 +258,9 @@ def cross_occurrence_streams(pool: SessionPool, mats: Sequence[DevCsr], params: 
             sd, m, p = pool[d], mats[d], params[d]
             raw_b = sd.column_counts(m.col_idx, m.nnz_bound, m.n_cols)
             sampled[d] = sd.downsample(m, m.nnz_bound, raw_b, seed, p.max_elements_per_row, row_rate_mode)
-    out = []
-    for d in range(len(mats)):
+    out = [None] * len(mats)
+    order = sorted(range(len(mats)), key=lambda d: -mats[d].nnz_bound)   # the heaviest event type is enqueued first
+    for d in order:
         with torch.cuda.stream(streams[d]):
             if streams[d] is not streams[0]:
                 streams[d].wait_event(a_ready)
@@ -268,7 +270,7 @@ def cross_occurrence_streams(pool: SessionPool, mats: Sequence[DevCsr], params: 
             ind = pool[d].cco_rows(0, n_items_a, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b, cnt_a, cnt_b, a_raw.n_rows, d == 0, params[d])
             for t in (ind.row_ptr, ind.col_idx, ind.llr, ind.stats, b.row_ptr):
                 t.record_stream(main)             # consumed by the caller on its stream
-            out.append(ind)
+            out[d] = ind
     for st in set(streams):
         main.wait_stream(st)
     return out
