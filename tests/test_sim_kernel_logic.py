@@ -151,3 +151,37 @@ def test_partitioned_column_counts_large_matrix(sim_session):
     cnt2 = sim_session.column_counts(view, m.nnz, m.n_cols)
     sim_session.synchronize()
     assert np.array_equal(cnt2.cpu().numpy(), O.column_counts(m))
+
+
+def test_large_matrix_full_pipeline(sim_session):
+    """>= 2^20 interactions in the primary matrix: partitioned column counts AND the bucketed CSR->CSC feed the SpGEMM;
+    the whole build (and an item-range slice, as a multi-GPU rank would run it) still equals the oracle."""
+    rng = np.random.default_rng(12)
+    a = rand_csr(rng, 90000, 60_000, 13, zipf_s=1.0)
+    b = rand_csr(rng, 90000, 300, 3, zipf_s=0.8)
+    assert a.nnz >= (1 << 20)
+    compare_with_oracle(sim_session, [a, b], [P(30, 8), P(30, 8)], 5)
+    compare_with_oracle(sim_session, [a, b], [P(30, 8), P(30, 8)], 5, 0, 20_000, 41_000)
+
+
+def test_bucketed_transpose_with_item_range(sim_session):
+    """urcco_dev_transpose on a large matrix restricted to an item range (what a multi-GPU rank does): columns inside
+    the range hold exactly their users (any order), columns outside are empty."""
+    rng = np.random.default_rng(13)
+    m = rand_csr(rng, 80000, 30_000, 15, zipf_s=0.9)
+    assert m.nnz >= (1 << 20)
+    dev = sim_session.device
+    d = to_dev(m, dev)
+    counts = torch.from_numpy(O.column_counts(m)).to(dev)
+    cp_ref, ri_ref = O.transpose(m)
+    for lo, hi in [(0, m.n_cols), (9000, 17123)]:
+        cp, ri = sim_session.transpose(d, counts, lo, hi)
+        sim_session.synchronize()
+        cp, ri = cp.cpu().numpy(), ri.cpu().numpy()
+        lens = np.diff(cp)
+        expect = np.diff(cp_ref).copy()
+        expect[:lo] = 0
+        expect[hi:] = 0
+        assert np.array_equal(lens, expect)
+        for j in list(range(lo, min(lo + 50, hi))) + [hi - 1] + rng.integers(lo, hi, 200).tolist():
+            assert np.array_equal(np.sort(ri[cp[j]:cp[j + 1]]), ri_ref[cp_ref[j]:cp_ref[j + 1]])
