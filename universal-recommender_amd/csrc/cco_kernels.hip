@@ -724,112 +724,6 @@ hipError_t launch_transpose(hipStream_t st, int n_cu, int64_t n_rows, const int6
   return hipGetLastError();
 }
 
-// --------------------------------------------------------------------------------------------
-// K3b  CSR -> CSC through column buckets (matrices large enough to repay five launches).
-// The direct kernel above writes every row id to a random place of a multi-MB array: each 4-byte store costs a full
-// memory transaction (measured 16x write amplification) and every entry takes a returning L2 atomic.  Here entries are
-// first grouped by column bucket (8192 columns, the same partitioning as the column-count histogram), then ONE block
-// per bucket places them with LDS cursors: its destination, the bucket's CSC segment, is contiguous and L2-sized.
-//   count   per part of TR_ROWS user rows: entries per bucket          scan   bucket-major offsets
-//   scatter (col & 8191, row) pairs grouped by bucket                  place  per bucket: LDS cursor per column
-// --------------------------------------------------------------------------------------------
-constexpr int TR_ROWS = 2048;  // user rows per part
-
-__global__ __launch_bounds__(256) void tr_count_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, int g_log2,
-                                                       int n_buckets, int64_t n_parts, int32_t col_lo, int32_t col_hi,
-                                                       int32_t* __restrict__ part_counts) {
-  __shared__ int s_cnt[PH_MAX_BUCKETS];
-  for (int b = threadIdx.x; b < n_buckets; b += 256) s_cnt[b] = 0;
-  __syncthreads();
-  const int G = 1 << g_log2;
-  const int gl = threadIdx.x & (G - 1);
-  const int64_t r0 = (int64_t)blockIdx.x * TR_ROWS;
-  const int64_t r1 = r0 + TR_ROWS < n_rows ? r0 + TR_ROWS : n_rows;
-  for (int64_t r = r0 + (threadIdx.x >> g_log2); r < r1; r += 256 >> g_log2) {
-    const int64_t s = rp[r], e = rp[r + 1];
-    for (int64_t p = s + gl; p < e; p += G) {
-      const int j = ci[p];
-      if (j >= col_lo && j < col_hi) atomicAdd(&s_cnt[j >> PH_BITS], 1);
-    }
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < n_buckets; b += 256) part_counts[(int64_t)b * n_parts + blockIdx.x] = s_cnt[b];
-}
-
-__global__ __launch_bounds__(256) void tr_scatter_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, int g_log2,
-                                                         int n_buckets, int64_t n_parts, int32_t col_lo, int32_t col_hi,
-                                                         const int64_t* __restrict__ offsets, unsigned short* __restrict__ bk_col,
-                                                         int32_t* __restrict__ bk_row) {
-  __shared__ long long s_base[PH_MAX_BUCKETS];
-  __shared__ int s_cur[PH_MAX_BUCKETS];
-  for (int b = threadIdx.x; b < n_buckets; b += 256) {
-    s_base[b] = offsets[(int64_t)b * n_parts + blockIdx.x];
-    s_cur[b] = 0;
-  }
-  __syncthreads();
-  const int G = 1 << g_log2;
-  const int gl = threadIdx.x & (G - 1);
-  const int64_t r0 = (int64_t)blockIdx.x * TR_ROWS;
-  const int64_t r1 = r0 + TR_ROWS < n_rows ? r0 + TR_ROWS : n_rows;
-  for (int64_t r = r0 + (threadIdx.x >> g_log2); r < r1; r += 256 >> g_log2) {
-    const int64_t s = rp[r], e = rp[r + 1];
-    for (int64_t p = s + gl; p < e; p += G) {
-      const int j = ci[p];
-      if (j < col_lo || j >= col_hi) continue;
-      const int b = j >> PH_BITS;
-      const int64_t pos = s_base[b] + atomicAdd(&s_cur[b], 1);
-      bk_col[pos] = (unsigned short)(j & (PH_BUCKET - 1));
-      bk_row[pos] = (int32_t)r;
-    }
-  }
-}
-
-__global__ __launch_bounds__(1024) void tr_place_kernel(const unsigned short* __restrict__ bk_col, const int32_t* __restrict__ bk_row,
-                                                        const int64_t* __restrict__ offsets, int64_t n_parts, const int64_t* __restrict__ col_ptr,
-                                                        int32_t n_cols, int32_t* __restrict__ out_rows) {
-  __shared__ int s_cur[PH_BUCKET];
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < PH_BUCKET; c += 1024) s_cur[c] = 0;
-  __syncthreads();
-  const int64_t e0 = offsets[(int64_t)b * n_parts], e1 = offsets[(int64_t)(b + 1) * n_parts];
-  const int64_t col0 = (int64_t)b << PH_BITS;
-  for (int64_t e = e0 + threadIdx.x; e < e1; e += 1024) {
-    const int c = bk_col[e];
-    const int p = atomicAdd(&s_cur[c], 1);
-    out_rows[col_ptr[col0 + c] + p] = bk_row[e];
-  }
-}
-
-int64_t transpose_scratch_bytes(int64_t n_rows, int64_t nnz, int32_t n_cols) {
-  const int64_t n_buckets = ((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS;
-  if (nnz < PH_MIN_NNZ || n_buckets > PH_MAX_BUCKETS || n_buckets < 1) return 0;
-  const int64_t n_parts = (n_rows + TR_ROWS - 1) / TR_ROWS;
-  const int64_t m = n_buckets * n_parts;
-  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
-  return al(m * 4) + al((m + 1) * 8) + al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8) + al(nnz * 2 + 16) + al(nnz * 4 + 16);
-}
-
-hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int g_log2,
-                                        int32_t n_cols, const int64_t* col_ptr, int32_t* out_row_idx, int32_t col_lo, int32_t col_hi, char* scratch) {
-  const int n_buckets = (int)(((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS);
-  const int64_t n_parts = (n_rows + TR_ROWS - 1) / TR_ROWS;
-  const int64_t m = (int64_t)n_buckets * n_parts;
-  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
-  int32_t* part_counts = reinterpret_cast<int32_t*>(scratch); scratch += al(m * 4);
-  int64_t* offsets = reinterpret_cast<int64_t*>(scratch); scratch += al((m + 1) * 8);
-  int64_t* tile_sums = reinterpret_cast<int64_t*>(scratch); scratch += al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8);
-  unsigned short* bk_col = reinterpret_cast<unsigned short*>(scratch); scratch += al(nnz * 2 + 16);
-  int32_t* bk_row = reinterpret_cast<int32_t*>(scratch);
-  hipLaunchKernelGGL(tr_count_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, n_rows, row_ptr, col_idx, g_log2, n_buckets, n_parts, col_lo, col_hi,
-                     part_counts);
-  hipError_t e = launch_scan_i32(st, part_counts, m, offsets, tile_sums);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(tr_scatter_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, n_rows, row_ptr, col_idx, g_log2, n_buckets, n_parts, col_lo, col_hi,
-                     offsets, bk_col, bk_row);
-  hipLaunchKernelGGL(tr_place_kernel, dim3((unsigned)n_buckets), dim3(1024), 0, st, bk_col, bk_row, offsets, n_parts, col_ptr, n_cols, out_row_idx);
-  return hipGetLastError();
-}
-
 // ============================================================================================
 // Row work from a USER shard (multi-GPU input phase): work[i] += d_B(u) for every local user u holding item i.
 // Summed over the ranks (all-reduce) this is the same w_i the expand prefix yields, but available before any rank
