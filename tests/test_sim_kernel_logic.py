@@ -164,7 +164,7 @@ def test_large_matrix_full_pipeline(sim_session):
     compare_with_oracle(sim_session, [a, b], [P(30, 8), P(30, 8)], 5, 0, 20_000, 41_000)
 
 
-def test_bucketed_transpose_with_item_range(sim_session):
+def test_large_transpose_with_item_range(sim_session):
     """urcco_dev_transpose on a large matrix restricted to an item range (what a multi-GPU rank does): columns inside
     the range hold exactly their users (any order), columns outside are empty."""
     rng = np.random.default_rng(13)
@@ -185,3 +185,36 @@ def test_bucketed_transpose_with_item_range(sim_session):
         assert np.array_equal(lens, expect)
         for j in list(range(lo, min(lo + 50, hi))) + [hi - 1] + rng.integers(lo, hi, 200).tolist():
             assert np.array_equal(np.sort(ri[cp[j]:cp[j + 1]]), ri_ref[cp_ref[j]:cp_ref[j + 1]])
+
+
+def _csr_from_lengths(rng, lengths, n_cols):
+    lengths = np.asarray(lengths, dtype=np.int64)
+    rp = np.zeros(len(lengths) + 1, dtype=np.int64)
+    np.cumsum(lengths, out=rp[1:])
+    ci = np.empty(int(rp[-1]), dtype=np.int32)
+    for r, n in enumerate(lengths):
+        if n:
+            ci[rp[r]:rp[r + 1]] = np.sort(rng.choice(n_cols, size=int(n), replace=False))
+    return O.Csr(len(lengths), n_cols, rp, ci)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_row_scan_tile_edges(sim_session, mode):
+    """sampleDownAndBinarize shapes that stress the tiled scan: runs of empty rows longer than the staged row_ptr
+    slice, rows longer than a tile (and than maxElementsPerRow: Int/Int rate 0 vs fractional), leading / trailing
+    empty rows, a tile boundary that coincides with a row boundary, a last partial tile."""
+    rng = np.random.default_rng(21 + mode)
+    n_cols = 20000
+    lengths = ([0] * 7 + [4096] + [0] * 6000 + [3, 0, 0, 5] + [9000] + [0] * 3 + [1] * 5000 + [0] * 4500 + [700, 2, 0, 11, 4093]
+               + list(rng.integers(0, 40, 3000)) + [0] * 9)
+    m = _csr_from_lengths(rng, lengths, n_cols)
+    dev = sim_session.device
+    raw_ref = O.column_counts(m)
+    raw = torch.from_numpy(raw_ref).to(dev)
+    for max_n in (3, 500):
+        out, post = sim_session.downsample(to_dev(m, dev), m.nnz, raw, 99, max_n, mode)
+        sim_session.synchronize()
+        ref = O.downsample(m, raw_ref, 99, max_n, mode)
+        assert np.array_equal(out.row_ptr.cpu().numpy(), ref.row_ptr)
+        assert np.array_equal(out.col_idx.cpu().numpy()[:ref.nnz], ref.col_idx)
+        assert np.array_equal(post.cpu().numpy()[:n_cols], O.column_counts(ref))

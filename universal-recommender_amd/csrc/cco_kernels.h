@@ -72,6 +72,10 @@ hipError_t launch_scan_popc64(hipStream_t st, const unsigned long long* in, int6
 hipError_t launch_downsample_flags(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
                                    const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n, int row_rate_mode,
                                    int64_t row_base, unsigned long long* flags, int32_t* post_counts);
+hipError_t launch_downsample_fused(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
+                                   const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n, int row_rate_mode,
+                                   int64_t row_base, unsigned long long* tile_state, int32_t* post_counts, int64_t* out_row_ptr,
+                                   int32_t* out_col_idx, int debug);
 hipError_t launch_downsample_compact(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
                                      const unsigned long long* flags, const int64_t* word_prefix, int64_t* out_row_ptr,
                                      int32_t* out_col_idx);

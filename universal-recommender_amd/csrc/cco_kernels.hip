@@ -640,6 +640,237 @@ __global__ __launch_bounds__(256) void downsample_rowptr_kernel(int64_t n_rows, 
   }
 }
 
+// ---- single-pass form of the CSR row scan -------------------------------------------------------------
+// One kernel per matrix: keep decisions, the tile-local prefix, a decoupled look-back across tiles for the tile's
+// global output offset, compaction of the kept column ids and the new row_ptr.  Every input byte is read once and the
+// keep words never leave LDS.  Tiles take their number from a ticket counter, so a tile's predecessors are always
+// resident or finished and the look-back cannot starve.  Output order = entry order: identical to the three-pass form.
+constexpr unsigned long long LB_AGG = 1ull << 62;        // tile_state: this tile's kept count is published
+constexpr unsigned long long LB_INC = 2ull << 62;        //             kept count of all tiles up to and including this one
+constexpr unsigned long long LB_VAL = (1ull << 62) - 1;
+constexpr int DS_WORDS = DS_TILE / 64;
+static_assert(DS_WORDS == WAVE, "one wave scans the keep words of a tile");
+
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+  for (int m = 1; m < WAVE; m <<= 1) v += (long long)shfl_xor_u64((unsigned long long)v, m);
+  return v;
+}
+
+// first idx in [lo, hi] with rp[idx] >= e   (rp[hi] >= e guaranteed by the caller)
+__device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ rp, int64_t lo, int64_t hi, int64_t e) {
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (rp[mid] >= e) hi = mid; else lo = mid + 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(DS_THREADS) void downsample_fused_kernel(int64_t n_rows, const int64_t* __restrict__ rp,
+                                                                      const int32_t* __restrict__ ci, int64_t nnz,
+                                                                      const unsigned long long* __restrict__ thresholds, uint32_t seed,
+                                                                      int32_t max_n, int row_rate_mode, int64_t row_base,
+                                                                      unsigned long long* __restrict__ tile_state,
+                                                                      unsigned* __restrict__ ticket, int32_t* __restrict__ post_counts,
+                                                                      int64_t* __restrict__ out_rp, int32_t* __restrict__ out_ci,
+                                                                      int vec_ok, int debug) {
+  __shared__ int s_rel[DS_SLICE];  // row_ptr slice of the tile, relative to the tile start
+  __shared__ long long s_rows[3];
+  __shared__ unsigned long long s_keep[DS_WORDS];
+  __shared__ int s_wpre[DS_WORDS + 1];
+  __shared__ long long s_off;
+  __shared__ unsigned s_tile;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const int64_t tile = (int64_t)s_tile;
+  const int64_t e0 = tile * DS_TILE;
+  const int64_t e1 = (e0 + DS_TILE < nnz) ? e0 + DS_TILE : nnz;
+  int cols[DS_ITERS][4];
+#pragma unroll
+  for (int it = 0; it < DS_ITERS; ++it) {
+    const int64_t e = e0 + ((int64_t)it * DS_THREADS + threadIdx.x) * 4;
+    if (vec_ok && e + 3 < nnz) {
+      const int4 x = *reinterpret_cast<const int4*>(ci + e);
+      cols[it][0] = x.x; cols[it][1] = x.y; cols[it][2] = x.z; cols[it][3] = x.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cols[it][q] = (e + q < nnz) ? ci[e + q] : 0;
+    }
+  }
+  if (threadIdx.x < 2) {
+    const int64_t e = threadIdx.x == 0 ? e0 : e1 - 1;
+    s_rows[threadIdx.x] = upper_bound_i64(rp, 0, n_rows, e) - 1;  // row holding entry e
+  } else if (threadIdx.x == 2) {
+    s_rows[2] = lower_bound_i64(rp, 0, n_rows, e0);  // first row starting at or after e0
+  }
+  __syncthreads();
+  const int64_t r_first = s_rows[0], r_last = s_rows[1], r_lo = s_rows[2];
+  const int64_t n_slice = r_last - r_first + 2;  // rp[r_first .. r_last+1]
+  const bool in_lds = n_slice <= DS_SLICE;
+  if (in_lds)
+    for (int64_t t = threadIdx.x; t < n_slice; t += DS_THREADS) s_rel[t] = (int)(rp[r_first + t] - e0);
+  __syncthreads();
+  const int lane = threadIdx.x & (WAVE - 1);
+  // slice-relative row of the first entry of each of the thread's four vectors: the four binary searches advance
+  // in lockstep so that their LDS reads overlap
+  int rrel[DS_ITERS];
+#pragma unroll
+  for (int it = 0; it < DS_ITERS; ++it) rrel[it] = 0;
+  if (in_lds && !(debug & 128)) {
+    const int last = (int)n_slice - 1;  // s_rel[last] = rp[r_last+1] - e0 > every entry of the tile
+    int top = 1;
+    while (top < last) top <<= 1;
+    for (int sft = top >> 1; sft > 0; sft >>= 1) {
+#pragma unroll
+      for (int it = 0; it < DS_ITERS; ++it) {
+        const int el = (it * DS_THREADS + (int)threadIdx.x) * 4;
+        const int idx = rrel[it] + sft;
+        if (idx < last && s_rel[idx] <= el) rrel[it] = idx;
+      }
+    }
+  }
+  const double dmax = (double)max_n;
+  unsigned nibs[DS_ITERS];
+#pragma unroll
+  for (int it = 0; it < DS_ITERS; ++it) {  // block-uniform trip count: wave ops below are legal
+    const int64_t e = e0 + ((int64_t)it * DS_THREADS + threadIdx.x) * 4;
+    unsigned nib = 0;
+    if (e < e1) {
+      unsigned long long thr_col[4];  // the four threshold gathers travel together
+#pragma unroll
+      for (int q = 0; q < 4; ++q) thr_col[q] = (debug & 64) ? RATE_ONE - 1 : thresholds[cols[it][q]];
+      const int el = (int)(e - e0);
+      int64_t r;
+      int64_t r_beg, r_end;  // relative to e0
+      if (in_lds) {
+        r = r_first + rrel[it];
+        r_beg = s_rel[rrel[it]];
+        r_end = s_rel[rrel[it] + 1];
+      } else {
+        r = upper_bound_i64(rp, r_first, r_last + 1, e) - 1;
+        r_beg = rp[r] - e0;
+        r_end = rp[r + 1] - e0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t rel = el + q;
+        if (e + q < e1) {
+          while (rel >= r_end && !(debug & 128)) {  // next non-empty row
+            ++r;
+            r_beg = r_end;
+            r_end = in_lds ? (int64_t)s_rel[r + 1 - r_first] : rp[r + 1] - e0;
+          }
+          // u01 = m * 2^-53 with integer m < 2^53, so  u01 <= rate  <=>  m <= floor(rate * 2^53)  (the scaling is exact)
+          const int64_t n_row = r_end - r_beg;
+          unsigned long long thr_row = RATE_ONE;
+          if (n_row > (int64_t)max_n)
+            thr_row = row_rate_mode == 0 ? 0ull /* Int / Int = 0 */ : (unsigned long long)((dmax / (double)n_row) * 9007199254740992.0);
+          const int j = cols[it][q];
+          const unsigned long long thr = thr_row < thr_col[q] ? thr_row : thr_col[q];
+          const unsigned long long h = (debug & 32) ? ((unsigned long long)(unsigned)(j * 0x9E3779B1u) << 21) : hash53(seed, (uint32_t)(row_base + r), (uint32_t)j);
+          if (thr == RATE_ONE || h <= thr) {
+            nib |= 1u << q;
+            if (post_counts) atomicAdd(&post_counts[j], 1);
+          }
+        }
+      }
+    }
+    nibs[it] = nib;
+    // keep word of 16 neighbouring lanes (64 consecutive entries)
+    unsigned long long m = (unsigned long long)nib << ((lane & 15) * 4);
+    m |= shfl_xor_u64(m, 1);
+    m |= shfl_xor_u64(m, 2);
+    m |= shfl_xor_u64(m, 4);
+    m |= shfl_xor_u64(m, 8);
+    if ((lane & 15) == 0) s_keep[(it * DS_THREADS + (int)threadIdx.x) >> 4] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x < WAVE) {  // wave 0: prefix over the tile's keep words, then the look-back
+    const int c = __popcll(s_keep[lane]);
+    int inc = c;
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const int o = __shfl_up(inc, d);
+      if (lane >= d) inc += o;
+    }
+    s_wpre[lane] = inc - c;
+    const long long agg = (long long)__shfl(inc, WAVE - 1);
+    if (lane == 0) s_wpre[DS_WORDS] = (int)agg;
+    long long excl = 0;
+    if (tile > 0) {
+      if (lane == 0) __hip_atomic_store(&tile_state[tile], LB_AGG | (unsigned long long)agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int64_t base = tile - 1;  // lane l looks at tile base - l; the tile before tile 0 has inclusive prefix 0
+      for (unsigned polls = 0;; ++polls) {
+        if (polls > (1u << 22)) __builtin_trap();  // seconds of polling for a sub-millisecond kernel: fail the launch instead of hanging
+        const int64_t idx = base - lane;
+        const unsigned long long stw = idx >= 0 ? __hip_atomic_load(&tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_INC;
+        const unsigned long long not_ready = __ballot((stw >> 62) == 0);
+        const unsigned long long inc_mask = __ballot((stw >> 62) == 2);
+        if (inc_mask) {
+          const int first = __ffsll(inc_mask) - 1;  // nearest predecessor whose inclusive prefix is known
+          const unsigned long long nearer = first == 0 ? 0ull : (~0ull >> (64 - first));
+          if (not_ready & nearer) {
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+          }
+          excl += wave_sum_i64(lane <= first ? (long long)(stw & LB_VAL) : 0ll);
+          break;
+        }
+        if (not_ready) {
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        excl += wave_sum_i64((long long)(stw & LB_VAL));
+        base -= WAVE;
+      }
+    }
+    if (lane == 0) {
+      __hip_atomic_store(&tile_state[tile], LB_INC | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_off = excl;
+    }
+  }
+  __syncthreads();
+  const int64_t off = s_off;
+  // compaction: kept column ids in entry order
+#pragma unroll
+  for (int it = 0; it < DS_ITERS; ++it) {
+    const unsigned nib = nibs[it];
+    if (nib) {
+      const int w = (it * DS_THREADS + (int)threadIdx.x) >> 4;
+      const int b = (lane & 15) * 4;
+      const unsigned long long word = s_keep[w];
+      int64_t pos = off + s_wpre[w] + __popcll(b == 0 ? 0ull : (word & ((1ull << b) - 1ull)));
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (nib & (1u << q)) out_ci[pos++] = cols[it][q];
+    }
+  }
+  // new row_ptr of the rows that start inside this tile
+  for (int64_t r = r_lo + threadIdx.x; r <= r_last; r += DS_THREADS) {
+    const int rel = (int)(rp[r] - e0);
+    const int w = rel >> 6, b = rel & 63;
+    out_rp[r] = off + s_wpre[w] + __popcll(b == 0 ? 0ull : (s_keep[w] & ((1ull << b) - 1ull)));
+  }
+  if (e1 == nnz) {  // last tile: rows behind the last entry (trailing empty rows and the end marker)
+    const int64_t total = off + s_wpre[DS_WORDS];
+    for (int64_t r = r_last + 1 + threadIdx.x; r <= n_rows; r += DS_THREADS) out_rp[r] = total;
+  }
+}
+
+hipError_t launch_downsample_fused(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
+                                   const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n, int row_rate_mode,
+                                   int64_t row_base, unsigned long long* tile_state, int32_t* post_counts, int64_t* out_row_ptr,
+                                   int32_t* out_col_idx, int debug) {
+  if (nnz == 0) return hipSuccess;
+  hipLaunchKernelGGL(sample_threshold_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, raw_counts, n_cols, max_n, thresholds);
+  const int64_t tiles = (nnz + DS_TILE - 1) / DS_TILE;
+  hipError_t e = hipMemsetAsync(tile_state, 0, sizeof(unsigned long long) * (size_t)(tiles + 1), st);  // + the ticket counter
+  if (e != hipSuccess) return e;
+  const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
+  hipLaunchKernelGGL(downsample_fused_kernel, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, thresholds, seed, max_n,
+                     row_rate_mode, row_base, tile_state, reinterpret_cast<unsigned*>(tile_state + tiles), post_counts, out_row_ptr, out_col_idx,
+                     vec_ok, debug);
+  return hipGetLastError();
+}
+
 hipError_t launch_downsample_flags(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
                                    const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n, int row_rate_mode,
                                    int64_t row_base, unsigned long long* flags, int32_t* post_counts) {

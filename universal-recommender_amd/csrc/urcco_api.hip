@@ -260,11 +260,21 @@ int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_pt
     HIPC(hipMemsetAsync(out_row_ptr, 0, sizeof(int64_t) * (size_t)(n_rows + 1), s->stream));
     return URCCO_OK;
   }
+  // post-sampling column counts: large matrices are counted after compaction by the atomic-free partitioned histogram
+  // (its length is read on the device: out_row_ptr[n_rows]); small ones by L2 atomics inside the scan kernel
+  const int64_t ph_bytes = post_counts ? urcco::column_counts_scratch_bytes(nnz, n_cols) : 0;
+  const int64_t ds_tiles = (nnz + urcco::DS_TILE - 1) / urcco::DS_TILE;
+  if (!(s->debug & 256)) {
+    URC(s->reserve(urcco_session::need((size_t)n_cols, 8) + urcco_session::need((size_t)ds_tiles + 1, 8) + (size_t)ph_bytes + 256));
+    unsigned long long* thresholds = s->take<unsigned long long>((size_t)n_cols);
+    unsigned long long* tile_state = s->take<unsigned long long>((size_t)ds_tiles + 1);
+    s->begin(URCCO_STAGE_DOWNSAMPLE_FLAGS);
+    HIPC(urcco::launch_downsample_fused(s->stream, n_rows, row_ptr, col_idx, nnz, n_cols, raw_counts, thresholds, (uint32_t)seed, max_elements_per_row,
+                                        row_rate_mode, row_base, tile_state, ph_bytes > 0 ? nullptr : post_counts, out_row_ptr, out_col_idx, s->debug));
+    s->end();
+  } else {
   const int64_t n_words = (nnz + 63) >> 6;
   const int64_t n_tiles = (n_words + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
-  // post-sampling column counts: large matrices are counted after compaction by the atomic-free partitioned histogram
-  // (its length is read on the device: out_row_ptr[n_rows]); small ones by L2 atomics inside the flags kernel
-  const int64_t ph_bytes = post_counts ? urcco::column_counts_scratch_bytes(nnz, n_cols) : 0;
   URC(s->reserve(urcco_session::need((size_t)n_words + 1, 8) * 2 + urcco_session::need((size_t)n_tiles + 2, 8) + urcco_session::need((size_t)n_cols, 8) +
                  (size_t)ph_bytes + 256));
   unsigned long long* thresholds = s->take<unsigned long long>((size_t)n_cols);
@@ -281,6 +291,7 @@ int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_pt
   s->begin(URCCO_STAGE_DOWNSAMPLE_COMPACT);
   HIPC(urcco::launch_downsample_compact(s->stream, s->n_cu, n_rows, row_ptr, col_idx, nnz, flags, word_prefix, out_row_ptr, out_col_idx));
   s->end();
+  }
   if (ph_bytes > 0) {
     s->begin(URCCO_STAGE_COLUMN_COUNTS);
     HIPC(urcco::launch_column_counts_partitioned(s->stream, out_col_idx, nnz, out_row_ptr + n_rows, n_cols, post_counts, s->take<char>((size_t)ph_bytes)));
