@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Profiling aid: the CSR row scan (urcco_dev_downsample) alone on the config-3 matrices, with parts switched off
-(urcco_session_set_debug: 256 = three-pass form, 32 = cheap hash, 64 = no threshold gather, 128 = no row lookup).
-Outputs of ablated runs are meaningless; only the unablated forms are compared with each other."""
+(urcco_session_set_debug: 32 = cheap hash, 64 = no threshold gather, 128 = no row lookup).  Outputs of ablated runs
+are meaningless.  `--sim` = dry run on the test-only host simulator."""
 import os
 import sys
 import time
@@ -14,39 +14,43 @@ import torch  # noqa: E402
 from universal_recommender_amd import _lib, synth  # noqa: E402
 from universal_recommender_amd.device import DevCsr, DeviceSession  # noqa: E402
 
-scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
-flags = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 256, 32, 64, 128, 224]
-reps = 10
-dev = torch.device("cuda", 0)
+sim = "--sim" in sys.argv
+argv = [a for a in sys.argv[1:] if a != "--sim"]
+scale = float(argv[0]) if len(argv) > 0 else 1.0
+flags = [int(x) for x in argv[1].split(",")] if len(argv) > 1 else [0, 32, 64, 128, 224]
+reps = 2 if sim else 10
+dev = torch.device("cpu") if sim else torch.device("cuda", 0)
 cfg = synth.config3(scale)
 data = synth.generate(cfg)
 mats = [DevCsr(cfg.n_users, nc, torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), int(rp[-1])) for (_, nc, rp, ci) in data]
-sess = DeviceSession(dev, _lib.load(_lib.DEFAULT_PATH))
-raws = [sess.column_counts(m.col_idx, m.nnz, m.n_cols) for m in mats]
-outs = {}
+if sim:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hostsim import build_sim
+    sess = DeviceSession(dev, _lib.load(build_sim.build()))
+    sync = lambda: None
+else:
+    sess = DeviceSession(dev, _lib.load(_lib.DEFAULT_PATH))
+    sync = torch.cuda.synchronize
+raws = [sess.column_counts(m.col_idx, m.nnz_bound, m.n_cols) for m in mats]
 for f in flags:
     sess.set_debug(f)
     line = []
     for i, (m, raw) in enumerate(zip(mats, raws)):
         for _ in range(2):
-            out, post = sess.downsample(m, m.nnz, raw, 1, 500)
-        torch.cuda.synchronize()
+            out, post = sess.downsample(m, m.nnz_bound, raw, 1, 500)
+        sync()
         sess.set_timing(True)
         t0 = time.perf_counter()
         for _ in range(reps):
-            out, post = sess.downsample(m, m.nnz, raw, 1, 500)
-        torch.cuda.synchronize()
+            out, post = sess.downsample(m, m.nnz_bound, raw, 1, 500)
+        sync()
         wall = (time.perf_counter() - t0) / reps * 1e3
         tm = sess.get_timings()
         sess.set_timing(False)
-        scan = sum(tm[k][0] for k in ("downsample_flags", "downsample_scan", "downsample_compact")) / reps
+        parts = [tm[k][0] / reps for k in ("downsample_flags", "downsample_scan", "downsample_compact")]
+        scan = sum(parts)
         kept = int(out.row_ptr[-1].item())
-        alg = m.nnz * 4 + kept * 4 + (m.n_rows + 1) * 16
-        line.append(f"m{i}: nnz={m.nnz} kept={kept} scan={scan:.4f} ms ({alg / scan / 1e6:.0f} GB/s) wall={wall:.3f}")
-        if f in (0, 256):
-            outs[(f, i)] = (out.row_ptr.clone(), out.col_idx[:kept].clone(), post.clone())
+        alg = m.nnz_bound * 4 + kept * 4 + (m.n_rows + 1) * 16
+        line.append(f"m{i}: nnz={m.nnz_bound} kept={kept} scan={scan:.4f} ms = " + "+".join(f"{x:.4f}" for x in parts) + f" ({alg / scan / 1e6:.0f} GB/s) wall={wall:.3f}")
     print(f"debug={f}: " + " | ".join(line), flush=True)
 sess.set_debug(0)
-if 0 in flags and 256 in flags:
-    same = all(torch.equal(a, b) for i in range(len(mats)) for a, b in zip(outs[(0, i)], outs[(256, i)]))
-    print("single-pass == three-pass:", same)

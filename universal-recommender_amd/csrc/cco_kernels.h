@@ -66,18 +66,16 @@ hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_i
 
 // scans: out[i] = sum_{t<i} in[t], out[n] = total.  tile_sums scratch: ceil(n / SCAN_TILE) + 1 int64.
 hipError_t launch_scan_i32(hipStream_t st, const int32_t* in, int64_t n, int64_t* out, int64_t* tile_sums);
-hipError_t launch_scan_popc64(hipStream_t st, const unsigned long long* in, int64_t n, int64_t* out, int64_t* tile_sums);
 
-// thresholds: scratch [n_cols] u64 (per-column sample-rate thresholds, filled here)
-hipError_t launch_downsample_flags(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
-                                   const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n, int row_rate_mode,
-                                   int64_t row_base, unsigned long long* flags, int32_t* post_counts);
-hipError_t launch_downsample_fused(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
-                                   const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n, int row_rate_mode,
-                                   int64_t row_base, unsigned long long* tile_state, int32_t* post_counts, int64_t* out_row_ptr,
-                                   int32_t* out_col_idx, int debug);
-hipError_t launch_downsample_compact(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
-                                     const unsigned long long* flags, const int64_t* word_prefix, int64_t* out_row_ptr,
+// CSR row scan.  Scratch: thresholds [n_cols] u64, tile_rows [tiles + 1] i64, flags [tiles * DS_TILE / 64] u64,
+// tile_count [tiles + 1] i64 (exclusive offsets after launch_downsample_scan), tiles = ceil(nnz / DS_TILE)
+hipError_t launch_downsample_flags(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
+                                   int32_t n_cols, const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n,
+                                   int row_rate_mode, int64_t row_base, int64_t* tile_rows, unsigned long long* flags, int64_t* tile_count,
+                                   int32_t* post_counts, int debug);
+hipError_t launch_downsample_scan(hipStream_t st, int64_t nnz, int64_t* tile_count);
+hipError_t launch_downsample_compact(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
+                                     const int64_t* tile_rows, const unsigned long long* flags, const int64_t* tile_off, int64_t* out_row_ptr,
                                      int32_t* out_col_idx);
 
 // only columns in [col_lo, col_hi) are transposed (col_ptr must come from launch_scan_i32_range with the same range)

@@ -144,24 +144,6 @@ struct LoadI64 {
     }
   }
 };
-struct LoadPopc64 {
-  const unsigned long long* p;
-  __device__ __forceinline__ long long operator()(int64_t i) const { return __popcll(p[i]); }
-  __device__ __forceinline__ void load8(int64_t i, long long* x) const {
-    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int4 a = *reinterpret_cast<const int4*>(p + i + 2 * q);
-        x[2 * q] = __popc((unsigned)a.x) + __popc((unsigned)a.y);
-        x[2 * q + 1] = __popc((unsigned)a.z) + __popc((unsigned)a.w);
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) x[q] = __popcll(p[i + q]);
-    }
-  }
-};
-
 // inclusive scan of one value per thread over the block; returns the exclusive prefix, *total = block sum.
 // All 256 threads must call it.
 __device__ __forceinline__ long long block_exclusive_scan(long long v, long long* s_wave /*[SCAN_THREADS/WAVE]*/, long long* total) {
@@ -280,9 +262,6 @@ hipError_t launch_scan_i32(hipStream_t st, const int32_t* in, int64_t n, int64_t
 }
 hipError_t launch_scan_i64(hipStream_t st, const int64_t* in, int64_t n, int64_t* out, int64_t* tile_sums) {
   return launch_scan(st, LoadI64{in}, n, out, tile_sums);
-}
-hipError_t launch_scan_popc64(hipStream_t st, const unsigned long long* in, int64_t n, int64_t* out, int64_t* tile_sums) {
-  return launch_scan(st, LoadPopc64{in}, n, out, tile_sums);
 }
 
 // ============================================================================================
@@ -462,17 +441,25 @@ hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_i
 }
 
 // ============================================================================================
-// K2  sampleDownAndBinarize -- the CSR row scan
-// Pass A (flags): flat over the nnz array, 16 B per lane, the block's row_ptr slice staged in LDS for the
-//   entry -> row lookup; keep decision per entry = u01(seed,row,col) <= min(perRowRate, perThingRate);
-//   the 4-bit nibbles of 16 neighbouring lanes are OR-assembled into one 64-bit keep word (bit e%64 of
-//   word e/64), post-sampling column counts accumulate by L2 atomics (<= ~max per address after the cut).
-// Pass B (compact): prefix over popcounts of the keep words -> out position of every kept entry; the new
-//   row_ptr is the same prefix evaluated at the old row starts.
+// K2  sampleDownAndBinarize -- the CSR row scan.  Tiles of DS_TILE consecutive entries, one block each.
+//   tile rows  g[t] = first row that starts at or after entry t*DS_TILE: one pass over row_ptr.  (A binary search per
+//              tile costs ~20 dependent global loads before the tile can start and was, measured, the larger part of
+//              the scan; a single-pass form with a decoupled look-back across tiles was measured slower still --
+//              the resident tiles finish their keep decisions in lock step and then queue on each other.)
+//   flags      16 B per lane coalesced column loads; the tile's row_ptr slice staged in LDS for the entry -> row
+//              lookup; keep decision per entry = u01(seed,row,col) <= min(perRowRate, perThingRate); the 4-bit nibbles
+//              of 16 neighbouring lanes OR-assembled into one 64-bit keep word; kept count per tile.  Post-sampling
+//              column counts by L2 atomics (small matrices only; <= ~max per address after the cut).
+//   scan       exclusive prefix of the per-tile counts (one block)
+//   compact    per tile: prefix over its 64 keep words in LDS -> output position of every kept entry, and the new
+//              row_ptr of the rows that start inside the tile
 // ============================================================================================
 constexpr int DS_THREADS = 256;
 constexpr int DS_ITERS = DS_TILE / (DS_THREADS * 4);  // 4
 constexpr int DS_SLICE = DS_TILE + 2;                 // row_ptr entries staged per tile
+constexpr int DS_WORDS = DS_TILE / 64;
+static_assert(DS_WORDS == WAVE, "one wave scans the keep words of a tile");
+static_assert((DS_TILE & (DS_TILE - 1)) == 0, "tile index by shift");
 
 constexpr unsigned long long RATE_ONE = 1ull << 53;  // threshold of a sample rate of 1.0 (every 53-bit hash passes)
 
@@ -495,15 +482,30 @@ __device__ __forceinline__ int64_t upper_bound_i64(const int64_t* __restrict__ r
   return lo;
 }
 
+// g[t] = first row r with rp[r] >= t * DS_TILE for t < n_tiles (row r writes the tiles with rp[r-1] < t*DS_TILE <= rp[r]:
+// one writer per tile); g[n_tiles] = n_rows + 1, so that [g[t], g[t+1]) partitions the rows 0..n_rows (end marker included).
+__global__ __launch_bounds__(256) void tile_rows_kernel(int64_t n_rows, const int64_t* __restrict__ rp, int64_t n_tiles, int64_t* __restrict__ g) {
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= n_rows; r += (int64_t)gridDim.x * 256) {
+    int64_t t = r == 0 ? 0 : rp[r - 1] / DS_TILE + 1;
+    const int64_t t_hi = rp[r] / DS_TILE;
+    for (; t <= t_hi && t < n_tiles; ++t) g[t] = r;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) g[n_tiles] = n_rows + 1;
+}
+
+// `debug` (profiling only, results meaningless): 32 = cheap hash, 64 = no threshold gather, 128 = no row lookup
 __global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_rows, const int64_t* __restrict__ rp,
                                                                       const int32_t* __restrict__ ci, int64_t nnz,
+                                                                      const int64_t* __restrict__ g,
                                                                       const unsigned long long* __restrict__ thresholds, uint32_t seed,
                                                                       int32_t max_n, int row_rate_mode, int64_t row_base,
                                                                       unsigned long long* __restrict__ flags,
-                                                                      int32_t* __restrict__ post_counts, int vec_ok) {
+                                                                      int64_t* __restrict__ tile_count,
+                                                                      int32_t* __restrict__ post_counts, int vec_ok, int debug) {
   __shared__ int s_rel[DS_SLICE];  // row_ptr slice of the tile, relative to the tile start (a row has < 2^31 entries)
-  __shared__ long long s_rows[2];
-  const int64_t e0 = (int64_t)blockIdx.x * DS_TILE;
+  __shared__ int s_cnt[DS_THREADS / WAVE];
+  const int64_t tile = blockIdx.x;
+  const int64_t e0 = tile * DS_TILE;
   const int64_t e1 = (e0 + DS_TILE < nnz) ? e0 + DS_TILE : nnz;
   // all four 16-byte column vectors of this thread are requested before anything else (independent of the row lookup)
   int cols[DS_ITERS][4];
@@ -518,205 +520,24 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_
       for (int q = 0; q < 4; ++q) cols[it][q] = (e + q < nnz) ? ci[e + q] : 0;
     }
   }
-  if (threadIdx.x < 2) {
-    const int64_t e = threadIdx.x == 0 ? e0 : e1 - 1;
-    s_rows[threadIdx.x] = upper_bound_i64(rp, 0, n_rows, e) - 1;  // row holding entry e
-  }
-  __syncthreads();
-  const int64_t r_first = s_rows[0], r_last = s_rows[1];
-  const int64_t n_slice = r_last - r_first + 2;  // rp[r_first .. r_last+1]
+  // slice rp[r_s .. r_e]: r_s = the last row known to start at or before e0, r_e = the first row starting at or after e1
+  const int64_t g0 = g[tile], g1 = g[tile + 1];
+  const int64_t r_s = rp[g0] == e0 ? g0 : g0 - 1;
+  const int64_t r_e = g1 < n_rows ? g1 : n_rows;
+  const int64_t n_slice = r_e - r_s + 1;
   const bool in_lds = n_slice <= DS_SLICE;
   if (in_lds)
-    for (int64_t t = threadIdx.x; t < n_slice; t += DS_THREADS) s_rel[t] = (int)(rp[r_first + t] - e0);
-  __syncthreads();
-  const double dmax = (double)max_n;
-  const int lane = threadIdx.x & (WAVE - 1);
-#pragma unroll
-  for (int it = 0; it < DS_ITERS; ++it) {  // block-uniform trip count: wave ops below are legal
-    const int64_t e = e0 + ((int64_t)it * DS_THREADS + threadIdx.x) * 4;
-    unsigned nib = 0;
-    if (e < e1) {
-      unsigned long long thr_col[4];  // the four threshold gathers travel together
-#pragma unroll
-      for (int q = 0; q < 4; ++q) thr_col[q] = thresholds[cols[it][q]];
-      // row of the first entry
-      const int el = (int)(e - e0);
-      int64_t r;
-      int64_t r_beg, r_end;  // relative to e0
-      if (in_lds) {
-        int lo = 0, hi = (int)n_slice - 1;  // s_rel[hi] = rp[r_last+1] - e0 > el
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (s_rel[mid] > el) hi = mid; else lo = mid + 1;
-        }
-        r = r_first + lo - 1;
-        r_beg = s_rel[lo - 1];
-        r_end = s_rel[lo];
-      } else {
-        r = upper_bound_i64(rp, r_first, r_last + 1, e) - 1;
-        r_beg = rp[r] - e0;
-        r_end = rp[r + 1] - e0;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int64_t rel = el + q;
-        if (e + q < e1) {
-          while (rel >= r_end) {  // next non-empty row
-            ++r;
-            r_beg = r_end;
-            r_end = in_lds ? (int64_t)s_rel[r + 1 - r_first] : rp[r + 1] - e0;
-          }
-          // u01 = m * 2^-53 with integer m < 2^53, so  u01 <= rate  <=>  m <= floor(rate * 2^53)  (the scaling is exact):
-          // the per-column threshold is precomputed (one division per column, not per interaction) and entries whose
-          // rate is 1.0 are kept without evaluating the hash.
-          const int64_t n_row = r_end - r_beg;
-          unsigned long long thr_row = RATE_ONE;
-          if (n_row > (int64_t)max_n)
-            thr_row = row_rate_mode == 0 ? 0ull /* Int / Int = 0 */ : (unsigned long long)((dmax / (double)n_row) * 9007199254740992.0);
-          const int j = cols[it][q];
-          const unsigned long long thr = thr_row < thr_col[q] ? thr_row : thr_col[q];
-          if (thr == RATE_ONE || hash53(seed, (uint32_t)(row_base + r), (uint32_t)j) <= thr) {
-            nib |= 1u << q;
-            if (post_counts) atomicAdd(&post_counts[j], 1);
-          }
-        }
-      }
-    }
-    // assemble the keep word of 16 neighbouring lanes (64 consecutive entries)
-    unsigned long long m = (unsigned long long)nib << ((lane & 15) * 4);
-    m |= shfl_xor_u64(m, 1);
-    m |= shfl_xor_u64(m, 2);
-    m |= shfl_xor_u64(m, 4);
-    m |= shfl_xor_u64(m, 8);
-    const int64_t e_grp = e - (int64_t)(lane & 15) * 4;  // first entry of the 16-lane group
-    if ((lane & 15) == 0 && e_grp < e1) flags[e_grp >> 6] = m;
-  }
-}
-
-// prefix position of entry e: kept entries with index < e
-__device__ __forceinline__ int64_t kept_before(const unsigned long long* __restrict__ flags, const int64_t* __restrict__ word_prefix,
-                                               int64_t e) {
-  const int64_t w = e >> 6;
-  const int b = (int)(e & 63);
-  const unsigned long long below = b == 0 ? 0ull : (flags[w] & ((1ull << b) - 1ull));
-  return word_prefix[w] + __popcll(below);
-}
-
-template <bool VEC>
-__global__ __launch_bounds__(DS_THREADS) void downsample_compact_kernel(const int32_t* __restrict__ ci, int64_t nnz,
-                                                                        const unsigned long long* __restrict__ flags,
-                                                                        const int64_t* __restrict__ word_prefix,
-                                                                        int32_t* __restrict__ out_ci) {
-  const int64_t nvec = (nnz + 3) >> 2;
-  for (int64_t v = (int64_t)blockIdx.x * DS_THREADS + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * DS_THREADS) {
-    const int64_t e = v << 2;
-    const int64_t w = e >> 6;
-    const int b = (int)(e & 63);
-    const unsigned long long word = flags[w];
-    const unsigned nib = (unsigned)(word >> b) & 0xFu;
-    if (nib == 0) continue;
-    int cols[4];
-    if (VEC && e + 3 < nnz) {
-      const int4 x = *reinterpret_cast<const int4*>(ci + e);
-      cols[0] = x.x; cols[1] = x.y; cols[2] = x.z; cols[3] = x.w;
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) cols[q] = (e + q < nnz) ? ci[e + q] : 0;
-    }
-    int64_t pos = word_prefix[w] + __popcll(b == 0 ? 0ull : (word & ((1ull << b) - 1ull)));
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (nib & (1u << q)) out_ci[pos++] = cols[q];
-  }
-}
-
-__global__ __launch_bounds__(256) void downsample_rowptr_kernel(int64_t n_rows, const int64_t* __restrict__ rp, int64_t nnz,
-                                                                const unsigned long long* __restrict__ flags,
-                                                                const int64_t* __restrict__ word_prefix, int64_t n_words,
-                                                                int64_t* __restrict__ out_rp) {
-  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= n_rows; r += (int64_t)gridDim.x * 256) {
-    const int64_t e = rp[r];
-    out_rp[r] = e >= nnz ? word_prefix[n_words] : kept_before(flags, word_prefix, e);
-  }
-}
-
-// ---- single-pass form of the CSR row scan -------------------------------------------------------------
-// One kernel per matrix: keep decisions, the tile-local prefix, a decoupled look-back across tiles for the tile's
-// global output offset, compaction of the kept column ids and the new row_ptr.  Every input byte is read once and the
-// keep words never leave LDS.  Tiles take their number from a ticket counter, so a tile's predecessors are always
-// resident or finished and the look-back cannot starve.  Output order = entry order: identical to the three-pass form.
-constexpr unsigned long long LB_AGG = 1ull << 62;        // tile_state: this tile's kept count is published
-constexpr unsigned long long LB_INC = 2ull << 62;        //             kept count of all tiles up to and including this one
-constexpr unsigned long long LB_VAL = (1ull << 62) - 1;
-constexpr int DS_WORDS = DS_TILE / 64;
-static_assert(DS_WORDS == WAVE, "one wave scans the keep words of a tile");
-
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-  for (int m = 1; m < WAVE; m <<= 1) v += (long long)shfl_xor_u64((unsigned long long)v, m);
-  return v;
-}
-
-// first idx in [lo, hi] with rp[idx] >= e   (rp[hi] >= e guaranteed by the caller)
-__device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ rp, int64_t lo, int64_t hi, int64_t e) {
-  while (lo < hi) {
-    const int64_t mid = lo + ((hi - lo) >> 1);
-    if (rp[mid] >= e) hi = mid; else lo = mid + 1;
-  }
-  return lo;
-}
-
-__global__ __launch_bounds__(DS_THREADS) void downsample_fused_kernel(int64_t n_rows, const int64_t* __restrict__ rp,
-                                                                      const int32_t* __restrict__ ci, int64_t nnz,
-                                                                      const unsigned long long* __restrict__ thresholds, uint32_t seed,
-                                                                      int32_t max_n, int row_rate_mode, int64_t row_base,
-                                                                      unsigned long long* __restrict__ tile_state,
-                                                                      unsigned* __restrict__ ticket, int32_t* __restrict__ post_counts,
-                                                                      int64_t* __restrict__ out_rp, int32_t* __restrict__ out_ci,
-                                                                      int vec_ok, int debug) {
-  __shared__ int s_rel[DS_SLICE];  // row_ptr slice of the tile, relative to the tile start
-  __shared__ long long s_rows[3];
-  __shared__ unsigned long long s_keep[DS_WORDS];
-  __shared__ int s_wpre[DS_WORDS + 1];
-  __shared__ long long s_off;
-  __shared__ unsigned s_tile;
-  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-  __syncthreads();
-  const int64_t tile = (int64_t)s_tile;
-  const int64_t e0 = tile * DS_TILE;
-  const int64_t e1 = (e0 + DS_TILE < nnz) ? e0 + DS_TILE : nnz;
-  int cols[DS_ITERS][4];
-#pragma unroll
-  for (int it = 0; it < DS_ITERS; ++it) {
-    const int64_t e = e0 + ((int64_t)it * DS_THREADS + threadIdx.x) * 4;
-    if (vec_ok && e + 3 < nnz) {
-      const int4 x = *reinterpret_cast<const int4*>(ci + e);
-      cols[it][0] = x.x; cols[it][1] = x.y; cols[it][2] = x.z; cols[it][3] = x.w;
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) cols[it][q] = (e + q < nnz) ? ci[e + q] : 0;
-    }
-  }
-  if (threadIdx.x < 2) {
-    const int64_t e = threadIdx.x == 0 ? e0 : e1 - 1;
-    s_rows[threadIdx.x] = upper_bound_i64(rp, 0, n_rows, e) - 1;  // row holding entry e
-  } else if (threadIdx.x == 2) {
-    s_rows[2] = lower_bound_i64(rp, 0, n_rows, e0);  // first row starting at or after e0
-  }
-  __syncthreads();
-  const int64_t r_first = s_rows[0], r_last = s_rows[1], r_lo = s_rows[2];
-  const int64_t n_slice = r_last - r_first + 2;  // rp[r_first .. r_last+1]
-  const bool in_lds = n_slice <= DS_SLICE;
-  if (in_lds)
-    for (int64_t t = threadIdx.x; t < n_slice; t += DS_THREADS) s_rel[t] = (int)(rp[r_first + t] - e0);
+    for (int64_t t = threadIdx.x; t < n_slice; t += DS_THREADS) s_rel[t] = (int)(rp[r_s + t] - e0);
   __syncthreads();
   const int lane = threadIdx.x & (WAVE - 1);
-  // slice-relative row of the first entry of each of the thread's four vectors: the four binary searches advance
-  // in lockstep so that their LDS reads overlap
+  // slice-relative row of the first entry of each of the thread's four vectors = the last slice index whose start is
+  // <= the entry (empty rows in front of it are skipped by construction); the four binary searches advance in lock
+  // step so that their LDS reads overlap
   int rrel[DS_ITERS];
 #pragma unroll
   for (int it = 0; it < DS_ITERS; ++it) rrel[it] = 0;
   if (in_lds && !(debug & 128)) {
-    const int last = (int)n_slice - 1;  // s_rel[last] = rp[r_last+1] - e0 > every entry of the tile
+    const int last = (int)n_slice - 1;  // s_rel[last] = rp[r_e] - e0 >= the tile length
     int top = 1;
     while (top < last) top <<= 1;
     for (int sft = top >> 1; sft > 0; sft >>= 1) {
@@ -729,7 +550,7 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_fused_kernel(int64_t n_
     }
   }
   const double dmax = (double)max_n;
-  unsigned nibs[DS_ITERS];
+  int kept = 0;
 #pragma unroll
   for (int it = 0; it < DS_ITERS; ++it) {  // block-uniform trip count: wave ops below are legal
     const int64_t e = e0 + ((int64_t)it * DS_THREADS + threadIdx.x) * 4;
@@ -742,11 +563,11 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_fused_kernel(int64_t n_
       int64_t r;
       int64_t r_beg, r_end;  // relative to e0
       if (in_lds) {
-        r = r_first + rrel[it];
+        r = r_s + rrel[it];
         r_beg = s_rel[rrel[it]];
         r_end = s_rel[rrel[it] + 1];
       } else {
-        r = upper_bound_i64(rp, r_first, r_last + 1, e) - 1;
+        r = upper_bound_i64(rp, r_s, r_e, e) - 1;
         r_beg = rp[r] - e0;
         r_end = rp[r + 1] - e0;
       }
@@ -757,16 +578,19 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_fused_kernel(int64_t n_
           while (rel >= r_end && !(debug & 128)) {  // next non-empty row
             ++r;
             r_beg = r_end;
-            r_end = in_lds ? (int64_t)s_rel[r + 1 - r_first] : rp[r + 1] - e0;
+            r_end = in_lds ? (int64_t)s_rel[r + 1 - r_s] : rp[r + 1] - e0;
           }
-          // u01 = m * 2^-53 with integer m < 2^53, so  u01 <= rate  <=>  m <= floor(rate * 2^53)  (the scaling is exact)
+          // u01 = m * 2^-53 with integer m < 2^53, so  u01 <= rate  <=>  m <= floor(rate * 2^53)  (the scaling is exact):
+          // the per-column threshold is precomputed (one division per column, not per interaction) and entries whose
+          // rate is 1.0 are kept without evaluating the hash.
           const int64_t n_row = r_end - r_beg;
           unsigned long long thr_row = RATE_ONE;
           if (n_row > (int64_t)max_n)
             thr_row = row_rate_mode == 0 ? 0ull /* Int / Int = 0 */ : (unsigned long long)((dmax / (double)n_row) * 9007199254740992.0);
           const int j = cols[it][q];
           const unsigned long long thr = thr_row < thr_col[q] ? thr_row : thr_col[q];
-          const unsigned long long h = (debug & 32) ? ((unsigned long long)(unsigned)(j * 0x9E3779B1u) << 21) : hash53(seed, (uint32_t)(row_base + r), (uint32_t)j);
+          const unsigned long long h =
+              (debug & 32) ? ((unsigned long long)((unsigned)j * 0x9E3779B1u) << 21) : hash53(seed, (uint32_t)(row_base + r), (uint32_t)j);
           if (thr == RATE_ONE || h <= thr) {
             nib |= 1u << q;
             if (post_counts) atomicAdd(&post_counts[j], 1);
@@ -774,136 +598,117 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_fused_kernel(int64_t n_
         }
       }
     }
-    nibs[it] = nib;
-    // keep word of 16 neighbouring lanes (64 consecutive entries)
+    kept += __popc(nib);
+    // keep word of 16 neighbouring lanes (64 consecutive entries); words behind the last entry are written as zero
     unsigned long long m = (unsigned long long)nib << ((lane & 15) * 4);
     m |= shfl_xor_u64(m, 1);
     m |= shfl_xor_u64(m, 2);
     m |= shfl_xor_u64(m, 4);
     m |= shfl_xor_u64(m, 8);
-    if ((lane & 15) == 0) s_keep[(it * DS_THREADS + (int)threadIdx.x) >> 4] = m;
+    if ((lane & 15) == 0) flags[tile * DS_WORDS + ((it * DS_THREADS + (int)threadIdx.x) >> 4)] = m;
   }
+  for (int msk = 1; msk < WAVE; msk <<= 1) kept += __shfl_xor(kept, msk);
+  if (lane == 0) s_cnt[threadIdx.x / WAVE] = kept;
   __syncthreads();
-  if (threadIdx.x < WAVE) {  // wave 0: prefix over the tile's keep words, then the look-back
-    const int c = __popcll(s_keep[lane]);
+  if (threadIdx.x == 0) {
+    int tot = 0;
+#pragma unroll
+    for (int w = 0; w < DS_THREADS / WAVE; ++w) tot += s_cnt[w];
+    tile_count[tile] = tot;
+  }
+}
+
+__global__ __launch_bounds__(DS_THREADS) void downsample_compact_kernel(int64_t n_rows, const int64_t* __restrict__ rp,
+                                                                        const int32_t* __restrict__ ci, int64_t nnz,
+                                                                        const int64_t* __restrict__ g,
+                                                                        const unsigned long long* __restrict__ flags,
+                                                                        const int64_t* __restrict__ tile_off,
+                                                                        int64_t* __restrict__ out_rp, int32_t* __restrict__ out_ci,
+                                                                        int vec_ok) {
+  __shared__ unsigned long long s_keep[DS_WORDS];
+  __shared__ int s_wpre[DS_WORDS + 1];
+  const int64_t tile = blockIdx.x;
+  const int64_t e0 = tile * DS_TILE;
+  const int lane = threadIdx.x & (WAVE - 1);
+  int cols[DS_ITERS][4];
+#pragma unroll
+  for (int it = 0; it < DS_ITERS; ++it) {
+    const int64_t e = e0 + ((int64_t)it * DS_THREADS + threadIdx.x) * 4;
+    if (vec_ok && e + 3 < nnz) {
+      const int4 x = *reinterpret_cast<const int4*>(ci + e);
+      cols[it][0] = x.x; cols[it][1] = x.y; cols[it][2] = x.z; cols[it][3] = x.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cols[it][q] = (e + q < nnz) ? ci[e + q] : 0;
+    }
+  }
+  if (threadIdx.x < WAVE) {  // wave 0: prefix over the tile's keep words
+    const unsigned long long word = flags[tile * DS_WORDS + lane];
+    s_keep[lane] = word;
+    const int c = __popcll(word);
     int inc = c;
     for (int d = 1; d < WAVE; d <<= 1) {
       const int o = __shfl_up(inc, d);
       if (lane >= d) inc += o;
     }
     s_wpre[lane] = inc - c;
-    const long long agg = (long long)__shfl(inc, WAVE - 1);
-    if (lane == 0) s_wpre[DS_WORDS] = (int)agg;
-    long long excl = 0;
-    if (tile > 0) {
-      if (lane == 0) __hip_atomic_store(&tile_state[tile], LB_AGG | (unsigned long long)agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int64_t base = tile - 1;  // lane l looks at tile base - l; the tile before tile 0 has inclusive prefix 0
-      for (unsigned polls = 0;; ++polls) {
-        if (polls > (1u << 22)) __builtin_trap();  // seconds of polling for a sub-millisecond kernel: fail the launch instead of hanging
-        const int64_t idx = base - lane;
-        const unsigned long long stw = idx >= 0 ? __hip_atomic_load(&tile_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : LB_INC;
-        const unsigned long long not_ready = __ballot((stw >> 62) == 0);
-        const unsigned long long inc_mask = __ballot((stw >> 62) == 2);
-        if (inc_mask) {
-          const int first = __ffsll(inc_mask) - 1;  // nearest predecessor whose inclusive prefix is known
-          const unsigned long long nearer = first == 0 ? 0ull : (~0ull >> (64 - first));
-          if (not_ready & nearer) {
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-          }
-          excl += wave_sum_i64(lane <= first ? (long long)(stw & LB_VAL) : 0ll);
-          break;
-        }
-        if (not_ready) {
-          __builtin_amdgcn_s_sleep(1);
-          continue;
-        }
-        excl += wave_sum_i64((long long)(stw & LB_VAL));
-        base -= WAVE;
-      }
-    }
-    if (lane == 0) {
-      __hip_atomic_store(&tile_state[tile], LB_INC | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_off = excl;
-    }
+    if (lane == WAVE - 1) s_wpre[DS_WORDS] = inc;
   }
   __syncthreads();
-  const int64_t off = s_off;
-  // compaction: kept column ids in entry order
+  const int64_t off = tile_off[tile];
 #pragma unroll
-  for (int it = 0; it < DS_ITERS; ++it) {
-    const unsigned nib = nibs[it];
+  for (int it = 0; it < DS_ITERS; ++it) {  // kept column ids in entry order
+    const int w = (it * DS_THREADS + (int)threadIdx.x) >> 4;
+    const int b = (lane & 15) * 4;
+    const unsigned long long word = s_keep[w];
+    const unsigned nib = (unsigned)(word >> b) & 0xFu;
     if (nib) {
-      const int w = (it * DS_THREADS + (int)threadIdx.x) >> 4;
-      const int b = (lane & 15) * 4;
-      const unsigned long long word = s_keep[w];
       int64_t pos = off + s_wpre[w] + __popcll(b == 0 ? 0ull : (word & ((1ull << b) - 1ull)));
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (nib & (1u << q)) out_ci[pos++] = cols[it][q];
     }
   }
-  // new row_ptr of the rows that start inside this tile
-  for (int64_t r = r_lo + threadIdx.x; r <= r_last; r += DS_THREADS) {
+  // new row_ptr of the rows that start inside this tile (the last tile also takes the rows behind the last entry)
+  for (int64_t r = g[tile] + threadIdx.x; r < g[tile + 1]; r += DS_THREADS) {
     const int rel = (int)(rp[r] - e0);
     const int w = rel >> 6, b = rel & 63;
-    out_rp[r] = off + s_wpre[w] + __popcll(b == 0 ? 0ull : (s_keep[w] & ((1ull << b) - 1ull)));
-  }
-  if (e1 == nnz) {  // last tile: rows behind the last entry (trailing empty rows and the end marker)
-    const int64_t total = off + s_wpre[DS_WORDS];
-    for (int64_t r = r_last + 1 + threadIdx.x; r <= n_rows; r += DS_THREADS) out_rp[r] = total;
+    out_rp[r] = off + s_wpre[w] + (b == 0 ? 0 : __popcll(s_keep[w] & ((1ull << b) - 1ull)));
   }
 }
 
-hipError_t launch_downsample_fused(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
-                                   const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n, int row_rate_mode,
-                                   int64_t row_base, unsigned long long* tile_state, int32_t* post_counts, int64_t* out_row_ptr,
-                                   int32_t* out_col_idx, int debug) {
+hipError_t launch_downsample_flags(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
+                                   int32_t n_cols, const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n,
+                                   int row_rate_mode, int64_t row_base, int64_t* tile_rows, unsigned long long* flags, int64_t* tile_count,
+                                   int32_t* post_counts, int debug) {
   if (nnz == 0) return hipSuccess;
   hipLaunchKernelGGL(sample_threshold_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, raw_counts, n_cols, max_n, thresholds);
   const int64_t tiles = (nnz + DS_TILE - 1) / DS_TILE;
-  hipError_t e = hipMemsetAsync(tile_state, 0, sizeof(unsigned long long) * (size_t)(tiles + 1), st);  // + the ticket counter
-  if (e != hipSuccess) return e;
-  const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
-  hipLaunchKernelGGL(downsample_fused_kernel, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, thresholds, seed, max_n,
-                     row_rate_mode, row_base, tile_state, reinterpret_cast<unsigned*>(tile_state + tiles), post_counts, out_row_ptr, out_col_idx,
-                     vec_ok, debug);
-  return hipGetLastError();
-}
-
-hipError_t launch_downsample_flags(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
-                                   const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n, int row_rate_mode,
-                                   int64_t row_base, unsigned long long* flags, int32_t* post_counts) {
-  if (nnz == 0) return hipSuccess;
-  hipLaunchKernelGGL(sample_threshold_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, raw_counts, n_cols, max_n, thresholds);
-  const int64_t tiles = (nnz + DS_TILE - 1) / DS_TILE;
-  const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
-  hipLaunchKernelGGL(downsample_flags_kernel, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, thresholds,
-                     seed, max_n, row_rate_mode, row_base, flags, post_counts, vec_ok);
-  return hipGetLastError();
-}
-
-hipError_t launch_downsample_compact(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
-                                     const unsigned long long* flags, const int64_t* word_prefix, int64_t* out_row_ptr,
-                                     int32_t* out_col_idx) {
-  const int64_t n_words = (nnz + 63) >> 6;
-  if (nnz > 0) {
-    const int64_t nvec = (nnz + 3) >> 2;
-    int64_t blocks = (nvec + DS_THREADS * 4 - 1) / (DS_THREADS * 4);
-    const int64_t cap = (int64_t)n_cu * 8;
-    if (blocks > cap) blocks = cap;
-    if ((reinterpret_cast<uintptr_t>(col_idx) & 15) == 0)
-      hipLaunchKernelGGL((downsample_compact_kernel<true>), dim3((unsigned)blocks), dim3(DS_THREADS), 0, st, col_idx, nnz, flags, word_prefix,
-                         out_col_idx);
-    else
-      hipLaunchKernelGGL((downsample_compact_kernel<false>), dim3((unsigned)blocks), dim3(DS_THREADS), 0, st, col_idx, nnz, flags, word_prefix,
-                         out_col_idx);
-  }
   int64_t rblocks = (n_rows + 1 + 255) / 256;
   const int64_t rcap = (int64_t)n_cu * 8;
   if (rblocks > rcap) rblocks = rcap;
-  hipLaunchKernelGGL(downsample_rowptr_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, n_rows, row_ptr, nnz, flags, word_prefix, n_words,
-                     out_row_ptr);
+  hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, n_rows, row_ptr, tiles, tile_rows);
+  const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
+  hipLaunchKernelGGL(downsample_flags_kernel, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds,
+                     seed, max_n, row_rate_mode, row_base, flags, tile_count, post_counts, vec_ok, debug);
+  return hipGetLastError();
+}
+
+// in place: tile_count[0..tiles) -> exclusive offsets, tile_count[tiles] = number of kept entries
+hipError_t launch_downsample_scan(hipStream_t st, int64_t nnz, int64_t* tile_count) {
+  if (nnz == 0) return hipSuccess;
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, tile_count, (nnz + DS_TILE - 1) / DS_TILE);
+  return hipGetLastError();
+}
+
+hipError_t launch_downsample_compact(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
+                                     const int64_t* tile_rows, const unsigned long long* flags, const int64_t* tile_off, int64_t* out_row_ptr,
+                                     int32_t* out_col_idx) {
+  if (nnz == 0) return hipSuccess;
+  const int64_t tiles = (nnz + DS_TILE - 1) / DS_TILE;
+  const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
+  hipLaunchKernelGGL(downsample_compact_kernel, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, flags,
+                     tile_off, out_row_ptr, out_col_idx, vec_ok);
   return hipGetLastError();
 }
 

@@ -264,34 +264,24 @@ int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_pt
   // (its length is read on the device: out_row_ptr[n_rows]); small ones by L2 atomics inside the scan kernel
   const int64_t ph_bytes = post_counts ? urcco::column_counts_scratch_bytes(nnz, n_cols) : 0;
   const int64_t ds_tiles = (nnz + urcco::DS_TILE - 1) / urcco::DS_TILE;
-  if (!(s->debug & 256)) {
-    URC(s->reserve(urcco_session::need((size_t)n_cols, 8) + urcco_session::need((size_t)ds_tiles + 1, 8) + (size_t)ph_bytes + 256));
-    unsigned long long* thresholds = s->take<unsigned long long>((size_t)n_cols);
-    unsigned long long* tile_state = s->take<unsigned long long>((size_t)ds_tiles + 1);
-    s->begin(URCCO_STAGE_DOWNSAMPLE_FLAGS);
-    HIPC(urcco::launch_downsample_fused(s->stream, n_rows, row_ptr, col_idx, nnz, n_cols, raw_counts, thresholds, (uint32_t)seed, max_elements_per_row,
-                                        row_rate_mode, row_base, tile_state, ph_bytes > 0 ? nullptr : post_counts, out_row_ptr, out_col_idx, s->debug));
-    s->end();
-  } else {
-  const int64_t n_words = (nnz + 63) >> 6;
-  const int64_t n_tiles = (n_words + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
-  URC(s->reserve(urcco_session::need((size_t)n_words + 1, 8) * 2 + urcco_session::need((size_t)n_tiles + 2, 8) + urcco_session::need((size_t)n_cols, 8) +
+  const size_t n_words = (size_t)ds_tiles * (urcco::DS_TILE / 64);
+  URC(s->reserve(urcco_session::need((size_t)n_cols, 8) + urcco_session::need((size_t)ds_tiles + 1, 8) * 2 + urcco_session::need(n_words, 8) +
                  (size_t)ph_bytes + 256));
   unsigned long long* thresholds = s->take<unsigned long long>((size_t)n_cols);
-  unsigned long long* flags = s->take<unsigned long long>((size_t)n_words + 1);
-  int64_t* word_prefix = s->take<int64_t>((size_t)n_words + 1);
-  int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
+  int64_t* tile_rows = s->take<int64_t>((size_t)ds_tiles + 1);
+  int64_t* tile_count = s->take<int64_t>((size_t)ds_tiles + 1);
+  unsigned long long* flags = s->take<unsigned long long>(n_words);
   s->begin(URCCO_STAGE_DOWNSAMPLE_FLAGS);
-  HIPC(urcco::launch_downsample_flags(s->stream, n_rows, row_ptr, col_idx, nnz, n_cols, raw_counts, thresholds, (uint32_t)seed, max_elements_per_row,
-                                      row_rate_mode, row_base, flags, ph_bytes > 0 ? nullptr : post_counts));
+  HIPC(urcco::launch_downsample_flags(s->stream, s->n_cu, n_rows, row_ptr, col_idx, nnz, n_cols, raw_counts, thresholds, (uint32_t)seed,
+                                      max_elements_per_row, row_rate_mode, row_base, tile_rows, flags, tile_count,
+                                      ph_bytes > 0 ? nullptr : post_counts, s->debug));
   s->end();
   s->begin(URCCO_STAGE_DOWNSAMPLE_SCAN);
-  HIPC(urcco::launch_scan_popc64(s->stream, flags, n_words, word_prefix, tile_sums));
+  HIPC(urcco::launch_downsample_scan(s->stream, nnz, tile_count));
   s->end();
   s->begin(URCCO_STAGE_DOWNSAMPLE_COMPACT);
-  HIPC(urcco::launch_downsample_compact(s->stream, s->n_cu, n_rows, row_ptr, col_idx, nnz, flags, word_prefix, out_row_ptr, out_col_idx));
+  HIPC(urcco::launch_downsample_compact(s->stream, n_rows, row_ptr, col_idx, nnz, tile_rows, flags, tile_count, out_row_ptr, out_col_idx));
   s->end();
-  }
   if (ph_bytes > 0) {
     s->begin(URCCO_STAGE_COLUMN_COUNTS);
     HIPC(urcco::launch_column_counts_partitioned(s->stream, out_col_idx, nnz, out_row_ptr + n_rows, n_cols, post_counts, s->take<char>((size_t)ph_bytes)));
