@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Profiling aid: per-stage HIP-event timings of the config-3 model build with kernel phases switched off
-(urcco_session_set_debug: 1 = gather only, 2 = no LLR, 4 = no top-k).  Results of ablated runs are meaningless."""
+(urcco_session_set_debug: 1 = gather only, 2 = no LLR, 4 = no top-k, 8 = no select, 16 = no rank).  Results of ablated runs are meaningless."""
 import os
 import sys
 import time

@@ -694,10 +694,54 @@ hipError_t launch_downsample_flags(hipStream_t st, int n_cu, int64_t n_rows, con
   return hipGetLastError();
 }
 
+// single block of 1024 threads, 8 consecutive values each: in-place exclusive scan of v[0..n), v[n] = total.  The tile
+// counts of even the largest matrix are a few passes of this loop; a multi-kernel scan would cost more in launches.
+constexpr int SS_THREADS = 1024;
+constexpr int SS_ITEMS = 8;
+__global__ __launch_bounds__(SS_THREADS) void scan_inplace_kernel(int64_t* __restrict__ v, int64_t n) {
+  __shared__ long long s_wave[SS_THREADS / WAVE];
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+  long long carry = 0;
+  for (int64_t base = 0; base < n; base += SS_THREADS * SS_ITEMS) {  // block-uniform trip count
+    const int64_t first = base + (int64_t)threadIdx.x * SS_ITEMS;
+    long long x[SS_ITEMS];
+    long long sum = 0;
+#pragma unroll
+    for (int q = 0; q < SS_ITEMS; ++q) {
+      x[q] = first + q < n ? v[first + q] : 0;
+      sum += x[q];
+    }
+    long long inc = sum;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const long long o = shfl_up_i64(inc, d);
+      if (lane >= d) inc += o;
+    }
+    if (lane == WAVE - 1) s_wave[wave] = inc;
+    __syncthreads();
+    long long before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SS_THREADS / WAVE; ++w) {
+      const long long sw = s_wave[w];
+      if (w < wave) before += sw;
+      tot += sw;
+    }
+    __syncthreads();
+    long long run = carry + before + inc - sum;
+#pragma unroll
+    for (int q = 0; q < SS_ITEMS; ++q) {
+      if (first + q < n) v[first + q] = run;
+      run += x[q];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) v[n] = carry;
+}
+
 // in place: tile_count[0..tiles) -> exclusive offsets, tile_count[tiles] = number of kept entries
 hipError_t launch_downsample_scan(hipStream_t st, int64_t nnz, int64_t* tile_count) {
   if (nnz == 0) return hipSuccess;
-  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, tile_count, (nnz + DS_TILE - 1) / DS_TILE);
+  hipLaunchKernelGGL(scan_inplace_kernel, dim3(1), dim3(SS_THREADS), 0, st, tile_count, (nnz + DS_TILE - 1) / DS_TILE);
   return hipGetLastError();
 }
 
@@ -1111,7 +1155,7 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
   return base + inc - v;
 }
 
-template <int T, int E>
+template <int T, int E, int U>
 __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T == 64 ? 6 : 1)) void cco_rows_kernel(CcoArgs a, int bin) {
   constexpr int BLOCK = T < 256 ? 256 : T;
   constexpr int TEAMS = BLOCK / T;
@@ -1215,21 +1259,34 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
           int64_t pos = ustart[o] + (first - uoff[o]);
           unsigned uend = uoff[o + 1];
           unsigned t = first;
+          // U column gathers are in flight before the first insert (a lane's pairs are a dependent chain otherwise: one
+          // HBM / L2 round trip each)
           while (t < last) {
-            const unsigned stop = last < uend ? last : uend;
-            for (; t < stop; ++t, ++pos) {
-              const unsigned jj = (unsigned)a.b_col_idx[pos];
-              if (a.debug & 1) {  // ablation: gather only
-                if (jj == 0xffffffffu) tab[0] = 1u;
-              } else if (!tab_insert(tab, jj + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) {
-                atomicAdd(a.err, 1ull);
+            const unsigned nb = last - t < (unsigned)U ? last - t : (unsigned)U;
+            unsigned jj[U];
+#pragma unroll
+            for (int x = 0; x < U; ++x) {
+              jj[x] = 0u;
+              if ((unsigned)x < nb) {
+                if (t + (unsigned)x >= uend) {  // next user with a non-empty B' row
+                  do { ++o; } while (uoff[o + 1] <= t + (unsigned)x);
+                  pos = ustart[o];
+                  uend = uoff[o + 1];
+                }
+                jj[x] = (unsigned)a.b_col_idx[pos++];
               }
             }
-            if (t < last) {  // next user with a non-empty B' row
-              do { ++o; } while (uoff[o + 1] <= t);
-              pos = ustart[o];
-              uend = uoff[o + 1];
+#pragma unroll
+            for (int x = 0; x < U; ++x) {
+              if ((unsigned)x < nb) {
+                if (a.debug & 1) {  // ablation: gather only
+                  if (jj[x] == 0xffffffffu) tab[0] = 1u;
+                } else if (!tab_insert(tab, jj[x] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) {
+                  atomicAdd(a.err, 1ull);
+                }
+              }
             }
+            t += nb;
           }
         }
       }
@@ -1259,20 +1316,39 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
     {
       const long long ca = a.cnt_a[i];
       const double row_entropy = a.ent_a[i];
-      for (unsigned t = (unsigned)tl; t < D; t += T) {
-        const unsigned vv = tab[t];
-        const int j = (int)(vv >> cb) - 1;
-        const long long k11 = (long long)(vv & cmask);
-        unsigned long long key = 0ull;
-        if (!(a.exclude_self && j == i)) {
-          const long long cbj = a.cnt_b[j];
-          const double llr = (a.debug & 2) ? (double)k11
-                                           : llr_from_entropies_tab(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11,
-                                                                    a.n_users - ca - cbj + k11, a.xlx_tab);
-          if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
+      for (unsigned t0 = (unsigned)tl; t0 < D; t0 += U * T) {  // the column-info gathers of U candidates travel together
+        unsigned vv[U];
+        int cbj[U];
+        double eb[U];
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+          const unsigned t = t0 + (unsigned)x * T;
+          vv[x] = t < D ? tab[t] : 0u;
+          cbj[x] = 0;
+          eb[x] = 0.0;
+          if (vv[x] != 0u) {
+            const int j = (int)(vv[x] >> cb) - 1;
+            cbj[x] = a.cnt_b[j];
+            eb[x] = a.ent_b[j];
+          }
         }
-        kk[t] = key;
-        n_valid += key != 0ull;
+#pragma unroll
+        for (int x = 0; x < U; ++x) {
+          const unsigned t = t0 + (unsigned)x * T;
+          if (t < D) {
+            const int j = (int)(vv[x] >> cb) - 1;
+            const long long k11 = (long long)(vv[x] & cmask);
+            unsigned long long key = 0ull;
+            if (!(a.exclude_self && j == i)) {
+              const double llr = (a.debug & 2) ? (double)k11
+                                               : llr_from_entropies_tab(row_entropy, eb[x], xlx_n, k11, ca - k11, (long long)cbj[x] - k11,
+                                                                        a.n_users - ca - (long long)cbj[x] + k11, a.xlx_tab);
+              if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
+            }
+            kk[t] = key;
+            n_valid += key != 0ull;
+          }
+        }
       }
     }
     if (has_next) {  // the next row's first-chunk operands travel while this row is ranked
@@ -1703,11 +1779,11 @@ static int blocks_per_cu(int bin) {
     int n = 0;
     hipError_t e = hipErrorUnknown;
     if (bin == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_micro_kernel, 256, 0);
-    if (bin == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<64, E0>, 256, 0);
-    if (bin == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1S>, 256, 0);
-    if (bin == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1>, 256, 0);
-    if (bin == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<512, E2S>, 512, 0);
-    if (bin == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2>, 1024, 0);
+    if (bin == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<64, E0, 1>, 256, 0);
+    if (bin == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1S, 1>, 256, 0);
+    if (bin == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1, 1>, 256, 0);
+    if (bin == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<512, E2S, 1>, 512, 0);
+    if (bin == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2, 1>, 1024, 0);
     cache[bin] = (e == hipSuccess && n > 0) ? n : 1;
   }
   return cache[bin];
@@ -1718,11 +1794,26 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
   // so no host synchronisation sits between binning and the SpGEMM.
   switch (bin) {
     case 0: hipLaunchKernelGGL(cco_rows_micro_kernel, dim3((unsigned)(n_cu * blocks_per_cu(0))), dim3(256), 0, st, args); break;
-    case 1: hipLaunchKernelGGL((cco_rows_kernel<64, E0>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1); break;
-    case 2: hipLaunchKernelGGL((cco_rows_kernel<256, E1S>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(256), 0, st, args, 2); break;
-    case 3: hipLaunchKernelGGL((cco_rows_kernel<256, E1>), dim3((unsigned)(n_cu * blocks_per_cu(3))), dim3(256), 0, st, args, 3); break;
-    case 4: hipLaunchKernelGGL((cco_rows_kernel<512, E2S>), dim3((unsigned)(n_cu * blocks_per_cu(4))), dim3(512), 0, st, args, 4); break;
-    case 5: hipLaunchKernelGGL((cco_rows_kernel<1024, E2>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5); break;
+    case 1:
+      if (args.debug & 512) hipLaunchKernelGGL((cco_rows_kernel<64, E0, 1>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1);
+      else hipLaunchKernelGGL((cco_rows_kernel<64, E0, 2>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1);
+      break;
+    case 2:
+      if (args.debug & 512) hipLaunchKernelGGL((cco_rows_kernel<256, E1S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(256), 0, st, args, 2);
+      else hipLaunchKernelGGL((cco_rows_kernel<256, E1S, 2>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(256), 0, st, args, 2);
+      break;
+    case 3:
+      if (args.debug & 512) hipLaunchKernelGGL((cco_rows_kernel<256, E1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(3))), dim3(256), 0, st, args, 3);
+      else hipLaunchKernelGGL((cco_rows_kernel<256, E1, 4>), dim3((unsigned)(n_cu * blocks_per_cu(3))), dim3(256), 0, st, args, 3);
+      break;
+    case 4:
+      if (args.debug & 512) hipLaunchKernelGGL((cco_rows_kernel<512, E2S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(4))), dim3(512), 0, st, args, 4);
+      else hipLaunchKernelGGL((cco_rows_kernel<512, E2S, 4>), dim3((unsigned)(n_cu * blocks_per_cu(4))), dim3(512), 0, st, args, 4);
+      break;
+    case 5:
+      if (args.debug & 512) hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 1>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5);
+      else hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 4>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5);
+      break;
     default: hipLaunchKernelGGL(cco_rows_global_kernel, dim3(GLOBAL_BIN_BLOCKS), dim3(GB_THREADS), 0, st, args); break;
   }
   return hipGetLastError();
