@@ -1259,8 +1259,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
           int64_t pos = ustart[o] + (first - uoff[o]);
           unsigned uend = uoff[o + 1];
           unsigned t = first;
-          // U column gathers are in flight before the first insert (a lane's pairs are a dependent chain otherwise: one
-          // HBM / L2 round trip each)
+          // U column gathers are issued before the first insert.  Measured on config 3: U = 2 / 4 are 2-7 % SLOWER than
+          // U = 1 in every accumulator class (the other resident waves already cover the gather latency; the extra
+          // instructions cost more), so every class is instantiated with U = 1.
           while (t < last) {
             const unsigned nb = last - t < (unsigned)U ? last - t : (unsigned)U;
             unsigned jj[U];
@@ -1794,26 +1795,11 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
   // so no host synchronisation sits between binning and the SpGEMM.
   switch (bin) {
     case 0: hipLaunchKernelGGL(cco_rows_micro_kernel, dim3((unsigned)(n_cu * blocks_per_cu(0))), dim3(256), 0, st, args); break;
-    case 1:
-      if (args.debug & 512) hipLaunchKernelGGL((cco_rows_kernel<64, E0, 1>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1);
-      else hipLaunchKernelGGL((cco_rows_kernel<64, E0, 2>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1);
-      break;
-    case 2:
-      if (args.debug & 512) hipLaunchKernelGGL((cco_rows_kernel<256, E1S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(256), 0, st, args, 2);
-      else hipLaunchKernelGGL((cco_rows_kernel<256, E1S, 2>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(256), 0, st, args, 2);
-      break;
-    case 3:
-      if (args.debug & 512) hipLaunchKernelGGL((cco_rows_kernel<256, E1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(3))), dim3(256), 0, st, args, 3);
-      else hipLaunchKernelGGL((cco_rows_kernel<256, E1, 4>), dim3((unsigned)(n_cu * blocks_per_cu(3))), dim3(256), 0, st, args, 3);
-      break;
-    case 4:
-      if (args.debug & 512) hipLaunchKernelGGL((cco_rows_kernel<512, E2S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(4))), dim3(512), 0, st, args, 4);
-      else hipLaunchKernelGGL((cco_rows_kernel<512, E2S, 4>), dim3((unsigned)(n_cu * blocks_per_cu(4))), dim3(512), 0, st, args, 4);
-      break;
-    case 5:
-      if (args.debug & 512) hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 1>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5);
-      else hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 4>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5);
-      break;
+    case 1: hipLaunchKernelGGL((cco_rows_kernel<64, E0, 1>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1); break;
+    case 2: hipLaunchKernelGGL((cco_rows_kernel<256, E1S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(256), 0, st, args, 2); break;
+    case 3: hipLaunchKernelGGL((cco_rows_kernel<256, E1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(3))), dim3(256), 0, st, args, 3); break;
+    case 4: hipLaunchKernelGGL((cco_rows_kernel<512, E2S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(4))), dim3(512), 0, st, args, 4); break;
+    case 5: hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 1>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5); break;
     default: hipLaunchKernelGGL(cco_rows_global_kernel, dim3(GLOBAL_BIN_BLOCKS), dim3(GB_THREADS), 0, st, args); break;
   }
   return hipGetLastError();
