@@ -218,3 +218,26 @@ def test_row_scan_tile_edges(sim_session, mode):
         assert np.array_equal(out.row_ptr.cpu().numpy(), ref.row_ptr)
         assert np.array_equal(out.col_idx.cpu().numpy()[:ref.nnz], ref.col_idx)
         assert np.array_equal(post.cpu().numpy()[:n_cols], O.column_counts(ref))
+
+
+def test_all_equal_llr_ties_cut_by_column(sim_session):
+    """Every candidate of a row has the same LLR and there are more of them than k: the radix select finds no
+    differing key byte and the cut is decided by the column order alone (llr desc, col asc).  A second block of
+    items shares only the exponent bytes.  Exact ids."""
+    rng = np.random.default_rng(17)
+    n_users, n_items = 900, 300
+    rows = []
+    for u in range(n_users):
+        if u < 120:
+            rows.append(np.arange(0, 200))                  # block 1: 200 items always together -> identical LLR
+        elif u < 400:
+            rows.append(np.sort(rng.choice(np.arange(200, 300), size=12, replace=False)))
+        else:
+            rows.append(np.zeros(0, np.int64))
+    lengths = [len(r) for r in rows]
+    rp = np.zeros(n_users + 1, np.int64)
+    np.cumsum(lengths, out=rp[1:])
+    ci = np.concatenate(rows).astype(np.int32)
+    a = O.Csr(n_users, n_items, rp, ci)
+    for k in (5, 50, 64, 150):
+        _, _, stats = compare_with_oracle(sim_session, [a, a], [P(100000, k), P(100000, k)], 3, exact_ids=True)

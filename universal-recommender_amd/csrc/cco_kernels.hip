@@ -1176,6 +1176,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
   __shared__ unsigned long long s_ambkey[TEAMS * SEL_M];
   __shared__ unsigned s_ambcol[TEAMS * SEL_M];
   __shared__ unsigned long long s_selthr[TEAMS * 2];
+  __shared__ unsigned long long s_kbits[2 * NW];  // per wave: AND / OR over its valid keys (teams larger than a wave)
 
   const int team = threadIdx.x / T;
   const int tl = threadIdx.x % T;
@@ -1314,6 +1315,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
     unsigned long long* kk = reinterpret_cast<unsigned long long*>(tab + ((D + 1u) & ~1u));
     // ---- 4. score candidates tl, tl + T, ... (dense); keys go to LDS behind the packed counts
     unsigned n_valid = 0;
+    unsigned long long kand = ~0ull, kor = 0ull;  // over this thread's valid keys: the bytes all keys share need no select pass
     {
       const long long ca = a.cnt_a[i];
       const double row_entropy = a.ent_a[i];
@@ -1347,7 +1349,11 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
               if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
             }
             kk[t] = key;
-            n_valid += key != 0ull;
+            if (key != 0ull) {
+              ++n_valid;
+              kand &= key;
+              kor |= key;
+            }
           }
         }
       }
@@ -1360,6 +1366,15 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
         pf_wp = a.wp[cs_nx + tl];
         pf_start = a.pstart[cs_nx + tl];
       }
+    }
+#pragma unroll
+    for (int msk = 1; msk < WAVE; msk <<= 1) {
+      kand &= shfl_xor_u64(kand, msk);
+      kor |= shfl_xor_u64(kor, msk);
+    }
+    if (T > WAVE && lane == 0) {  // published by the barriers inside the scan below
+      s_kbits[2 * (tl / WAVE)] = kand;
+      s_kbits[2 * (tl / WAVE) + 1] = kor;
     }
     unsigned C;
     team_exclusive_scan<T>(n_valid, s_wsum, &C);
@@ -1384,6 +1399,18 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
         //    composite, so ties by column are exact); the need-th best becomes the threshold.
         unsigned need = (unsigned)a.k;
         if (a.col_bytes < 4) thr_ncol = 0xffffffffu << (8 * a.col_bytes);  // digits of ~col above the highest used byte are all ones
+        // LLRs of one row share their sign / high exponent bits: the leading bytes common to every valid key are the
+        // threshold's too and are not searched (typically the whole first pass)
+        if (T > WAVE) {
+#pragma unroll
+          for (int w = 0; w < NW; ++w) {
+            kand &= s_kbits[2 * w];
+            kor |= s_kbits[2 * w + 1];
+          }
+        }
+        const unsigned long long kdiff = kand ^ kor;
+        const int p0 = kdiff == 0ull ? 8 : (__clzll((long long)kdiff) >> 3);
+        thr_key = p0 == 0 ? 0ull : (kor & ~(p0 >= 8 ? 0ull : (~0ull >> (8 * p0))));
         for (int b = tl; b < NH * 128; b += T) hist[b] = 0u;
         if (tl == 0) { sel_res[0] = 0u; sel_res[1] = 0u; }  // list length, ambiguous-set length
         team_sync<T>();
@@ -1391,7 +1418,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
         bool have_list = false;
         unsigned list_n = 0, prev_cnt = C;
         bool first_pass = true;
-        for (int p = 0; p < 12; ++p) {  // team-uniform trip count (the breaks below are on values every thread agrees on)
+        for (int p = p0; p < 12; ++p) {  // team-uniform trip count (the breaks below are on values every thread agrees on)
           if (p >= 8 && p < first_col_pass) continue;
           unsigned* H = hist + (p % NH) * 128;
           const bool build = SEL_CAP > 0 && !have_list && !first_pass && prev_cnt <= (unsigned)SEL_CAP;  // this sweep also records the survivors
