@@ -1176,7 +1176,12 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
   __shared__ unsigned long long s_ambkey[TEAMS * SEL_M];
   __shared__ unsigned s_ambcol[TEAMS * SEL_M];
   __shared__ unsigned long long s_selthr[TEAMS * 2];
-  __shared__ unsigned long long s_kbits[2 * NW];  // per wave: AND / OR over its valid keys (teams larger than a wave)
+  // The leading key bytes shared by every candidate of a row need no select pass (LLRs of one row share sign and high
+  // exponent bits: typically the whole first pass).  Measured on config 3: -7..9 % for the 256-thread classes, but the
+  // extra live registers cost the one-wave class +4 % (spills at its 80-VGPR cap) and the 512/1024-thread classes
+  // +0..4 %, so only T == 256 tracks the shared bytes.
+  constexpr bool SKIP_SHARED = T == 256;
+  __shared__ unsigned long long s_kbits[2 * NW];  // per wave: AND / OR over its valid keys
 
   const int team = threadIdx.x / T;
   const int tl = threadIdx.x % T;
@@ -1351,8 +1356,10 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
             kk[t] = key;
             if (key != 0ull) {
               ++n_valid;
-              kand &= key;
-              kor |= key;
+              if (SKIP_SHARED) {
+                kand &= key;
+                kor |= key;
+              }
             }
           }
         }
@@ -1367,14 +1374,16 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
         pf_start = a.pstart[cs_nx + tl];
       }
     }
+    if (SKIP_SHARED) {
 #pragma unroll
-    for (int msk = 1; msk < WAVE; msk <<= 1) {
-      kand &= shfl_xor_u64(kand, msk);
-      kor |= shfl_xor_u64(kor, msk);
-    }
-    if (T > WAVE && lane == 0) {  // published by the barriers inside the scan below
-      s_kbits[2 * (tl / WAVE)] = kand;
-      s_kbits[2 * (tl / WAVE) + 1] = kor;
+      for (int msk = 1; msk < WAVE; msk <<= 1) {
+        kand &= shfl_xor_u64(kand, msk);
+        kor |= shfl_xor_u64(kor, msk);
+      }
+      if (lane == 0) {  // published by the barriers inside the scan below
+        s_kbits[2 * (tl / WAVE)] = kand;
+        s_kbits[2 * (tl / WAVE) + 1] = kor;
+      }
     }
     unsigned C;
     team_exclusive_scan<T>(n_valid, s_wsum, &C);
@@ -1399,18 +1408,17 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
         //    composite, so ties by column are exact); the need-th best becomes the threshold.
         unsigned need = (unsigned)a.k;
         if (a.col_bytes < 4) thr_ncol = 0xffffffffu << (8 * a.col_bytes);  // digits of ~col above the highest used byte are all ones
-        // LLRs of one row share their sign / high exponent bits: the leading bytes common to every valid key are the
-        // threshold's too and are not searched (typically the whole first pass)
-        if (T > WAVE) {
+        int p0 = 0;  // first key byte that differs between candidates
+        if (SKIP_SHARED) {
 #pragma unroll
           for (int w = 0; w < NW; ++w) {
             kand &= s_kbits[2 * w];
             kor |= s_kbits[2 * w + 1];
           }
+          const unsigned long long kdiff = kand ^ kor;
+          p0 = kdiff == 0ull ? 8 : (__clzll((long long)kdiff) >> 3);
+          thr_key = p0 == 0 ? 0ull : (kor & ~(p0 >= 8 ? 0ull : (~0ull >> (8 * p0))));
         }
-        const unsigned long long kdiff = kand ^ kor;
-        const int p0 = kdiff == 0ull ? 8 : (__clzll((long long)kdiff) >> 3);
-        thr_key = p0 == 0 ? 0ull : (kor & ~(p0 >= 8 ? 0ull : (~0ull >> (8 * p0))));
         for (int b = tl; b < NH * 128; b += T) hist[b] = 0u;
         if (tl == 0) { sel_res[0] = 0u; sel_res[1] = 0u; }  // list length, ambiguous-set length
         team_sync<T>();
