@@ -118,14 +118,18 @@ def main():
     shards = [DevCsr(hi - lo, nc, torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), int(rp[-1])) for (_, nc, rp, ci) in data]
     from universal_recommender_amd.device import SessionPool, cross_occurrence_streams
     library = _lib.load(_lib.DEFAULT_PATH)
+    pool = None
     if distributed:
         sess = DeviceSession(dev, library)
+        if not args.single_stream:
+            pool = SessionPool(dev, len(shards), library)   # the A'B_d of each event type on its own HIP stream
     else:
         sess = SessionPool(dev, 1 if args.single_stream else len(shards), library)   # one HIP stream per event type
 
-    def step():
+    def step(use_pool=True):
         if distributed:
-            return sharded.cross_occurrence_sharded(sess, shards, params, args.seed, cfg.n_users, lo, force_exchange=args.force_exchange)
+            return sharded.cross_occurrence_sharded(sess, shards, params, args.seed, cfg.n_users, lo, force_exchange=args.force_exchange,
+                                                    pool=pool if use_pool else None)
         return sharded.ShardedResult(cross_occurrence_streams(sess, shards, params, args.seed), [[0, shards[0].n_cols]] * len(shards), [-1] * len(shards))
 
     def barrier():
@@ -136,7 +140,7 @@ def main():
     for _ in range(args.warmup):
         res = step()
     barrier()
-    serial_pass = not distributed and not args.single_stream and len(sess) > 1
+    serial_pass = not args.single_stream and (pool is not None or (not distributed and len(sess) > 1))
     if not serial_pass:
         sess.set_timing(True)   # HIP events around every launch group, on the launching stream
     t0 = time.perf_counter()
@@ -147,7 +151,19 @@ def main():
     timings = sess.get_timings() if not serial_pass else {}
     sess.set_timing(False)
     kernel_timing_mode = "timed region (one stream)"
-    if serial_pass:
+    if serial_pass and distributed:
+        # per-kernel durations from a second pass with every launch on the one main stream (all ranks take part)
+        for _ in range(args.warmup):
+            step(use_pool=False)
+        barrier()
+        sess.set_timing(True)
+        for _ in range(args.steps):
+            res = step(use_pool=False)
+        barrier()
+        timings = sess.get_timings()
+        sess.set_timing(False)
+        kernel_timing_mode = "separate single-stream pass of the same steps (the timed region runs the event types on separate HIP streams)"
+    elif serial_pass:
         # The timed region overlaps the event types on separate HIP streams, so a kernel's event-bracketed duration there
         # includes time it shared the GPU with other kernels.  Per-kernel durations (roofline) are therefore taken from a
         # second pass of the same steps with the event types serialised on one stream (== `bench.py --single-stream`,
@@ -267,8 +283,8 @@ def main():
                    "n_users": cfg.n_users, "n_items": [ev.n_items for ev in cfg.events], "events": [ev.name for ev in cfg.events],
                    "nnz_raw": [s.nnz_bound for s in shards] if world == 1 else None, "nnz_sampled": nnz_sampled,
                    "pairs_per_event": pairs_per_event, "maxEventsPerEventType": 500, "maxCorrelatorsPerEventType": 50, "seed": args.seed,
-                   "parallelism": f"items range-partitioned over {world} GPU(s)" + (", RCCL all-reduce + all-gather per event type" if world > 1 else
-                                                                                      ("" if args.single_stream else ", one HIP stream per event type"))},
+                   "parallelism": f"items range-partitioned over {world} GPU(s)" + (", RCCL: 3 all-reduces + asynchronous all-gathers per event type" if world > 1 else "")
+                                  + ("" if args.single_stream else ", one HIP stream per event type")},
         "pairs_per_step": pairs, "items_per_sec": round(items / (llr_ms / 1e3), 1) if llr_ms > 0 else None,
         "items_per_sec_note": "sum over event types of nItems(A) / time of the SpGEMM+LLR+top-k stages",
         "indicator_entries": int(nnz_out.sum()), "rows_by_accumulator": dict(zip(["micro", "wave", "block_small", "block", "cu_half", "cu", "global"], [int(sum(s[1 + b] for s in stats)) for b in range(_lib.N_BINS)])),

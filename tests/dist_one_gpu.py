@@ -38,6 +38,17 @@ def main():
         assert int(ind.stats[0]) == r.pairs
         check_indicators(ind.to_host(), r)
     assert all(b[0] == 0 and b[-1] == mats[0].n_cols for b in res.item_ranges)
+    # the same build with the A'B_d of each event type on its own HIP stream behind its own (asynchronous) gather
+    from universal_recommender_amd.device import SessionPool
+    pool = SessionPool(dev, len(mats), sess.lib)
+    for _ in range(3):
+        res2 = sharded.cross_occurrence_sharded(sess, [to_dev(m, dev) for m in mats], to_params(params), 99, n_users, 0, force_exchange=True, pool=pool)
+        torch.cuda.synchronize()
+        for i1, i2 in zip(res.indicators, res2.indicators):
+            n1 = int(i1.row_ptr[-1])
+            for t1, t2 in ((i1.row_ptr, i2.row_ptr), (i1.col_idx[:n1], i2.col_idx[:n1]), (i1.llr[:n1], i2.llr[:n1]), (i1.stats, i2.stats)):
+                assert torch.equal(t1, t2), "stream-per-event sharded build differs from the one-stream build"
+    pool.close()
     dist.destroy_process_group()
     print("EXCHANGE_PATH_OK")
 

@@ -116,10 +116,10 @@ class DeviceSession:
         return out
 
     def downsample(self, m: DevCsr, nnz: int, raw_counts: torch.Tensor, seed: int, max_elements_per_row: int,
-                   row_rate_mode: int = _lib.ROW_RATE_MAHOUT_INT_DIV, row_base: int = 0):
+                   row_rate_mode: int = _lib.ROW_RATE_MAHOUT_INT_DIV, row_base: int = 0, post_out: Optional[torch.Tensor] = None):
         out_rp = self.empty(m.n_rows + 1, torch.int64)
         out_ci = self.empty(max(nnz, 1), torch.int32)
-        post = self.empty(max(m.n_cols, 1), torch.int32)
+        post = post_out if post_out is not None else self.empty(max(m.n_cols, 1), torch.int32)
         self._check(self.lib.urcco_dev_downsample(self.handle, m.n_rows, _ptr(m.row_ptr), _ptr(m.col_idx), nnz, m.n_cols, _ptr(raw_counts),
                                                  _to_i32(seed), max_elements_per_row, row_rate_mode, row_base, _ptr(out_rp), _ptr(out_ci),
                                                  _ptr(post)))

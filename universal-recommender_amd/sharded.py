@@ -2,20 +2,25 @@
 
 The path shards with ONE exchange step:
 
-  input phase   -- users are range-sharded: rank r holds rows [row_base, row_base + n_local) of every raw matrix,
-                   computes local column counts (all-reduce -> the raw counts sampleDownAndBinarize needs), down-samples
-                   its rows (the RNG is keyed by the GLOBAL row, so the result does not depend on the sharding) and
-                   all-reduces the post-sampling column counts;
-  exchange      -- all-gather of the down-sampled CSR shards (variable length: padded to the largest shard, then
-                   compacted), after which every rank holds A' and each B'_i whole;
-  compute phase -- items of A are split into world_size contiguous ranges of equal summed row work (not equal count:
-                   Zipf skew; the per-item work is summed from the user shards by one all-reduce, so the ranges are known
-                   before any whole-matrix work), each rank transposes and expands ONLY its item range of A' and emits
-                   the indicator rows of that range -- disjoint rows, no further traffic.
+  input phase   -- users are range-sharded: rank r holds rows [row_base, row_base + n_local) of every raw matrix.  Local
+                   column counts of ALL event types go through one all-reduce (-> the raw counts sampleDownAndBinarize
+                   needs), every shard is down-sampled (the RNG is keyed by the GLOBAL row, so the result does not
+                   depend on the sharding), and the post-sampling counts go through a second all-reduce;
+  ranges        -- items of A are split into world_size contiguous ranges of equal summed row work (not equal count:
+                   Zipf skew).  The per-item work, summed over event types, is added up from the user shards by a third
+                   all-reduce, so the ranges are known before any whole-matrix work; one range set serves every event
+                   type (a rank's time is the sum over event types), hence ONE transposition of its slice of A';
+  exchange      -- all-gathers of the down-sampled CSR shards (row lengths + column indices, padded to the largest
+                   shard).  They are issued asynchronously in the order they are consumed -- A, then B_1, B_2, ... -- and
+                   each is waited for only when its event type is about to be processed, so the gather of B_{d+1} runs
+                   under the SpGEMM of B_d;
+  compute phase -- each rank transposes and expands ONLY its item range of A' and emits the indicator rows of that
+                   range -- disjoint rows, no further traffic.
 
-Collectives per event type: 2 small all-reduces (int32[n_items]) + 1 all-reduce of the row work (int64[n_items]) +
-1 all-gather of row lengths + 1 all-gather of column indices.  Mahout does the same job with Spark broadcasts of the count vectors and a shuffle inside `A.t %*% B`
-(reference call sites URAlgorithm.scala:323-346).  With world_size == 1 nothing is exchanged.
+Collectives per model build: 3 all-reduces (int32 counts x2, int64 work), 1 tiny all-gather of shard sizes, and per
+event type 1 all-gather of row lengths + 1 of column indices.  There is one host synchronisation (shard sizes and range
+bounds are read together).  Mahout does the same job with Spark broadcasts of the count vectors and a shuffle inside
+`A.t %*% B` (reference call sites URAlgorithm.scala:323-346).  With world_size == 1 nothing is exchanged.
 """
 from __future__ import annotations
 
@@ -40,20 +45,36 @@ def _all_reduce_sum(t: torch.Tensor, group) -> None:
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
 
 
-def _exchange_sizes(locals_: Sequence[DevCsr], group) -> List[List[List[int]]]:
-    """(rows, nnz) of every rank's down-sampled shard for ALL event types in one tiny all-gather: the first of the two
-    host syncs of a multi-GPU build (it sizes the receive buffers of the exchange)."""
+def _exchange_sizes_start(locals_: Sequence[DevCsr], group) -> torch.Tensor:
+    """(rows, nnz) of every rank's down-sampled shard for ALL event types in one tiny all-gather (device tensor: the
+    caller reads it together with the range bounds, one host sync for both)."""
     world = dist.get_world_size(group)
     dev = locals_[0].row_ptr.device
     mine = torch.stack([v for m in locals_ for v in (torch.tensor(m.n_rows, dtype=torch.int64, device=dev), m.row_ptr[-1])])
     sizes = torch.empty(world * mine.numel(), dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(sizes, mine, group=group)
-    sizes = sizes.cpu().view(world, len(locals_), 2)
-    return [[[int(sizes[r, d, 0]), int(sizes[r, d, 1])] for r in range(world)] for d in range(len(locals_))]
+    return sizes
 
 
-def _gather_sampled(local: DevCsr, sizes: List[List[int]], n_rows_global: int, group) -> DevCsr:
-    """All-gather a down-sampled row shard into the whole matrix (rows in rank order).  sizes[r] = (rows, nnz) of rank r."""
+def _exchange_sizes_finish(sizes: torch.Tensor, n_ds: int, group) -> List[List[List[int]]]:
+    world = dist.get_world_size(group)
+    sizes = sizes.cpu().view(world, n_ds, 2)
+    return [[[int(sizes[r, d, 0]), int(sizes[r, d, 1])] for r in range(world)] for d in range(n_ds)]
+
+
+@dataclass
+class _PendingGather:
+    local: DevCsr
+    rows: List[int]
+    nnzs: List[int]
+    n_rows_global: int
+    bufs: tuple            # (deg, all_deg, ci, all_ci): kept alive until the collectives have run
+    works: tuple
+
+
+def _gather_start(local: DevCsr, sizes: List[List[int]], n_rows_global: int, group) -> _PendingGather:
+    """Issue the all-gather of a down-sampled row shard (row lengths as int32 + column indices, padded to the largest
+    shard) without waiting for it.  sizes[r] = (rows, nnz) of rank r."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = local.row_ptr.device
@@ -61,35 +82,46 @@ def _gather_sampled(local: DevCsr, sizes: List[List[int]], n_rows_global: int, g
     nnzs = [s[1] for s in sizes]
     if sum(rows) != n_rows_global:
         raise ValueError(f"row shards sum to {sum(rows)} rows, expected {n_rows_global}")
-    max_rows, max_nnz = max(rows), max(max(nnzs), 1)
-    # row lengths (int32) and column indices, padded to the largest shard
+    max_rows, max_nnz = max(max(rows), 1), max(max(nnzs), 1)
     deg = torch.zeros(max_rows, dtype=torch.int32, device=dev)
     deg[: local.n_rows] = (local.row_ptr[1:] - local.row_ptr[:-1]).to(torch.int32)
     all_deg = torch.empty(world * max_rows, dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(all_deg, deg, group=group)
+    w1 = dist.all_gather_into_tensor(all_deg, deg, group=group, async_op=True)
     ci = torch.zeros(max_nnz, dtype=torch.int32, device=dev)
     ci[: nnzs[rank]] = local.col_idx[: nnzs[rank]]
     all_ci = torch.empty(world * max_nnz, dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(all_ci, ci, group=group)
+    w2 = dist.all_gather_into_tensor(all_ci, ci, group=group, async_op=True)
+    return _PendingGather(local, rows, nnzs, n_rows_global, (deg, all_deg, ci, all_ci), (w1, w2))
+
+
+def _gather_finish(p: _PendingGather) -> DevCsr:
+    """Wait for the gather (the CURRENT stream waits, not the host) and assemble the whole matrix, rows in rank order."""
+    for w in p.works:
+        w.wait()
+    _, all_deg, _, all_ci = p.bufs
+    world = len(p.rows)
+    dev = all_deg.device
+    max_rows, max_nnz = all_deg.numel() // world, all_ci.numel() // world
     if world == 1:
-        deg_cat, col_idx = all_deg[: rows[0]], all_ci[: max(nnzs[0], 1)]
+        deg_cat, col_idx = all_deg[: p.rows[0]], all_ci[: max(p.nnzs[0], 1)]
     else:
-        deg_cat = torch.cat([all_deg[r * max_rows: r * max_rows + rows[r]] for r in range(world)])
-        col_idx = torch.cat([all_ci[r * max_nnz: r * max_nnz + nnzs[r]] for r in range(world)])
-    row_ptr = torch.zeros(n_rows_global + 1, dtype=torch.int64, device=dev)
+        deg_cat = torch.cat([all_deg[r * max_rows: r * max_rows + p.rows[r]] for r in range(world)])
+        col_idx = torch.cat([all_ci[r * max_nnz: r * max_nnz + p.nnzs[r]] for r in range(world)])
+    row_ptr = torch.zeros(p.n_rows_global + 1, dtype=torch.int64, device=dev)
     torch.cumsum(deg_cat, 0, out=row_ptr[1:])
-    total = sum(nnzs)
+    total = sum(p.nnzs)
     if total == 0:
         col_idx = torch.zeros(1, dtype=torch.int32, device=dev)
-    return DevCsr(n_rows_global, local.n_cols, row_ptr, col_idx, total)
+    return DevCsr(p.n_rows_global, p.local.n_cols, row_ptr, col_idx, total)
 
 
 def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], params: Sequence[DatasetParams], seed: int,
                              n_rows_global: int, row_base: int, row_rate_mode: int = _lib.ROW_RATE_MAHOUT_INT_DIV,
-                             group=None, force_exchange: bool = False) -> ShardedResult:
+                             group=None, force_exchange: bool = False, pool=None) -> ShardedResult:
     """SimilarityAnalysis.crossOccurrenceDownsampled over world_size GPUs.  shards[d] = this rank's user rows of
     event type d (shards[0] = primary).  force_exchange runs the collectives and the range logic even in a one-rank
-    group (used to exercise the RCCL path on a single GPU)."""
+    group (used to exercise the RCCL path on a single GPU).  pool (device.SessionPool, optional): the A'B_d of each
+    event type runs on its own HIP stream (as the single-GPU driver does), each behind its own gather; same results."""
     n_ranks = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     exchange = n_ranks > 1 or (force_exchange and dist.is_initialized())
@@ -98,18 +130,28 @@ def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], para
     n_items_a = shards[0].n_cols
     n_ds = len(shards)
 
-    # ---- input phase: every event type's shard is down-sampled (nothing here waits for the host)
+    dev = shards[0].row_ptr.device
+    col_off = [0]
+    for m in shards:
+        col_off.append(col_off[-1] + max(m.n_cols, 1))
+
+    # ---- input phase: raw counts of every event type -> one all-reduce -> down-sampling -> one all-reduce of the
+    #      post-sampling counts (nothing here waits for the host)
+    raw_all = torch.empty(col_off[-1], dtype=torch.int32, device=dev)
+    post_all = torch.empty(col_off[-1], dtype=torch.int32, device=dev)
+    for d, m in enumerate(shards):
+        sess.column_counts(m.col_idx, m.nnz_bound, m.n_cols, out=raw_all[col_off[d]: col_off[d + 1]])
+    if exchange:
+        _all_reduce_sum(raw_all, group)
     locals_: List[DevCsr] = []
     counts: List[torch.Tensor] = []
-    for m, p in zip(shards, params):
-        raw = sess.column_counts(m.col_idx, m.nnz_bound, m.n_cols)
-        if exchange:
-            _all_reduce_sum(raw, group)
-        local, post = sess.downsample(m, m.nnz_bound, raw, seed, p.max_elements_per_row, row_rate_mode, row_base)
-        if exchange:
-            _all_reduce_sum(post, group)
+    for d, (m, p) in enumerate(zip(shards, params)):
+        local, post = sess.downsample(m, m.nnz_bound, raw_all[col_off[d]: col_off[d + 1]], seed, p.max_elements_per_row, row_rate_mode, row_base,
+                                      post_out=post_all[col_off[d]: col_off[d + 1]])
         locals_.append(local)
         counts.append(post)
+    if exchange:
+        _all_reduce_sum(post_all, group)
 
     if not exchange:  # (kept for callers that pass a plain session; bench.py uses device.cross_occurrence_streams at N = 1)
         a = locals_[0]
@@ -119,25 +161,48 @@ def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], para
         return ShardedResult(out, [[0, n_items_a]] * n_ds, [-1] * n_ds)
 
     # ---- work-balanced item ranges, fixed BEFORE any whole-matrix work: every rank adds up the row work its own users
-    #      contribute (per event type), one all-reduce makes it global, the same prefix split runs on every rank.
-    works = []
+    #      contribute (summed over event types), one all-reduce makes it global, the same prefix split runs on every
+    #      rank.  The shard sizes travel at the same time; both are read by the one host sync of the build.
+    work = None
     for d in range(n_ds):
         w = sess.row_work_csr(locals_[0], locals_[d].row_ptr)
-        _all_reduce_sum(w, group)
-        works.append(w)
-    # ---- exchange: sizes of all shards in one tiny all-gather (host sync #1), then the all-gathers
-    sizes = _exchange_sizes(locals_, group)
-    wholes = [_gather_sampled(locals_[d], sizes[d], n_rows_global, group) for d in range(n_ds)]
-    bounds_all = [sess.partition(works[d], n_ranks) for d in range(n_ds)]   # host sync #2 (one small D2H per event type, GPU idle-free: queued behind the gathers)
+        work = w if work is None else work.add_(w)
+    _all_reduce_sum(work, group)
+    sizes_dev = _exchange_sizes_start(locals_, group)
+    bounds = sess.partition(work, n_ranks)                    # synchronises the stream
+    sizes = _exchange_sizes_finish(sizes_dev, n_ds, group)
+    # ---- exchange: all gathers are issued now, each is waited for (by the stream) when its event type comes up
+    pending = [_gather_start(locals_[d], sizes[d], n_rows_global, group) for d in range(n_ds)]
     # ---- compute phase: a rank transposes and expands only the item range it owns
-    a = wholes[0]
-    out: List[DevIndicators] = []
-    for d in range(n_ds):
-        bounds = bounds_all[d]
-        a_col_ptr, a_row_idx = sess.transpose(a, counts[0], bounds[rank], bounds[rank + 1])
-        out.append(sess.cco_rows(bounds[rank], bounds[rank + 1], n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, wholes[d], counts[0], counts[d],
-                                 n_rows_global, d == 0, params[d]))
-    return ShardedResult(out, bounds_all, [w.nnz_bound for w in wholes])
+    lo, hi = bounds[rank], bounds[rank + 1]
+    a = _gather_finish(pending[0])
+    a_col_ptr, a_row_idx = sess.transpose(a, counts[0], lo, hi)
+    out: List[Optional[DevIndicators]] = [None] * n_ds
+    nnz_sampled = [sum(sz[1] for sz in sizes[d]) for d in range(n_ds)]
+    if pool is None or dev.type != "cuda":
+        for d in range(n_ds):
+            b = a if d == 0 else _gather_finish(pending[d])
+            out[d] = sess.cco_rows(lo, hi, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b, counts[0], counts[d], n_rows_global, d == 0, params[d])
+        return ShardedResult(out, [list(bounds)] * n_ds, nnz_sampled)
+    # one HIP stream per event type: stream d waits for A's CSC slice and for its own gather only
+    main = torch.cuda.current_stream(dev)
+    a_ready = torch.cuda.Event()
+    a_ready.record(main)
+    streams = [pool[d].torch_stream for d in range(n_ds)]
+    for d in sorted(range(n_ds), key=lambda d: -nnz_sampled[d]):   # the heaviest event type is enqueued first
+        st = streams[d]
+        with torch.cuda.stream(st):
+            st.wait_event(a_ready)
+            for t in (a_col_ptr, a_row_idx, counts[0], counts[d], a.row_ptr, a.col_idx) + (pending[d].bufs if d else ()):
+                t.record_stream(st)               # allocated on the caller's stream, read here
+            b = a if d == 0 else _gather_finish(pending[d])
+            ind = pool[d].cco_rows(lo, hi, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b, counts[0], counts[d], n_rows_global, d == 0, params[d])
+            for t in (ind.row_ptr, ind.col_idx, ind.llr, ind.stats, b.row_ptr, b.col_idx):
+                t.record_stream(main)             # consumed by the caller on its stream
+            out[d] = ind
+    for st in set(streams):
+        main.wait_stream(st)
+    return ShardedResult(out, [list(bounds)] * n_ds, nnz_sampled)
 
 
 def gather_indicators_to_host(res: ShardedResult, group=None):
