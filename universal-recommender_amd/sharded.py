@@ -83,12 +83,18 @@ def _gather_start(local: DevCsr, sizes: List[List[int]], n_rows_global: int, gro
     if sum(rows) != n_rows_global:
         raise ValueError(f"row shards sum to {sum(rows)} rows, expected {n_rows_global}")
     max_rows, max_nnz = max(max(rows), 1), max(max(nnzs), 1)
-    deg = torch.zeros(max_rows, dtype=torch.int32, device=dev)
-    deg[: local.n_rows] = (local.row_ptr[1:] - local.row_ptr[:-1]).to(torch.int32)
+    if local.n_rows == max_rows:
+        deg = torch.diff(local.row_ptr).to(torch.int32)
+    else:
+        deg = torch.zeros(max_rows, dtype=torch.int32, device=dev)
+        deg[: local.n_rows] = torch.diff(local.row_ptr).to(torch.int32)
     all_deg = torch.empty(world * max_rows, dtype=torch.int32, device=dev)
     w1 = dist.all_gather_into_tensor(all_deg, deg, group=group, async_op=True)
-    ci = torch.zeros(max_nnz, dtype=torch.int32, device=dev)
-    ci[: nnzs[rank]] = local.col_idx[: nnzs[rank]]
+    if local.col_idx.numel() >= max_nnz:
+        ci = local.col_idx[:max_nnz]              # the shard's buffer is long enough: entries behind its nnz are never read
+    else:
+        ci = torch.zeros(max_nnz, dtype=torch.int32, device=dev)
+        ci[: nnzs[rank]] = local.col_idx[: nnzs[rank]]
     all_ci = torch.empty(world * max_nnz, dtype=torch.int32, device=dev)
     w2 = dist.all_gather_into_tensor(all_ci, ci, group=group, async_op=True)
     return _PendingGather(local, rows, nnzs, n_rows_global, (deg, all_deg, ci, all_ci), (w1, w2))
