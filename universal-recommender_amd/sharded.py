@@ -24,6 +24,7 @@ bounds are read together).  Mahout does the same job with Spark broadcasts of th
 """
 from __future__ import annotations
 
+import contextlib
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -142,20 +143,51 @@ def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], para
         col_off.append(col_off[-1] + max(m.n_cols, 1))
 
     # ---- input phase: raw counts of every event type -> one all-reduce -> down-sampling -> one all-reduce of the
-    #      post-sampling counts (nothing here waits for the host)
+    #      post-sampling counts (nothing here waits for the host).  With a pool the per-event-type work runs on the
+    #      event type's own HIP stream; the collectives join them on the caller's stream.
+    use_streams = pool is not None and dev.type == "cuda"
+    main = torch.cuda.current_stream(dev) if use_streams else None
+    streams = [pool[d].torch_stream for d in range(n_ds)] if use_streams else []
+
+    def fork():
+        for st in set(streams):
+            st.wait_stream(main)
+
+    def join():
+        for st in set(streams):
+            main.wait_stream(st)
+
+    def on(d):
+        return torch.cuda.stream(streams[d]) if use_streams else contextlib.nullcontext()
+
+    def worker(d):
+        return pool[d] if use_streams else sess
+
     raw_all = torch.empty(col_off[-1], dtype=torch.int32, device=dev)
     post_all = torch.empty(col_off[-1], dtype=torch.int32, device=dev)
+    for st in set(streams):
+        raw_all.record_stream(st)
+        post_all.record_stream(st)
+    fork()
     for d, m in enumerate(shards):
-        sess.column_counts(m.col_idx, m.nnz_bound, m.n_cols, out=raw_all[col_off[d]: col_off[d + 1]])
+        with on(d):
+            worker(d).column_counts(m.col_idx, m.nnz_bound, m.n_cols, out=raw_all[col_off[d]: col_off[d + 1]])
+    join()
     if exchange:
         _all_reduce_sum(raw_all, group)
     locals_: List[DevCsr] = []
     counts: List[torch.Tensor] = []
+    fork()
     for d, (m, p) in enumerate(zip(shards, params)):
-        local, post = sess.downsample(m, m.nnz_bound, raw_all[col_off[d]: col_off[d + 1]], seed, p.max_elements_per_row, row_rate_mode, row_base,
-                                      post_out=post_all[col_off[d]: col_off[d + 1]])
+        with on(d):
+            local, post = worker(d).downsample(m, m.nnz_bound, raw_all[col_off[d]: col_off[d + 1]], seed, p.max_elements_per_row, row_rate_mode,
+                                               row_base, post_out=post_all[col_off[d]: col_off[d + 1]])
+            if use_streams:
+                local.row_ptr.record_stream(main)     # allocated on stream d, read by the collectives / compute phase on main
+                local.col_idx.record_stream(main)
         locals_.append(local)
         counts.append(post)
+    join()
     if exchange:
         _all_reduce_sum(post_all, group)
 
@@ -169,10 +201,10 @@ def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], para
     # ---- work-balanced item ranges, fixed BEFORE any whole-matrix work: every rank adds up the row work its own users
     #      contribute (summed over event types), one all-reduce makes it global, the same prefix split runs on every
     #      rank.  The shard sizes travel at the same time; both are read by the one host sync of the build.
-    work = None
-    for d in range(n_ds):
-        w = sess.row_work_csr(locals_[0], locals_[d].row_ptr)
-        work = w if work is None else work.add_(w)
+    #      (Row work is linear in the B row lengths, so the sum over event types is ONE pass over the A shard against
+    #      the element-wise sum of the B row_ptr arrays -- one atomic per interaction of A instead of one per event type.)
+    rp_sum = locals_[0].row_ptr if n_ds == 1 else torch.stack([m.row_ptr for m in locals_]).sum(0)
+    work = sess.row_work_csr(locals_[0], rp_sum)
     _all_reduce_sum(work, group)
     sizes_dev = _exchange_sizes_start(locals_, group)
     bounds = sess.partition(work, n_ranks)                    # synchronises the stream
@@ -185,16 +217,14 @@ def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], para
     a_col_ptr, a_row_idx = sess.transpose(a, counts[0], lo, hi)
     out: List[Optional[DevIndicators]] = [None] * n_ds
     nnz_sampled = [sum(sz[1] for sz in sizes[d]) for d in range(n_ds)]
-    if pool is None or dev.type != "cuda":
+    if not use_streams:
         for d in range(n_ds):
             b = a if d == 0 else _gather_finish(pending[d])
             out[d] = sess.cco_rows(lo, hi, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b, counts[0], counts[d], n_rows_global, d == 0, params[d])
         return ShardedResult(out, [list(bounds)] * n_ds, nnz_sampled)
     # one HIP stream per event type: stream d waits for A's CSC slice and for its own gather only
-    main = torch.cuda.current_stream(dev)
     a_ready = torch.cuda.Event()
     a_ready.record(main)
-    streams = [pool[d].torch_stream for d in range(n_ds)]
     for d in sorted(range(n_ds), key=lambda d: -nnz_sampled[d]):   # the heaviest event type is enqueued first
         st = streams[d]
         with torch.cuda.stream(st):
