@@ -146,8 +146,9 @@ enum {
   URCCO_STAGE_COMPACT_INDICATORS = 15
 };
 int urcco_session_set_timing(urcco_session* s, int32_t enable);
-/* Profiling aid: kernel ablation switches (1 = gather only, 2 = no LLR, 4 = no top-k); results are meaningless when
- * non-zero.  0 in production. */
+/* Profiling aid: kernel ablation switches; results are meaningless when non-zero.  0 in production.
+ * SpGEMM rows: 1 = gather only, 2 = no LLR, 4 = no top-k, 8 = no select, 16 = no rank / output.
+ * CSR row scan: 32 = cheap hash, 64 = no threshold gather, 128 = no entry -> row lookup. */
 int urcco_session_set_debug(urcco_session* s, int32_t flags);
 int urcco_session_get_timings(urcco_session* s, double* ms /*[URCCO_N_STAGES]*/, int64_t* launches /*[URCCO_N_STAGES]*/);
 /* bytes of device scratch currently held */
