@@ -51,10 +51,12 @@ def wrap(obj, name, label):
     setattr(obj, name, g)
 
 
-wrap(sess, "partition", "partition(host sync)")
+for owner in (sess, pool[0]):
+    wrap(owner, "partition", "partition(host sync)")
+    wrap(owner, "transpose", "transpose")
 wrap(sharded, "_gather_start", "gather_start")
 wrap(sharded, "_gather_finish", "gather_finish")
-wrap(sess, "transpose", "transpose")
+wrap(sharded, "_exchange_sizes_finish", "sizes(host read)")
 for use_pool in (False, True):
     for it in range(4):
         marks.clear()

@@ -2,24 +2,27 @@
 
 The path shards with ONE exchange step:
 
-  input phase   -- users are range-sharded: rank r holds rows [row_base, row_base + n_local) of every raw matrix.  Local
-                   column counts of ALL event types go through one all-reduce (-> the raw counts sampleDownAndBinarize
-                   needs), every shard is down-sampled (the RNG is keyed by the GLOBAL row, so the result does not
-                   depend on the sharding), and the post-sampling counts go through a second all-reduce;
+  input phase   -- users are range-sharded: rank r holds rows [row_base, row_base + n_local) of every raw matrix.  Per
+                   event type: local column counts -> all-reduce (the raw counts sampleDownAndBinarize needs) ->
+                   down-sampling of the shard (the RNG is keyed by the GLOBAL row, so the result does not depend on
+                   the sharding) -> all-reduce of the post-sampling counts.  Each event type runs on its own HIP stream
+                   when a SessionPool is given; collectives synchronise with that stream only;
   ranges        -- items of A are split into world_size contiguous ranges of equal summed row work (not equal count:
-                   Zipf skew).  The per-item work, summed over event types, is added up from the user shards by a third
-                   all-reduce, so the ranges are known before any whole-matrix work; one range set serves every event
-                   type (a rank's time is the sum over event types), hence ONE transposition of its slice of A';
+                   Zipf skew).  The key is the A'A row work, added up from the user shards by one all-reduce as soon as
+                   A is sampled (the work of A'B_d sums the same users' B_d row lengths and follows it closely), so the
+                   ranges are known before any whole-matrix work and the ONE blocking host read of the build (range
+                   bounds + A's shard sizes) happens while the secondary event types are still being sampled.  One
+                   range set serves every event type, hence ONE transposition of the rank's slice of A';
   exchange      -- all-gathers of the down-sampled CSR shards (row lengths + column indices, padded to the largest
-                   shard).  They are issued asynchronously in the order they are consumed -- A, then B_1, B_2, ... -- and
-                   each is waited for only when its event type is about to be processed, so the gather of B_{d+1} runs
-                   under the SpGEMM of B_d;
+                   shard), issued asynchronously per event type: A first, B_d on stream d behind its own sampling, so
+                   the gathers of the secondaries run under the SpGEMM of A'A;
   compute phase -- each rank transposes and expands ONLY its item range of A' and emits the indicator rows of that
                    range -- disjoint rows, no further traffic.
 
-Collectives per model build: 3 all-reduces (int32 counts x2, int64 work), 1 tiny all-gather of shard sizes, and per
-event type 1 all-gather of row lengths + 1 of column indices.  There is one host synchronisation (shard sizes and range
-bounds are read together).  Mahout does the same job with Spark broadcasts of the count vectors and a shuffle inside
+Collectives per model build: per event type 2 all-reduces (int32 counts), 1 tiny all-gather of shard sizes, 1
+all-gather of row lengths + 1 of column indices; plus 1 all-reduce of the int64 work key.  The host blocks once on the
+primary's stream (bounds + sizes of A); the secondaries' shard sizes are read when their gathers are issued, by which time
+the GPU is busy with A'A.  Mahout does the same job with Spark broadcasts of the count vectors and a shuffle inside
 `A.t %*% B` (reference call sites URAlgorithm.scala:323-346).  With world_size == 1 nothing is exchanged.
 """
 from __future__ import annotations
@@ -138,104 +141,98 @@ def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], para
     n_ds = len(shards)
 
     dev = shards[0].row_ptr.device
-    col_off = [0]
-    for m in shards:
-        col_off.append(col_off[-1] + max(m.n_cols, 1))
-
-    # ---- input phase: raw counts of every event type -> one all-reduce -> down-sampling -> one all-reduce of the
-    #      post-sampling counts (nothing here waits for the host).  With a pool the per-event-type work runs on the
-    #      event type's own HIP stream; the collectives join them on the caller's stream.
     use_streams = pool is not None and dev.type == "cuda"
     main = torch.cuda.current_stream(dev) if use_streams else None
     streams = [pool[d].torch_stream for d in range(n_ds)] if use_streams else []
 
-    def fork():
-        for st in set(streams):
-            st.wait_stream(main)
-
-    def join():
-        for st in set(streams):
-            main.wait_stream(st)
-
     def on(d):
+        """Event type d's stream (collectives issued inside synchronise with that stream only)."""
         return torch.cuda.stream(streams[d]) if use_streams else contextlib.nullcontext()
 
-    def worker(d):
+    def worker(d) -> DeviceSession:
         return pool[d] if use_streams else sess
 
-    raw_all = torch.empty(col_off[-1], dtype=torch.int32, device=dev)
-    post_all = torch.empty(col_off[-1], dtype=torch.int32, device=dev)
+    def to_main(*tensors):
+        if use_streams:
+            for t in tensors:
+                t.record_stream(main)
+
     for st in set(streams):
-        raw_all.record_stream(st)
-        post_all.record_stream(st)
-    fork()
-    for d, m in enumerate(shards):
-        with on(d):
-            worker(d).column_counts(m.col_idx, m.nnz_bound, m.n_cols, out=raw_all[col_off[d]: col_off[d + 1]])
-    join()
-    if exchange:
-        _all_reduce_sum(raw_all, group)
-    locals_: List[DevCsr] = []
-    counts: List[torch.Tensor] = []
-    fork()
-    for d, (m, p) in enumerate(zip(shards, params)):
-        with on(d):
-            local, post = worker(d).downsample(m, m.nnz_bound, raw_all[col_off[d]: col_off[d + 1]], seed, p.max_elements_per_row, row_rate_mode,
-                                               row_base, post_out=post_all[col_off[d]: col_off[d + 1]])
-            if use_streams:
-                local.row_ptr.record_stream(main)     # allocated on stream d, read by the collectives / compute phase on main
-                local.col_idx.record_stream(main)
-        locals_.append(local)
-        counts.append(post)
-    join()
-    if exchange:
-        _all_reduce_sum(post_all, group)
+        st.wait_stream(main)                          # the shards were produced on the caller's stream
+
+    def input_phase(d):
+        """raw counts -> all-reduce -> down-sampling -> all-reduce of the post-sampling counts; nothing waits for the host"""
+        m, p = shards[d], params[d]
+        w = worker(d)
+        raw = w.column_counts(m.col_idx, m.nnz_bound, m.n_cols)
+        if exchange:
+            _all_reduce_sum(raw, group)
+        local, post = w.downsample(m, m.nnz_bound, raw, seed, p.max_elements_per_row, row_rate_mode, row_base)
+        if exchange:
+            _all_reduce_sum(post, group)
+        to_main(local.row_ptr, local.col_idx, post)
+        return local, post
+
+    locals_: List[Optional[DevCsr]] = [None] * n_ds
+    counts: List[Optional[torch.Tensor]] = [None] * n_ds
 
     if not exchange:  # (kept for callers that pass a plain session; bench.py uses device.cross_occurrence_streams at N = 1)
+        for d in range(n_ds):
+            with on(d):
+                locals_[d], counts[d] = input_phase(d)
+        for st in set(streams):
+            main.wait_stream(st)
         a = locals_[0]
         a_col_ptr, a_row_idx = sess.transpose(a, counts[0])
         out = [sess.cco_rows(0, n_items_a, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, locals_[d], counts[0], counts[d], n_rows_global, d == 0,
                              params[d]) for d in range(n_ds)]
         return ShardedResult(out, [[0, n_items_a]] * n_ds, [-1] * n_ds)
 
-    # ---- work-balanced item ranges, fixed BEFORE any whole-matrix work: every rank adds up the row work its own users
-    #      contribute (summed over event types), one all-reduce makes it global, the same prefix split runs on every
-    #      rank.  The shard sizes travel at the same time; both are read by the one host sync of the build.
-    #      (Row work is linear in the B row lengths, so the sum over event types is ONE pass over the A shard against
-    #      the element-wise sum of the B row_ptr arrays -- one atomic per interaction of A instead of one per event type.)
-    rp_sum = locals_[0].row_ptr if n_ds == 1 else torch.stack([m.row_ptr for m in locals_]).sum(0)
-    work = sess.row_work_csr(locals_[0], rp_sum)
-    _all_reduce_sum(work, group)
-    sizes_dev = _exchange_sizes_start(locals_, group)
-    bounds = sess.partition(work, n_ranks)                    # synchronises the stream
-    sizes = _exchange_sizes_finish(sizes_dev, n_ds, group)
-    # ---- exchange: all gathers are issued now, each is waited for (by the stream) when its event type comes up
-    pending = [_gather_start(locals_[d], sizes[d], n_rows_global, group) for d in range(n_ds)]
-    # ---- compute phase: a rank transposes and expands only the item range it owns
-    lo, hi = bounds[rank], bounds[rank + 1]
-    a = _gather_finish(pending[0])
-    a_col_ptr, a_row_idx = sess.transpose(a, counts[0], lo, hi)
+    # ---- primary event type first: its input phase, the balance key and the shard sizes of A
+    with on(0):
+        locals_[0], counts[0] = input_phase(0)
+        # Work-balanced item ranges, fixed BEFORE any whole-matrix work and before the secondary event types are even
+        # sampled: the key is the A'A row work, summed from the user shards by one all-reduce.  (The work of A'B_d for
+        # item i is the sum over the same users of their B_d row lengths, so it follows the A'A key closely; using it
+        # as the proxy lets the one blocking host read happen while the other event types are still being sampled.)
+        work = worker(0).row_work_csr(locals_[0], locals_[0].row_ptr)
+        _all_reduce_sum(work, group)
+        sizes_dev: List[Optional[torch.Tensor]] = [None] * n_ds
+        sizes_dev[0] = _exchange_sizes_start([locals_[0]], group)
+    # ---- secondary event types: enqueued now, on their own streams, so that they run under the host read below
+    for d in range(1, n_ds):
+        with on(d):
+            locals_[d], counts[d] = input_phase(d)
+            sizes_dev[d] = _exchange_sizes_start([locals_[d]], group)
+    # ---- ranges + exchange + compute of the primary
     out: List[Optional[DevIndicators]] = [None] * n_ds
-    nnz_sampled = [sum(sz[1] for sz in sizes[d]) for d in range(n_ds)]
-    if not use_streams:
-        for d in range(n_ds):
-            b = a if d == 0 else _gather_finish(pending[d])
-            out[d] = sess.cco_rows(lo, hi, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b, counts[0], counts[d], n_rows_global, d == 0, params[d])
-        return ShardedResult(out, [list(bounds)] * n_ds, nnz_sampled)
-    # one HIP stream per event type: stream d waits for A's CSC slice and for its own gather only
-    a_ready = torch.cuda.Event()
-    a_ready.record(main)
-    for d in sorted(range(n_ds), key=lambda d: -nnz_sampled[d]):   # the heaviest event type is enqueued first
-        st = streams[d]
-        with torch.cuda.stream(st):
-            st.wait_event(a_ready)
-            for t in (a_col_ptr, a_row_idx, counts[0], counts[d], a.row_ptr, a.col_idx) + (pending[d].bufs if d else ()):
-                t.record_stream(st)               # allocated on the caller's stream, read here
-            b = a if d == 0 else _gather_finish(pending[d])
-            ind = pool[d].cco_rows(lo, hi, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b, counts[0], counts[d], n_rows_global, d == 0, params[d])
-            for t in (ind.row_ptr, ind.col_idx, ind.llr, ind.stats, b.row_ptr, b.col_idx):
-                t.record_stream(main)             # consumed by the caller on its stream
-            out[d] = ind
+    nnz_sampled = [0] * n_ds
+    with on(0):
+        bounds = worker(0).partition(work, n_ranks)                  # synchronises stream 0 (the host read)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        sizes0 = _exchange_sizes_finish(sizes_dev[0], 1, group)[0]
+        nnz_sampled[0] = sum(sz[1] for sz in sizes0)
+        a = _gather_finish(_gather_start(locals_[0], sizes0, n_rows_global, group))
+        a_col_ptr, a_row_idx = worker(0).transpose(a, counts[0], lo, hi)
+        if use_streams:
+            a_ready = torch.cuda.Event()
+            a_ready.record(streams[0])
+        out[0] = worker(0).cco_rows(lo, hi, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, a, counts[0], counts[0], n_rows_global, True, params[0])
+        to_main(out[0].row_ptr, out[0].col_idx, out[0].llr, out[0].stats, a.row_ptr, a.col_idx)
+    # ---- secondaries: sizes are read per event type (that stream's down-sampling is long done: the GPU is busy with
+    #      A'A), the gather is issued and A'B_d runs behind it and behind A's CSC slice
+    for d in range(1, n_ds):
+        with on(d):
+            sizes_d = _exchange_sizes_finish(sizes_dev[d], 1, group)[0]
+            nnz_sampled[d] = sum(sz[1] for sz in sizes_d)
+            pending = _gather_start(locals_[d], sizes_d, n_rows_global, group)
+            if use_streams:
+                streams[d].wait_event(a_ready)
+                for t in (a_col_ptr, a_row_idx, counts[0], a.row_ptr, a.col_idx):
+                    t.record_stream(streams[d])               # produced on stream 0, read here
+            b = _gather_finish(pending)
+            out[d] = worker(d).cco_rows(lo, hi, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b, counts[0], counts[d], n_rows_global, False, params[d])
+            to_main(out[d].row_ptr, out[d].col_idx, out[d].llr, out[d].stats, b.row_ptr, b.col_idx)
     for st in set(streams):
         main.wait_stream(st)
     return ShardedResult(out, [list(bounds)] * n_ds, nnz_sampled)
