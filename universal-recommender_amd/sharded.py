@@ -10,9 +10,10 @@ The path shards with ONE exchange step:
   ranges        -- items of A are split into world_size contiguous ranges of equal summed row work (not equal count:
                    Zipf skew).  The key is the A'A row work, added up from the user shards by one all-reduce as soon as
                    A is sampled (the work of A'B_d sums the same users' B_d row lengths and follows it closely), so the
-                   ranges are known before any whole-matrix work and the ONE blocking host read of the build (range
-                   bounds + A's shard sizes) happens while the secondary event types are still being sampled.  One
-                   range set serves every event type, hence ONE transposition of the rank's slice of A';
+                   ranges are known before any whole-matrix work and the blocking host read of the build (range bounds
+                   + A's shard sizes) comes after the primary's short chain only; the secondary event types are sampled
+                   afterwards, under the SpGEMM of A'A.  One range set serves every event type, hence ONE
+                   transposition of the rank's slice of A';
   exchange      -- all-gathers of the down-sampled CSR shards (row lengths + column indices, padded to the largest
                    shard), issued asynchronously per event type: A first, B_d on stream d behind its own sampling, so
                    the gathers of the secondaries run under the SpGEMM of A'A;
@@ -199,12 +200,9 @@ def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], para
         _all_reduce_sum(work, group)
         sizes_dev: List[Optional[torch.Tensor]] = [None] * n_ds
         sizes_dev[0] = _exchange_sizes_start([locals_[0]], group)
-    # ---- secondary event types: enqueued now, on their own streams, so that they run under the host read below
-    for d in range(1, n_ds):
-        with on(d):
-            locals_[d], counts[d] = input_phase(d)
-            sizes_dev[d] = _exchange_sizes_start([locals_[d]], group)
-    # ---- ranges + exchange + compute of the primary
+    # ---- ranges + exchange + compute of the primary.  (The secondaries are enqueued only afterwards: measured on one
+    #      GPU, sampling them concurrently delays the primary's short dependent chain -- and with it the host read every
+    #      rank blocks on -- by more than it saves; behind A'A they fill the SpGEMM kernels' ragged tails instead.)
     out: List[Optional[DevIndicators]] = [None] * n_ds
     nnz_sampled = [0] * n_ds
     with on(0):
@@ -219,8 +217,13 @@ def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], para
             a_ready.record(streams[0])
         out[0] = worker(0).cco_rows(lo, hi, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, a, counts[0], counts[0], n_rows_global, True, params[0])
         to_main(out[0].row_ptr, out[0].col_idx, out[0].llr, out[0].stats, a.row_ptr, a.col_idx)
-    # ---- secondaries: sizes are read per event type (that stream's down-sampling is long done: the GPU is busy with
-    #      A'A), the gather is issued and A'B_d runs behind it and behind A's CSC slice
+    # ---- secondaries: every input phase is enqueued on its own stream (they run under A'A); then, per event type, the
+    #      shard sizes are read (the host waits for that stream's sampling only, the GPU stays busy), the gather is issued
+    #      and A'B_d runs behind it and behind A's CSC slice
+    for d in range(1, n_ds):
+        with on(d):
+            locals_[d], counts[d] = input_phase(d)
+            sizes_dev[d] = _exchange_sizes_start([locals_[d]], group)
     for d in range(1, n_ds):
         with on(d):
             sizes_d = _exchange_sizes_finish(sizes_dev[d], 1, group)[0]
