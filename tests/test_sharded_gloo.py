@@ -39,7 +39,12 @@ def _worker(rank, world, port, uneven, q):
         n_users = 1201
         mats = [rand_csr(rng, n_users, 300, 9, zipf_s=1.2), rand_csr(rng, n_users, 700, 14), rand_csr(rng, n_users, 11, 2, empty_frac=0.3)]
         params = [O.DatasetParams(30, 10, None), O.DatasetParams(40, 12, None), O.DatasetParams(500, 50, 0.1)]
-        cuts = [0, 900, n_users] if (uneven and world == 2) else [n_users * r // world for r in range(world + 1)]
+        if uneven == "empty":                                 # rank 0 holds no users at all
+            cuts = [0, 0] + [n_users * r // (world - 1) for r in range(1, world)]
+        elif uneven and world == 2:
+            cuts = [0, 900, n_users]
+        else:
+            cuts = [n_users * r // world for r in range(world + 1)]
         lo, hi = cuts[rank], cuts[rank + 1]
         shards = [O.Csr(hi - lo, m.n_cols, m.row_ptr[lo:hi + 1] - m.row_ptr[lo], m.col_idx[m.row_ptr[lo]:m.row_ptr[hi]]) for m in mats]
         res = sharded.cross_occurrence_sharded(sess, [to_dev(s, "cpu") for s in shards], to_params(params), 2024, n_users, lo)
@@ -61,7 +66,7 @@ def _worker(rank, world, port, uneven, q):
         q.put((rank, "fail: " + traceback.format_exc(), None))
 
 
-@pytest.mark.parametrize("world,uneven", [(2, False), (2, True), (3, False)])
+@pytest.mark.parametrize("world,uneven", [(2, False), (2, True), (3, False), (2, "empty")])
 def test_sharded_equals_single_process_oracle(world, uneven, sim_lib):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
