@@ -804,6 +804,151 @@ hipError_t launch_transpose(hipStream_t st, int n_cu, int64_t n_rows, const int6
   return hipGetLastError();
 }
 
+// --------------------------------------------------------------------------------------------
+// K3b  CSR -> CSC as a counting sort by column (matrices large enough to repay the launches).
+// The cursor-atomic kernel above takes one RETURNING L2 atomic per entry (~25 G/s on this part, the whole of its
+// 0.24 ms on config 3).  Here the entries are grouped by column bucket (8192 columns, the partitioning of the
+// column-count histogram), counted per (histogram block, column) in LDS, prefixed across the blocks of a bucket, and
+// placed with LDS cursors -- every atomic is an LDS atomic, every pass streams, and a Zipf-head bucket is spread over as
+// many blocks as it has 32768-entry chunks (one block per BUCKET was measured at 0.55 ms: the head bucket serialised).
+//   count    per part of TR_ROWS user rows: entries per bucket        scan     bucket-major offsets
+//   scatter  (col & 8191, row) pairs grouped by bucket                blockmap buckets -> chunks of 32768 entries
+//   hist     per chunk: dense LDS counters -> partial[chunk][col]     prefix   per column, exclusive over its chunks
+//   place    per chunk: cursor[col] = col_ptr[col] - bucket start + prefix[chunk][col]; row ids to their slots
+// Only columns in [col_lo, col_hi) are kept (multi-GPU item range).  Order inside a column is arbitrary, as above.
+// --------------------------------------------------------------------------------------------
+constexpr int TR_ROWS = 512;  // user rows per part
+
+__global__ __launch_bounds__(256) void tr_count_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, int g_log2,
+                                                       int n_buckets, int64_t n_parts, int32_t col_lo, int32_t col_hi,
+                                                       int32_t* __restrict__ part_counts) {
+  __shared__ int s_cnt[PH_MAX_BUCKETS];
+  for (int b = threadIdx.x; b < n_buckets; b += 256) s_cnt[b] = 0;
+  __syncthreads();
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t r0 = (int64_t)blockIdx.x * TR_ROWS;
+  const int64_t r1 = r0 + TR_ROWS < n_rows ? r0 + TR_ROWS : n_rows;
+  for (int64_t r = r0 + (threadIdx.x >> g_log2); r < r1; r += 256 >> g_log2) {
+    const int64_t s = rp[r], e = rp[r + 1];
+    for (int64_t p = s + gl; p < e; p += G) {
+      const int j = ci[p];
+      if (j >= col_lo && j < col_hi) atomicAdd(&s_cnt[j >> PH_BITS], 1);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < n_buckets; b += 256) part_counts[(int64_t)b * n_parts + blockIdx.x] = s_cnt[b];
+}
+
+__global__ __launch_bounds__(256) void tr_scatter_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, int g_log2,
+                                                         int n_buckets, int64_t n_parts, int32_t col_lo, int32_t col_hi,
+                                                         const int64_t* __restrict__ offsets, unsigned short* __restrict__ bk_col,
+                                                         int32_t* __restrict__ bk_row) {
+  __shared__ long long s_base[PH_MAX_BUCKETS];
+  __shared__ int s_cur[PH_MAX_BUCKETS];
+  for (int b = threadIdx.x; b < n_buckets; b += 256) {
+    s_base[b] = offsets[(int64_t)b * n_parts + blockIdx.x];
+    s_cur[b] = 0;
+  }
+  __syncthreads();
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t r0 = (int64_t)blockIdx.x * TR_ROWS;
+  const int64_t r1 = r0 + TR_ROWS < n_rows ? r0 + TR_ROWS : n_rows;
+  for (int64_t r = r0 + (threadIdx.x >> g_log2); r < r1; r += 256 >> g_log2) {
+    const int64_t s = rp[r], e = rp[r + 1];
+    for (int64_t p = s + gl; p < e; p += G) {
+      const int j = ci[p];
+      if (j < col_lo || j >= col_hi) continue;
+      const int b = j >> PH_BITS;
+      const int64_t pos = s_base[b] + atomicAdd(&s_cur[b], 1);
+      bk_col[pos] = (unsigned short)(j & (PH_BUCKET - 1));
+      bk_row[pos] = (int32_t)r;
+    }
+  }
+}
+
+// prefix[chunk][c] = entries of column c in the earlier chunks of the same bucket
+__global__ __launch_bounds__(256) void tr_prefix_kernel(const unsigned* __restrict__ partial, const int32_t* __restrict__ blk_prefix, int32_t n_cols,
+                                                        unsigned* __restrict__ prefix) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_cols) return;
+  const int b = (int)(j >> PH_BITS);
+  const int c = (int)(j & (PH_BUCKET - 1));
+  unsigned run = 0;
+  for (int blk = blk_prefix[b]; blk < blk_prefix[b + 1]; ++blk) {
+    prefix[(int64_t)blk * PH_BUCKET + c] = run;
+    run += partial[(int64_t)blk * PH_BUCKET + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void tr_place_kernel(const unsigned short* __restrict__ bk_col, const int32_t* __restrict__ bk_row,
+                                                       const int64_t* __restrict__ offsets, int n_buckets, int64_t n_parts,
+                                                       const int32_t* __restrict__ blk_prefix, const unsigned* __restrict__ prefix,
+                                                       const int64_t* __restrict__ col_ptr, int32_t n_cols, int32_t* __restrict__ out_rows) {
+  __shared__ unsigned s_cur[PH_BUCKET];
+  const int blk = blockIdx.x;
+  if (blk >= blk_prefix[n_buckets]) return;  // block-uniform
+  int lo = 0, hi = n_buckets;  // last b with blk_prefix[b] <= blk
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (blk_prefix[mid] <= blk) lo = mid; else hi = mid;
+  }
+  const int b = lo;
+  const int64_t col0 = (int64_t)b << PH_BITS;
+  const int64_t base = col_ptr[col0];  // where the bucket's CSC segment starts (a bucket holds < 2^32 entries)
+  for (int c = threadIdx.x; c < PH_BUCKET; c += 256)
+    s_cur[c] = (col0 + c < n_cols ? (unsigned)(col_ptr[col0 + c] - base) : 0u) + prefix[(int64_t)blk * PH_BUCKET + c];
+  __syncthreads();
+  const int64_t bs = offsets[(int64_t)b * n_parts], be = offsets[(int64_t)(b + 1) * n_parts];
+  const int64_t e0 = bs + (int64_t)(blk - blk_prefix[b]) * PH_CHUNK;
+  const int64_t e1 = e0 + PH_CHUNK < be ? e0 + PH_CHUNK : be;
+  for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+    const unsigned p = atomicAdd(&s_cur[bk_col[e]], 1u);
+    out_rows[base + p] = bk_row[e];
+  }
+}
+
+int64_t transpose_scratch_bytes(int64_t n_rows, int64_t nnz, int32_t n_cols) {
+  const int64_t n_buckets = ((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS;
+  if (nnz < PH_MIN_NNZ || n_buckets > PH_MAX_BUCKETS || n_buckets < 1) return 0;
+  const int64_t n_parts = (n_rows + TR_ROWS - 1) / TR_ROWS;
+  const int64_t m = n_buckets * n_parts;
+  const int64_t max_blocks = n_buckets + (nnz + PH_CHUNK - 1) / PH_CHUNK;
+  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  return al(m * 4) + al((m + 1) * 8) + al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8) + al(nnz * 2 + 16) + al(nnz * 4 + 16) + al((n_buckets + 1) * 4) +
+         2 * al(max_blocks * PH_BUCKET * 4);
+}
+
+hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int g_log2,
+                                        int32_t n_cols, const int64_t* col_ptr, int32_t* out_row_idx, int32_t col_lo, int32_t col_hi, char* scratch) {
+  const int n_buckets = (int)(((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS);
+  const int64_t n_parts = (n_rows + TR_ROWS - 1) / TR_ROWS;
+  const int64_t m = (int64_t)n_buckets * n_parts;
+  const int64_t max_blocks = n_buckets + (nnz + PH_CHUNK - 1) / PH_CHUNK;
+  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  int32_t* part_counts = reinterpret_cast<int32_t*>(scratch); scratch += al(m * 4);
+  int64_t* offsets = reinterpret_cast<int64_t*>(scratch); scratch += al((m + 1) * 8);
+  int64_t* tile_sums = reinterpret_cast<int64_t*>(scratch); scratch += al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8);
+  unsigned short* bk_col = reinterpret_cast<unsigned short*>(scratch); scratch += al(nnz * 2 + 16);
+  int32_t* bk_row = reinterpret_cast<int32_t*>(scratch); scratch += al(nnz * 4 + 16);
+  int32_t* blk_prefix = reinterpret_cast<int32_t*>(scratch); scratch += al(((int64_t)n_buckets + 1) * 4);
+  unsigned* partial = reinterpret_cast<unsigned*>(scratch); scratch += al(max_blocks * PH_BUCKET * 4);
+  unsigned* prefix = reinterpret_cast<unsigned*>(scratch);
+  hipLaunchKernelGGL(tr_count_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, n_rows, row_ptr, col_idx, g_log2, n_buckets, n_parts, col_lo, col_hi,
+                     part_counts);
+  hipError_t e = launch_scan_i32(st, part_counts, m, offsets, tile_sums);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(tr_scatter_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, n_rows, row_ptr, col_idx, g_log2, n_buckets, n_parts, col_lo, col_hi,
+                     offsets, bk_col, bk_row);
+  hipLaunchKernelGGL(ph_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, offsets, n_buckets, n_parts, blk_prefix);
+  hipLaunchKernelGGL(ph_hist_kernel, dim3((unsigned)max_blocks), dim3(256), 0, st, bk_col, offsets, n_buckets, n_parts, blk_prefix, partial);
+  hipLaunchKernelGGL(tr_prefix_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, partial, blk_prefix, n_cols, prefix);
+  hipLaunchKernelGGL(tr_place_kernel, dim3((unsigned)max_blocks), dim3(256), 0, st, bk_col, bk_row, offsets, n_buckets, n_parts, blk_prefix, prefix,
+                     col_ptr, n_cols, out_row_idx);
+  return hipGetLastError();
+}
+
 // ============================================================================================
 // Row work from a USER shard (multi-GPU input phase): work[i] += d_B(u) for every local user u holding item i.
 // Summed over the ranks (all-reduce) this is the same w_i the expand prefix yields, but available before any rank

@@ -296,17 +296,23 @@ int urcco_dev_transpose(urcco_session* s, int64_t n_rows, const int64_t* row_ptr
       col_lo < 0 || col_hi < col_lo || col_hi > n_cols)
     return fail(URCCO_BAD_ARG, "urcco_dev_transpose: bad argument");
   const int64_t n_tiles = ((int64_t)n_cols + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
-  URC(s->reserve(urcco_session::need((size_t)n_cols, 4) + urcco_session::need((size_t)n_tiles + 2, 8)));
+  const int64_t tr_bytes = (s->debug & 256) ? 0 : urcco::transpose_scratch_bytes(n_rows, nnz, n_cols);  // 256: profiling, force the cursor-atomic kernel
+  URC(s->reserve(urcco_session::need((size_t)n_cols, 4) + urcco_session::need((size_t)n_tiles + 2, 8) + (size_t)tr_bytes + 256));
   int32_t* cursor = s->take<int32_t>((size_t)n_cols);
   int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
   s->begin(URCCO_STAGE_TRANSPOSE);
   HIPC(urcco::launch_scan_i32_range(s->stream, counts, n_cols, col_lo, col_hi, out_col_ptr, tile_sums));
   if (nnz > 0 && n_rows > 0) {
-    HIPC(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)n_cols, s->stream));
     int g = ceil_log2_i64((nnz + n_rows - 1) / n_rows);
     if (g < 1) g = 1;
     if (g > 6) g = 6;
-    HIPC(urcco::launch_transpose(s->stream, s->n_cu, n_rows, row_ptr, col_idx, g, out_col_ptr, cursor, out_row_idx, col_lo, col_hi));
+    if (tr_bytes > 0) {
+      HIPC(urcco::launch_transpose_partitioned(s->stream, n_rows, row_ptr, col_idx, nnz, g, n_cols, out_col_ptr, out_row_idx, col_lo, col_hi,
+                                               s->take<char>((size_t)tr_bytes)));
+    } else {
+      HIPC(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)n_cols, s->stream));
+      HIPC(urcco::launch_transpose(s->stream, s->n_cu, n_rows, row_ptr, col_idx, g, out_col_ptr, cursor, out_row_idx, col_lo, col_hi));
+    }
   }
   s->end();
   return URCCO_OK;
