@@ -220,6 +220,29 @@ int urcco_dev_llr(urcco_session* s, int64_t n, const int64_t* with_a, const int6
                   const int64_t* n_users, double* out);
 int urcco_dev_u01(urcco_session* s, int64_t n, int32_t seed, const int32_t* row, const int32_t* col, double* out);
 
+/* ---- DEVICE level: Preparator (reference src/main/scala/Preparator.scala:44-87, :102-158, :160-214) -------------
+ * Dictionaries and binary CSR matrices from event streams of 64-bit keys resident in HBM (the host hashes its id
+ * strings or passes integer ids; the value ~0 is reserved).  Dense ids follow FIRST APPEARANCE in the stream
+ * (oracle decision D8), so the host recovers the id -> string dictionary from `first_pos` alone. */
+typedef struct urcco_key_table urcco_key_table;
+
+/* BiDictionary over keys[0..n): id = rank of the key's first position among the first positions of the keys that
+ * occur at least min_count times (`minEventsPerUser` counts RAW events, Preparator.scala:129-132); other keys get no id.
+ * select (nullable, device int32[n]): positions with select[p] < 0 do not take part (events of dropped users,
+ * Preparator.scala:173-179).  first_pos (device int64, capacity n): first_pos[id] = stream position of the id's first
+ * occurrence.  *n_ids is written on the host (the call synchronises the stream). */
+int urcco_dev_dictionary_build(urcco_session* s, int64_t n, const uint64_t* keys, const int32_t* select, int32_t min_count,
+                               int64_t* first_pos, urcco_key_table** table, int64_t* n_ids);
+/* ids[p] = dense id of keys[p], or -1 (key without id, or select[p] < 0).  No host synchronisation. */
+int urcco_dev_dictionary_lookup(urcco_session* s, const urcco_key_table* table, int64_t n, const uint64_t* keys,
+                                const int32_t* select, int32_t* ids);
+void urcco_key_table_destroy(urcco_key_table* table);
+/* IndexedDatasetSpark's row assembly: (row id, column id) pairs (pairs with a negative id are skipped) -> binary CSR
+ * with sorted, duplicate-free columns (`setQuick(col, 1.0)`, Preparator.scala:146, :205).  out_row_ptr: int64[n_rows + 1],
+ * out_col_idx: capacity >= n.  nnz (nullable, host): written after a stream synchronisation when not NULL. */
+int urcco_dev_csr_from_pairs(urcco_session* s, int64_t n, const int32_t* rows, const int32_t* cols, int64_t n_rows,
+                             int64_t* out_row_ptr, int32_t* out_col_idx, int64_t* nnz);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,6 +89,24 @@ hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const in
 hipError_t launch_row_work_csr(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* a_row_ptr, const int32_t* a_col_idx,
                                const int64_t* b_row_ptr, int g_log2, int32_t n_items_a, int64_t* work);
 
+// ---- device-side Preparator (ingest_kernels.hip) ------------------------------------------------------
+// open-addressing dictionary of 64-bit keys: capacity = mask + 1 (power of two, >= 2 x keys), ~0 = empty slot
+struct KeyTable {
+  unsigned long long* keys;  // [capacity] initialised to ~0
+  unsigned* minpos;          // [capacity] smallest stream position of the key, initialised to ~0
+  unsigned* count;           // [capacity] occurrences, initialised to 0
+  int32_t* id;               // [capacity] dense id (first-appearance order), -1 = none
+  unsigned long long mask;
+};
+// flag: int32[n] scratch, prefix: int64[n + 1] scratch (prefix[n] = number of ids), first_pos: int64[>= ids] out
+hipError_t launch_dictionary_build(hipStream_t st, int n_cu, KeyTable t, int64_t n, const unsigned long long* keys, const int32_t* select,
+                                   int32_t min_count, int32_t* flag, int64_t* prefix, int64_t* tile_sums, int64_t* first_pos);
+hipError_t launch_dictionary_lookup(hipStream_t st, int n_cu, KeyTable t, int64_t n, const unsigned long long* keys, const int32_t* select,
+                                    int32_t* ids);
+// cnt: int32[n_rows] scratch, raw_ptr: int64[n_rows + 1] scratch, tmp: int32[n] scratch
+hipError_t launch_csr_from_pairs(hipStream_t st, int n_cu, int64_t n, const int32_t* rows, const int32_t* cols, int64_t n_rows, int32_t* cnt,
+                                 int64_t* raw_ptr, int32_t* tmp, int64_t* tile_sums, int64_t* out_row_ptr, int32_t* out_col_idx);
+
 hipError_t launch_xlx_table(hipStream_t st, double* tab);
 hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, double* xlx_n);
 

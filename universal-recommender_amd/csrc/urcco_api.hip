@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <memory>
 #include <vector>
 
 #include "../../include/urcco.h"
@@ -458,6 +459,82 @@ int urcco_dev_compact_indicators(urcco_session* s, int32_t n_rows, int32_t k, co
   HIPC(urcco::launch_scan_i32(s->stream, count, n_rows, out_row_ptr, tile_sums));
   HIPC(urcco::launch_compact_indicators(s->stream, n_rows, k, count, idx, llr, out_row_ptr, out_col_idx, out_llr));
   s->end();
+  return URCCO_OK;
+}
+
+struct urcco_key_table {
+  urcco::KeyTable t{};
+  int64_t capacity = 0;
+  int device = 0;
+};
+
+void urcco_key_table_destroy(urcco_key_table* table) {
+  if (!table) return;
+  (void)hipSetDevice(table->device);
+  if (table->t.keys) (void)hipFree(table->t.keys);
+  if (table->t.minpos) (void)hipFree(table->t.minpos);
+  if (table->t.count) (void)hipFree(table->t.count);
+  if (table->t.id) (void)hipFree(table->t.id);
+  delete table;
+}
+
+int urcco_dev_dictionary_build(urcco_session* s, int64_t n, const uint64_t* keys, const int32_t* select, int32_t min_count,
+                               int64_t* first_pos, urcco_key_table** table, int64_t* n_ids) {
+  if (!s || n < 0 || (n > 0 && (!keys || !first_pos)) || !table || !n_ids) return fail(URCCO_BAD_ARG, "urcco_dev_dictionary_build: bad argument");
+  if (n >= ((int64_t)1 << 32) - 1) return fail(URCCO_BAD_ARG, "urcco_dev_dictionary_build: at most 2^32 - 2 events per stream, got %lld", (long long)n);
+  *table = nullptr;
+  std::unique_ptr<urcco_key_table, void (*)(urcco_key_table*)> tab(new urcco_key_table(), urcco_key_table_destroy);
+  tab->device = s->device;
+  int64_t cap = 1024;
+  while (cap < 2 * n) cap <<= 1;
+  tab->capacity = cap;
+  tab->t.mask = (unsigned long long)cap - 1ull;
+  HIPC(hipMalloc((void**)&tab->t.keys, sizeof(unsigned long long) * (size_t)cap));
+  HIPC(hipMalloc((void**)&tab->t.minpos, sizeof(unsigned) * (size_t)cap));
+  HIPC(hipMalloc((void**)&tab->t.count, sizeof(unsigned) * (size_t)cap));
+  HIPC(hipMalloc((void**)&tab->t.id, sizeof(int32_t) * (size_t)cap));
+  HIPC(hipMemsetAsync(tab->t.keys, 0xFF, sizeof(unsigned long long) * (size_t)cap, s->stream));
+  HIPC(hipMemsetAsync(tab->t.minpos, 0xFF, sizeof(unsigned) * (size_t)cap, s->stream));
+  HIPC(hipMemsetAsync(tab->t.count, 0, sizeof(unsigned) * (size_t)cap, s->stream));
+  HIPC(hipMemsetAsync(tab->t.id, 0xFF, sizeof(int32_t) * (size_t)cap, s->stream));
+  const int64_t n_tiles = (n + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
+  URC(s->reserve(urcco_session::need((size_t)n, 4) + urcco_session::need((size_t)n + 1, 8) + urcco_session::need((size_t)n_tiles + 2, 8)));
+  int32_t* flag = s->take<int32_t>((size_t)n);
+  int64_t* prefix = s->take<int64_t>((size_t)n + 1);
+  int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
+  HIPC(urcco::launch_dictionary_build(s->stream, s->n_cu, tab->t, n, reinterpret_cast<const unsigned long long*>(keys), select, min_count, flag, prefix,
+                                      tile_sums, first_pos));
+  int64_t ids = 0;
+  HIPC(hipMemcpyAsync(&ids, prefix + n, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
+  HIPC(hipStreamSynchronize(s->stream));
+  *n_ids = ids;
+  *table = tab.release();
+  return URCCO_OK;
+}
+
+int urcco_dev_dictionary_lookup(urcco_session* s, const urcco_key_table* table, int64_t n, const uint64_t* keys, const int32_t* select,
+                                int32_t* ids) {
+  if (!s || !table || n < 0 || (n > 0 && (!keys || !ids))) return fail(URCCO_BAD_ARG, "urcco_dev_dictionary_lookup: bad argument");
+  HIPC(urcco::launch_dictionary_lookup(s->stream, s->n_cu, table->t, n, reinterpret_cast<const unsigned long long*>(keys), select, ids));
+  return URCCO_OK;
+}
+
+int urcco_dev_csr_from_pairs(urcco_session* s, int64_t n, const int32_t* rows, const int32_t* cols, int64_t n_rows, int64_t* out_row_ptr,
+                             int32_t* out_col_idx, int64_t* nnz) {
+  if (!s || n < 0 || n_rows < 0 || !out_row_ptr || (n > 0 && (!rows || !cols || !out_col_idx)))
+    return fail(URCCO_BAD_ARG, "urcco_dev_csr_from_pairs: bad argument");
+  const int64_t n_tiles = (n_rows + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
+  URC(s->reserve(urcco_session::need((size_t)n_rows, 4) + urcco_session::need((size_t)n_rows + 1, 8) + urcco_session::need((size_t)n, 4) +
+                 urcco_session::need((size_t)n_tiles + 2, 8)));
+  int32_t* cnt = s->take<int32_t>((size_t)n_rows);
+  int64_t* raw_ptr = s->take<int64_t>((size_t)n_rows + 1);
+  int32_t* tmp = s->take<int32_t>((size_t)n);
+  int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
+  HIPC(urcco::launch_csr_from_pairs(s->stream, s->n_cu, n, rows, cols, n_rows, cnt, raw_ptr, tmp, tile_sums, out_row_ptr, out_col_idx));
+  if (nnz) {
+    HIPC(hipMemcpyAsync(nnz, out_row_ptr + n_rows, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
+    HIPC(hipStreamSynchronize(s->stream));
+  }
   return URCCO_OK;
 }
 
