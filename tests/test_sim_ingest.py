@@ -90,3 +90,72 @@ def test_prepare_long_rows_take_the_block_sorts(sim_session):
     order = rng.permutation(len(ev))
     acts = [("purchase", [ev[k] for k in order])]
     check_prepare(sim_session, acts, None)
+
+
+def _same_prepared(a, b):
+    assert [n for n, _ in a.actions] == [n for n, _ in b.actions]
+    for (_, x), (_, y) in zip(a.actions, b.actions):
+        assert x.rowIDs.keys == y.rowIDs.keys and x.columnIDs.keys == y.columnIDs.keys
+        assert np.array_equal(x.row_ptr, y.row_ptr) and np.array_equal(x.col_idx, y.col_idx)
+
+
+def test_preparator_mirror_device_equals_host(sim_session):
+    """universal_recommender_amd.Preparator: prepare_on_device (ingest kernels) == prepare (numpy), on the reference's
+    handmade events with its minEventsPerUser = 3 and on a random stream."""
+    import json
+    import os
+    from universal_recommender_amd.data_source import DataSource, DataSourceParams, TrainingData
+    from universal_recommender_amd.preparator import Preparator
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "handmade.json")))
+    lines = [",".join(e) for e in doc["events"]]
+    dsp = doc["datasource_params"]
+    td = DataSource(DataSourceParams(dsp["appName"], dsp["eventNames"], None, dsp["minEventsPerUser"])).readTraining(lines)
+    host = Preparator().prepare(td)
+    _same_prepared(Preparator().prepare_on_device(td, sim_session), host)
+    assert [(d.row_ptr.size - 1, d.columnIDs.size, d.col_idx.size) for _, d in host.actions] == [(3, 6, 11), (3, 4, 10), (3, 2, 5)]  # SURVEY 8a
+    rng = np.random.default_rng(41)
+    acts = random_actions(rng, 300, [90, 400, 7], [2500, 6000, 800], user_pool_extra=40)
+    for min_events in (None, 1, 3):
+        td = TrainingData(acts, {}, min_events)
+        _same_prepared(Preparator().prepare_on_device(td, sim_session), Preparator().prepare(td))
+
+
+def test_events_to_model_without_leaving_the_device(sim_session, sim_lib):
+    """URAlgorithm.train_events_on_device (ingest kernels -> device matrices -> CCO build) builds the same model documents
+    as the host-boundary path and as the oracle, on the reference's handmade and item-set goldens."""
+    import json
+    import os
+    from universal_recommender_amd.data_source import DataSource, DataSourceParams
+    from universal_recommender_amd.preparator import Preparator
+    from universal_recommender_amd.ur_algorithm import URAlgorithm, URAlgorithmParams, toStringMap
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name in ("handmade.json", "item_sets.json"):
+        doc = json.load(open(os.path.join(golden, name)))
+        lines = [",".join(e) for e in doc["events"]]
+        engine = {"datasource": {"params": doc["datasource_params"]}, "algorithms": [{"name": "ur", "params": doc["algorithm_params"]}]}
+        td = DataSource(DataSourceParams.from_engine_json(engine)).readTraining(lines)
+        ap = URAlgorithmParams.from_engine_json(engine)
+        ap.seed = 1
+        algo = URAlgorithm(ap, library=sim_lib)
+
+        def docs(result):
+            model = {}
+            for ev, ind in result:
+                for item, m in toStringMap(ind, ev).items():
+                    model.setdefault(item, {}).update(m)
+            return model
+        on_device = algo.train_events_on_device(td, sim_session)
+        via_host = algo.train(Preparator().prepare(td))
+        assert docs(on_device) == docs(via_host)
+        for (_, a), (_, b) in zip(on_device, via_host):
+            assert np.array_equal(a.row_ptr, b.row_ptr) and np.array_equal(a.col_idx, b.col_idx) and np.array_equal(a.values, b.values)
+        by_event = {}
+        for u, e, i in doc["events"]:
+            by_event.setdefault(e, []).append((u, i))
+        names = doc["datasource_params"]["eventNames"]
+        prepared = PO.prepare(PO.split_actions(by_event, names), doc["datasource_params"].get("minEventsPerUser"))
+        ref = {}
+        for ev, ind in PO.calc_all(prepared, {**doc["algorithm_params"], "seed": 1}):
+            for item, m in PO.to_string_map(ev, ind).items():
+                ref.setdefault(item, {}).update(m)
+        assert docs(on_device) == ref

@@ -23,3 +23,11 @@ def test_prepare_larger_stream_on_gpu(gpu_session):
     rng = np.random.default_rng(99)
     acts = logic.random_actions(rng, 20000, [8000, 30000], [150000, 250000], n_types=2, user_pool_extra=3000)
     logic.check_prepare(gpu_session, acts, 2)
+
+
+def test_preparator_mirror_device_equals_host_on_gpu(gpu_session):
+    logic.test_preparator_mirror_device_equals_host(gpu_session)
+
+
+def test_events_to_model_without_leaving_the_device_on_gpu(gpu_session):
+    logic.test_events_to_model_without_leaving_the_device(gpu_session, gpu_session.lib)

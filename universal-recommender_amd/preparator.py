@@ -1,6 +1,8 @@
 """Host-side mirror of Preparator.prepare (reference src/main/scala/Preparator.scala:44-87 and the two
 `object IndexedDatasetSpark.apply` overloads at :102-158, :160-214): one binary user x item matrix per event type,
-all sharing one user dictionary; `minEventsPerUser` filters users on their RAW primary-event count."""
+all sharing one user dictionary; `minEventsPerUser` filters users on their RAW primary-event count.
+`Preparator.prepare` builds them on the host (numpy); `Preparator.prepare_on_device` builds them with the GPU ingest
+kernels (ingest.py: device dictionaries + CSR builder) from 64-bit hashes of the id strings -- same result."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -56,7 +58,44 @@ def _min_events_row_ids(elements: Sequence[Tuple[str, str]], min_events: int) ->
     return BiDictionary([u for u, c in counts.items() if c >= min_events])
 
 
+def hash_keys(strings: Sequence[str]) -> np.ndarray:
+    """64-bit keys of id strings (blake2b-64; ~0 is the device dictionary's reserved value and is remapped).  Two distinct
+    strings collide with probability ~n^2 / 2^65 -- 3e-5 for a billion ids."""
+    import hashlib
+    out = np.empty(len(strings), dtype=np.uint64)
+    for k, s in enumerate(strings):
+        v = int.from_bytes(hashlib.blake2b(s.encode("utf-8"), digest_size=8).digest(), "little")
+        out[k] = 0 if v == 0xFFFFFFFFFFFFFFFF else v
+    return out.view(np.int64)
+
+
 class Preparator:
+    def prepare_on_device(self, trainingData: TrainingData, sess, keep_on_device: bool = False):
+        """Preparator.prepare through the GPU ingest kernels.  The host hashes the id strings, the device builds the
+        dictionaries and the matrices (ingest.prepare_device), and the BiDictionaries are rebuilt from the stream positions
+        of every id's first occurrence.  Returns PreparedData (matrices copied to the host); with keep_on_device also the
+        ingest.DevPreparedData whose matrices can go straight into the CCO build without touching PCIe again."""
+        import torch
+        from . import ingest
+        if not trainingData.actions:
+            raise ValueError("no event type with events")
+        dev_actions = []
+        for name, elements in trainingData.actions:
+            uk = torch.from_numpy(hash_keys([u for u, _ in elements])).to(sess.device)
+            ik = torch.from_numpy(hash_keys([i for _, i in elements])).to(sess.device)
+            dev_actions.append((name, uk, ik))
+        dp = ingest.prepare_device(sess, dev_actions, trainingData.minEventsPerUser)
+        primary = trainingData.actions[0][1]
+        row_ids = BiDictionary([primary[p][0] for p in dp.user_first_pos.cpu().numpy()])
+        out: List[Tuple[str, IndexedDataset]] = []
+        for (name, elements), ev in zip(trainingData.actions, dp.events):
+            column_ids = BiDictionary([elements[p][1] for p in ev.item_first_pos.cpu().numpy()])
+            rp = ev.matrix.row_ptr.cpu().numpy()
+            ci = ev.matrix.col_idx[: int(rp[-1])].cpu().numpy()
+            out.append((name, IndexedDataset(rp, ci, row_ids, column_ids)))
+        pd = PreparedData(out, trainingData.fields)
+        return (pd, dp) if keep_on_device else pd
+
     def prepare(self, trainingData: TrainingData) -> PreparedData:
         user_dictionary: Optional[BiDictionary] = None
         out: List[Tuple[str, IndexedDataset]] = []

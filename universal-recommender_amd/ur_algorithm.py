@@ -101,6 +101,38 @@ class URAlgorithm:
         return list(zip([n for n, _ in data.actions], res))                                    # :349
 
 
+    def train_events_on_device(self, trainingData, sess) -> List[Tuple[str, IndexedDataset]]:
+        """Preparator.prepare + URAlgorithm.calcAll without leaving the GPU in between: the event streams are hashed on
+        the host, dictionaries and matrices are built in HBM (Preparator.prepare_on_device) and those device matrices go
+        straight into the CCO build (device.cross_occurrence_device); only the indicator rows come back.  Same model as
+        `train(Preparator().prepare(trainingData))`."""
+        from .device import DatasetParams, cross_occurrence_device
+        from .preparator import Preparator
+        from .similarity_analysis import _seed_to_int
+        if self.recsModel not in ("all", "collabFiltering"):
+            return self.train(Preparator().prepare(trainingData))
+        ap = self.ap
+        pd, dp = Preparator().prepare_on_device(trainingData, sess, keep_on_device=True)
+        seed = ap.seed if ap.seed is not None else int(time.time() * 1000)
+        if not ap.indicators:
+            params = [DatasetParams(ap.maxEventsPerEventType or DefaultURAlgoParams.MaxEventsPerEventType,
+                                    ap.maxCorrelatorsPerEventType or DefaultURAlgoParams.MaxCorrelatorsPerEventType, None) for _ in dp.events]
+        else:
+            if len(ap.indicators) < len(dp.events):
+                raise IndexError("indicators(i) is matched to the event matrices by position (URAlgorithm.scala:334-340)")
+            params = [DatasetParams(ap.indicators[i].maxItemsPerUser or DefaultURAlgoParams.MaxEventsPerEventType,
+                                    ap.indicators[i].maxCorrelatorsPerItem or DefaultURAlgoParams.MaxCorrelatorsPerEventType,
+                                    ap.indicators[i].minLLR) for i in range(len(dp.events))]
+        res = cross_occurrence_device(sess, [ev.matrix for ev in dp.events], params, _seed_to_int(seed))
+        sess.synchronize()
+        primary = pd.actions[0][1]
+        out: List[Tuple[str, IndexedDataset]] = []
+        for (name, ids), ind in zip(pd.actions, res):
+            rp, ci, llr = ind.to_host()
+            out.append((name, primary.create(rp, ci, primary.columnIDs, ids.columnIDs, llr)))
+        return out
+
+
 def toStringMap(indexedDataset: IndexedDataset, actionName: str) -> Dict[str, Dict[str, List[str]]]:
     """IndexedDatasetConversions.toStringMapRDD (package.scala:82-110): itemID -> {actionName: [ids, score desc]}.
     Rows arrive (llr desc, col asc) from the library; the reference's stable sortBy(-score) keeps that order.
