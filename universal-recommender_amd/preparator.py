@@ -59,13 +59,18 @@ def _min_events_row_ids(elements: Sequence[Tuple[str, str]], min_events: int) ->
 
 
 def hash_keys(strings: Sequence[str]) -> np.ndarray:
-    """64-bit keys of id strings (blake2b-64; ~0 is the device dictionary's reserved value and is remapped).  Two distinct
-    strings collide with probability ~n^2 / 2^65 -- 3e-5 for a billion ids."""
-    import hashlib
-    out = np.empty(len(strings), dtype=np.uint64)
-    for k, s in enumerate(strings):
-        v = int.from_bytes(hashlib.blake2b(s.encode("utf-8"), digest_size=8).digest(), "little")
-        out[k] = 0 if v == 0xFFFFFFFFFFFFFFFF else v
+    """64-bit keys of id strings: xxHash64 of the UTF-8 bytes (blake2b-64 when the xxhash module is absent) -- a fixed
+    function of the string, so every rank of a multi-GPU build maps the same id to the same key.  ~0 is the device
+    dictionary's reserved value and is remapped.  Two distinct strings collide with probability ~n^2 / 2^65 (3e-5 for
+    a billion ids)."""
+    try:
+        import xxhash
+        out = np.fromiter(map(xxhash.xxh64_intdigest, strings), dtype=np.uint64, count=len(strings))
+    except ImportError:
+        import hashlib
+        out = np.fromiter((int.from_bytes(hashlib.blake2b(s.encode("utf-8"), digest_size=8).digest(), "little") for s in strings),
+                          dtype=np.uint64, count=len(strings))
+    out[out == np.uint64(0xFFFFFFFFFFFFFFFF)] = 0
     return out.view(np.int64)
 
 
