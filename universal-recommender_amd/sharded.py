@@ -195,7 +195,7 @@ def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], para
         # Work-balanced item ranges, fixed BEFORE any whole-matrix work and before the secondary event types are even
         # sampled: the key is the A'A row work, summed from the user shards by one all-reduce.  (The work of A'B_d for
         # item i is the sum over the same users of their B_d row lengths, so it follows the A'A key closely; using it
-        # as the proxy lets the one blocking host read happen while the other event types are still being sampled.)
+        # as the proxy lets the one blocking host read come right after the primary's short chain.)
         work = worker(0).row_work_csr(locals_[0], locals_[0].row_ptr)
         _all_reduce_sum(work, group)
         sizes_dev: List[Optional[torch.Tensor]] = [None] * n_ds
