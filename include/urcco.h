@@ -236,6 +236,7 @@ int urcco_dev_dictionary_build(urcco_session* s, int64_t n, const uint64_t* keys
 /* ids[p] = dense id of keys[p], or -1 (key without id, or select[p] < 0).  No host synchronisation. */
 int urcco_dev_dictionary_lookup(urcco_session* s, const urcco_key_table* table, int64_t n, const uint64_t* keys,
                                 const int32_t* select, int32_t* ids);
+/* Frees the table (hipFree: waits for device work still using it). */
 void urcco_key_table_destroy(urcco_key_table* table);
 /* IndexedDatasetSpark's row assembly: (row id, column id) pairs (pairs with a negative id are skipped) -> binary CSR
  * with sorted, duplicate-free columns (`setQuick(col, 1.0)`, Preparator.scala:146, :205).  out_row_ptr: int64[n_rows + 1],
