@@ -9,6 +9,10 @@
   movielens.json           data/sample_movielens_data.txt split into buy / rate events exactly as
                            examples/import_movielens_eventserver.py does (random.seed(3), two randint draws per line)
 
+  downsample.json          data/sample-downsamplable-data.txt with the engine params of examples/handmade-engine-downsample.json
+                           (minEventsPerUser = 6): the reference ships no expected output for it -- an input-only fixture that
+                           exercises the Preparator's user filter on the reference's own data
+
 Usage: python tests/golden/make_golden.py [/root/reference]
 """
 import json
@@ -84,6 +88,16 @@ def handmade(name, data, engine, queries, expected):
     print(name, len(events), "events", len(q), "queries")
 
 
+def inputs_only(name, data, engine):
+    events, sets = parse_events(os.path.join(REF, "data", data))
+    eng = json.load(open(os.path.join(REF, "examples", engine)))
+    doc = {"source": {"data": "data/" + data, "engine": "examples/" + engine, "expected": None},
+           "datasource_params": eng["datasource"]["params"], "algorithm_params": eng["algorithms"][0]["params"],
+           "events": events, "sets": sets}
+    json.dump(doc, open(os.path.join(HERE, name), "w"), indent=1)
+    print(name, len(events), "events (no reference golden)")
+
+
 def movielens():
     random.seed(3)                                   # import_movielens_eventserver.py:10,14
     events = []
@@ -102,4 +116,5 @@ if __name__ == "__main__":
     handmade("handmade.json", "sample-handmade-data.txt", "handmade-engine.json", "multi-query-handmade.sh", "integration-test-expected.txt")
     handmade("item_sets.json", "sample-handmade-item-set-data.txt", "handmade-engine-item-sets.json", "multi-query-handmade-item-sets.sh",
              "integration-test-item-set-expected.txt")
+    inputs_only("downsample.json", "sample-downsamplable-data.txt", "handmade-engine-downsample.json")
     movielens()

@@ -159,3 +159,42 @@ def test_events_to_model_without_leaving_the_device(sim_session, sim_lib):
             for item, m in PO.to_string_map(ev, ind).items():
                 ref.setdefault(item, {}).update(m)
         assert docs(on_device) == ref
+
+
+def test_reference_downsample_fixture_user_filter(sim_session, sim_lib):
+    """data/sample-downsamplable-data.txt with examples/handmade-engine-downsample.json (minEventsPerUser = 6; the reference
+    ships no expected output for it): u3 and u4 have 5 purchases and are dropped, the items only they bought (p11, p12)
+    leave the purchase dictionary, their views are dropped too.  Oracle == host mirror == device ingest, and the model
+    built from the device matrices equals the oracle's."""
+    import json
+    import os
+    from universal_recommender_amd.data_source import DataSource, DataSourceParams
+    from universal_recommender_amd.preparator import Preparator
+    from universal_recommender_amd.ur_algorithm import URAlgorithm, URAlgorithmParams, toStringMap
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "downsample.json")))
+    engine = {"datasource": {"params": doc["datasource_params"]}, "algorithms": [{"name": "ur", "params": doc["algorithm_params"]}]}
+    td = DataSource(DataSourceParams.from_engine_json(engine)).readTraining([",".join(e) for e in doc["events"]])
+    assert td.minEventsPerUser == 6
+    by_event = {}
+    for u, e, i in doc["events"]:
+        by_event.setdefault(e, []).append((u, i))
+    prepared = PO.prepare(PO.split_actions(by_event, doc["datasource_params"]["eventNames"]), 6)
+    users = prepared[0][1].row_ids.keys
+    assert "u3" not in users and "u4" not in users and {"u1", "u2", "u5"} <= set(users)
+    assert "p11" not in prepared[0][1].column_ids.keys and "p12" not in prepared[0][1].column_ids.keys
+    host = Preparator().prepare(td)
+    _same_prepared(Preparator().prepare_on_device(td, sim_session), host)
+    for (_, ids), (_, ref) in zip(host.actions, prepared):
+        assert ids.rowIDs.keys == ref.row_ids.keys and ids.columnIDs.keys == ref.column_ids.keys
+        assert [list(ids.col_idx[ids.row_ptr[r]:ids.row_ptr[r + 1]]) for r in range(ref.nrow)] == ref.rows
+    ap = URAlgorithmParams.from_engine_json(engine)
+    ap.seed = 7
+    model = {}
+    for ev, ind in URAlgorithm(ap, library=sim_lib).train_events_on_device(td, sim_session):
+        for item, m in toStringMap(ind, ev).items():
+            model.setdefault(item, {}).update(m)
+    ref_model = {}
+    for ev, ind in PO.calc_all(prepared, {**doc["algorithm_params"], "seed": 7}):
+        for item, m in PO.to_string_map(ev, ind).items():
+            ref_model.setdefault(item, {}).update(m)
+    assert model == ref_model
