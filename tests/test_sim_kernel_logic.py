@@ -241,3 +241,45 @@ def test_all_equal_llr_ties_cut_by_column(sim_session):
     a = O.Csr(n_users, n_items, rp, ci)
     for k in (5, 50, 64, 150):
         _, _, stats = compare_with_oracle(sim_session, [a, a], [P(100000, k), P(100000, k)], 3, exact_ids=True)
+
+
+def _tied_block(n_users, n_items, holders, block, extra_rows=()):
+    """`holders` users each hold every item of `block`; extra_rows = [(user, items)] of further interactions."""
+    rows = [np.zeros(0, np.int64) for _ in range(n_users)]
+    for u in range(holders):
+        rows[u] = np.asarray(block, np.int64)
+    for u, items in extra_rows:
+        rows[u] = np.union1d(rows[u], np.asarray(items, np.int64))
+    rp = np.zeros(n_users + 1, np.int64)
+    np.cumsum([len(r) for r in rows], out=rp[1:])
+    return O.Csr(n_users, n_items, rp, np.concatenate(rows).astype(np.int32))
+
+
+def test_many_ties_at_the_cut_after_skipped_column_passes(sim_session):
+    """Radix select, column passes: more than SEL_M candidates tied exactly at the k boundary, so the cut is decided in
+    the COLUMN digits -- reached after the constant high column bytes were skipped.  The rotating histograms must be
+    indexed by executed pass, not by digit position (round-1 defect: a stale histogram truncated these rows).  Covers
+    col_bytes 1 / 3 for the one-wave class (two histograms) and col_bytes 2 for the 256-/512-thread classes (three),
+    with several N so that the LLR's low byte lands on both sides of the cut digit.  Exact ids."""
+    # one-wave class, col_bytes = 1: 150 items always together, 2 users (w = 300), k = 20
+    for n_users in (11, 12, 13, 17, 23, 31, 57, 101):
+        a = _tied_block(n_users, 150, 2, np.arange(150))
+        _, _, st = compare_with_oracle(sim_session, [a, a], [P(100000, 20), P(100000, 20)], 3, exact_ids=True)
+        assert st[1][0][2] > 0          # wave class used
+    # one-wave class, col_bytes = 3 (hash-addressed table): the tied columns sit above 2^16
+    for n_users in (11, 13, 29, 64):
+        cols = 70000 + 3 * np.arange(150)
+        b = _tied_block(n_users, 70600, 2, cols)
+        a = _tied_block(n_users, 150, 2, np.arange(150))
+        compare_with_oracle(sim_session, [a, b], [P(100000, 20), P(100000, 20)], 3, exact_ids=True)
+    # 512-thread class, col_bytes = 2: 1000 tied columns at 30000..30999, 3 users (w = 3000), k = 50
+    for n_users in (7, 9, 14, 33):
+        a = _tied_block(n_users, 40000, 3, np.arange(30000, 31000))
+        _, _, st = compare_with_oracle(sim_session, [a, a], [P(100000, 50), P(100000, 50)], 3, exact_ids=True)
+        assert st[1][0][5] > 0          # half-CU class used
+    # 256-thread class (tracks shared key bytes): a second LLR value below the tied block keeps the key passes alive
+    for n_users in (9, 15, 40):
+        extra = [(5, np.arange(20000, 20040)), (6, np.arange(20000, 20040))]
+        a = _tied_block(n_users, 40000, 2, np.arange(30000, 30400), extra_rows=[(0, np.arange(20000, 20040))] + extra)
+        _, _, st = compare_with_oracle(sim_session, [a, a], [P(100000, 50), P(100000, 50)], 3, exact_ids=True)
+        assert st[1][0][3] + st[1][0][4] > 0

@@ -1571,9 +1571,13 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
         bool have_list = false;
         unsigned list_n = 0, prev_cnt = C;
         bool first_pass = true;
+        // The rotating histograms are indexed by the ordinal q of the passes that actually run, not by the digit position
+        // p: passes are skipped (shared key bytes, constant high column bytes), and a rotation keyed by p would count the
+        // first column pass into the buffer the last key pass left full.
+        int q = 0;
         for (int p = p0; p < 12; ++p) {  // team-uniform trip count (the breaks below are on values every thread agrees on)
           if (p >= 8 && p < first_col_pass) continue;
-          unsigned* H = hist + (p % NH) * 128;
+          unsigned* H = hist + (q % NH) * 128;
           const bool build = SEL_CAP > 0 && !have_list && !first_pass && prev_cnt <= (unsigned)SEL_CAP;  // this sweep also records the survivors
           const unsigned n_scan = have_list ? list_n : D;
           const int shk = p < 8 ? 56 - 8 * p : 0, shc = p < 8 ? 0 : 24 - 8 * (p - 8);
@@ -1603,8 +1607,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
           }
           first_pass = false;
           {  // every wave locates the digit that holds the cut (lanes own 4 bins each, higher lanes = higher digits)
-            unsigned* Hz = hist + ((p + NH - 1) % NH) * 128;
-            for (int b = tl; b < 128; b += T) Hz[b] = 0u;  // last read two passes ago
+            unsigned* Hz = hist + ((q + NH - 1) % NH) * 128;
+            for (int b = tl; b < 128; b += T) Hz[b] = 0u;  // the previous pass's buffer: every wave is past its reads of it
             const unsigned w01 = H[2 * lane], w23 = H[2 * lane + 1];
             const unsigned h0 = w01 & 0xffffu, h1 = w01 >> 16, h2 = w23 & 0xffffu, h3 = w23 >> 16;
             const unsigned v4 = h0 + h1 + h2 + h3;
@@ -1632,6 +1636,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
             prev_cnt = cnt;
             if (cnt == need) break;  // the whole bin is wanted: every composite >= the prefix (low bits zero) is selected
             if (NH == 2) team_sync<T>();  // the buffer just cleared is the next pass's target
+            ++q;
           }
           if (prev_cnt <= (unsigned)SEL_M) {
             // finish: copy out the members of the cut bin (they match the prefix through digit p) ...
