@@ -1,0 +1,24 @@
+"""Round-2 CANDIDATE code paths (off by default, selected by urcco_session_set_debug bits that do not change results):
+their logic is checked here on the host simulator so that they are ready to be measured on hardware."""
+import numpy as np
+import pytest
+
+import test_sim_kernel_logic as logic
+
+
+@pytest.fixture
+def with_debug(sim_session):
+    def run(bits, fn, *args):
+        sim_session.set_debug(bits)
+        try:
+            return fn(sim_session, *args)
+        finally:
+            sim_session.set_debug(0)
+    return run
+
+
+@pytest.mark.parametrize("case", [logic.test_small_three_events_all_modes, logic.test_hash_tables_and_all_bins,
+                                  logic.test_all_equal_llr_ties_cut_by_column, logic.test_item_range_slices_concatenate],
+                         ids=lambda f: f.__name__)
+def test_bitonic_rank_of_survivors(with_debug, case):
+    with_debug(1024, case)

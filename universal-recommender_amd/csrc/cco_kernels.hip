@@ -1690,13 +1690,39 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
       }
       team_sync<T>();
       const unsigned n = (a.debug & 16) ? 0u : *nsel;  // ablation 16: no ranking / output
-      for (unsigned t = (unsigned)tl; t < n; t += T) {
-        const unsigned long long mk = selk[t];
-        const int mc = (int)selc[t];
-        unsigned rank = 0;
-        for (unsigned u = 0; u < n; ++u) rank += best_before(selk[u], (int)selc[u], mk, mc) ? 1u : 0u;
-        a.out_idx[obase + rank] = mc;
-        a.out_llr[obase + rank] = __longlong_as_double((long long)mk);
+      if (n <= (unsigned)WAVE && (a.debug & 1024)) {
+        // CANDIDATE (round 2, unmeasured; debug 1024 switches it on): the <= 64 survivors are put in output order by a
+        // bitonic network in the registers of the team's first wave (21 compare-exchange steps of 3 shuffles) instead
+        // of n rounds of LDS-broadcast counting, and leave as contiguous stores.
+        if (tl < WAVE) {  // wave-uniform
+          unsigned long long mk = (unsigned)lane < n ? selk[lane] : 0ull;
+          int mc = (unsigned)lane < n ? (int)selc[lane] : 0x7fffffff;
+          for (int k2 = 2; k2 <= WAVE; k2 <<= 1) {
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+              const unsigned long long ok = shfl_xor_u64(mk, j);
+              const int oc = __shfl_xor(mc, j);
+              const bool keep_better = ((lane & j) == 0) == ((lane & k2) == 0);  // lower lane of a descending block
+              const bool take = keep_better ? best_before(ok, oc, mk, mc) : best_before(mk, mc, ok, oc);
+              if (take) {
+                mk = ok;
+                mc = oc;
+              }
+            }
+          }
+          if ((unsigned)lane < n) {
+            a.out_idx[obase + lane] = mc;
+            a.out_llr[obase + lane] = __longlong_as_double((long long)mk);
+          }
+        }
+      } else {
+        for (unsigned t = (unsigned)tl; t < n; t += T) {
+          const unsigned long long mk = selk[t];
+          const int mc = (int)selc[t];
+          unsigned rank = 0;
+          for (unsigned u = 0; u < n; ++u) rank += best_before(selk[u], (int)selc[u], mk, mc) ? 1u : 0u;
+          a.out_idx[obase + rank] = mc;
+          a.out_llr[obase + rank] = __longlong_as_double((long long)mk);
+        }
       }
       if (tl == 0) a.out_count[i - a.item_lo] = (int)n;
     }
