@@ -22,3 +22,9 @@ def with_debug(sim_session):
                          ids=lambda f: f.__name__)
 def test_bitonic_rank_of_survivors(with_debug, case):
     with_debug(1024, case)
+
+
+@pytest.mark.parametrize("case", [logic.test_partitioned_column_counts_large_matrix, logic.test_large_matrix_full_pipeline],
+                         ids=lambda f: f.__name__)
+def test_lds_staged_bucket_scatter(with_debug, case):
+    with_debug(2048, case)

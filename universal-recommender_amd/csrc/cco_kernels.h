@@ -62,7 +62,7 @@ hipError_t launch_column_counts(hipStream_t st, int n_cu, const int32_t* col_idx
 constexpr int64_t PH_MIN_NNZ = 1 << 20;
 int64_t column_counts_scratch_bytes(int64_t nnz, int32_t n_cols);
 hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_idx, int64_t nnz, const int64_t* nnz_dev, int32_t n_cols,
-                                            int32_t* counts, char* scratch);
+                                            int32_t* counts, char* scratch, int debug);
 
 // scans: out[i] = sum_{t<i} in[t], out[n] = total.  tile_sums scratch: ceil(n / SCAN_TILE) + 1 int64.
 hipError_t launch_scan_i32(hipStream_t st, const int32_t* in, int64_t n, int64_t* out, int64_t* tile_sums);

@@ -338,6 +338,63 @@ __global__ __launch_bounds__(256) void ph_scatter_kernel(const int32_t* __restri
   }
 }
 
+// CANDIDATE (round 2, unmeasured; debug 2048 switches it on): the part's ids are first grouped by bucket in LDS (the
+// (bucket, part) slice lengths are already known from the offsets), then every slice leaves as one run of consecutive
+// 2-byte stores -- whole lines instead of 16384 isolated 2-byte writes.
+__global__ __launch_bounds__(256) void ph_scatter_staged_kernel(const int32_t* __restrict__ ci, int64_t nnz_host, const int64_t* __restrict__ nnz_dev,
+                                                                int n_buckets, int64_t n_parts, const int64_t* __restrict__ offsets,
+                                                                unsigned short* __restrict__ bucketed, int vec_ok) {
+  __shared__ long long s_base[PH_MAX_BUCKETS];
+  __shared__ int s_loc[PH_MAX_BUCKETS + 1];  // where the bucket's run starts inside the staging array
+  __shared__ int s_cur[PH_MAX_BUCKETS];
+  __shared__ unsigned short s_stage[PH_PART];
+  __shared__ long long s_wave[SCAN_THREADS / WAVE];
+  const int64_t nnz = nnz_dev ? *nnz_dev : nnz_host;
+  int carry = 0;
+  for (int base = 0; base < n_buckets; base += 256) {  // block-uniform: exclusive prefix of this part's slice lengths
+    const int b = base + threadIdx.x;
+    long long len = 0;
+    if (b < n_buckets) {
+      const int64_t idx = (int64_t)b * n_parts + blockIdx.x;
+      const long long o = offsets[idx];
+      s_base[b] = o;
+      len = offsets[idx + 1] - o;
+      s_cur[b] = 0;
+    }
+    long long tot;
+    const long long ex = block_exclusive_scan(len, s_wave, &tot);
+    if (b < n_buckets) s_loc[b] = carry + (int)ex;
+    carry += (int)tot;
+  }
+  if (threadIdx.x == 0) s_loc[n_buckets] = carry;
+  __syncthreads();
+  const int64_t e0 = (int64_t)blockIdx.x * PH_PART;
+  const int64_t e1 = e0 + PH_PART < nnz ? e0 + PH_PART : nnz;
+  for (int64_t e = e0 + (int64_t)threadIdx.x * 4; e < e1; e += 256 * 4) {
+    int cols[4];
+    int n = 4;
+    if (vec_ok && e + 3 < e1) {
+      const int4 x = *reinterpret_cast<const int4*>(ci + e);
+      cols[0] = x.x; cols[1] = x.y; cols[2] = x.z; cols[3] = x.w;
+    } else {
+      n = (int)(e1 - e < 4 ? e1 - e : 4);
+      for (int q = 0; q < n; ++q) cols[q] = ci[e + q];
+    }
+    for (int q = 0; q < n; ++q) {
+      const int b = cols[q] >> PH_BITS;
+      s_stage[s_loc[b] + atomicAdd(&s_cur[b], 1)] = (unsigned short)(cols[q] & (PH_BUCKET - 1));
+    }
+  }
+  __syncthreads();
+  // one wave per bucket run, lanes on consecutive ids
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+  for (int b = wave; b < n_buckets; b += 256 / WAVE) {
+    const int l0 = s_loc[b], len = s_loc[b + 1] - l0;
+    const long long dst = s_base[b];
+    for (int t = lane; t < len; t += WAVE) bucketed[dst + t] = s_stage[l0 + t];
+  }
+}
+
 // single block: blk_prefix[b] = first histogram block of bucket b, blk_prefix[n_buckets] = number of blocks
 __global__ __launch_bounds__(SCAN_THREADS) void ph_blockmap_kernel(const int64_t* __restrict__ offsets, int n_buckets, int64_t n_parts,
                                                                   int32_t* __restrict__ blk_prefix) {
@@ -417,7 +474,7 @@ int64_t column_counts_scratch_bytes(int64_t nnz, int32_t n_cols) {
 }
 
 hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_idx, int64_t nnz, const int64_t* nnz_dev, int32_t n_cols,
-                                            int32_t* counts, char* scratch) {
+                                            int32_t* counts, char* scratch, int debug) {
   const int n_buckets = (int)(((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS);
   const int64_t n_parts = (nnz + PH_PART - 1) / PH_PART;
   const int64_t m = (int64_t)n_buckets * n_parts;
@@ -433,7 +490,11 @@ hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_i
   hipLaunchKernelGGL(ph_count_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, part_counts, vec_ok);
   hipError_t e = launch_scan_i32(st, part_counts, m, offsets, tile_sums);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(ph_scatter_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, offsets, bucketed, vec_ok);
+  if (debug & 2048)
+    hipLaunchKernelGGL(ph_scatter_staged_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, offsets, bucketed,
+                       vec_ok);
+  else
+    hipLaunchKernelGGL(ph_scatter_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, offsets, bucketed, vec_ok);
   hipLaunchKernelGGL(ph_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, offsets, n_buckets, n_parts, blk_prefix);
   hipLaunchKernelGGL(ph_hist_kernel, dim3((unsigned)max_blocks), dim3(256), 0, st, bucketed, offsets, n_buckets, n_parts, blk_prefix, partial);
   hipLaunchKernelGGL(ph_reduce_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, partial, blk_prefix, n_cols, counts);

@@ -241,7 +241,7 @@ int urcco_dev_column_counts(urcco_session* s, int64_t nnz, const int32_t* col_id
   if (ph_bytes > 0) URC(s->reserve((size_t)ph_bytes));
   s->begin(URCCO_STAGE_COLUMN_COUNTS);
   if (ph_bytes > 0)
-    HIPC(urcco::launch_column_counts_partitioned(s->stream, col_idx, nnz, nullptr, n_cols, counts, s->take<char>((size_t)ph_bytes)));
+    HIPC(urcco::launch_column_counts_partitioned(s->stream, col_idx, nnz, nullptr, n_cols, counts, s->take<char>((size_t)ph_bytes), s->debug));
   else
     HIPC(urcco::launch_column_counts(s->stream, s->n_cu, col_idx, nnz, n_cols, counts));
   s->end();
@@ -285,7 +285,7 @@ int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_pt
   s->end();
   if (ph_bytes > 0) {
     s->begin(URCCO_STAGE_COLUMN_COUNTS);
-    HIPC(urcco::launch_column_counts_partitioned(s->stream, out_col_idx, nnz, out_row_ptr + n_rows, n_cols, post_counts, s->take<char>((size_t)ph_bytes)));
+    HIPC(urcco::launch_column_counts_partitioned(s->stream, out_col_idx, nnz, out_row_ptr + n_rows, n_cols, post_counts, s->take<char>((size_t)ph_bytes), s->debug));
     s->end();
   }
   return URCCO_OK;
