@@ -28,3 +28,9 @@ def test_bitonic_rank_of_survivors(with_debug, case):
                          ids=lambda f: f.__name__)
 def test_lds_staged_bucket_scatter(with_debug, case):
     with_debug(2048, case)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_tile_table_carries_the_row_start_bit(with_debug, mode):
+    with_debug(4096, logic.test_row_scan_tile_edges, mode)
+    with_debug(4096, logic.test_downsample_row_base_matches_sharded_rows)

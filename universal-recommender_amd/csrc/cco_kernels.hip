@@ -543,15 +543,16 @@ __device__ __forceinline__ int64_t upper_bound_i64(const int64_t* __restrict__ r
   return lo;
 }
 
-// g[t] = first row r with rp[r] >= t * DS_TILE for t < n_tiles (row r writes the tiles with rp[r-1] < t*DS_TILE <= rp[r]:
+// g[t] >> 1 = first row r with rp[r] >= t * DS_TILE for t < n_tiles (row r writes the tiles with rp[r-1] < t*DS_TILE <= rp[r]:
 // one writer per tile); g[n_tiles] = n_rows + 1, so that [g[t], g[t+1]) partitions the rows 0..n_rows (end marker included).
 __global__ __launch_bounds__(256) void tile_rows_kernel(int64_t n_rows, const int64_t* __restrict__ rp, int64_t n_tiles, int64_t* __restrict__ g) {
   for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= n_rows; r += (int64_t)gridDim.x * 256) {
     int64_t t = r == 0 ? 0 : rp[r - 1] / DS_TILE + 1;
-    const int64_t t_hi = rp[r] / DS_TILE;
-    for (; t <= t_hi && t < n_tiles; ++t) g[t] = r;
+    const int64_t e = rp[r];
+    const int64_t t_hi = e / DS_TILE;
+    for (; t <= t_hi && t < n_tiles; ++t) g[t] = (r << 1) | (int64_t)(e == t * DS_TILE);  // low bit: row r starts exactly at the tile start
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) g[n_tiles] = n_rows + 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) g[n_tiles] = (n_rows + 1) << 1;
 }
 
 // `debug` (profiling only, results meaningless): 32 = cheap hash, 64 = no threshold gather, 128 = no row lookup
@@ -582,8 +583,11 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_
     }
   }
   // slice rp[r_s .. r_e]: r_s = the last row known to start at or before e0, r_e = the first row starting at or after e1
-  const int64_t g0 = g[tile], g1 = g[tile + 1];
-  const int64_t r_s = rp[g0] == e0 ? g0 : g0 - 1;
+  const int64_t gp0 = g[tile];
+  const int64_t g0 = gp0 >> 1, g1 = g[tile + 1] >> 1;
+  // CANDIDATE (round 2, unmeasured; debug 4096): the "row starts at the tile start" bit travels in the tile table, which
+  // takes one dependent global load out of every tile's prologue
+  const int64_t r_s = (debug & 4096) ? ((gp0 & 1) ? g0 : g0 - 1) : (rp[g0] == e0 ? g0 : g0 - 1);
   const int64_t r_e = g1 < n_rows ? g1 : n_rows;
   const int64_t n_slice = r_e - r_s + 1;
   const bool in_lds = n_slice <= DS_SLICE;
@@ -731,7 +735,7 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_compact_kernel(int64_t 
     }
   }
   // new row_ptr of the rows that start inside this tile (the last tile also takes the rows behind the last entry)
-  for (int64_t r = g[tile] + threadIdx.x; r < g[tile + 1]; r += DS_THREADS) {
+  for (int64_t r = (g[tile] >> 1) + threadIdx.x; r < (g[tile + 1] >> 1); r += DS_THREADS) {
     const int rel = (int)(rp[r] - e0);
     const int w = rel >> 6, b = rel & 63;
     out_rp[r] = off + s_wpre[w] + (b == 0 ? 0 : __popcll(s_keep[w] & ((1ull << b) - 1ull)));
