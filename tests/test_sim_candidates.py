@@ -34,3 +34,10 @@ def test_lds_staged_bucket_scatter(with_debug, case):
 def test_tile_table_carries_the_row_start_bit(with_debug, mode):
     with_debug(4096, logic.test_row_scan_tile_edges, mode)
     with_debug(4096, logic.test_downsample_row_base_matches_sharded_rows)
+
+
+@pytest.mark.parametrize("case", [logic.test_small_three_events_all_modes, logic.test_hash_tables_and_all_bins,
+                                  logic.test_packed_count_overflow_goes_global, logic.test_large_matrix_full_pipeline],
+                         ids=lambda f: f.__name__)
+def test_claim_first_insert(with_debug, case):
+    with_debug(8192, case)

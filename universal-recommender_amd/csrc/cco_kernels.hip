@@ -1324,6 +1324,28 @@ __device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int coun
   return false;
 }
 
+// CANDIDATE (round 2, unmeasured; debug 8192 selects the kernels instantiated with it): claim-first insert.  One CAS per
+// probe instead of a relaxed load followed by a CAS (a new column costs 1 LDS round trip instead of 2, a known one 2
+// as before), a single rolled loop with one exit -- the unrolled probe loop of tab_insert compiles to more exec-mask
+// bookkeeping (SALU) than useful work.
+__device__ __forceinline__ bool tab_insert_claim_first(unsigned* tab, unsigned key, int count_bits, unsigned mask, int hshift, bool ident) {
+  unsigned h = ident ? (key - 1u) : ((key * 0x9E3779B1u) >> hshift);
+  const unsigned fresh = (key << count_bits) | 1u;
+  bool ok = false;
+#pragma unroll 1
+  for (unsigned probe = 0; probe <= mask; ++probe) {
+    const unsigned v = atomicCAS(&tab[h], 0u, fresh);
+    if (v == 0u) { ok = true; break; }
+    if ((v >> count_bits) == key) {
+      atomicAdd(&tab[h], 1u);
+      ok = true;
+      break;
+    }
+    h = (h + 1u) & mask;
+  }
+  return ok;
+}
+
 // LDS hand-off inside ONE wave: DS operations of a wave execute in program order, so a compiler-level fence is all that
 // is needed between a lane's write and another lane's read.
 __device__ __forceinline__ void wave_sync() {
@@ -1365,7 +1387,7 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
   return base + inc - v;
 }
 
-template <int T, int E, int U>
+template <int T, int E, int U, int INS = 0>
 __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T == 64 ? 6 : 1)) void cco_rows_kernel(CcoArgs a, int bin) {
   constexpr int BLOCK = T < 256 ? 256 : T;
   constexpr int TEAMS = BLOCK / T;
@@ -1498,7 +1520,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
               if ((unsigned)x < nb) {
                 if (a.debug & 1) {  // ablation: gather only
                   if (jj[x] == 0xffffffffu) tab[0] = 1u;
-                } else if (!tab_insert(tab, jj[x] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) {
+                } else if (!(INS ? tab_insert_claim_first(tab, jj[x] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)
+                                 : tab_insert(tab, jj[x] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident))) {
                   atomicAdd(a.err, 1ull);
                 }
               }
@@ -2071,11 +2094,26 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
   // so no host synchronisation sits between binning and the SpGEMM.
   switch (bin) {
     case 0: hipLaunchKernelGGL(cco_rows_micro_kernel, dim3((unsigned)(n_cu * blocks_per_cu(0))), dim3(256), 0, st, args); break;
-    case 1: hipLaunchKernelGGL((cco_rows_kernel<64, E0, 1>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1); break;
-    case 2: hipLaunchKernelGGL((cco_rows_kernel<256, E1S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(256), 0, st, args, 2); break;
-    case 3: hipLaunchKernelGGL((cco_rows_kernel<256, E1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(3))), dim3(256), 0, st, args, 3); break;
-    case 4: hipLaunchKernelGGL((cco_rows_kernel<512, E2S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(4))), dim3(512), 0, st, args, 4); break;
-    case 5: hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 1>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5); break;
+    case 1:
+      if (args.debug & 8192) hipLaunchKernelGGL((cco_rows_kernel<64, E0, 1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1);
+      else hipLaunchKernelGGL((cco_rows_kernel<64, E0, 1>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1);
+      break;
+    case 2:
+      if (args.debug & 8192) hipLaunchKernelGGL((cco_rows_kernel<256, E1S, 1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(256), 0, st, args, 2);
+      else hipLaunchKernelGGL((cco_rows_kernel<256, E1S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(256), 0, st, args, 2);
+      break;
+    case 3:
+      if (args.debug & 8192) hipLaunchKernelGGL((cco_rows_kernel<256, E1, 1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(3))), dim3(256), 0, st, args, 3);
+      else hipLaunchKernelGGL((cco_rows_kernel<256, E1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(3))), dim3(256), 0, st, args, 3);
+      break;
+    case 4:
+      if (args.debug & 8192) hipLaunchKernelGGL((cco_rows_kernel<512, E2S, 1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(4))), dim3(512), 0, st, args, 4);
+      else hipLaunchKernelGGL((cco_rows_kernel<512, E2S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(4))), dim3(512), 0, st, args, 4);
+      break;
+    case 5:
+      if (args.debug & 8192) hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5);
+      else hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 1>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5);
+      break;
     default: hipLaunchKernelGGL(cco_rows_global_kernel, dim3(GLOBAL_BIN_BLOCKS), dim3(GB_THREADS), 0, st, args); break;
   }
   return hipGetLastError();
