@@ -61,32 +61,47 @@ void orc_column_counts(int64_t nnz, const int32_t* col_idx, int32_t n_cols, int3
   for (int64_t e = 0; e < nnz; ++e) counts[col_idx[e]]++;
 }
 
-/* sampleDownAndBinarize.  raw_counts = column counts of the RAW matrix (all users, D11).
- * row_base = global index of local row 0 (sharded inputs keep the same RNG stream).
- * out_rp has n_rows+1 entries, out_ci capacity = nnz.  Returns kept nnz. */
-int64_t orc_downsample(int64_t n_rows, const int64_t* rp, const int32_t* ci, const int32_t* raw_counts, uint32_t seed,
-                       int32_t max_n, int row_rate_mode, int64_t row_base, int64_t* out_rp, int32_t* out_ci) {
-  int64_t w = 0;
-  for (int64_t r = 0; r < n_rows; ++r) {
-    out_rp[r] = w;
-    int64_t n_row = rp[r + 1] - rp[r];
-    if (n_row == 0) continue;
-    int64_t capped = n_row < max_n ? n_row : max_n;
-    double per_row = row_rate_mode == ORC_ROW_RATE_MAHOUT_INT_DIV ? (double)(capped / n_row) /* Int / Int (D9) */
-                                                                  : (double)capped / (double)n_row;
-    for (int64_t e = rp[r]; e < rp[r + 1]; ++e) {
-      int32_t j = ci[e];
-      double n_thing = (double)raw_counts[j];
-      double per_thing = (n_thing < (double)max_n ? n_thing : (double)max_n) / n_thing;
-      double rate = per_row < per_thing ? per_row : per_thing;
-      if (orc_u01(seed, (uint32_t)(row_base + r), (uint32_t)j) <= rate) out_ci[w++] = j;
-    }
-  }
-  out_rp[n_rows] = w;
-  return w;
+/* keep decision of sampleDownAndBinarize for one interaction (r = global row index) */
+static inline int orc_keep(uint32_t seed, int64_t r, int32_t j, int64_t n_row, const int32_t* raw_counts, int32_t max_n, int row_rate_mode) {
+  int64_t capped = n_row < max_n ? n_row : max_n;
+  double per_row = row_rate_mode == ORC_ROW_RATE_MAHOUT_INT_DIV ? (double)(capped / n_row) /* Int / Int (D9) */
+                                                                : (double)capped / (double)n_row;
+  double n_thing = (double)raw_counts[j];
+  double per_thing = (n_thing < (double)max_n ? n_thing : (double)max_n) / n_thing;
+  double rate = per_row < per_thing ? per_row : per_thing;
+  return orc_u01(seed, (uint32_t)r, (uint32_t)j) <= rate;
 }
 
-/* CSR (n_rows x n_cols) -> CSC; rows inside a column ascending. */
+/* sampleDownAndBinarize.  raw_counts = column counts of the RAW matrix (all users, D11).
+ * row_base = global index of local row 0 (sharded inputs keep the same RNG stream).
+ * out_rp has n_rows+1 entries, out_ci capacity = nnz.  Returns kept nnz.
+ * The RNG is stateless (D10), so rows are independent: counted in parallel, prefix-summed, written in parallel --
+ * the result is the one the sequential loop over rows gives. */
+int64_t orc_downsample(int64_t n_rows, const int64_t* rp, const int32_t* ci, const int32_t* raw_counts, uint32_t seed,
+                       int32_t max_n, int row_rate_mode, int64_t row_base, int64_t* out_rp, int32_t* out_ci) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 4096)
+#endif
+  for (int64_t r = 0; r < n_rows; ++r) {
+    int64_t n_row = rp[r + 1] - rp[r], kept = 0;
+    for (int64_t e = rp[r]; e < rp[r + 1]; ++e) kept += orc_keep(seed, row_base + r, ci[e], n_row, raw_counts, max_n, row_rate_mode);
+    out_rp[r + 1] = kept;
+  }
+  out_rp[0] = 0;
+  for (int64_t r = 0; r < n_rows; ++r) out_rp[r + 1] += out_rp[r];
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 4096)
+#endif
+  for (int64_t r = 0; r < n_rows; ++r) {
+    int64_t n_row = rp[r + 1] - rp[r], w = out_rp[r];
+    for (int64_t e = rp[r]; e < rp[r + 1]; ++e)
+      if (orc_keep(seed, row_base + r, ci[e], n_row, raw_counts, max_n, row_rate_mode)) out_ci[w++] = ci[e];
+  }
+  return out_rp[n_rows];
+}
+
+/* CSR (n_rows x n_cols) -> CSC; rows inside a column ascending.  Threads own disjoint column ranges and each walks
+ * the whole matrix in row order (streaming, no shared writes), which keeps the ascending order of the sequential loop. */
 void orc_transpose(int64_t n_rows, const int64_t* rp, const int32_t* ci, int32_t n_cols, int64_t* col_ptr, int32_t* row_idx) {
   memset(col_ptr, 0, sizeof(int64_t) * ((size_t)n_cols + 1));
   int64_t nnz = rp[n_rows];
@@ -94,8 +109,33 @@ void orc_transpose(int64_t n_rows, const int64_t* rp, const int32_t* ci, int32_t
   for (int32_t j = 0; j < n_cols; ++j) col_ptr[j + 1] += col_ptr[j];
   int64_t* cur = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_cols > 0 ? n_cols : 1));
   memcpy(cur, col_ptr, sizeof(int64_t) * (size_t)n_cols);
-  for (int64_t r = 0; r < n_rows; ++r)
-    for (int64_t e = rp[r]; e < rp[r + 1]; ++e) row_idx[cur[ci[e]]++] = (int32_t)r;
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
+    int t = 0, nt = 1;
+#ifdef _OPENMP
+    t = omp_get_thread_num(); nt = omp_get_num_threads();
+#endif
+    if (nnz < (1 << 22)) nt = 1;             /* small matrices: one pass by thread 0 */
+    if (t < nt) {
+      /* column ranges of ~equal nnz */
+      int32_t lo = 0, hi = n_cols;
+      if (nt > 1) {
+        int64_t t0 = nnz / nt * t, t1 = t == nt - 1 ? nnz : nnz / nt * (t + 1);
+        int32_t a = 0, b = n_cols;
+        while (a < b) { int32_t m = a + (b - a) / 2; if (col_ptr[m] >= t0) b = m; else a = m + 1; }
+        lo = a; a = 0; b = n_cols;
+        while (a < b) { int32_t m = a + (b - a) / 2; if (col_ptr[m] >= t1) b = m; else a = m + 1; }
+        hi = t == nt - 1 ? n_cols : a;
+      }
+      for (int64_t r = 0; r < n_rows; ++r)
+        for (int64_t e = rp[r]; e < rp[r + 1]; ++e) {
+          int32_t j = ci[e];
+          if (j >= lo && j < hi) row_idx[cur[j]++] = (int32_t)r;
+        }
+    }
+  }
   free(cur);
 }
 

@@ -1,6 +1,8 @@
 """Shared test helpers: seeded matrix generators, host<->device conversion, the tie-aware parity checker."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -90,3 +92,29 @@ def compare_with_oracle(sess, mats, params, seed, mode=0, item_lo=0, item_hi=Non
         n, ties = check_indicators(o.to_host(), r, exact_ids=exact_ids)
         stats.append((st.copy(), n, ties))
     return out, ref, stats
+
+
+def compare_with_oracle_large(sess, mats, params, seed, mode=0, threads=None):
+    """compare_with_oracle for workloads of 10^8..10^9 pairs: the C oracle runs on every host core, one event type at a
+    time (its strided outputs are freed before the next), and the down-sampled matrices themselves -- row_ptr AND
+    col_idx -- are compared bit for bit before the indicator rows (every row) are.  Returns per event
+    (stats vector, rows needing the k-boundary tie rule)."""
+    threads = threads or min(os.cpu_count() or 1, O.lib().orc_max_threads())
+    out = run_device(sess, mats, params, seed, mode)
+    a = O.downsample(mats[0], O.column_counts(mats[0]), seed, params[0].max_elements_per_row, mode)
+    cnt_a = O.column_counts(a)
+    a_cp, a_ri = O.transpose(a)
+    res = []
+    for d, (m, p, o) in enumerate(zip(mats, params, out)):
+        b = a if d == 0 else O.downsample(m, O.column_counts(m), seed, p.max_elements_per_row, mode)
+        cnt_b = cnt_a if d == 0 else O.column_counts(b)
+        assert np.array_equal(o.sampled_row_ptr.cpu().numpy(), b.row_ptr), f"event {d}: down-sampled row_ptr differs"
+        assert np.array_equal(o.sampled_col_idx[:b.nnz].cpu().numpy(), b.col_idx), f"event {d}: down-sampled col_idx differs"
+        ref = O.cco_rows(a_cp, a_ri, b, cnt_a, cnt_b, mats[0].n_rows, d == 0, p.max_interesting_elements, p.min_llr, 0, None, threads)
+        st = o.stats.cpu().numpy()
+        assert int(st[0]) == ref.pairs, f"event {d}: pairs {int(st[0])} vs oracle {ref.pairs}"
+        assert int(st[1 + 4 * 7]) == 0, "LDS accumulator overflow reported"
+        _, ties = check_indicators(o.to_host(), ref)
+        res.append((st.copy(), ties))
+        del ref, b
+    return out, res

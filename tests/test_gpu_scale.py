@@ -1,0 +1,60 @@
+"""PARITY AT SCALE (-m gpu): the workloads the BASELINE configs name, compared with the C oracle ROW BY ROW -- every
+indicator row of every event type, and the down-sampled matrices themselves (row_ptr and col_idx) -- not through
+samples.  The 10M x 2M configurations keep their 2M-wide item spaces (21-bit packed keys -> 11-bit packed counts, 245
+column buckets); the users are scaled so that a test stays within minutes of host time for the oracle."""
+import numpy as np
+import pytest
+
+from helpers import compare_with_oracle_large
+from oracle import c_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def P(max_rows=500, k=50, min_llr=None):
+    return O.DatasetParams(max_rows, k, min_llr)
+
+
+def _mats(cfg):
+    from universal_recommender_amd import synth
+    return [O.Csr(cfg.n_users, nc, rp, ci) for (_, nc, rp, ci) in synth.generate(cfg)]
+
+
+def test_full_config3_every_row(gpu_session):
+    """BASELINE config 3 at FULL size (1M x 200K, 3 events; the bench workload): all 600K indicator rows, the three
+    down-sampled matrices bit for bit, pairs."""
+    from universal_recommender_amd import synth
+    mats = _mats(synth.config3(1.0))
+    _, res = compare_with_oracle_large(gpu_session, mats, [P(), P(), P()], 20260925)
+    assert sum(int(st[0]) for st, _ in res) == 90668283        # the pairs figure bench.py reports for this seed
+
+
+def test_config4_quarter_scale_full_item_space(gpu_session):
+    """BASELINE config 4 with 2.5M users (1/4) x the full 2M / 2M / 2M / 200K / 2K item spaces, 5 event types."""
+    from universal_recommender_amd import synth
+    cfg = synth.config4(0.25, item_scale=1.0)
+    mats = _mats(cfg)
+    assert mats[0].n_cols == 2_000_000 and len(mats) == 5
+    _, res = compare_with_oracle_large(gpu_session, mats, [P()] * 5, 4)
+    rows_by_bin = np.sum([st[1:8] for st, _ in res], axis=0)
+    assert rows_by_bin[0] > 0 and rows_by_bin[1] > 0 and rows_by_bin[5] + rows_by_bin[6] > 0, rows_by_bin
+
+
+def test_config5_tenth_scale_full_item_space_skew(gpu_session):
+    """BASELINE config 5 (hot head: top 0.1 % of the items draw 40 % of the interactions; 1 % heavy users) with 1M users
+    (1/10) x the full item spaces, `indicators` form.  maxItemsPerUser = 500 drops the heavy users' rows (Int/Int row
+    rate); one event type runs with maxItemsPerUser = 3000, which leaves columns with more than 2047 interactions --
+    beyond the 11-bit packed count of a 2M-wide column space -- so those rows must take the global accumulator."""
+    from universal_recommender_amd import synth
+    cfg = synth.config5(0.1, item_scale=1.0)
+    mats = _mats(cfg)
+    assert max(int(np.diff(m.row_ptr).max()) for m in mats) > 500
+    params = [P(3000, 50), P(500, 50), P(500, 20, 2.0), P(500, 50), P(500, 50)]
+    out, res = compare_with_oracle_large(gpu_session, mats, params, 5)
+    rows_by_bin = np.sum([st[1:8] for st, _ in res], axis=0)
+    assert rows_by_bin[6] > 0, rows_by_bin                      # global-accumulator class used
+    raw_len = np.diff(mats[1].row_ptr)
+    kept_len = np.diff(out[1].sampled_row_ptr.cpu().numpy())
+    assert np.all(kept_len[raw_len > 500] == 0) and (raw_len > 500).sum() > 1000    # maxElementsPerRow drops
+    # fractional row rate on the two heaviest event types
+    compare_with_oracle_large(gpu_session, mats[:2], [P(500, 50), P(500, 50)], 5, mode=1)

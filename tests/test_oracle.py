@@ -82,3 +82,29 @@ def test_min_llr_and_zero_drop():
     hi = PO.cross_occurrence_downsampled([PO.DownsamplableCrossOccurrenceDataset(ids, 500, 50, 1e9)], 1)[0]
     assert all(len(r) == 0 for r in hi.rows)                                 # D12: minLLR filters before the cut
     assert PO.seed_to_int(0xdeadbeef) == -559038737 and PO.seed_to_int(2**40 + 5) == 5   # D14
+
+
+def test_parallel_c_oracle_paths_against_scipy():
+    """The OpenMP forms of orc_downsample / orc_transpose (matrices >= 2^22 entries take the threaded transposition)
+    equal the sequential definitions: transposition vs scipy's CSC (rows ascending inside a column), down-sampling vs
+    a vectorised numpy evaluation of the same keep rule."""
+    rng = np.random.default_rng(31)
+    m = rand_csr(rng, 150_000, 50_000, 34, zipf_s=1.0)
+    assert m.nnz >= (1 << 22)
+    cp, ri = O.transpose(m)
+    M = sp.csr_matrix((np.ones(m.nnz, np.int8), m.col_idx, m.row_ptr), shape=(m.n_rows, m.n_cols)).tocsc()
+    M.sort_indices()
+    assert np.array_equal(cp, M.indptr) and np.array_equal(ri, M.indices)
+    raw = O.column_counts(m)
+    ds = O.downsample(m, raw, 77, 40, 1)
+    L = O.lib()
+    rows = np.repeat(np.arange(m.n_rows), np.diff(m.row_ptr))
+    n_row = np.diff(m.row_ptr)[rows].astype(np.float64)
+    rate = np.minimum(np.minimum(n_row, 40.0) / n_row, np.minimum(raw[m.col_idx], 40.0) / raw[m.col_idx])
+    pick = rng.integers(0, m.nnz, 20000)
+    u = np.array([L.orc_u01(77, int(rows[e]), int(m.col_idx[e])) for e in pick])
+    keep = u <= rate[pick]
+    pos = np.searchsorted(ds.row_ptr, np.arange(ds.nnz), side="right") - 1
+    kept = set(zip(pos.tolist(), ds.col_idx.tolist()))
+    assert all(((int(rows[e]), int(m.col_idx[e])) in kept) == bool(k) for e, k in zip(pick, keep))
+    assert np.all(np.diff(ds.row_ptr) <= np.diff(m.row_ptr))

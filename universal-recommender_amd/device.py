@@ -47,6 +47,7 @@ class DevIndicators:
     llr: torch.Tensor       # float64 [n * k]
     stats: torch.Tensor     # int64 [STATS_LEN]: pairs, then rows / pairs / users / emitted entries per accumulator bin
     sampled_row_ptr: Optional[torch.Tensor] = None  # row_ptr of the down-sampled B (its last entry = nnz')
+    sampled_col_idx: Optional[torch.Tensor] = None  # col_idx of the down-sampled B (first nnz' entries live)
 
     def to_host(self):
         rp = self.row_ptr.cpu().numpy()
@@ -169,7 +170,7 @@ class DeviceSession:
         c_llr = self.empty(max(n * k, 1), torch.float64)
         self._check(self.lib.urcco_dev_compact_indicators(self.handle, n, k, _ptr(o_count), _ptr(o_idx), _ptr(o_llr), _ptr(c_rp), _ptr(c_idx),
                                                          _ptr(c_llr)))
-        return DevIndicators(item_lo, item_hi, b.n_cols, k, c_rp, c_idx, c_llr, stats, b.row_ptr)
+        return DevIndicators(item_lo, item_hi, b.n_cols, k, c_rp, c_idx, c_llr, stats, b.row_ptr, b.col_idx)
 
     def llr(self, with_a, with_b, with_ab, n_users) -> torch.Tensor:
         out = self.empty(with_a.numel(), torch.float64)
@@ -268,7 +269,7 @@ def cross_occurrence_streams(pool: SessionPool, mats: Sequence[DevCsr], params: 
                     t.record_stream(streams[d])   # produced on stream 0, read here
             b, cnt_b = sampled[d]
             ind = pool[d].cco_rows(0, n_items_a, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b, cnt_a, cnt_b, a_raw.n_rows, d == 0, params[d])
-            for t in (ind.row_ptr, ind.col_idx, ind.llr, ind.stats, b.row_ptr):
+            for t in (ind.row_ptr, ind.col_idx, ind.llr, ind.stats, b.row_ptr, b.col_idx):
                 t.record_stream(main)             # consumed by the caller on its stream
             out[d] = ind
     for st in set(streams):

@@ -41,16 +41,19 @@ def config3(scale: float = 1.0) -> SynthConfig:
         seed=20260925 + 3)
 
 
-def config4(scale: float = 1.0) -> SynthConfig:
-    nu, ni = int(10_000_000 * scale), max(int(2_000_000 * scale), 16)
+def config4(scale: float = 1.0, item_scale: Optional[float] = None) -> SynthConfig:
+    """scale shrinks the users; the item spaces follow unless item_scale says otherwise (item_scale = 1.0 keeps the
+    2M-wide column spaces of the full configuration -- what the packed accumulator keys and bucket counts depend on)."""
+    isc = scale if item_scale is None else item_scale
+    nu, ni = int(10_000_000 * scale), max(int(2_000_000 * isc), 16)
     return SynthConfig("config4-10Mx2M-zipf1.0-5events", nu, [
         EventSpec("purchase", 9, ni), EventSpec("view", 39, ni), EventSpec("add-to-cart", 14, ni),
-        EventSpec("search", 19, max(int(200_000 * scale), 16)), EventSpec("category-pref", 2, max(int(2000 * min(scale * 10, 1.0)), 8))],
+        EventSpec("search", 19, max(int(200_000 * isc), 16)), EventSpec("category-pref", 2, max(int(2000 * min(isc * 10, 1.0)), 8))],
         seed=20260925 + 4)
 
 
-def config5(scale: float = 1.0) -> SynthConfig:
-    c = config4(scale)
+def config5(scale: float = 1.0, item_scale: Optional[float] = None) -> SynthConfig:
+    c = config4(scale, item_scale)
     c.name = "config5-10Mx2M-skewed-5events"
     c.seed = 20260925 + 5
     c.skew_top_frac, c.skew_top_prob = 0.001, 0.40
