@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define URCCO_VERSION 100 /* 0.1.0 */
+#define URCCO_VERSION 200 /* 0.2.0 */
 
 typedef enum urcco_status {
   URCCO_OK = 0,
@@ -38,7 +38,8 @@ typedef enum urcco_status {
   URCCO_OOM_DEVICE = 3,
   URCCO_HIP_ERROR = 4,
   URCCO_INTERNAL = 5,
-  URCCO_NO_DEVICE = 6
+  URCCO_NO_DEVICE = 6,
+  URCCO_RCCL_ERROR = 7   /* a collective failed, or more than one GPU was asked for and librccl could not be loaded */
 } urcco_status;
 
 /* D9: how sampleDownAndBinarize's perRowSampleRate is evaluated */
@@ -66,10 +67,14 @@ typedef struct urcco_dataset {
 } urcco_dataset;
 
 typedef struct urcco_options {
-  int32_t device;        /* HIP device ordinal */
+  int32_t device;        /* HIP device ordinal of the first GPU */
   int32_t row_rate_mode; /* URCCO_ROW_RATE_* */
-  int32_t reserved[6];
+  int32_t n_gpus;        /* GPUs of THIS process to use, starting at `device`; 0 = every visible one (engine.json "numGPUs") */
+  int32_t flags;         /* URCCO_FLAG_* */
+  int32_t reserved[4];
 } urcco_options;
+#define URCCO_FLAG_SINGLE_STREAM 1  /* run the event types back to back on one HIP stream per GPU (profiling) */
+#define URCCO_FLAG_FORCE_EXCHANGE 2 /* run the multi-GPU exchange path (collectives, work-balanced ranges) even with one rank */
 
 /* One returned IndexedDataset: rows = items of the primary matrix A (rowIDs = A.columnIDs), columns = items
  * of B_i (columnIDs = B_i.columnIDs), values = raw LLR.  Inside a row entries are ordered (llr desc, col asc)
@@ -96,6 +101,9 @@ typedef struct urcco_dataset_stats {
 
 int urcco_version(void);
 int urcco_device_count(void); /* 0 when no HIP device is visible */
+/* Tears down the process-wide context the one-shot entry points below create on first use (streams, scratch arenas,
+ * pinned staging buffers, RCCL communicators).  Safe to call when nothing was created; the next call re-creates it. */
+int urcco_shutdown(void);
 const char* urcco_last_error(void);
 const char* urcco_status_string(int status);
 
@@ -113,6 +121,100 @@ int urcco_cross_occurrence_downsampled(const urcco_dataset* datasets, int32_t n_
                                        const urcco_options* options, urcco_indicators* out, urcco_dataset_stats* stats);
 
 void urcco_free_indicators(urcco_indicators* indicators, int32_t n);
+
+/* ---- CONTEXT level: the persistent form of the host level, and the multi-GPU build ------------------------------
+ * A context owns, per GPU, one HIP stream + scratch arena per event type, every intermediate and output buffer (grown
+ * on demand, reused by the next build), pinned staging memory and -- with more than one rank -- a communicator.  The
+ * one-shot functions above run on a lazily created process-wide context (urcco_shutdown frees it); a long-lived host
+ * (the Spark driver JVM) may also hold its own.  Not re-entrant: one build at a time per context, as URAlgorithm.train
+ * calls it (URAlgorithm.scala:292-306, driver thread).
+ *
+ * Ranks: a build runs on world_size GPUs ("ranks").  Either ONE process drives them all (what a JVM does: comm = NULL,
+ * n_gpus of the options, collectives through RCCL communicators created with ncclCommInitAll), or one process per GPU
+ * (what bench.py does under torch.distributed.run: world_size / first_rank / nccl_unique_id filled in, n_gpus = 1).
+ * Users are range-sharded over the ranks for the input phase (column counts, sampleDownAndBinarize), items of the
+ * primary matrix are range-partitioned by work for the compute phase; the exchange between the two is
+ * two all-reduces of column counts per event type, one all-reduce of the row-work key and one all-gather-v of the
+ * down-sampled shards. */
+typedef struct urcco_context urcco_context;
+
+/* Replacement for the built-in RCCL collectives (the CPU test-suite runs the multi-rank build over `gloo` through this;
+ * product callers pass NULL).  `rank` = global rank of the calling GPU; calls between group_start and group_end are
+ * one collective each across all ranks and may complete at group_end.  stream = the HIP stream the buffers are
+ * produced / consumed on.  Return 0 on success. */
+typedef struct urcco_collectives {
+  void* user;
+  int (*group_start)(void* user);
+  int (*group_end)(void* user);
+  /* in place; dtype 0 = int32, 1 = int64 */
+  int (*all_reduce_sum)(void* user, int32_t rank, void* buf, int64_t count, int32_t dtype, void* stream);
+  /* recv + byte_offsets[r] receives byte_counts[r] bytes = rank r's send buffer; send holds byte_counts[rank] bytes */
+  int (*all_gather_v)(void* user, int32_t rank, const void* send, void* recv, const int64_t* byte_offsets,
+                      const int64_t* byte_counts, void* stream);
+} urcco_collectives;
+
+typedef struct urcco_comm_config {
+  int32_t world_size;         /* ranks of the job; 0 = the options' n_gpus (single process) */
+  int32_t first_rank;         /* global rank of this process's first GPU */
+  const void* nccl_unique_id; /* URCCO_UNIQUE_ID_BYTES from urcco_comm_unique_id on one rank, distributed by the caller
+                                 (NULL when one process holds every rank) */
+  const urcco_collectives* collectives; /* NULL = RCCL */
+} urcco_comm_config;
+#define URCCO_UNIQUE_ID_BYTES 128
+int urcco_comm_unique_id(void* out /*[URCCO_UNIQUE_ID_BYTES]*/);
+
+int urcco_context_create(const urcco_options* options, const urcco_comm_config* comm, urcco_context** out);
+void urcco_context_destroy(urcco_context* ctx);
+int32_t urcco_context_local_gpus(const urcco_context* ctx);
+
+/* SimilarityAnalysis.crossOccurrenceDownsampled on a context: host CSR in (caller-owned, pageable is fine: staged
+ * through pinned memory by a few copy threads while the GPU already works), host indicator CSR out (pinned memory of the
+ * context's pool; release with urcco_free_indicators).  Single-process contexts only. */
+int urcco_context_cross_occurrence(urcco_context* ctx, const urcco_dataset* datasets, int32_t n_datasets, int32_t random_seed,
+                                   urcco_indicators* out, urcco_dataset_stats* stats);
+
+/* The same build with the matrices already resident in HBM -- what bench.py times.  Per event type and per local GPU
+ * one user-range shard (rows [row_base, row_base + n_rows) of the n_users_total x n_cols matrix). */
+typedef struct urcco_dev_shard {
+  int64_t n_rows;
+  int64_t row_base;
+  const int64_t* row_ptr; /* device, n_rows + 1, starts at 0 */
+  const int32_t* col_idx; /* device */
+  int64_t nnz;            /* == row_ptr[n_rows] (known to the host) */
+} urcco_dev_shard;
+typedef struct urcco_dev_dataset {
+  int64_t n_cols;
+  int32_t max_elements_per_row;
+  int32_t max_interesting_elements;
+  double min_llr;
+  int32_t has_min_llr;
+  int32_t reserved;
+  const urcco_dev_shard* shards; /* [urcco_context_local_gpus] */
+} urcco_dev_dataset;
+/* One indicator matrix slice: rows = items [item_lo, item_hi) of A.  Device memory owned by the context, valid until
+ * its next build or destruction. */
+typedef struct urcco_dev_result {
+  int32_t item_lo, item_hi;
+  const int64_t* row_ptr;  /* item_hi - item_lo + 1 */
+  const int32_t* col_idx;
+  const double* llr;
+  const int64_t* stats;    /* URCCO_STATS_LEN, see urcco_dev_cco_rows */
+  const int64_t* sampled_row_ptr; /* the down-sampled B this GPU multiplied with (whole matrix), sampled_rows + 1 */
+  const int32_t* sampled_col_idx;
+  int64_t sampled_rows;
+} urcco_dev_result;
+/* input_stream (nullable hipStream_t): the stream the shards were produced on -- the build waits for it on the device.
+ * out[d * local_gpus + g].  Returns after ENQUEUEING (except for the one blocking read of range bounds / shard sizes
+ * with more than one rank); follow with urcco_context_wait_stream or urcco_context_synchronize. */
+int urcco_context_build_device(urcco_context* ctx, const urcco_dev_dataset* datasets, int32_t n_datasets, int64_t n_users_total,
+                               int32_t random_seed, void* input_stream, urcco_dev_result* out);
+int urcco_context_wait_stream(urcco_context* ctx, void* stream); /* `stream` waits (on the device) for the last build */
+int urcco_context_synchronize(urcco_context* ctx);               /* the host waits */
+/* per-stage timing / ablation switches of every session of the context (see urcco_session_set_timing / _set_debug) */
+int urcco_context_set_timing(urcco_context* ctx, int32_t enable);
+int urcco_context_get_timings(urcco_context* ctx, double* ms, int64_t* launches);
+int urcco_context_set_debug(urcco_context* ctx, int32_t flags);
+int urcco_context_set_flags(urcco_context* ctx, int32_t flags); /* URCCO_FLAG_* */
 
 /* ---- DEVICE level ----------------------------------------------------------------------------------- */
 

@@ -205,7 +205,12 @@ static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return 
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int* n) {  // HIPSIM_DEVICE_COUNT: pretend to hold several GPUs (multi-GPU orchestration tests)
+  const char* e = getenv("HIPSIM_DEVICE_COUNT");
+  *n = e ? atoi(e) : 1;
+  if (*n < 1) *n = 1;
+  return hipSuccess;
+}
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   memset(p, 0, sizeof(*p));
   p->multiProcessorCount = 8;
@@ -216,6 +221,9 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
 }
 template <typename F> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 2; return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipsimEvent(); return hipSuccess; }
+enum { hipEventDefault = 0, hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

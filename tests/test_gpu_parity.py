@@ -155,28 +155,11 @@ def test_determinism_and_size_independent_properties_full_config3(gpu_session):
 
 
 def test_host_level_c_abi(gpu_session):
-    """urcco_cross_occurrence_downsampled / urcco_cooccurrences_idss (what the JNI shim binds): host CSR in/out."""
+    """urcco_cross_occurrence_downsampled / urcco_cooccurrences_idss (what the JNI shim binds): host CSR in/out, the
+    process-wide persistent context behind them, urcco_shutdown, BAD_ARG for broken inputs (incl. bad column indices)."""
     from universal_recommender_amd import _lib
-    from universal_recommender_amd import similarity_analysis as SA
-    from universal_recommender_amd.indexed_dataset import BiDictionary, IndexedDataset
-    rng = np.random.default_rng(12)
-    mats = [rand_csr(rng, 3000, 700, 9), rand_csr(rng, 3000, 1500, 14)]
-    ids = [IndexedDataset(m.row_ptr, m.col_idx, BiDictionary([f"u{i}" for i in range(m.n_rows)]),
-                          BiDictionary([f"i{d}_{i}" for i in range(m.n_cols)])) for d, m in enumerate(mats)]
-    lib = _lib.load(_lib.DEFAULT_PATH)
-    res = SA.cooccurrencesIDSs(ids, randomSeed=99, maxInterestingItemsPerThing=10, maxNumInteractions=30, library=lib)
-    ref = O.cross_occurrence_downsampled(mats, [P(30, 10), P(30, 10)], 99)
-    for r, o, st in zip(res, ref, SA.last_stats):
-        check_indicators((r.row_ptr, r.col_idx, r.values), o)
-        assert st.pairs == o.pairs and st.nnz_out == r.nnz
-    assert res[1].rowIDs is ids[0].columnIDs and res[1].columnIDs is ids[1].columnIDs
-    # error behaviour: row-count mismatch and non-positive limits are BAD_ARG, not crashes
-    bad = IndexedDataset(np.zeros(11, np.int64), np.zeros(0, np.int32), BiDictionary([str(i) for i in range(10)]), BiDictionary(["x"]))
-    with pytest.raises(_lib.UrccoError) as ei:
-        SA.cooccurrencesIDSs([ids[0], bad], library=lib)
-    assert ei.value.status == _lib.BAD_ARG
-    with pytest.raises(_lib.UrccoError):
-        SA.cooccurrencesIDSs(ids, maxInterestingItemsPerThing=0, library=lib)
+    import test_sim_context as ctx_cases
+    ctx_cases.host_level_case(_lib.load(_lib.DEFAULT_PATH))
 
 
 def test_hardware_execution_equals_simulated_logic(gpu_session, sim_session):
@@ -209,21 +192,8 @@ def test_exchange_path_over_rccl_on_one_gpu():
 
 
 def test_stream_per_event_type_is_bit_identical(gpu_session):
-    """device.cross_occurrence_streams (one HIP stream + scratch arena per event type) == the single-stream pipeline."""
+    """urcco_context (one HIP stream + scratch arena per event type, buffers reused across builds of different shapes)
+    == the one-session stage-by-stage pipeline, bit for bit; also with URCCO_FLAG_SINGLE_STREAM."""
     from universal_recommender_amd import _lib
-    from universal_recommender_amd.device import SessionPool, cross_occurrence_streams
-    from helpers import to_params
-    rng = np.random.default_rng(41)
-    mats = [rand_csr(rng, 30000, 4000, 10, zipf_s=1.1), rand_csr(rng, 30000, 6000, 16), rand_csr(rng, 30000, 50, 2)]
-    ps = [P(80, 20), P(80, 20), P(500, 50)]
-    dev = gpu_session.device
-    ref = run_device(gpu_session, mats, ps, 17)
-    pool = SessionPool(dev, 3, _lib.load(_lib.DEFAULT_PATH))
-    for _ in range(3):
-        out = cross_occurrence_streams(pool, [to_dev(m, dev) for m in mats], to_params(ps), 17)
-    torch.cuda.synchronize()
-    for a, b in zip(out, ref):
-        for x, y in zip(a.to_host(), b.to_host()):
-            assert np.array_equal(x, y)
-        assert torch.equal(a.stats[:1].cpu(), b.stats[:1].cpu())
-    pool.close()
+    import test_sim_context as ctx_cases
+    ctx_cases.context_reuse_case(_lib.load(_lib.DEFAULT_PATH), gpu_session.device)

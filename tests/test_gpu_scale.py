@@ -58,3 +58,39 @@ def test_config5_tenth_scale_full_item_space_skew(gpu_session):
     assert np.all(kept_len[raw_len > 500] == 0) and (raw_len > 500).sum() > 1000    # maxElementsPerRow drops
     # fractional row rate on the two heaviest event types
     compare_with_oracle_large(gpu_session, mats[:2], [P(500, 50), P(500, 50)], 5, mode=1)
+
+
+def test_host_level_c_abi_config3_size(gpu_session):
+    """The host-level entry point a JNI shim binds (urcco_cross_occurrence_downsampled: pageable host CSR in through the
+    pinned staging ring, indicator CSR out in pinned host memory) on the FULL config-3 input: every row against the
+    oracle, twice (the second call runs on the warm persistent context), then urcco_shutdown."""
+    import ctypes as C
+    import os
+    from helpers import check_indicators
+    from universal_recommender_amd import _lib, synth
+    lib = _lib.load(_lib.DEFAULT_PATH)
+    cfg = synth.config3(1.0)
+    data = synth.generate(cfg)
+    mats = [O.Csr(cfg.n_users, nc, rp, ci) for (_, nc, rp, ci) in data]
+    n = len(mats)
+    threads = min(os.cpu_count() or 1, O.lib().orc_max_threads())
+    ref = O.cross_occurrence_downsampled(mats, [P(), P(), P()], 77, 0, threads)
+    arr = (_lib.Dataset * n)()
+    for d, m in enumerate(mats):
+        arr[d].matrix.n_rows, arr[d].matrix.n_cols = m.n_rows, m.n_cols
+        arr[d].matrix.row_ptr, arr[d].matrix.col_idx = m.row_ptr.ctypes.data, m.col_idx.ctypes.data
+        arr[d].max_elements_per_row, arr[d].max_interesting_elements = 500, 50
+    opts = _lib.Options(device=0, row_rate_mode=0, n_gpus=1)
+    for _ in range(2):
+        out = (_lib.Indicators * n)()
+        stats = (_lib.DatasetStats * n)()
+        _lib.check(lib.urcco_cross_occurrence_downsampled(arr, n, 77, C.byref(opts), out, stats), lib)
+        for d, r in enumerate(ref):
+            o = out[d]
+            nnz = int(o.nnz)
+            got = (np.ctypeslib.as_array(o.row_ptr, shape=(o.n_rows + 1,)).copy(), np.ctypeslib.as_array(o.col_idx, shape=(max(nnz, 1),))[:nnz].copy(),
+                   np.ctypeslib.as_array(o.llr, shape=(max(nnz, 1),))[:nnz].copy())
+            check_indicators(got, r)
+            assert stats[d].pairs == r.pairs and stats[d].nnz_out == nnz and stats[d].nnz_raw == mats[d].nnz
+        lib.urcco_free_indicators(out, n)
+    assert lib.urcco_shutdown() == 0

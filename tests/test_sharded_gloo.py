@@ -1,5 +1,6 @@
-"""The N > 1 path on CPU: world_size-2 and -3 `gloo` process groups drive sharded.py end to end (user-range shards,
-count all-reduces, all-gather of the down-sampled shards, work-balanced item ranges).  Compute underneath is the
+"""The N > 1 path on CPU: world_size-2 and -3 `gloo` process groups drive the library's multi-rank build
+(urcco_context_build_device: user-range shards, count all-reduces, all-gather-v of the down-sampled shards, work-balanced
+item ranges) end to end, the collectives going through the urcco_collectives callbacks instead of RCCL.  Compute underneath is the
 kernel sources on the TEST-ONLY host simulator; the result must equal the single-process oracle exactly the way the
 single-GPU path does -- i.e. the sharding is invisible."""
 import os
@@ -33,12 +34,20 @@ def _worker(rank, world, port, uneven, q):
         from hostsim import build_sim
         from oracle import c_oracle as O
         from universal_recommender_amd import _lib, sharded
-        from universal_recommender_amd.device import DeviceSession
-        sess = DeviceSession(torch.device("cpu"), _lib.load(build_sim.build()))
+        ctx = sharded.make_context(torch.device("cpu"), _lib.load(build_sim.build()))
         rng = np.random.default_rng(77)                       # same matrices on every rank
-        n_users = 1201
-        mats = [rand_csr(rng, n_users, 300, 9, zipf_s=1.2), rand_csr(rng, n_users, 700, 14), rand_csr(rng, n_users, 11, 2, empty_frac=0.3)]
-        params = [O.DatasetParams(30, 10, None), O.DatasetParams(40, 12, None), O.DatasetParams(500, 50, 0.1)]
+        if uneven == "skew5":                                 # five event types with config 5's skew (hot head + heavy users)
+            from universal_recommender_amd import synth
+            cfg = synth.config5(0.0003)
+            n_users = cfg.n_users
+            mats = [O.Csr(n_users, nc, rp, ci) for (_, nc, rp, ci) in synth.generate(cfg)]
+            params = [O.DatasetParams(60, 20, None), O.DatasetParams(80, 20, None), O.DatasetParams(500, 10, None), O.DatasetParams(40, 50, 0.5),
+                      O.DatasetParams(500, 50, None)]
+            assert len(mats) == 5 and max(int(np.diff(m.row_ptr).max()) for m in mats) > 80
+        else:
+            n_users = 1201
+            mats = [rand_csr(rng, n_users, 300, 9, zipf_s=1.2), rand_csr(rng, n_users, 700, 14), rand_csr(rng, n_users, 11, 2, empty_frac=0.3)]
+            params = [O.DatasetParams(30, 10, None), O.DatasetParams(40, 12, None), O.DatasetParams(500, 50, 0.1)]
         if uneven == "empty":                                 # rank 0 holds no users at all
             cuts = [0, 0] + [n_users * r // (world - 1) for r in range(1, world)]
         elif uneven and world == 2:
@@ -47,26 +56,26 @@ def _worker(rank, world, port, uneven, q):
             cuts = [n_users * r // world for r in range(world + 1)]
         lo, hi = cuts[rank], cuts[rank + 1]
         shards = [O.Csr(hi - lo, m.n_cols, m.row_ptr[lo:hi + 1] - m.row_ptr[lo], m.col_idx[m.row_ptr[lo]:m.row_ptr[hi]]) for m in mats]
-        res = sharded.cross_occurrence_sharded(sess, [to_dev(s, "cpu") for s in shards], to_params(params), 2024, n_users, lo)
-        sess.synchronize()
+        res = sharded.cross_occurrence_sharded(ctx, [to_dev(s, "cpu") for s in shards], to_params(params), 2024, n_users, lo)
         full = sharded.gather_indicators_to_host(res)
+        ranges = sharded.gather_item_ranges(res, mats[0].n_cols)
         ref = O.cross_occurrence_downsampled(mats, params, 2024)
         pairs = [int(i.stats[0]) for i in res.indicators]
         all_pairs = [None] * world
         dist.all_gather_object(all_pairs, pairs)
         for d, (got, r) in enumerate(zip(full, ref)):
-            check_indicators(got, r, exact_ids=True)
+            check_indicators(got, r, exact_ids=uneven != "skew5")
             assert sum(p[d] for p in all_pairs) == r.pairs
-            b = res.item_ranges[d]
-            assert b[0] == 0 and b[-1] == mats[0].n_cols and len(b) == world + 1
-        q.put((rank, "ok", res.item_ranges))
+        assert ranges[0] == 0 and ranges[-1] == mats[0].n_cols and len(ranges) == world + 1
+        q.put((rank, "ok", ranges))
+        ctx.close()
         dist.destroy_process_group()
     except Exception as e:  # surface the failure in the parent
         import traceback
         q.put((rank, "fail: " + traceback.format_exc(), None))
 
 
-@pytest.mark.parametrize("world,uneven", [(2, False), (2, True), (3, False), (2, "empty")])
+@pytest.mark.parametrize("world,uneven", [(2, False), (2, True), (3, False), (2, "empty"), (2, "skew5")])
 def test_sharded_equals_single_process_oracle(world, uneven, sim_lib):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -1,0 +1,163 @@
+"""The CONTEXT level of the C ABI on CPU (kernel sources on the test-only host simulator): the host-level entry points
+a JNI shim binds, the persistent context behind them, and ONE process driving several (simulated) GPUs -- the shape a
+JVM host has -- with the collectives looped back in-process.  Logic only; the parity claims are the -m gpu tests."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import check_indicators, rand_csr, to_dev, to_params
+from oracle import c_oracle as O
+
+
+def P(max_rows=500, k=50, min_llr=None):
+    return O.DatasetParams(max_rows, k, min_llr)
+
+
+def host_level_case(lib):
+    """urcco_cooccurrences_idss / urcco_cross_occurrence_downsampled exactly as the Scala host calls them: host CSR in,
+    host indicator CSR out, BAD_ARG (never a crash) for inputs that break the stated preconditions."""
+    from universal_recommender_amd import _lib
+    from universal_recommender_amd import similarity_analysis as SA
+    from universal_recommender_amd.indexed_dataset import BiDictionary, IndexedDataset
+    rng = np.random.default_rng(12)
+    mats = [rand_csr(rng, 3000, 700, 9), rand_csr(rng, 3000, 1500, 14)]
+    ids = [IndexedDataset(m.row_ptr, m.col_idx, BiDictionary([f"u{i}" for i in range(m.n_rows)]),
+                          BiDictionary([f"i{d}_{i}" for i in range(m.n_cols)])) for d, m in enumerate(mats)]
+    ref = O.cross_occurrence_downsampled(mats, [P(30, 10), P(30, 10)], 99)
+    for _ in range(2):                                   # the second call reuses the process-wide context and its buffers
+        res = SA.cooccurrencesIDSs(ids, randomSeed=99, maxInterestingItemsPerThing=10, maxNumInteractions=30, library=lib)
+        for r, o, st in zip(res, ref, SA.last_stats):
+            check_indicators((r.row_ptr, r.col_idx, r.values), o)
+            assert st.pairs == o.pairs and st.nnz_out == r.nnz and st.nnz_raw > st.nnz_sampled > 0
+        assert res[1].rowIDs is ids[0].columnIDs and res[1].columnIDs is ids[1].columnIDs
+    assert lib.urcco_shutdown() == 0                     # tears the context down; the next call re-creates it
+    res = SA.crossOccurrenceDownsampled([SA.DownsamplableCrossOccurrenceDataset(ids[0], 30, 10, None),
+                                         SA.DownsamplableCrossOccurrenceDataset(ids[1], 30, 10, 0.7)], 99, library=lib)
+    ref2 = O.cross_occurrence_downsampled(mats, [P(30, 10), P(30, 10, 0.7)], 99)
+    for r, o in zip(res, ref2):
+        check_indicators((r.row_ptr, r.col_idx, r.values), o)
+    # ---- error behaviour: BAD_ARG, not crashes
+    u10 = BiDictionary([str(i) for i in range(10)])
+    bad_rows = IndexedDataset(np.zeros(11, np.int64), np.zeros(0, np.int32), u10, BiDictionary(["x"]))
+    with pytest.raises(_lib.UrccoError) as ei:
+        SA.cooccurrencesIDSs([ids[0], bad_rows], library=lib)
+    assert ei.value.status == _lib.BAD_ARG
+    with pytest.raises(_lib.UrccoError):
+        SA.cooccurrencesIDSs(ids, maxInterestingItemsPerThing=0, library=lib)
+    cols4 = BiDictionary(["a", "b", "c", "d"])
+    rp = np.array([0, 2, 4] + [4] * 8, np.int64)
+    for ci, what in [([0, 7, 1, 2], "column out of range"), ([0, -1, 1, 2], "negative column"), ([1, 0, 1, 2], "not increasing"),
+                     ([1, 1, 1, 2], "duplicate column")]:
+        bad = IndexedDataset(rp, np.array(ci, np.int32), u10, cols4)
+        with pytest.raises(_lib.UrccoError) as ei:
+            SA.cooccurrencesIDSs([bad], library=lib)
+        assert ei.value.status == _lib.BAD_ARG, what
+    bad = IndexedDataset(np.array([0, 3, 2] + [4] * 8, np.int64), np.array([0, 1, 2, 3], np.int32), u10, cols4)
+    with pytest.raises(_lib.UrccoError) as ei:
+        SA.cooccurrencesIDSs([bad], library=lib)
+    assert ei.value.status == _lib.BAD_ARG
+    good = IndexedDataset(rp, np.array([0, 3, 1, 2], np.int32), u10, cols4)
+    assert SA.cooccurrencesIDSs([good], library=lib)[0].nrow == 4
+    lib.urcco_shutdown()
+
+
+def test_host_level_entry_points(sim_lib):
+    host_level_case(sim_lib)
+
+
+def context_reuse_case(lib, device):
+    """One context, several builds of different shapes (its buffers grow, then are reused): each equals the one-session
+    stage-by-stage driver bit for bit, in stream-per-event and single-stream mode."""
+    from universal_recommender_amd import _lib
+    from universal_recommender_amd.device import Context, DeviceSession, cross_occurrence_context, cross_occurrence_device
+    rng = np.random.default_rng(41)
+    cases = [([rand_csr(rng, 3000, 400, 10, zipf_s=1.1), rand_csr(rng, 3000, 600, 16), rand_csr(rng, 3000, 50, 2)], [P(80, 20), P(80, 20), P(500, 50)]),
+             ([rand_csr(rng, 9000, 900, 12), rand_csr(rng, 9000, 30, 3)], [P(40, 10), P(40, 5, 0.2)]),
+             ([rand_csr(rng, 500, 40, 5)], [P(20, 7)])]
+    sess = DeviceSession(device, lib)
+    ctx = Context(device, lib)
+    try:
+        for flags in (0, _lib.FLAG_SINGLE_STREAM):
+            ctx.set_flags(flags)
+            for mats, ps in cases:
+                ref = cross_occurrence_device(sess, [to_dev(m, device) for m in mats], to_params(ps), 17)
+                sess.synchronize()
+                for _ in range(2):
+                    out = cross_occurrence_context(ctx, [to_dev(m, device) for m in mats], to_params(ps), 17)
+                    for a, b in zip(out, ref):
+                        for x, y in zip(a.to_host(), b.to_host()):
+                            assert np.array_equal(x, y)
+                        assert torch.equal(a.stats[:1].cpu(), b.stats[:1].cpu())
+                        assert torch.equal(a.sampled_row_ptr.cpu(), b.sampled_row_ptr.cpu())
+    finally:
+        ctx.close()
+        sess.close()
+
+
+def test_context_reuse_and_stream_modes(sim_lib):
+    context_reuse_case(sim_lib, torch.device("cpu"))
+
+
+@pytest.mark.parametrize("n_gpus", [2, 3])
+def test_one_process_drives_several_gpus(sim_lib, n_gpus, monkeypatch):
+    """n_gpus ranks in ONE process (what the JVM host does; here simulated devices, collectives looped back in-process
+    through the urcco_collectives callbacks): the device-resident build on user-range shards and the host-level build
+    (the library shards the users itself, balances the item ranges by work, concatenates the slices) both equal the
+    single-GPU oracle."""
+    from universal_recommender_amd import _lib, sharded
+    from universal_recommender_amd.device import Context
+    monkeypatch.setenv("HIPSIM_DEVICE_COUNT", str(n_gpus))
+    rng = np.random.default_rng(5)
+    n_users = 2500
+    mats = [rand_csr(rng, n_users, 300, 9, zipf_s=1.2), rand_csr(rng, n_users, 700, 14), rand_csr(rng, n_users, 900, 6),
+            rand_csr(rng, n_users, 40, 4), rand_csr(rng, n_users, 11, 2, empty_frac=0.3)]
+    params = [P(30, 10), P(40, 12), P(25, 50), P(500, 8), P(500, 50, 0.1)]
+    ref = O.cross_occurrence_downsampled(mats, params, 2024)
+    coll = sharded.TorchCollectives(n_gpus, list(range(n_gpus)))
+    ctx = Context(torch.device("cpu"), sim_lib, n_gpus=n_gpus, collectives=coll)
+    try:
+        assert ctx.n_local == n_gpus
+        cuts = [n_users * g // n_gpus for g in range(n_gpus + 1)]
+        cuts[1] = 100                                                     # uneven shards
+        shards = [[to_dev(O.Csr(hi - lo, m.n_cols, m.row_ptr[lo:hi + 1] - m.row_ptr[lo], m.col_idx[m.row_ptr[lo]:m.row_ptr[hi]]), "cpu")
+                   for lo, hi in zip(cuts, cuts[1:])] for m in mats]
+        ctx.build(shards, to_params(params), 2024, n_users, cuts[:-1])
+        res = ctx.results()
+        for d, r in enumerate(ref):
+            parts = [ind.to_host() for ind in res[d]]
+            assert res[d][0].item_lo == 0 and res[d][-1].item_hi == mats[0].n_cols
+            assert all(a.item_hi == b.item_lo for a, b in zip(res[d], res[d][1:]))
+            lens = np.concatenate([np.diff(p[0]) for p in parts])
+            rp = np.zeros(lens.size + 1, np.int64)
+            np.cumsum(lens, out=rp[1:])
+            check_indicators((rp, np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])), r, exact_ids=True)
+            assert sum(int(ind.stats[0]) for ind in res[d]) == r.pairs
+            full = O.downsample(mats[d], O.column_counts(mats[d]), 2024, params[d].max_elements_per_row)
+            for ind in res[d]:                                            # every GPU holds the whole down-sampled B
+                assert np.array_equal(ind.sampled_row_ptr.numpy(), full.row_ptr)
+                assert np.array_equal(ind.sampled_col_idx.numpy()[:full.nnz], full.col_idx)
+        # host level on the same context
+        n = len(mats)
+        arr = (_lib.Dataset * n)()
+        for d, (m, p) in enumerate(zip(mats, params)):
+            arr[d].matrix.n_rows, arr[d].matrix.n_cols = m.n_rows, m.n_cols
+            arr[d].matrix.row_ptr, arr[d].matrix.col_idx = m.row_ptr.ctypes.data, m.col_idx.ctypes.data
+            arr[d].max_elements_per_row, arr[d].max_interesting_elements = p.max_elements_per_row, p.max_interesting_elements
+            arr[d].has_min_llr, arr[d].min_llr = int(p.min_llr is not None), float(p.min_llr or 0.0)
+        out = (_lib.Indicators * n)()
+        stats = (_lib.DatasetStats * n)()
+        _lib.check(sim_lib.urcco_context_cross_occurrence(ctx.handle, arr, n, 2024, out, stats), sim_lib)
+        for d, r in enumerate(ref):
+            o = out[d]
+            nnz = int(o.nnz)
+            got = (np.ctypeslib.as_array(o.row_ptr, shape=(o.n_rows + 1,)).copy(), np.ctypeslib.as_array(o.col_idx, shape=(max(nnz, 1),))[:nnz].copy(),
+                   np.ctypeslib.as_array(o.llr, shape=(max(nnz, 1),))[:nnz].copy())
+            check_indicators(got, r, exact_ids=True)
+            assert stats[d].pairs == r.pairs and stats[d].nnz_out == nnz and stats[d].nnz_raw == mats[d].nnz
+        sim_lib.urcco_free_indicators(out, n)
+        assert coll.error is None
+    finally:
+        ctx.close()

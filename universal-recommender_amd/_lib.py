@@ -13,7 +13,10 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_PATH = os.path.join(_HERE, "lib", "liburcco.so")
 
-OK, BAD_ARG, OOM_HOST, OOM_DEVICE, HIP_ERROR, INTERNAL, NO_DEVICE = range(7)
+OK, BAD_ARG, OOM_HOST, OOM_DEVICE, HIP_ERROR, INTERNAL, NO_DEVICE, RCCL_ERROR = range(8)
+FLAG_SINGLE_STREAM = 1
+FLAG_FORCE_EXCHANGE = 2
+UNIQUE_ID_BYTES = 128
 ROW_RATE_MAHOUT_INT_DIV = 0
 ROW_RATE_FRACTIONAL = 1
 N_STAGES = 16
@@ -39,7 +42,35 @@ class Dataset(C.Structure):
 
 
 class Options(C.Structure):
-    _fields_ = [("device", C.c_int32), ("row_rate_mode", C.c_int32), ("reserved", C.c_int32 * 6)]
+    _fields_ = [("device", C.c_int32), ("row_rate_mode", C.c_int32), ("n_gpus", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+GROUP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p)
+ALL_GATHER_V_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p)
+
+
+class Collectives(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("group_start", GROUP_FN), ("group_end", GROUP_FN), ("all_reduce_sum", ALL_REDUCE_FN),
+                ("all_gather_v", ALL_GATHER_V_FN)]
+
+
+class CommConfig(C.Structure):
+    _fields_ = [("world_size", C.c_int32), ("first_rank", C.c_int32), ("nccl_unique_id", C.c_void_p), ("collectives", C.POINTER(Collectives))]
+
+
+class DevShard(C.Structure):
+    _fields_ = [("n_rows", C.c_int64), ("row_base", C.c_int64), ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("nnz", C.c_int64)]
+
+
+class DevDataset(C.Structure):
+    _fields_ = [("n_cols", C.c_int64), ("max_elements_per_row", C.c_int32), ("max_interesting_elements", C.c_int32), ("min_llr", C.c_double),
+                ("has_min_llr", C.c_int32), ("reserved", C.c_int32), ("shards", C.POINTER(DevShard))]
+
+
+class DevResult(C.Structure):
+    _fields_ = [("item_lo", C.c_int32), ("item_hi", C.c_int32), ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("llr", C.c_void_p),
+                ("stats", C.c_void_p), ("sampled_row_ptr", C.c_void_p), ("sampled_col_idx", C.c_void_p), ("sampled_rows", C.c_int64)]
 
 
 class Indicators(C.Structure):
@@ -64,6 +95,19 @@ SYMBOLS = {
     "urcco_cross_occurrence_downsampled": (C.c_int, [C.POINTER(Dataset), C.c_int32, C.c_int32, C.POINTER(Options),
                                                      C.POINTER(Indicators), C.POINTER(DatasetStats)]),
     "urcco_free_indicators": (None, [C.POINTER(Indicators), C.c_int32]),
+    "urcco_shutdown": (C.c_int, []),
+    "urcco_comm_unique_id": (C.c_int, [_p]),
+    "urcco_context_create": (C.c_int, [C.POINTER(Options), C.POINTER(CommConfig), C.POINTER(_p)]),
+    "urcco_context_destroy": (None, [_p]),
+    "urcco_context_local_gpus": (C.c_int32, [_p]),
+    "urcco_context_cross_occurrence": (C.c_int, [_p, C.POINTER(Dataset), C.c_int32, C.c_int32, C.POINTER(Indicators), C.POINTER(DatasetStats)]),
+    "urcco_context_build_device": (C.c_int, [_p, C.POINTER(DevDataset), C.c_int32, C.c_int64, C.c_int32, _p, C.POINTER(DevResult)]),
+    "urcco_context_wait_stream": (C.c_int, [_p, _p]),
+    "urcco_context_synchronize": (C.c_int, [_p]),
+    "urcco_context_set_timing": (C.c_int, [_p, C.c_int32]),
+    "urcco_context_get_timings": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "urcco_context_set_debug": (C.c_int, [_p, C.c_int32]),
+    "urcco_context_set_flags": (C.c_int, [_p, C.c_int32]),
     "urcco_session_create": (C.c_int, [C.c_int32, _p, C.POINTER(_p)]),
     "urcco_session_destroy": (None, [_p]),
     "urcco_session_synchronize": (C.c_int, [_p]),

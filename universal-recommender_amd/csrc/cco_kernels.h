@@ -13,7 +13,7 @@ constexpr int NBINS = 7;  // accumulator classes: 0 micro (one wave, <= 64 pairs
 // Geometry the host side needs for scratch sizing.
 constexpr int SCAN_TILE = 2048;          // elements per scan tile (256 threads x 8)
 constexpr int DS_TILE = 4096;            // entries per down-sample tile (256 threads x 4 x 4)
-constexpr int GLOBAL_BIN_BLOCKS = 64;    // persistent blocks of the global-accumulator kernel
+constexpr int GLOBAL_BIN_BLOCKS = 64;    // persistent blocks of the global-accumulator kernel (upper bound)
 constexpr int BIN_TILE = 1024;           // items per binning tile
 constexpr int XLX_TABLE_HOST = 4096;     // entries of the small-integer xLogX table (== XLX_TABLE in cco_device.h)
 constexpr int BIN_COLS_HOST = 3 * NBINS + 1;  // int64 per binning tile
@@ -54,6 +54,7 @@ struct CcoArgs {
   int32_t* g_counts;         // [GLOBAL_BIN_BLOCKS][n_cols_b] zero on entry, zero on exit
   unsigned long long* g_cand_key;  // [GLOBAL_BIN_BLOCKS][n_cols_b]
   int32_t* g_cand_col;       // [GLOBAL_BIN_BLOCKS][n_cols_b]
+  int32_t g_blocks;          // resident blocks of the global-accumulator kernel (<= GLOBAL_BIN_BLOCKS; fewer for very wide B)
 };
 
 hipError_t launch_column_counts(hipStream_t st, int n_cu, const int32_t* col_idx, int64_t nnz, int32_t n_cols, int32_t* counts);
@@ -106,6 +107,14 @@ hipError_t launch_dictionary_lookup(hipStream_t st, int n_cu, KeyTable t, int64_
 // cnt: int32[n_rows] scratch, raw_ptr: int64[n_rows + 1] scratch, tmp: int32[n] scratch
 hipError_t launch_csr_from_pairs(hipStream_t st, int n_cu, int64_t n, const int32_t* rows, const int32_t* cols, int64_t n_rows, int32_t* cnt,
                                  int64_t* raw_ptr, int32_t* tmp, int64_t* tile_sums, int64_t* out_row_ptr, int32_t* out_col_idx);
+
+// len[n_rows] = row lengths; sizes (nullable) = {n_rows, nnz}
+hipError_t launch_row_lengths(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, int32_t* len, int64_t* sizes);
+
+// boundary checks of a caller-supplied CSR (rp0 = value of row_ptr[0] of the slice); err[0] += violations
+hipError_t launch_validate_csr(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
+                               int g_log2, int64_t rp0, unsigned long long* err);
+hipError_t launch_rebase_i64(hipStream_t st, int n_cu, int64_t* p, int64_t n, int64_t delta);
 
 hipError_t launch_xlx_table(hipStream_t st, double* tab);
 hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, double* xlx_n);

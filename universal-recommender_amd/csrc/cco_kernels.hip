@@ -2114,7 +2114,7 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
       if (args.debug & 8192) hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5);
       else hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 1>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5);
       break;
-    default: hipLaunchKernelGGL(cco_rows_global_kernel, dim3(GLOBAL_BIN_BLOCKS), dim3(GB_THREADS), 0, st, args); break;
+    default: hipLaunchKernelGGL(cco_rows_global_kernel, dim3((unsigned)(args.g_blocks > 0 ? args.g_blocks : 1)), dim3(GB_THREADS), 0, st, args); break;
   }
   return hipGetLastError();
 }
@@ -2185,6 +2185,79 @@ __global__ void partition_kernel(int32_t n_items, const int64_t* __restrict__ wo
 
 hipError_t launch_partition(hipStream_t st, int32_t n_items, const int64_t* work_prefix, int32_t n_parts, int32_t* bounds) {
   hipLaunchKernelGGL(partition_kernel, dim3(1), dim3(64 * ((n_parts + 64) / 64)), 0, st, n_items, work_prefix, n_parts, bounds);
+  return hipGetLastError();
+}
+
+// ============================================================================================
+// Multi-GPU exchange helpers: row lengths of a CSR shard as int32 (what travels in the all-gather-v next to the column
+// indices; the receiver rebuilds row_ptr with one scan over the concatenated lengths), and the (rows, nnz) record a rank
+// publishes about its down-sampled shard.
+// ============================================================================================
+__global__ __launch_bounds__(256) void row_lengths_kernel(int64_t n_rows, const int64_t* __restrict__ rp, int32_t* __restrict__ len,
+                                                          int64_t* __restrict__ sizes) {
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * 256) len[r] = (int32_t)(rp[r + 1] - rp[r]);
+  if (sizes && blockIdx.x == 0 && threadIdx.x == 0) {
+    sizes[0] = n_rows;
+    sizes[1] = rp[n_rows];
+  }
+}
+hipError_t launch_row_lengths(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, int32_t* len, int64_t* sizes) {
+  int64_t blocks = (n_rows + 255) / 256;
+  const int64_t cap = (int64_t)n_cu * 8;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(row_lengths_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, row_ptr, len, sizes);
+  return hipGetLastError();
+}
+
+// ============================================================================================
+// Boundary checks of a caller-supplied CSR (the host level hands over JVM arrays): row_ptr monotone inside [0, nnz],
+// column indices inside [0, n_cols) and strictly increasing inside a row (the precondition of every kernel above:
+// an out-of-range column would become an out-of-bounds atomic, a duplicate would inflate the counts).  2^g lanes walk a
+// row; err[0] counts violations.  row_ptr is checked before col_idx is touched, so a corrupt row_ptr cannot send the
+// walk out of bounds.
+// ============================================================================================
+__global__ __launch_bounds__(256) void validate_csr_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, int64_t nnz,
+                                                           int32_t n_cols, int g_log2, int64_t rp0, unsigned long long* __restrict__ err) {
+  const int G = 1 << g_log2;
+  const int gl = threadIdx.x & (G - 1);
+  const int64_t groups_per_block = 256 >> g_log2;
+  unsigned bad = 0;
+  for (int64_t r = (int64_t)blockIdx.x * groups_per_block + (threadIdx.x >> g_log2); r < n_rows; r += (int64_t)gridDim.x * groups_per_block) {
+    const int64_t s = rp[r] - rp0, e = rp[r + 1] - rp0;
+    if (s < 0 || e < s || e > nnz) {
+      bad += gl == 0;
+      continue;
+    }
+    for (int64_t p = s + gl; p < e; p += G) {
+      const int j = ci[p];
+      if (j < 0 || j >= n_cols || (p > s && ci[p - 1] >= j)) ++bad;
+    }
+  }
+  if (bad) atomicAdd(err, (unsigned long long)bad);
+}
+hipError_t launch_validate_csr(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
+                               int g_log2, int64_t rp0, unsigned long long* err) {
+  if (n_rows <= 0) return hipSuccess;
+  const int64_t gpb = 256 >> g_log2;
+  int64_t blocks = (n_rows + gpb - 1) / gpb;
+  const int64_t cap = (int64_t)n_cu * 16;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(validate_csr_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, row_ptr, col_idx, nnz, n_cols, g_log2, rp0, err);
+  return hipGetLastError();
+}
+
+// p[i] -= delta (a row_ptr slice of a user shard re-based to start at 0); p2 (nullable): out[i] = p[i] + add (indicator row_ptr
+// slices of the GPUs of one process re-based onto the concatenated output)
+__global__ __launch_bounds__(256) void rebase_kernel(int64_t* __restrict__ p, int64_t n, int64_t delta) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] -= delta;
+}
+hipError_t launch_rebase_i64(hipStream_t st, int n_cu, int64_t* p, int64_t n, int64_t delta) {
+  if (n <= 0 || delta == 0) return hipSuccess;
+  int64_t blocks = (n + 255) / 256;
+  const int64_t cap = (int64_t)n_cu * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(rebase_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n, delta);
   return hipGetLastError();
 }
 

@@ -2,144 +2,18 @@
 // host-level one-shot entry points that stand in for Mahout's SimilarityAnalysis.cooccurrencesIDSs and
 // crossOccurrenceDownsampled (reference call sites: src/main/scala/URAlgorithm.scala:323-329, :343-346).
 // No CPU fallback: without a HIP device the compute entry points return URCCO_NO_DEVICE.
-#include <hip/hip_runtime.h>
-
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
 #include <memory>
-#include <vector>
 
-#include "../../include/urcco.h"
-#include "cco_kernels.h"
+#include "urcco_internal.h"
 
-namespace {
+using namespace urcco_detail;
 
-thread_local char g_err[512] = "";
-
-int fail(int status, const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-  return status;
+namespace urcco_detail {
+char* err_buf() {
+  static thread_local char buf[512] = "";
+  return buf;
 }
-
-int hip_fail(hipError_t e, const char* what) {
-  return fail(e == hipErrorOutOfMemory ? URCCO_OOM_DEVICE : URCCO_HIP_ERROR, "%s: %s", what, hipGetErrorString(e));
-}
-
-#define HIPC(expr)                                 \
-  do {                                             \
-    hipError_t _e = (expr);                        \
-    if (_e != hipSuccess) return hip_fail(_e, #expr); \
-  } while (0)
-
-#define URC(expr)              \
-  do {                         \
-    int _s = (expr);           \
-    if (_s != URCCO_OK) return _s; \
-  } while (0)
-
-inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-int ceil_log2_i64(int64_t v) {
-  int l = 0;
-  while (((int64_t)1 << l) < v) ++l;
-  return l;
-}
-
-}  // namespace
-
-struct urcco_session {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  int n_cu = 256;
-  char* arena = nullptr;
-  size_t arena_cap = 0;
-  size_t arena_off = 0;
-  // persistent zeroed dense counters + candidate scratch of the global-accumulator kernel
-  int32_t* g_counts = nullptr;
-  unsigned long long* g_cand_key = nullptr;
-  int32_t* g_cand_col = nullptr;
-  int64_t g_cols = 0;
-  double* xlx_tab = nullptr;  // xLogX of small integers (N-independent), filled once
-  int debug = 0;              // kernel ablation switches (profiling only)
-  // optional per-stage HIP-event timing (bench.py's roofline numbers)
-  bool timing = false;
-  struct Rec { int stage; hipEvent_t e0, e1; };
-  std::vector<Rec> recs;
-  std::vector<hipEvent_t> free_events;
-  double acc_ms[URCCO_N_STAGES] = {0};
-  int64_t acc_n[URCCO_N_STAGES] = {0};
-
-  hipEvent_t get_event() {
-    if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
-    hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
-    return e;
-  }
-  void begin(int stage) {
-    if (!timing) return;
-    Rec r{stage, get_event(), get_event()};
-    (void)hipEventRecord(r.e0, stream);
-    recs.push_back(r);
-  }
-  void end() {
-    if (!timing) return;
-    (void)hipEventRecord(recs.back().e1, stream);
-  }
-  void collect() {
-    (void)hipStreamSynchronize(stream);
-    for (const Rec& r : recs) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { acc_ms[r.stage] += ms; acc_n[r.stage] += 1; }
-      free_events.push_back(r.e0);
-      free_events.push_back(r.e1);
-    }
-    recs.clear();
-  }
-
-  int reserve(size_t bytes) {
-    arena_off = 0;
-    if (bytes <= arena_cap) return URCCO_OK;
-    if (arena) {
-      HIPC(hipStreamSynchronize(stream));
-      HIPC(hipFree(arena));
-      arena = nullptr;
-      arena_cap = 0;
-    }
-    const size_t want = align_up(bytes + bytes / 4, (size_t)1 << 20);
-    HIPC(hipMalloc((void**)&arena, want));
-    arena_cap = want;
-    return URCCO_OK;
-  }
-  template <typename T>
-  T* take(size_t n) {
-    const size_t bytes = align_up((n ? n : 1) * sizeof(T), 256);
-    char* p = arena + arena_off;
-    arena_off += bytes;
-    return reinterpret_cast<T*>(p);
-  }
-  static size_t need(size_t n, size_t elem) { return align_up((n ? n : 1) * elem, 256); }
-
-  int ensure_global_bin(int64_t n_cols_b) {
-    if (n_cols_b <= g_cols) return URCCO_OK;
-    HIPC(hipStreamSynchronize(stream));
-    if (g_counts) { HIPC(hipFree(g_counts)); HIPC(hipFree(g_cand_key)); HIPC(hipFree(g_cand_col)); }
-    g_counts = nullptr; g_cols = 0;
-    const size_t n = (size_t)urcco::GLOBAL_BIN_BLOCKS * (size_t)n_cols_b;
-    HIPC(hipMalloc((void**)&g_counts, n * sizeof(int32_t)));
-    HIPC(hipMalloc((void**)&g_cand_key, n * sizeof(unsigned long long)));
-    HIPC(hipMalloc((void**)&g_cand_col, n * sizeof(int32_t)));
-    HIPC(hipMemsetAsync(g_counts, 0, n * sizeof(int32_t), stream));
-    g_cols = n_cols_b;
-    return URCCO_OK;
-  }
-};
+}  // namespace urcco_detail
 
 extern "C" {
 
@@ -151,7 +25,7 @@ int urcco_device_count(void) {
   return n;
 }
 
-const char* urcco_last_error(void) { return g_err; }
+const char* urcco_last_error(void) { return err_buf(); }
 
 const char* urcco_status_string(int status) {
   switch (status) {
@@ -162,6 +36,7 @@ const char* urcco_status_string(int status) {
     case URCCO_HIP_ERROR: return "HIP_ERROR";
     case URCCO_INTERNAL: return "INTERNAL";
     case URCCO_NO_DEVICE: return "NO_DEVICE";
+    case URCCO_RCCL_ERROR: return "RCCL_ERROR";
     default: return "UNKNOWN";
   }
 }
@@ -231,7 +106,7 @@ int urcco_session_get_timings(urcco_session* s, double* ms, int64_t* launches) {
 
 int64_t urcco_session_scratch_bytes(const urcco_session* s) {
   if (!s) return 0;
-  return (int64_t)s->arena_cap + (int64_t)s->g_cols * urcco::GLOBAL_BIN_BLOCKS * 16;
+  return (int64_t)s->arena_cap + (int64_t)s->g_cap * 16;
 }
 
 int urcco_dev_column_counts(urcco_session* s, int64_t nnz, const int32_t* col_idx, int32_t n_cols, int32_t* counts) {
@@ -438,7 +313,7 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   a.g_log2 = 4;  // 16 lanes stream one user's B' row: 64 B segments, matches the ~10-40 item rows the cut leaves
   a.out_count = out_count; a.out_idx = out_idx; a.out_llr = out_llr;
   a.err = reinterpret_cast<unsigned long long*>(stats + 1 + 4 * urcco::NBINS);
-  a.g_counts = s->g_counts; a.g_cand_key = s->g_cand_key; a.g_cand_col = s->g_cand_col;
+  a.g_counts = s->g_counts; a.g_cand_key = s->g_cand_key; a.g_cand_col = s->g_cand_col; a.g_blocks = s->g_blocks;
   for (int bin = 0; bin < urcco::NBINS; ++bin) {
     s->begin(URCCO_STAGE_CCO_BIN0 + bin);
     HIPC(urcco::launch_cco_rows_bin(s->stream, s->n_cu, a, bin));
@@ -551,225 +426,5 @@ int urcco_dev_u01(urcco_session* s, int64_t n, int32_t seed, const int32_t* row,
   return URCCO_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// HOST level
-// ---------------------------------------------------------------------------------------------------------
-}  // extern "C"
-
-namespace {
-
-struct DevBufs {
-  std::vector<void*> ptrs;
-  ~DevBufs() {
-    for (void* p : ptrs) (void)hipFree(p);
-  }
-  template <typename T>
-  int alloc(T** out, size_t n) {
-    void* p = nullptr;
-    hipError_t e = hipMalloc(&p, (n ? n : 1) * sizeof(T));
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
-    ptrs.push_back(p);
-    *out = reinterpret_cast<T*>(p);
-    return URCCO_OK;
-  }
-  void release(void* p) {
-    for (size_t i = 0; i < ptrs.size(); ++i)
-      if (ptrs[i] == p) {
-        (void)hipFree(p);
-        ptrs.erase(ptrs.begin() + (long)i);
-        return;
-      }
-  }
-};
-
-struct SessionGuard {
-  urcco_session* s = nullptr;
-  ~SessionGuard() { urcco_session_destroy(s); }
-};
-
-struct SampledMatrix {
-  int64_t* row_ptr = nullptr;
-  int32_t* col_idx = nullptr;
-  int32_t* counts = nullptr;
-  int64_t nnz = 0;
-};
-
-int validate_csr(const urcco_csr& m, int d) {
-  if (m.n_rows < 0 || m.n_cols < 0 || m.n_rows > 0x7fffffffll || m.n_cols > 0x7ffffff0ll) return fail(URCCO_BAD_ARG, "dataset %d: bad shape", d);
-  if (!m.row_ptr) return fail(URCCO_BAD_ARG, "dataset %d: row_ptr is NULL", d);
-  if (m.row_ptr[0] != 0) return fail(URCCO_BAD_ARG, "dataset %d: row_ptr[0] != 0", d);
-  const int64_t nnz = m.row_ptr[m.n_rows];
-  if (nnz < 0 || (nnz > 0 && !m.col_idx)) return fail(URCCO_BAD_ARG, "dataset %d: bad nnz / col_idx", d);
-  for (int64_t r = 0; r < m.n_rows; ++r)
-    if (m.row_ptr[r + 1] < m.row_ptr[r]) return fail(URCCO_BAD_ARG, "dataset %d: row_ptr not monotone at row %lld", d, (long long)r);
-  return URCCO_OK;
-}
-
-// upload + sampleDownAndBinarize of one matrix
-int sample_matrix(urcco_session* s, DevBufs& bufs, const urcco_dataset& ds, int32_t seed, int32_t row_rate_mode, SampledMatrix* out,
-                  urcco_dataset_stats* st) {
-  const urcco_csr& m = ds.matrix;
-  const int64_t nnz = m.row_ptr[m.n_rows];
-  int64_t* d_rp = nullptr;
-  int32_t* d_ci = nullptr;
-  int32_t* d_raw = nullptr;
-  URC(bufs.alloc(&d_rp, (size_t)m.n_rows + 1));
-  URC(bufs.alloc(&d_ci, (size_t)nnz));
-  URC(bufs.alloc(&d_raw, (size_t)m.n_cols));
-  URC(bufs.alloc(&out->row_ptr, (size_t)m.n_rows + 1));
-  URC(bufs.alloc(&out->col_idx, (size_t)nnz));
-  URC(bufs.alloc(&out->counts, (size_t)m.n_cols));
-  HIPC(hipMemcpyAsync(d_rp, m.row_ptr, sizeof(int64_t) * (size_t)(m.n_rows + 1), hipMemcpyHostToDevice, s->stream));
-  if (nnz > 0) HIPC(hipMemcpyAsync(d_ci, m.col_idx, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, s->stream));
-  URC(urcco_dev_column_counts(s, nnz, d_ci, (int32_t)m.n_cols, d_raw));
-  URC(urcco_dev_downsample(s, m.n_rows, d_rp, d_ci, nnz, (int32_t)m.n_cols, d_raw, seed, ds.max_elements_per_row, row_rate_mode, 0, out->row_ptr,
-                           out->col_idx, out->counts));
-  HIPC(hipMemcpyAsync(&out->nnz, out->row_ptr + m.n_rows, sizeof(int64_t), hipMemcpyDeviceToHost, s->stream));
-  HIPC(hipStreamSynchronize(s->stream));  // the host copy of the raw matrix may be unpinned after this point
-  bufs.release(d_rp);
-  bufs.release(d_ci);
-  bufs.release(d_raw);
-  if (st) {
-    st->nnz_raw = nnz;
-    st->nnz_sampled = out->nnz;
-  }
-  return URCCO_OK;
-}
-
-int build_impl(const urcco_dataset* datasets, int32_t n_datasets, int32_t seed, const urcco_options* options, urcco_indicators* out,
-               urcco_dataset_stats* stats) {
-  if (!datasets || n_datasets <= 0 || !out) return fail(URCCO_BAD_ARG, "datasets / out is NULL or n_datasets <= 0");
-  for (int d = 0; d < n_datasets; ++d) {
-    URC(validate_csr(datasets[d].matrix, d));
-    if (datasets[d].matrix.n_rows != datasets[0].matrix.n_rows)
-      return fail(URCCO_BAD_ARG, "dataset %d has %lld rows, the primary has %lld: all matrices share the user dictionary", d,
-                  (long long)datasets[d].matrix.n_rows, (long long)datasets[0].matrix.n_rows);
-    if (datasets[d].max_elements_per_row <= 0 || datasets[d].max_interesting_elements <= 0)
-      return fail(URCCO_BAD_ARG, "dataset %d: maxElementsPerRow / maxInterestingElements must be positive", d);
-    memset(&out[d], 0, sizeof(urcco_indicators));
-    if (stats) memset(&stats[d], 0, sizeof(urcco_dataset_stats));
-  }
-  const int32_t device = options ? options->device : 0;
-  const int32_t row_rate_mode = options ? options->row_rate_mode : URCCO_ROW_RATE_MAHOUT_INT_DIV;
-  SessionGuard guard;
-  URC(urcco_session_create(device, nullptr, &guard.s));
-  urcco_session* s = guard.s;
-  DevBufs bufs;
-
-  const urcco_csr& A = datasets[0].matrix;
-  const int64_t n_users = A.n_rows;
-  const int32_t n_items_a = (int32_t)A.n_cols;
-  hipEvent_t ev0, ev1;
-  HIPC(hipEventCreate(&ev0));
-  HIPC(hipEventCreate(&ev1));
-
-  SampledMatrix a;
-  HIPC(hipEventRecord(ev0, s->stream));
-  URC(sample_matrix(s, bufs, datasets[0], seed, row_rate_mode, &a, stats ? &stats[0] : nullptr));
-  int64_t* a_col_ptr = nullptr;
-  int32_t* a_row_idx = nullptr;
-  URC(bufs.alloc(&a_col_ptr, (size_t)n_items_a + 1));
-  URC(bufs.alloc(&a_row_idx, (size_t)a.nnz));
-  URC(urcco_dev_transpose(s, n_users, a.row_ptr, a.col_idx, a.nnz, n_items_a, a.counts, 0, n_items_a, a_col_ptr, a_row_idx));
-
-  for (int d = 0; d < n_datasets; ++d) {
-    SampledMatrix b = a;
-    if (d > 0) {
-      HIPC(hipEventRecord(ev0, s->stream));
-      URC(sample_matrix(s, bufs, datasets[d], seed, row_rate_mode, &b, stats ? &stats[d] : nullptr));
-    }
-    const int32_t n_cols_b = (int32_t)datasets[d].matrix.n_cols;
-    const int32_t k = datasets[d].max_interesting_elements;
-    int32_t* o_count = nullptr;
-    int32_t* o_idx = nullptr;
-    double* o_llr = nullptr;
-    int64_t* c_rp = nullptr;
-    int32_t* c_idx = nullptr;
-    double* c_llr = nullptr;
-    int64_t* d_stats = nullptr;
-    const size_t strided = (size_t)n_items_a * (size_t)k;
-    URC(bufs.alloc(&o_count, (size_t)n_items_a));
-    URC(bufs.alloc(&o_idx, strided));
-    URC(bufs.alloc(&o_llr, strided));
-    URC(bufs.alloc(&c_rp, (size_t)n_items_a + 1));
-    URC(bufs.alloc(&c_idx, strided));
-    URC(bufs.alloc(&c_llr, strided));
-    URC(bufs.alloc(&d_stats, URCCO_STATS_LEN));
-    URC(urcco_dev_cco_rows(s, 0, n_items_a, n_items_a, a_col_ptr, a_row_idx, a.nnz, b.row_ptr, b.col_idx, n_cols_b, a.counts, b.counts, n_users,
-                           d == 0 ? 1 : 0, k, datasets[d].has_min_llr, datasets[d].min_llr, o_count, o_idx, o_llr, d_stats));
-    URC(urcco_dev_compact_indicators(s, n_items_a, k, o_count, o_idx, o_llr, c_rp, c_idx, c_llr));
-    HIPC(hipEventRecord(ev1, s->stream));
-    urcco_indicators& o = out[d];
-    o.n_rows = n_items_a;
-    o.n_cols = n_cols_b;
-    o.row_ptr = (int64_t*)malloc(sizeof(int64_t) * ((size_t)n_items_a + 1));
-    if (!o.row_ptr) return fail(URCCO_OOM_HOST, "indicator row_ptr");
-    HIPC(hipMemcpyAsync(o.row_ptr, c_rp, sizeof(int64_t) * ((size_t)n_items_a + 1), hipMemcpyDeviceToHost, s->stream));
-    int64_t h_stats[URCCO_STATS_LEN];
-    HIPC(hipMemcpyAsync(h_stats, d_stats, sizeof(h_stats), hipMemcpyDeviceToHost, s->stream));
-    HIPC(hipStreamSynchronize(s->stream));
-    o.nnz = o.row_ptr[n_items_a];
-    o.col_idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)(o.nnz ? o.nnz : 1));
-    o.llr = (double*)malloc(sizeof(double) * (size_t)(o.nnz ? o.nnz : 1));
-    if (!o.col_idx || !o.llr) return fail(URCCO_OOM_HOST, "indicator arrays");
-    if (o.nnz > 0) {
-      HIPC(hipMemcpyAsync(o.col_idx, c_idx, sizeof(int32_t) * (size_t)o.nnz, hipMemcpyDeviceToHost, s->stream));
-      HIPC(hipMemcpyAsync(o.llr, c_llr, sizeof(double) * (size_t)o.nnz, hipMemcpyDeviceToHost, s->stream));
-      HIPC(hipStreamSynchronize(s->stream));
-    }
-    if (stats) {
-      float ms = 0.f;
-      (void)hipEventElapsedTime(&ms, ev0, ev1);
-      stats[d].ms_total = ms;
-      stats[d].pairs = h_stats[0];
-      for (int b2 = 0; b2 < URCCO_N_BINS; ++b2) stats[d].rows_by_bin[b2] = h_stats[1 + b2];
-      stats[d].nnz_out = o.nnz;
-    }
-    bufs.release(o_count); bufs.release(o_idx); bufs.release(o_llr); bufs.release(c_rp); bufs.release(c_idx); bufs.release(c_llr);
-    bufs.release(d_stats);
-    if (d > 0) { bufs.release(b.row_ptr); bufs.release(b.col_idx); bufs.release(b.counts); }
-  }
-  (void)hipEventDestroy(ev0);
-  (void)hipEventDestroy(ev1);
-  return URCCO_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-void urcco_free_indicators(urcco_indicators* ind, int32_t n) {
-  if (!ind) return;
-  for (int32_t d = 0; d < n; ++d) {
-    free(ind[d].row_ptr);
-    free(ind[d].col_idx);
-    free(ind[d].llr);
-    memset(&ind[d], 0, sizeof(urcco_indicators));
-  }
-}
-
-int urcco_cross_occurrence_downsampled(const urcco_dataset* datasets, int32_t n_datasets, int32_t random_seed, const urcco_options* options,
-                                       urcco_indicators* out, urcco_dataset_stats* stats) {
-  g_err[0] = 0;
-  const int st = build_impl(datasets, n_datasets, random_seed, options, out, stats);
-  if (st != URCCO_OK && out && n_datasets > 0) urcco_free_indicators(out, n_datasets);
-  return st;
-}
-
-int urcco_cooccurrences_idss(const urcco_csr* datasets, int32_t n_datasets, int32_t random_seed, int32_t max_interesting_items_per_thing,
-                             int32_t max_num_interactions, const urcco_options* options, urcco_indicators* out, urcco_dataset_stats* stats) {
-  g_err[0] = 0;
-  if (!datasets || n_datasets <= 0) return fail(URCCO_BAD_ARG, "datasets is NULL or n_datasets <= 0");
-  std::vector<urcco_dataset> ds((size_t)n_datasets);
-  for (int d = 0; d < n_datasets; ++d) {
-    ds[(size_t)d].matrix = datasets[d];
-    ds[(size_t)d].max_elements_per_row = max_num_interactions;
-    ds[(size_t)d].max_interesting_elements = max_interesting_items_per_thing;
-    ds[(size_t)d].min_llr = 0.0;
-    ds[(size_t)d].has_min_llr = 0;
-    ds[(size_t)d].reserved = 0;
-  }
-  return urcco_cross_occurrence_downsampled(ds.data(), n_datasets, random_seed, options, out, stats);
-}
 
 }  // extern "C"

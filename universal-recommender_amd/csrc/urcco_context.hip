@@ -1,0 +1,1018 @@
+// Persistent contexts of liburcco (include/urcco.h, "CONTEXT level"): the host-level entry points that stand in for
+// Mahout's SimilarityAnalysis.cooccurrencesIDSs / crossOccurrenceDownsampled (reference call sites
+// src/main/scala/URAlgorithm.scala:323-329, :343-346), the device-resident build bench.py times, and the multi-GPU build
+// (user-range input phase, work-balanced item ranges, RCCL exchange -- SURVEY.md 8e) driven from C++ so that a single
+// JVM process reaches every GPU of the node.
+//
+// Per GPU the context keeps one urcco_session (HIP stream + scratch arena) per event type and every intermediate /
+// output buffer; buffers only grow, so from the second build on a model build allocates nothing.  One host thread
+// enqueues everything: with several GPUs in one process it walks them phase by phase and brackets every collective in a
+// group (RCCL requires that of a thread that owns more than one rank).
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <atomic>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <unordered_map>
+
+#include "urcco_internal.h"
+
+using namespace urcco_detail;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// RCCL, bound at run time (librccl.so.1 -- the copy already in the process when PyTorch loaded one, else ROCm's).  Only
+// multi-rank contexts need it; a single-GPU build never touches it.
+// ---------------------------------------------------------------------------------------------------------
+struct Rccl {
+  typedef struct { char internal[URCCO_UNIQUE_ID_BYTES]; } UniqueId;
+  typedef void* Comm;
+  void* handle = nullptr;
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+  int (*CommInitAll)(Comm*, int, const int*) = nullptr;
+  int (*CommDestroy)(Comm) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  // rccl.h: ncclInt8 = 0, ncclInt32 = 2, ncclInt64 = 4; ncclSum = 0
+  static constexpr int kInt8 = 0, kInt32 = 2, kInt64 = 4, kSum = 0;
+
+  static Rccl* get() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+      for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.handle) break;
+      }
+      if (!r.handle) return;
+      auto sym = [&](const char* n) { return dlsym(r.handle, n); };
+      r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+      r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+      r.CommInitAll = (decltype(r.CommInitAll))sym("ncclCommInitAll");
+      r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+      r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+      r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+      r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+      r.Send = (decltype(r.Send))sym("ncclSend");
+      r.Recv = (decltype(r.Recv))sym("ncclRecv");
+      r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+      if (!r.GetUniqueId || !r.CommInitRank || !r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.AllReduce || !r.Send || !r.Recv)
+        r.handle = nullptr;
+    });
+    return r.handle ? &r : nullptr;
+  }
+};
+
+int rccl_fail(Rccl* r, int code, const char* what) {
+  return fail(URCCO_RCCL_ERROR, "%s: %s", what, (r && r->GetErrorString) ? r->GetErrorString(code) : "RCCL error");
+}
+#define RCCLC(r, expr)                            \
+  do {                                            \
+    int _c = (expr);                              \
+    if (_c != 0) return rccl_fail((r), _c, #expr); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// buffers
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+struct DBuf {  // device buffer that only grows (hipFree synchronises the device: growth happens on the first builds only)
+  T* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t n) {
+    if (n <= cap && p) return URCCO_OK;
+    if (p) HIPC(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    const size_t want = n + n / 16 + 64;
+    HIPC(hipMalloc((void**)&p, want * sizeof(T)));
+    cap = want;
+    return URCCO_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// Pinned host memory handed out as indicator arrays.  Process-wide: blocks may outlive the context that filled them
+// (the caller releases them with urcco_free_indicators whenever it is done).
+struct PinnedPool {
+  struct Block { void* p; size_t cap; bool used; };
+  std::mutex mu;
+  std::vector<Block> blocks;
+  void* get(size_t bytes) {
+    std::lock_guard<std::mutex> g(mu);
+    bytes = bytes ? bytes : 1;
+    int best = -1;
+    for (size_t i = 0; i < blocks.size(); ++i)
+      if (!blocks[i].used && blocks[i].cap >= bytes && (best < 0 || blocks[i].cap < blocks[(size_t)best].cap)) best = (int)i;
+    if (best >= 0) {
+      blocks[(size_t)best].used = true;
+      return blocks[(size_t)best].p;
+    }
+    void* p = nullptr;
+    const size_t want = align_up(bytes + bytes / 8, 4096);
+    if (hipHostMalloc(&p, want, 0) != hipSuccess || !p) return nullptr;
+    blocks.push_back(Block{p, want, true});
+    return p;
+  }
+  bool put(void* p) {  // false: not one of ours
+    std::lock_guard<std::mutex> g(mu);
+    for (Block& b : blocks)
+      if (b.p == p) {
+        b.used = false;
+        return true;
+      }
+    return false;
+  }
+  void trim() {  // frees the blocks nobody holds
+    std::lock_guard<std::mutex> g(mu);
+    std::vector<Block> keep;
+    for (Block& b : blocks) {
+      if (b.used) keep.push_back(b);
+      else (void)hipHostFree(b.p);
+    }
+    blocks.swap(keep);
+  }
+};
+PinnedPool& pinned_pool() {
+  static PinnedPool* pool = new PinnedPool();  // never destroyed: blocks may be returned during process teardown
+  return *pool;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per event type, per GPU
+// ---------------------------------------------------------------------------------------------------------
+struct EvState {
+  urcco_session* s = nullptr;   // own stream + arena (borrowed from DevState::sessions)
+  DBuf<int64_t> in_rp;          // host level: the staged raw shard
+  DBuf<int32_t> in_ci;
+  DBuf<int32_t> raw, post;      // column counts before / after sampling (whole matrix once the all-reduce has run)
+  DBuf<int64_t> s_rp;           // down-sampled shard
+  DBuf<int32_t> s_ci;
+  DBuf<int32_t> deg, f_deg;     // exchange: row lengths of the shard / of the whole matrix
+  DBuf<int64_t> f_rp;           // whole down-sampled matrix (multi-rank builds)
+  DBuf<int32_t> f_ci;
+  DBuf<int64_t> sizes;          // [2 * world] (rows, nnz') of every rank's shard; own record at [2 * rank]
+  DBuf<int64_t> scan_tmp;
+  DBuf<int32_t> o_count, o_idx; // strided top-k
+  DBuf<double> o_llr;
+  DBuf<int64_t> c_rp;           // indicator CSR of this GPU's item range
+  DBuf<int32_t> c_idx;
+  DBuf<double> c_llr;
+  DBuf<int64_t> stats;
+  DBuf<unsigned long long> verr;
+  hipEvent_t ev_sampled = nullptr, ev_done = nullptr, ev_rp = nullptr;
+  // facts of the current build
+  const int64_t* b_rp = nullptr;  // the B this GPU multiplies with
+  const int32_t* b_ci = nullptr;
+  int64_t b_rows = 0, b_nnz_bound = 0;
+  void release() {
+    in_rp.release(); in_ci.release(); raw.release(); post.release(); s_rp.release(); s_ci.release(); deg.release(); f_deg.release();
+    f_rp.release(); f_ci.release(); sizes.release(); scan_tmp.release(); o_count.release(); o_idx.release(); o_llr.release(); c_rp.release();
+    c_idx.release(); c_llr.release(); stats.release(); verr.release();
+    if (ev_sampled) (void)hipEventDestroy(ev_sampled);
+    if (ev_done) (void)hipEventDestroy(ev_done);
+    if (ev_rp) (void)hipEventDestroy(ev_rp);
+    ev_sampled = ev_done = ev_rp = nullptr;
+  }
+};
+
+struct DevState {
+  int device = 0;
+  int rank = 0;  // global rank
+  int n_cu = 256;
+  std::vector<urcco_session*> sessions;
+  std::vector<EvState> ev;
+  DBuf<int64_t> a_cp;
+  DBuf<int32_t> a_ri;
+  DBuf<int64_t> work;
+  DBuf<int32_t> bounds;
+  hipEvent_t a_ready = nullptr, in_ready = nullptr;
+  Rccl::Comm comm = nullptr;
+  int32_t item_lo = 0, item_hi = 0;
+};
+
+struct Shard {  // one device-resident user-range shard handed to the pipelines
+  int64_t n_rows = 0, row_base = 0, nnz = 0;
+  const int64_t* rp = nullptr;
+  const int32_t* ci = nullptr;
+};
+struct DsParams {
+  int64_t n_cols = 0;
+  int32_t max_rows = 500, k = 50, has_min_llr = 0;
+  double min_llr = 0.0;
+};
+
+}  // namespace
+
+struct urcco_context {
+  std::vector<DevState> devs;
+  int world = 1, first_rank = 0;
+  int row_rate_mode = URCCO_ROW_RATE_MAHOUT_INT_DIV;
+  int flags = 0, debug = 0;
+  bool timing = false;
+  bool have_cb = false;
+  urcco_collectives cb{};
+  Rccl* rccl = nullptr;
+  std::vector<int32_t> h_bounds;                // host copy of the item range bounds of the last multi-rank build
+  std::vector<int64_t> h_sizes;
+  // staging (host level)
+  void* stage = nullptr;
+  size_t stage_cap = 0;
+  int copy_threads = 4;
+
+  bool exchange() const { return world > 1 || (flags & URCCO_FLAG_FORCE_EXCHANGE); }
+  bool single_stream() const { return (flags & URCCO_FLAG_SINGLE_STREAM) != 0; }
+
+  // ---- collectives ------------------------------------------------------------------------------------
+  int group_start() {
+    if (have_cb) return cb.group_start(cb.user) == 0 ? URCCO_OK : fail(URCCO_RCCL_ERROR, "collectives.group_start failed");
+    RCCLC(rccl, rccl->GroupStart());
+    return URCCO_OK;
+  }
+  int group_end() {
+    if (have_cb) return cb.group_end(cb.user) == 0 ? URCCO_OK : fail(URCCO_RCCL_ERROR, "collectives.group_end failed");
+    RCCLC(rccl, rccl->GroupEnd());
+    return URCCO_OK;
+  }
+  int all_reduce(DevState& D, void* buf, int64_t count, int dtype, hipStream_t st) {
+    if (count <= 0) return URCCO_OK;
+    if (have_cb) return cb.all_reduce_sum(cb.user, D.rank, buf, count, dtype, (void*)st) == 0 ? URCCO_OK : fail(URCCO_RCCL_ERROR, "collectives.all_reduce_sum failed");
+    RCCLC(rccl, rccl->AllReduce(buf, buf, (size_t)count, dtype == 0 ? Rccl::kInt32 : Rccl::kInt64, Rccl::kSum, D.comm, st));
+    return URCCO_OK;
+  }
+  int all_gather_v(DevState& D, const void* send, void* recv, const int64_t* off, const int64_t* cnt, hipStream_t st) {
+    if (have_cb) return cb.all_gather_v(cb.user, D.rank, send, recv, off, cnt, (void*)st) == 0 ? URCCO_OK : fail(URCCO_RCCL_ERROR, "collectives.all_gather_v failed");
+    RCCLC(rccl, rccl->GroupStart());
+    for (int p = 0; p < world; ++p) {
+      if (cnt[D.rank] > 0) RCCLC(rccl, rccl->Send(send, (size_t)cnt[D.rank], Rccl::kInt8, p, D.comm, st));
+      if (cnt[p] > 0) RCCLC(rccl, rccl->Recv((char*)recv + off[p], (size_t)cnt[p], Rccl::kInt8, p, D.comm, st));
+    }
+    RCCLC(rccl, rccl->GroupEnd());
+    return URCCO_OK;
+  }
+};
+
+namespace {
+
+int set_dev(const DevState& D) {
+  HIPC(hipSetDevice(D.device));
+  return URCCO_OK;
+}
+
+urcco_session* sess_of(urcco_context* c, DevState& D, int d) { return D.sessions[c->single_stream() ? 0 : (size_t)d]; }
+
+int ensure_events(urcco_context* c, DevState& D, int n_ds) {
+  URC(set_dev(D));
+  while ((int)D.sessions.size() < n_ds) {
+    urcco_session* s = nullptr;
+    URC(urcco_session_create(D.device, nullptr, &s));
+    s->debug = c->debug;
+    s->timing = c->timing;
+    D.sessions.push_back(s);
+  }
+  if ((int)D.ev.size() < n_ds) D.ev.resize((size_t)n_ds);
+  for (int d = 0; d < n_ds; ++d) {
+    EvState& E = D.ev[(size_t)d];
+    E.s = sess_of(c, D, d);
+    if (!E.ev_sampled) HIPC(hipEventCreateWithFlags(&E.ev_sampled, hipEventDisableTiming));
+    if (!E.ev_done) HIPC(hipEventCreateWithFlags(&E.ev_done, hipEventDisableTiming));
+    if (!E.ev_rp) HIPC(hipEventCreateWithFlags(&E.ev_rp, hipEventDisableTiming));
+  }
+  if (!D.a_ready) HIPC(hipEventCreateWithFlags(&D.a_ready, hipEventDisableTiming));
+  if (!D.in_ready) HIPC(hipEventCreateWithFlags(&D.in_ready, hipEventDisableTiming));
+  return URCCO_OK;
+}
+
+// column counts + sampleDownAndBinarize of one shard on its event stream; with several ranks the two count vectors are
+// all-reduced by the caller between the halves
+int stage_raw_counts(DevState& D, EvState& E, const Shard& sh, const DsParams& p) {
+  URC(E.raw.ensure((size_t)p.n_cols + 1));
+  return urcco_dev_column_counts(E.s, sh.nnz, sh.ci, (int32_t)p.n_cols, E.raw.p);
+}
+int stage_downsample(urcco_context* c, DevState& D, EvState& E, const Shard& sh, const DsParams& p, int32_t seed) {
+  URC(E.s_rp.ensure((size_t)sh.n_rows + 1));
+  URC(E.s_ci.ensure((size_t)sh.nnz + 4));
+  URC(E.post.ensure((size_t)p.n_cols + 1));
+  return urcco_dev_downsample(E.s, sh.n_rows, sh.rp, sh.ci, sh.nnz, (int32_t)p.n_cols, E.raw.p, seed, p.max_rows, c->row_rate_mode, sh.row_base, E.s_rp.p,
+                              E.s_ci.p, E.post.p);
+}
+
+// A'B_d for the GPU's item range + strided -> CSR, on event d's stream
+int stage_rows(DevState& D, EvState& E, EvState& A, int d, const DsParams& pa, const DsParams& p, int64_t n_users, int64_t a_nnz_bound) {
+  const int32_t n = D.item_hi - D.item_lo;
+  const size_t strided = (size_t)(n > 0 ? n : 1) * (size_t)p.k;
+  URC(E.o_count.ensure((size_t)n + 1));
+  URC(E.o_idx.ensure(strided));
+  URC(E.o_llr.ensure(strided));
+  URC(E.c_rp.ensure((size_t)n + 2));
+  URC(E.c_idx.ensure(strided));
+  URC(E.c_llr.ensure(strided));
+  URC(E.stats.ensure(URCCO_STATS_LEN));
+  URC(urcco_dev_cco_rows(E.s, D.item_lo, D.item_hi, (int32_t)pa.n_cols, D.a_cp.p, D.a_ri.p, a_nnz_bound, E.b_rp, E.b_ci, (int32_t)p.n_cols, A.post.p, E.post.p,
+                         n_users, d == 0 ? 1 : 0, p.k, p.has_min_llr, p.min_llr, E.o_count.p, E.o_idx.p, E.o_llr.p, E.stats.p));
+  URC(urcco_dev_compact_indicators(E.s, n, p.k, E.o_count.p, E.o_idx.p, E.o_llr.p, E.c_rp.p, E.c_idx.p, E.c_llr.p));
+  HIPC(hipEventRecord(E.ev_done, E.s->stream));
+  return URCCO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// one rank, nothing to exchange: every event type on its own stream; B_d is sampled while A is sampled and transposed,
+// every A'B_d runs behind an event on A's CSC; the heaviest event type is enqueued first
+// ---------------------------------------------------------------------------------------------------------
+int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, const std::vector<DsParams>& ps, int64_t n_users, int32_t seed) {
+  const int n_ds = (int)sh.size();
+  URC(set_dev(D));
+  EvState& A = D.ev[0];
+  D.item_lo = 0;
+  D.item_hi = (int32_t)ps[0].n_cols;
+  URC(stage_raw_counts(D, A, sh[0], ps[0]));
+  URC(stage_downsample(c, D, A, sh[0], ps[0], seed));
+  URC(D.a_cp.ensure((size_t)ps[0].n_cols + 2));
+  URC(D.a_ri.ensure((size_t)sh[0].nnz + 4));
+  URC(urcco_dev_transpose(A.s, sh[0].n_rows, A.s_rp.p, A.s_ci.p, sh[0].nnz, (int32_t)ps[0].n_cols, A.post.p, 0, (int32_t)ps[0].n_cols, D.a_cp.p, D.a_ri.p));
+  HIPC(hipEventRecord(D.a_ready, A.s->stream));
+  for (int d = 1; d < n_ds; ++d) {
+    EvState& E = D.ev[(size_t)d];
+    URC(stage_raw_counts(D, E, sh[(size_t)d], ps[(size_t)d]));
+    URC(stage_downsample(c, D, E, sh[(size_t)d], ps[(size_t)d], seed));
+  }
+  std::vector<int> order((size_t)n_ds);
+  for (int d = 0; d < n_ds; ++d) order[(size_t)d] = d;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sh[(size_t)x].nnz > sh[(size_t)y].nnz; });
+  for (int d : order) {
+    EvState& E = D.ev[(size_t)d];
+    if (E.s != A.s) HIPC(hipStreamWaitEvent(E.s->stream, D.a_ready, 0));
+    E.b_rp = E.s_rp.p;
+    E.b_ci = E.s_ci.p;
+    E.b_rows = sh[(size_t)d].n_rows;
+    E.b_nnz_bound = sh[(size_t)d].nnz;
+    URC(stage_rows(D, E, A, d, ps[0], ps[(size_t)d], n_users, sh[0].nnz));
+  }
+  return URCCO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// several ranks (or the forced exchange path): SURVEY.md 8e.  `L` = this process's GPUs; every phase walks them.
+// ---------------------------------------------------------------------------------------------------------
+int input_phase(urcco_context* c, int d, const std::vector<std::vector<Shard>>& sh, const std::vector<DsParams>& ps, int32_t seed) {
+  const DsParams& p = ps[(size_t)d];
+  for (DevState& D : c->devs) {
+    URC(set_dev(D));
+    URC(stage_raw_counts(D, D.ev[(size_t)d], sh[(size_t)d][(size_t)(&D - c->devs.data())], p));
+  }
+  URC(c->group_start());
+  for (DevState& D : c->devs) {
+    URC(set_dev(D));
+    URC(c->all_reduce(D, D.ev[(size_t)d].raw.p, p.n_cols, 0, D.ev[(size_t)d].s->stream));
+  }
+  URC(c->group_end());
+  for (DevState& D : c->devs) {
+    URC(set_dev(D));
+    URC(stage_downsample(c, D, D.ev[(size_t)d], sh[(size_t)d][(size_t)(&D - c->devs.data())], p, seed));
+  }
+  URC(c->group_start());
+  for (DevState& D : c->devs) {
+    URC(set_dev(D));
+    URC(c->all_reduce(D, D.ev[(size_t)d].post.p, p.n_cols, 0, D.ev[(size_t)d].s->stream));
+  }
+  URC(c->group_end());
+  // row lengths (what travels) + the (rows, nnz') record of the shard, gathered over the ranks
+  for (DevState& D : c->devs) {
+    URC(set_dev(D));
+    EvState& E = D.ev[(size_t)d];
+    const Shard& s = sh[(size_t)d][(size_t)(&D - c->devs.data())];
+    URC(E.deg.ensure((size_t)s.n_rows + 1));
+    URC(E.sizes.ensure((size_t)2 * (size_t)c->world));
+    HIPC(urcco::launch_row_lengths(E.s->stream, D.n_cu, s.n_rows, E.s_rp.p, E.deg.p, E.sizes.p + 2 * D.rank));
+  }
+  std::vector<int64_t> off((size_t)c->world), cnt((size_t)c->world, 16);
+  for (int r = 0; r < c->world; ++r) off[(size_t)r] = 16 * (int64_t)r;
+  URC(c->group_start());
+  for (DevState& D : c->devs) {
+    URC(set_dev(D));
+    EvState& E = D.ev[(size_t)d];
+    URC(c->all_gather_v(D, E.sizes.p + 2 * D.rank, E.sizes.p, off.data(), cnt.data(), E.s->stream));
+  }
+  URC(c->group_end());
+  return URCCO_OK;
+}
+
+// reads event d's shard sizes on the host (waits for that event's stream only), exchanges the down-sampled shards and
+// rebuilds the whole matrix on every GPU
+int exchange_phase(urcco_context* c, int d, const std::vector<DsParams>& ps, int64_t n_users, std::vector<int64_t>& sizes /*out [2 * world]*/) {
+  const int W = c->world;
+  sizes.assign((size_t)2 * (size_t)W, 0);
+  {
+    DevState& D = c->devs[0];
+    URC(set_dev(D));
+    EvState& E = D.ev[(size_t)d];
+    HIPC(hipMemcpyAsync(sizes.data(), E.sizes.p, sizeof(int64_t) * 2 * (size_t)W, hipMemcpyDeviceToHost, E.s->stream));
+    HIPC(hipStreamSynchronize(E.s->stream));
+  }
+  std::vector<int64_t> off_r((size_t)W), cnt_r((size_t)W), off_c((size_t)W), cnt_c((size_t)W);
+  int64_t rows = 0, nnz = 0;
+  for (int r = 0; r < W; ++r) {
+    off_r[(size_t)r] = rows * 4;
+    cnt_r[(size_t)r] = sizes[(size_t)2 * r] * 4;
+    off_c[(size_t)r] = nnz * 4;
+    cnt_c[(size_t)r] = sizes[(size_t)2 * r + 1] * 4;
+    rows += sizes[(size_t)2 * r];
+    nnz += sizes[(size_t)2 * r + 1];
+  }
+  if (rows != n_users) return fail(URCCO_BAD_ARG, "event type %d: the user shards hold %lld rows, n_users_total is %lld", d, (long long)rows, (long long)n_users);
+  for (DevState& D : c->devs) {
+    URC(set_dev(D));
+    EvState& E = D.ev[(size_t)d];
+    URC(E.f_deg.ensure((size_t)rows + 1));
+    URC(E.f_rp.ensure((size_t)rows + 2));
+    URC(E.f_ci.ensure((size_t)nnz + 4));
+    URC(E.scan_tmp.ensure((size_t)(rows / urcco::SCAN_TILE + 4)));
+  }
+  URC(c->group_start());
+  for (DevState& D : c->devs) {
+    URC(set_dev(D));
+    EvState& E = D.ev[(size_t)d];
+    URC(c->all_gather_v(D, E.deg.p, E.f_deg.p, off_r.data(), cnt_r.data(), E.s->stream));
+    URC(c->all_gather_v(D, E.s_ci.p, E.f_ci.p, off_c.data(), cnt_c.data(), E.s->stream));
+  }
+  URC(c->group_end());
+  for (DevState& D : c->devs) {
+    URC(set_dev(D));
+    EvState& E = D.ev[(size_t)d];
+    HIPC(urcco::launch_scan_i32(E.s->stream, E.f_deg.p, rows, E.f_rp.p, E.scan_tmp.p));
+    E.b_rp = E.f_rp.p;
+    E.b_ci = E.f_ci.p;
+    E.b_rows = rows;
+    E.b_nnz_bound = nnz;
+  }
+  return URCCO_OK;
+}
+
+int build_sharded(urcco_context* c, const std::vector<std::vector<Shard>>& sh, const std::vector<DsParams>& ps, int64_t n_users, int32_t seed) {
+  const int n_ds = (int)ps.size();
+  const int W = c->world;
+  const int32_t n_items_a = (int32_t)ps[0].n_cols;
+  // ---- primary: input phase, then the balance key.  The key is the A'A row work added up from the user shards (the
+  // work of A'B_d sums the same users' B_d row lengths and follows it closely), so the ranges are fixed before any
+  // whole-matrix work and the one blocking host read comes right after the primary's short chain.
+  URC(input_phase(c, 0, sh, ps, seed));
+  for (DevState& D : c->devs) {
+    URC(set_dev(D));
+    EvState& A = D.ev[0];
+    const Shard& s = sh[0][(size_t)(&D - c->devs.data())];
+    URC(D.work.ensure((size_t)n_items_a + 1));
+    URC(urcco_dev_row_work_csr(A.s, s.n_rows, A.s_rp.p, A.s_ci.p, s.nnz, A.s_rp.p, n_items_a, D.work.p));
+  }
+  URC(c->group_start());
+  for (DevState& D : c->devs) {
+    URC(set_dev(D));
+    URC(c->all_reduce(D, D.work.p, n_items_a, 1, D.ev[0].s->stream));
+  }
+  URC(c->group_end());
+  c->h_bounds.assign((size_t)W + 1, 0);
+  for (DevState& D : c->devs) {  // identical bounds on every rank: the same scan + split of the same summed key
+    URC(set_dev(D));
+    std::vector<int32_t> b((size_t)W + 1);
+    URC(urcco_dev_partition(D.ev[0].s, n_items_a, D.work.p, W, b.data()));  // synchronises the primary's stream
+    c->h_bounds = b;
+    D.item_lo = b[(size_t)D.rank];
+    D.item_hi = b[(size_t)D.rank + 1];
+  }
+  std::vector<int64_t> sizes;
+  URC(exchange_phase(c, 0, ps, n_users, sizes));
+  c->h_sizes.assign((size_t)n_ds, 0);
+  int64_t a_nnz = 0;
+  for (int r = 0; r < W; ++r) a_nnz += sizes[(size_t)2 * r + 1];
+  c->h_sizes[0] = a_nnz;
+  for (DevState& D : c->devs) {
+    URC(set_dev(D));
+    EvState& A = D.ev[0];
+    URC(D.a_cp.ensure((size_t)n_items_a + 2));
+    URC(D.a_ri.ensure((size_t)a_nnz + 4));
+    URC(urcco_dev_transpose(A.s, n_users, A.f_rp.p, A.f_ci.p, a_nnz, n_items_a, A.post.p, D.item_lo, D.item_hi, D.a_cp.p, D.a_ri.p));
+    HIPC(hipEventRecord(D.a_ready, A.s->stream));
+    URC(stage_rows(D, A, A, 0, ps[0], ps[0], n_users, a_nnz));
+  }
+  // ---- secondaries: every input phase is enqueued on its own stream (they run under A'A); then per event type the shard
+  // sizes are read (the host waits for that stream's sampling only), the exchange is issued and A'B_d runs behind it
+  for (int d = 1; d < n_ds; ++d) URC(input_phase(c, d, sh, ps, seed));
+  for (int d = 1; d < n_ds; ++d) {
+    URC(exchange_phase(c, d, ps, n_users, sizes));
+    int64_t b_nnz = 0;
+    for (int r = 0; r < W; ++r) b_nnz += sizes[(size_t)2 * r + 1];
+    c->h_sizes[(size_t)d] = b_nnz;
+    for (DevState& D : c->devs) {
+      URC(set_dev(D));
+      EvState& E = D.ev[(size_t)d];
+      if (E.s != D.ev[0].s) HIPC(hipStreamWaitEvent(E.s->stream, D.a_ready, 0));
+      URC(stage_rows(D, E, D.ev[0], d, ps[0], ps[(size_t)d], n_users, a_nnz));
+    }
+  }
+  return URCCO_OK;
+}
+
+int check_params(const DsParams& p, int d) {
+  if (p.n_cols < 0 || p.n_cols > 0x7ffffff0ll) return fail(URCCO_BAD_ARG, "dataset %d: bad column count", d);
+  if (p.max_rows <= 0 || p.k <= 0) return fail(URCCO_BAD_ARG, "dataset %d: maxElementsPerRow / maxInterestingElements must be positive", d);
+  return URCCO_OK;
+}
+
+int run_build(urcco_context* c, const std::vector<std::vector<Shard>>& sh, const std::vector<DsParams>& ps, int64_t n_users, int32_t seed,
+              hipStream_t input_stream) {
+  const int n_ds = (int)ps.size();
+  for (DevState& D : c->devs) {
+    URC(ensure_events(c, D, n_ds));
+    if (input_stream && c->devs.size() == 1) {
+      HIPC(hipEventRecord(D.in_ready, input_stream));
+      for (int d = 0; d < n_ds; ++d) HIPC(hipStreamWaitEvent(D.ev[(size_t)d].s->stream, D.in_ready, 0));
+    }
+  }
+  if (!c->exchange()) return build_single(c, c->devs[0], [&] {
+    std::vector<Shard> one((size_t)n_ds);
+    for (int d = 0; d < n_ds; ++d) one[(size_t)d] = sh[(size_t)d][0];
+    return one;
+  }(), ps, n_users, seed);
+  return build_sharded(c, sh, ps, n_users, seed);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host level: staging
+// ---------------------------------------------------------------------------------------------------------
+constexpr size_t STAGE_CHUNK = (size_t)8 << 20;
+
+// pageable host memory -> device through the context's pinned ring, `threads` copy threads; every chunk's H2D is enqueued
+// on `st` as soon as the chunk sits in pinned memory, so the link is busy while later chunks are still being copied.
+// Returns after all copies of this array are ENQUEUED.
+struct Stager {
+  urcco_context* c;
+  struct Slot { hipEvent_t ev = nullptr; std::atomic<long long> gen{0}; };
+  std::vector<std::unique_ptr<Slot>> slots;
+  std::atomic<long long> next_chunk{0};  // global chunk counter: chunk q uses slot q % n_slots in generation q / n_slots
+  int ensure(size_t n_slots) {
+    if (c->stage_cap < n_slots * STAGE_CHUNK) {
+      if (c->stage) (void)hipHostFree(c->stage);
+      c->stage = nullptr;
+      c->stage_cap = 0;
+      HIPC(hipHostMalloc(&c->stage, n_slots * STAGE_CHUNK, 0));
+      c->stage_cap = n_slots * STAGE_CHUNK;
+    }
+    while (slots.size() < n_slots) {
+      slots.emplace_back(new Slot());
+      HIPC(hipEventCreateWithFlags(&slots.back()->ev, hipEventDisableTiming));
+    }
+    return URCCO_OK;
+  }
+  ~Stager() {
+    for (auto& s : slots)
+      if (s->ev) (void)hipEventDestroy(s->ev);
+  }
+  int copy(int device, hipStream_t st, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return URCCO_OK;
+    const size_t n_chunks = (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK;
+    const long long base = next_chunk.fetch_add((long long)n_chunks);
+    const size_t n_slots = slots.size();
+    std::atomic<size_t> take{0};
+    std::atomic<int> status{URCCO_OK};
+    auto worker = [&]() {
+      if (hipSetDevice(device) != hipSuccess) { status = URCCO_HIP_ERROR; return; }
+      for (;;) {
+        const size_t k = take.fetch_add(1);
+        if (k >= n_chunks) break;
+        const long long q = base + (long long)k;
+        Slot& s = *slots[(size_t)(q % (long long)n_slots)];
+        const long long gen = q / (long long)n_slots;
+        while (s.gen.load(std::memory_order_acquire) != gen) std::this_thread::yield();  // the slot's previous user has recorded its event
+        if (gen > 0 && hipEventSynchronize(s.ev) != hipSuccess) status = URCCO_HIP_ERROR;  // ... and its H2D has left the slot
+        const size_t o = k * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - o);
+        char* pin = (char*)c->stage + (size_t)(q % (long long)n_slots) * STAGE_CHUNK;
+        memcpy(pin, (const char*)src + o, len);
+        if (hipMemcpyAsync((char*)dst + o, pin, len, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(s.ev, st) != hipSuccess) status = URCCO_HIP_ERROR;
+        s.gen.store(gen + 1, std::memory_order_release);
+      }
+    };
+    const int nt = (int)std::min<size_t>((size_t)c->copy_threads, n_chunks);
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+    if (status != URCCO_OK) return fail(URCCO_HIP_ERROR, "host -> device staging failed");
+    return URCCO_OK;
+  }
+};
+
+std::mutex g_default_mu;
+urcco_context* g_default_ctx = nullptr;
+int g_default_n_gpus = -1, g_default_device = -1, g_default_mode = -1;
+
+}  // namespace
+
+extern "C" {
+
+int urcco_comm_unique_id(void* out) {
+  if (!out) return fail(URCCO_BAD_ARG, "urcco_comm_unique_id: out is NULL");
+  Rccl* r = Rccl::get();
+  if (!r) return fail(URCCO_RCCL_ERROR, "librccl could not be loaded: %s", dlerror() ? dlerror() : "not found");
+  Rccl::UniqueId id;
+  RCCLC(r, r->GetUniqueId(&id));
+  memcpy(out, &id, URCCO_UNIQUE_ID_BYTES);
+  return URCCO_OK;
+}
+
+void urcco_context_destroy(urcco_context* c) {
+  if (!c) return;
+  for (DevState& D : c->devs) {
+    (void)hipSetDevice(D.device);
+    for (urcco_session* s : D.sessions) (void)hipStreamSynchronize(s->stream);
+    if (D.comm && c->rccl) (void)c->rccl->CommDestroy(D.comm);
+    for (EvState& E : D.ev) E.release();
+    D.a_cp.release(); D.a_ri.release(); D.work.release(); D.bounds.release();
+    if (D.a_ready) (void)hipEventDestroy(D.a_ready);
+    if (D.in_ready) (void)hipEventDestroy(D.in_ready);
+    for (urcco_session* s : D.sessions) urcco_session_destroy(s);
+  }
+  if (c->stage) (void)hipHostFree(c->stage);
+  delete c;
+}
+
+int urcco_context_create(const urcco_options* options, const urcco_comm_config* comm, urcco_context** out) {
+  return guarded([&]() -> int {
+    if (!out) return fail(URCCO_BAD_ARG, "urcco_context_create: out is NULL");
+    *out = nullptr;
+    const int n_dev = urcco_device_count();
+    if (n_dev <= 0) return fail(URCCO_NO_DEVICE, "no HIP device visible (liburcco has no CPU fallback)");
+    const int first = options ? options->device : 0;
+    int n_local = options ? options->n_gpus : 0;
+    if (first < 0 || first >= n_dev) return fail(URCCO_BAD_ARG, "device %d out of range [0,%d)", first, n_dev);
+    if (n_local < 0 || first + n_local > n_dev) return fail(URCCO_BAD_ARG, "n_gpus %d from device %d: only %d device(s) visible", n_local, first, n_dev);
+    if (n_local == 0) n_local = n_dev - first;
+    const int mode = options ? options->row_rate_mode : URCCO_ROW_RATE_MAHOUT_INT_DIV;
+    if (mode != URCCO_ROW_RATE_MAHOUT_INT_DIV && mode != URCCO_ROW_RATE_FRACTIONAL) return fail(URCCO_BAD_ARG, "unknown row_rate_mode %d", mode);
+    std::unique_ptr<urcco_context, void (*)(urcco_context*)> c(new urcco_context(), urcco_context_destroy);
+    c->row_rate_mode = mode;
+    c->flags = options ? options->flags : 0;
+    c->world = (comm && comm->world_size > 0) ? comm->world_size : n_local;
+    c->first_rank = comm ? comm->first_rank : 0;
+    if (c->first_rank < 0 || c->first_rank + n_local > c->world) return fail(URCCO_BAD_ARG, "ranks [%d, %d) outside a world of %d", c->first_rank, c->first_rank + n_local, c->world);
+    if (comm && comm->collectives) {
+      const urcco_collectives* k = comm->collectives;
+      if (!k->group_start || !k->group_end || !k->all_reduce_sum || !k->all_gather_v) return fail(URCCO_BAD_ARG, "urcco_collectives: every callback must be set");
+      c->cb = *k;
+      c->have_cb = true;
+    }
+    c->devs.resize((size_t)n_local);
+    for (int g = 0; g < n_local; ++g) {
+      DevState& D = c->devs[(size_t)g];
+      D.device = first + g;
+      D.rank = c->first_rank + g;
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, D.device) == hipSuccess && prop.multiProcessorCount > 0) D.n_cu = prop.multiProcessorCount;
+    }
+    const unsigned hc = std::thread::hardware_concurrency();
+    c->copy_threads = hc >= 32 ? 8 : (hc >= 8 ? 4 : 2);
+    if (!c->have_cb && (c->world > 1 || (c->flags & URCCO_FLAG_FORCE_EXCHANGE))) {
+      c->rccl = Rccl::get();
+      if (!c->rccl) return fail(URCCO_RCCL_ERROR, "a multi-rank build needs librccl, which could not be loaded");
+      if (n_local == c->world) {
+        std::vector<int> ids((size_t)n_local);
+        std::vector<Rccl::Comm> comms((size_t)n_local, nullptr);
+        for (int g = 0; g < n_local; ++g) ids[(size_t)g] = first + g;
+        RCCLC(c->rccl, c->rccl->CommInitAll(comms.data(), n_local, ids.data()));
+        for (int g = 0; g < n_local; ++g) c->devs[(size_t)g].comm = comms[(size_t)g];
+      } else {
+        if (!comm || !comm->nccl_unique_id) return fail(URCCO_BAD_ARG, "ranks spread over processes need comm->nccl_unique_id");
+        Rccl::UniqueId id;
+        memcpy(&id, comm->nccl_unique_id, URCCO_UNIQUE_ID_BYTES);
+        RCCLC(c->rccl, c->rccl->GroupStart());
+        for (int g = 0; g < n_local; ++g) {
+          HIPC(hipSetDevice(first + g));
+          RCCLC(c->rccl, c->rccl->CommInitRank(&c->devs[(size_t)g].comm, c->world, id, c->first_rank + g));
+        }
+        RCCLC(c->rccl, c->rccl->GroupEnd());
+      }
+    }
+    *out = c.release();
+    return URCCO_OK;
+  });
+}
+
+int32_t urcco_context_local_gpus(const urcco_context* c) { return c ? (int32_t)c->devs.size() : 0; }
+
+int urcco_context_set_flags(urcco_context* c, int32_t flags) {
+  if (!c) return fail(URCCO_BAD_ARG, "context is NULL");
+  if (!c->have_cb && !c->rccl && c->world == 1 && (flags & URCCO_FLAG_FORCE_EXCHANGE))
+    return fail(URCCO_BAD_ARG, "URCCO_FLAG_FORCE_EXCHANGE must be given to urcco_context_create (the communicator is created there)");
+  c->flags = flags;
+  return URCCO_OK;
+}
+
+int urcco_context_set_debug(urcco_context* c, int32_t flags) {
+  if (!c) return fail(URCCO_BAD_ARG, "context is NULL");
+  c->debug = flags;
+  for (DevState& D : c->devs)
+    for (urcco_session* s : D.sessions) s->debug = flags;
+  return URCCO_OK;
+}
+
+int urcco_context_set_timing(urcco_context* c, int32_t enable) {
+  if (!c) return fail(URCCO_BAD_ARG, "context is NULL");
+  c->timing = enable != 0;
+  for (DevState& D : c->devs) {
+    HIPC(hipSetDevice(D.device));
+    for (urcco_session* s : D.sessions) URC(urcco_session_set_timing(s, enable));
+  }
+  return URCCO_OK;
+}
+
+int urcco_context_get_timings(urcco_context* c, double* ms, int64_t* launches) {
+  if (!c || !ms || !launches) return fail(URCCO_BAD_ARG, "urcco_context_get_timings: bad argument");
+  for (int i = 0; i < URCCO_N_STAGES; ++i) { ms[i] = 0; launches[i] = 0; }
+  for (DevState& D : c->devs) {
+    HIPC(hipSetDevice(D.device));
+    for (urcco_session* s : D.sessions) {
+      double m[URCCO_N_STAGES];
+      int64_t n[URCCO_N_STAGES];
+      URC(urcco_session_get_timings(s, m, n));
+      for (int i = 0; i < URCCO_N_STAGES; ++i) { ms[i] += m[i]; launches[i] += n[i]; }
+    }
+  }
+  return URCCO_OK;
+}
+
+int urcco_context_synchronize(urcco_context* c) {
+  if (!c) return fail(URCCO_BAD_ARG, "context is NULL");
+  for (DevState& D : c->devs) {
+    HIPC(hipSetDevice(D.device));
+    for (urcco_session* s : D.sessions) HIPC(hipStreamSynchronize(s->stream));
+  }
+  return URCCO_OK;
+}
+
+int urcco_context_wait_stream(urcco_context* c, void* stream) {
+  if (!c) return fail(URCCO_BAD_ARG, "context is NULL");
+  if (c->devs.size() != 1) return fail(URCCO_BAD_ARG, "urcco_context_wait_stream: single-GPU contexts only");
+  DevState& D = c->devs[0];
+  HIPC(hipSetDevice(D.device));
+  for (EvState& E : D.ev)
+    if (E.ev_done) HIPC(hipStreamWaitEvent((hipStream_t)stream, E.ev_done, 0));
+  return URCCO_OK;
+}
+
+int urcco_context_build_device(urcco_context* c, const urcco_dev_dataset* datasets, int32_t n_ds, int64_t n_users, int32_t seed, void* input_stream,
+                               urcco_dev_result* out) {
+  return guarded([&]() -> int {
+    err_buf()[0] = 0;
+    if (!c || !datasets || n_ds <= 0 || !out || n_users < 0) return fail(URCCO_BAD_ARG, "urcco_context_build_device: bad argument");
+    const size_t L = c->devs.size();
+    std::vector<DsParams> ps((size_t)n_ds);
+    std::vector<std::vector<Shard>> sh((size_t)n_ds, std::vector<Shard>(L));
+    for (int d = 0; d < n_ds; ++d) {
+      const urcco_dev_dataset& ds = datasets[d];
+      DsParams& p = ps[(size_t)d];
+      p.n_cols = ds.n_cols; p.max_rows = ds.max_elements_per_row; p.k = ds.max_interesting_elements; p.has_min_llr = ds.has_min_llr; p.min_llr = ds.min_llr;
+      URC(check_params(p, d));
+      if (!ds.shards) return fail(URCCO_BAD_ARG, "dataset %d: shards is NULL", d);
+      for (size_t g = 0; g < L; ++g) {
+        const urcco_dev_shard& s = ds.shards[g];
+        if (s.n_rows < 0 || s.nnz < 0 || s.row_base < 0 || !s.row_ptr || (s.nnz > 0 && !s.col_idx)) return fail(URCCO_BAD_ARG, "dataset %d shard %zu: bad shard", d, g);
+        if (s.n_rows != datasets[0].shards[g].n_rows || s.row_base != datasets[0].shards[g].row_base)
+          return fail(URCCO_BAD_ARG, "dataset %d shard %zu: every event type shards the users the same way", d, g);
+        sh[(size_t)d][g] = Shard{s.n_rows, s.row_base, s.nnz, s.row_ptr, s.col_idx};
+      }
+    }
+    if (!c->exchange() && sh[0][0].n_rows != n_users) return fail(URCCO_BAD_ARG, "one rank holds %lld rows, n_users_total is %lld", (long long)sh[0][0].n_rows, (long long)n_users);
+    URC(run_build(c, sh, ps, n_users, seed, (hipStream_t)input_stream));
+    for (int d = 0; d < n_ds; ++d)
+      for (size_t g = 0; g < L; ++g) {
+        DevState& D = c->devs[g];
+        EvState& E = D.ev[(size_t)d];
+        urcco_dev_result& r = out[(size_t)d * L + g];
+        r.item_lo = D.item_lo; r.item_hi = D.item_hi;
+        r.row_ptr = E.c_rp.p; r.col_idx = E.c_idx.p; r.llr = E.c_llr.p; r.stats = E.stats.p;
+        r.sampled_row_ptr = E.b_rp; r.sampled_col_idx = E.b_ci; r.sampled_rows = E.b_rows;
+      }
+    return URCCO_OK;
+  });
+}
+
+int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datasets, int32_t n_ds, int32_t seed, urcco_indicators* out,
+                                   urcco_dataset_stats* stats) {
+  const int status = guarded([&]() -> int {
+    err_buf()[0] = 0;
+    if (!c || !datasets || n_ds <= 0 || !out) return fail(URCCO_BAD_ARG, "datasets / out is NULL or n_datasets <= 0");
+    const size_t L = c->devs.size();
+    if ((int)L != c->world) return fail(URCCO_BAD_ARG, "the host-level build needs every rank in this process");
+    for (int d = 0; d < n_ds; ++d) {
+      memset(&out[d], 0, sizeof(urcco_indicators));
+      if (stats) memset(&stats[d], 0, sizeof(urcco_dataset_stats));
+    }
+    std::vector<DsParams> ps((size_t)n_ds);
+    const int64_t n_users = datasets[0].matrix.n_rows;
+    for (int d = 0; d < n_ds; ++d) {
+      const urcco_csr& m = datasets[d].matrix;
+      if (m.n_rows < 0 || m.n_cols < 0 || m.n_rows > 0x7fffffffll) return fail(URCCO_BAD_ARG, "dataset %d: bad shape", d);
+      if (!m.row_ptr) return fail(URCCO_BAD_ARG, "dataset %d: row_ptr is NULL", d);
+      if (m.row_ptr[0] != 0) return fail(URCCO_BAD_ARG, "dataset %d: row_ptr[0] != 0", d);
+      if (m.n_rows != n_users)
+        return fail(URCCO_BAD_ARG, "dataset %d has %lld rows, the primary has %lld: all matrices share the user dictionary", d, (long long)m.n_rows, (long long)n_users);
+      const int64_t nnz = m.row_ptr[m.n_rows];
+      if (nnz < 0 || (nnz > 0 && !m.col_idx)) return fail(URCCO_BAD_ARG, "dataset %d: bad nnz / col_idx", d);
+      DsParams& p = ps[(size_t)d];
+      p.n_cols = m.n_cols; p.max_rows = datasets[d].max_elements_per_row; p.k = datasets[d].max_interesting_elements;
+      p.has_min_llr = datasets[d].has_min_llr; p.min_llr = datasets[d].min_llr;
+      URC(check_params(p, d));
+    }
+    // ---- user ranges of the GPUs: contiguous, ~equal interactions summed over the event types
+    std::vector<int64_t> cut(L + 1, 0);
+    cut[L] = n_users;
+    if (L > 1) {
+      auto total_at = [&](int64_t u) { int64_t t = 0; for (int d = 0; d < n_ds; ++d) t += datasets[d].matrix.row_ptr[u]; return t; };
+      const int64_t total = total_at(n_users);
+      for (size_t g = 1; g < L; ++g) {
+        const int64_t target = total / (int64_t)L * (int64_t)g;
+        int64_t lo = cut[g - 1], hi = n_users;
+        while (lo < hi) { const int64_t mid = lo + (hi - lo) / 2; if (total_at(mid) >= target) hi = mid; else lo = mid + 1; }
+        cut[g] = lo;
+      }
+    }
+    for (DevState& D : c->devs) URC(ensure_events(c, D, n_ds));
+    // ---- stage + validate every shard on its event stream (copy threads feed the pinned ring; the link is busy while
+    // the next chunks are copied), heaviest transfers last so that the primary starts first
+    Stager stager{c};
+    URC(stager.ensure(24));
+    std::vector<std::vector<Shard>> sh((size_t)n_ds, std::vector<Shard>(L));
+    for (int d = 0; d < n_ds; ++d) {
+      const urcco_csr& m = datasets[d].matrix;
+      for (size_t g = 0; g < L; ++g) {
+        DevState& D = c->devs[g];
+        URC(set_dev(D));
+        EvState& E = D.ev[(size_t)d];
+        const int64_t u0 = cut[g], u1 = cut[g + 1], rows = u1 - u0;
+        const int64_t e0 = m.row_ptr[u0], e1 = m.row_ptr[u1], nnz = e1 - e0;
+        if (nnz < 0) return fail(URCCO_BAD_ARG, "dataset %d: row_ptr not monotone", d);
+        URC(E.in_rp.ensure((size_t)rows + 1));
+        URC(E.in_ci.ensure((size_t)nnz + 4));
+        URC(E.verr.ensure(1));
+        URC(stager.copy(D.device, E.s->stream, E.in_rp.p, m.row_ptr + u0, sizeof(int64_t) * ((size_t)rows + 1)));
+        URC(stager.copy(D.device, E.s->stream, E.in_ci.p, m.col_idx + e0, sizeof(int32_t) * (size_t)nnz));
+        HIPC(hipMemsetAsync(E.verr.p, 0, sizeof(unsigned long long), E.s->stream));
+        int gl = rows > 0 ? ceil_log2_i64((nnz + rows - 1) / rows) : 1;
+        gl = gl < 1 ? 1 : (gl > 6 ? 6 : gl);
+        HIPC(urcco::launch_validate_csr(E.s->stream, D.n_cu, rows, E.in_rp.p, E.in_ci.p, nnz, (int32_t)m.n_cols, gl, e0, E.verr.p));
+        HIPC(urcco::launch_rebase_i64(E.s->stream, D.n_cu, E.in_rp.p, rows + 1, e0));
+        sh[(size_t)d][g] = Shard{rows, u0, nnz, E.in_rp.p, E.in_ci.p};
+      }
+    }
+    // the boundary check must have passed before any kernel consumes the matrices
+    for (int d = 0; d < n_ds; ++d)
+      for (size_t g = 0; g < L; ++g) {
+        DevState& D = c->devs[g];
+        URC(set_dev(D));
+        EvState& E = D.ev[(size_t)d];
+        unsigned long long bad = 0;
+        HIPC(hipMemcpyAsync(&bad, E.verr.p, sizeof(bad), hipMemcpyDeviceToHost, E.s->stream));
+        HIPC(hipStreamSynchronize(E.s->stream));
+        if (bad) return fail(URCCO_BAD_ARG, "dataset %d: %llu invalid entries (row_ptr not monotone, or col_idx out of [0, n_cols) / not strictly increasing inside a row)", d, bad);
+      }
+    URC(run_build(c, sh, ps, n_users, seed, nullptr));
+    // ---- results: row_ptr of every GPU's slice first (small), then exactly nnz entries each
+    const int32_t n_items_a = (int32_t)ps[0].n_cols;
+    std::vector<std::vector<int64_t>> h_stats((size_t)n_ds * L, std::vector<int64_t>(URCCO_STATS_LEN, 0));
+    for (int d = 0; d < n_ds; ++d) {
+      urcco_indicators& o = out[d];
+      o.n_rows = n_items_a;
+      o.n_cols = ps[(size_t)d].n_cols;
+      o.row_ptr = (int64_t*)pinned_pool().get(sizeof(int64_t) * ((size_t)n_items_a + 1));
+      if (!o.row_ptr) return fail(URCCO_OOM_HOST, "pinned indicator row_ptr");
+      o.row_ptr[0] = 0;
+      for (size_t g = 0; g < L; ++g) {
+        DevState& D = c->devs[g];
+        URC(set_dev(D));
+        EvState& E = D.ev[(size_t)d];
+        const int32_t n = D.item_hi - D.item_lo;
+        // slice row_ptr[1..n] lands at out.row_ptr[item_lo + 1 ..]; re-based below once the slices' sizes are known
+        if (n > 0) HIPC(hipMemcpyAsync(o.row_ptr + D.item_lo + 1, E.c_rp.p + 1, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, E.s->stream));
+        HIPC(hipMemcpyAsync(h_stats[(size_t)d * L + g].data(), E.stats.p, sizeof(int64_t) * URCCO_STATS_LEN, hipMemcpyDeviceToHost, E.s->stream));
+        HIPC(hipEventRecord(E.ev_rp, E.s->stream));
+      }
+    }
+    for (int d = 0; d < n_ds; ++d) {
+      urcco_indicators& o = out[d];
+      std::vector<int64_t> base(L + 1, 0);
+      for (size_t g = 0; g < L; ++g) {
+        DevState& D = c->devs[g];
+        URC(set_dev(D));
+        HIPC(hipEventSynchronize(D.ev[(size_t)d].ev_rp));
+        const int32_t n = D.item_hi - D.item_lo;
+        base[g + 1] = base[g] + (n > 0 ? o.row_ptr[D.item_hi] : 0);
+      }
+      o.nnz = base[L];
+      o.col_idx = (int32_t*)pinned_pool().get(sizeof(int32_t) * (size_t)(o.nnz ? o.nnz : 1));
+      o.llr = (double*)pinned_pool().get(sizeof(double) * (size_t)(o.nnz ? o.nnz : 1));
+      if (!o.col_idx || !o.llr) return fail(URCCO_OOM_HOST, "pinned indicator arrays");
+      for (size_t g = 0; g < L; ++g) {
+        DevState& D = c->devs[g];
+        URC(set_dev(D));
+        EvState& E = D.ev[(size_t)d];
+        const int64_t nz = base[g + 1] - base[g];
+        if (nz > 0) {
+          HIPC(hipMemcpyAsync(o.col_idx + base[g], E.c_idx.p, sizeof(int32_t) * (size_t)nz, hipMemcpyDeviceToHost, E.s->stream));
+          HIPC(hipMemcpyAsync(o.llr + base[g], E.c_llr.p, sizeof(double) * (size_t)nz, hipMemcpyDeviceToHost, E.s->stream));
+        }
+        if (base[g] != 0)
+          for (int32_t i = D.item_lo + 1; i <= D.item_hi; ++i) o.row_ptr[i] += base[g];
+      }
+    }
+    URC(urcco_context_synchronize(c));
+    if (stats)
+      for (int d = 0; d < n_ds; ++d) {
+        urcco_dataset_stats& st = stats[d];
+        st.nnz_raw = datasets[d].matrix.row_ptr[n_users];
+        st.nnz_out = out[d].nnz;
+        for (size_t g = 0; g < L; ++g) {
+          const std::vector<int64_t>& h = h_stats[(size_t)d * L + g];
+          st.pairs += h[0];
+          for (int b = 0; b < URCCO_N_BINS; ++b) st.rows_by_bin[b] += h[1 + (size_t)b];
+        }
+        if (c->exchange()) {
+          st.nnz_sampled = c->h_sizes[(size_t)d];
+        } else {
+          DevState& D = c->devs[0];
+          HIPC(hipMemcpy(&st.nnz_sampled, D.ev[(size_t)d].s_rp.p + n_users, sizeof(int64_t), hipMemcpyDeviceToHost));
+        }
+      }
+    return URCCO_OK;
+  });
+  if (status != URCCO_OK && out && n_ds > 0) urcco_free_indicators(out, n_ds);
+  return status;
+}
+
+// ---- process-wide default context + the Mahout-shaped one-shot entry points ---------------------------------
+int urcco_shutdown(void) {
+  std::lock_guard<std::mutex> g(g_default_mu);
+  if (g_default_ctx) urcco_context_destroy(g_default_ctx);
+  g_default_ctx = nullptr;
+  pinned_pool().trim();
+  return URCCO_OK;
+}
+
+void urcco_free_indicators(urcco_indicators* ind, int32_t n) {
+  if (!ind) return;
+  for (int32_t d = 0; d < n; ++d) {
+    for (void* p : {(void*)ind[d].row_ptr, (void*)ind[d].col_idx, (void*)ind[d].llr})
+      if (p && !pinned_pool().put(p)) free(p);
+    memset(&ind[d], 0, sizeof(urcco_indicators));
+  }
+}
+
+int urcco_cross_occurrence_downsampled(const urcco_dataset* datasets, int32_t n_datasets, int32_t random_seed, const urcco_options* options,
+                                       urcco_indicators* out, urcco_dataset_stats* stats) {
+  int st = guarded([&]() -> int {
+    err_buf()[0] = 0;
+    std::lock_guard<std::mutex> g(g_default_mu);
+    const int want_dev = options ? options->device : 0, want_n = options ? options->n_gpus : 0;
+    const int want_mode = options ? options->row_rate_mode : URCCO_ROW_RATE_MAHOUT_INT_DIV;
+    if (g_default_ctx && (g_default_device != want_dev || g_default_n_gpus != want_n || g_default_mode != want_mode)) {
+      urcco_context_destroy(g_default_ctx);
+      g_default_ctx = nullptr;
+    }
+    if (!g_default_ctx) {
+      URC(urcco_context_create(options, nullptr, &g_default_ctx));
+      g_default_device = want_dev; g_default_n_gpus = want_n; g_default_mode = want_mode;
+    }
+    return urcco_context_cross_occurrence(g_default_ctx, datasets, n_datasets, random_seed, out, stats);
+  });
+  if (st != URCCO_OK && out && n_datasets > 0) urcco_free_indicators(out, n_datasets);
+  return st;
+}
+
+int urcco_cooccurrences_idss(const urcco_csr* datasets, int32_t n_datasets, int32_t random_seed, int32_t max_interesting_items_per_thing,
+                             int32_t max_num_interactions, const urcco_options* options, urcco_indicators* out, urcco_dataset_stats* stats) {
+  return guarded([&]() -> int {
+    err_buf()[0] = 0;
+    if (!datasets || n_datasets <= 0) return fail(URCCO_BAD_ARG, "datasets is NULL or n_datasets <= 0");
+    std::vector<urcco_dataset> ds((size_t)n_datasets);
+    for (int d = 0; d < n_datasets; ++d) {
+      ds[(size_t)d].matrix = datasets[d];
+      ds[(size_t)d].max_elements_per_row = max_num_interactions;
+      ds[(size_t)d].max_interesting_elements = max_interesting_items_per_thing;
+      ds[(size_t)d].min_llr = 0.0;
+      ds[(size_t)d].has_min_llr = 0;
+      ds[(size_t)d].reserved = 0;
+    }
+    return urcco_cross_occurrence_downsampled(ds.data(), n_datasets, random_seed, options, out, stats);
+  });
+}
+
+}  // extern "C"

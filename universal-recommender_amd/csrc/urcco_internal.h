@@ -1,0 +1,173 @@
+// Internals shared by the C-ABI translation units of liburcco (urcco_api.hip: sessions + device-level stages;
+// urcco_context.hip: persistent contexts, the host level, the multi-GPU build).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/urcco.h"
+#include "cco_kernels.h"
+
+namespace urcco_detail {
+
+char* err_buf();  // thread-local message buffer of urcco_last_error (512 bytes)
+
+inline int fail(int status, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return status;
+}
+
+inline int hip_fail(hipError_t e, const char* what) {
+  return fail(e == hipErrorOutOfMemory ? URCCO_OOM_DEVICE : URCCO_HIP_ERROR, "%s: %s", what, hipGetErrorString(e));
+}
+
+#define HIPC(expr)                                                  \
+  do {                                                              \
+    hipError_t _e = (expr);                                         \
+    if (_e != hipSuccess) return urcco_detail::hip_fail(_e, #expr); \
+  } while (0)
+
+#define URC(expr)                  \
+  do {                             \
+    int _s = (expr);               \
+    if (_s != URCCO_OK) return _s; \
+  } while (0)
+
+// No C++ exception crosses the C ABI: every extern "C" entry point that can allocate runs its body through this.
+template <typename F>
+inline int guarded(F&& body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return fail(URCCO_OOM_HOST, "out of host memory");
+  } catch (const std::exception& e) {
+    return fail(URCCO_INTERNAL, "unexpected exception: %s", e.what());
+  } catch (...) {
+    return fail(URCCO_INTERNAL, "unexpected exception");
+  }
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+inline int ceil_log2_i64(int64_t v) {
+  int l = 0;
+  while (((int64_t)1 << l) < v) ++l;
+  return l;
+}
+
+}  // namespace urcco_detail
+
+using namespace urcco_detail;
+
+struct urcco_session {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int n_cu = 256;
+  char* arena = nullptr;
+  size_t arena_cap = 0;
+  size_t arena_off = 0;
+  // persistent zeroed dense counters + candidate scratch of the global-accumulator kernel
+  int32_t* g_counts = nullptr;
+  unsigned long long* g_cand_key = nullptr;
+  int32_t* g_cand_col = nullptr;
+  int64_t g_cols = 0;
+  double* xlx_tab = nullptr;  // xLogX of small integers (N-independent), filled once
+  int debug = 0;              // kernel ablation switches (profiling only)
+  // optional per-stage HIP-event timing (bench.py's roofline numbers)
+  bool timing = false;
+  struct Rec { int stage; hipEvent_t e0, e1; };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> free_events;
+  double acc_ms[URCCO_N_STAGES] = {0};
+  int64_t acc_n[URCCO_N_STAGES] = {0};
+
+  hipEvent_t get_event() {
+    if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void begin(int stage) {
+    if (!timing) return;
+    Rec r{stage, get_event(), get_event()};
+    (void)hipEventRecord(r.e0, stream);
+    recs.push_back(r);
+  }
+  void end() {
+    if (!timing) return;
+    (void)hipEventRecord(recs.back().e1, stream);
+  }
+  void collect() {
+    (void)hipStreamSynchronize(stream);
+    for (const Rec& r : recs) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) { acc_ms[r.stage] += ms; acc_n[r.stage] += 1; }
+      free_events.push_back(r.e0);
+      free_events.push_back(r.e1);
+    }
+    recs.clear();
+  }
+
+  int reserve(size_t bytes) {
+    arena_off = 0;
+    if (bytes <= arena_cap) return URCCO_OK;
+    if (arena) {
+      HIPC(hipStreamSynchronize(stream));
+      HIPC(hipFree(arena));
+      arena = nullptr;
+      arena_cap = 0;
+    }
+    const size_t want = align_up(bytes + bytes / 4, (size_t)1 << 20);
+    HIPC(hipMalloc((void**)&arena, want));
+    arena_cap = want;
+    return URCCO_OK;
+  }
+  template <typename T>
+  T* take(size_t n) {
+    const size_t bytes = align_up((n ? n : 1) * sizeof(T), 256);
+    char* p = arena + arena_off;
+    arena_off += bytes;
+    return reinterpret_cast<T*>(p);
+  }
+  static size_t need(size_t n, size_t elem) { return align_up((n ? n : 1) * elem, 256); }
+
+  // Dense per-block counters of the global-accumulator class: g_blocks x n_cols_b x 16 B.  The block count shrinks with
+  // the width of B so that the scratch stays within ~512 MiB per session (64 blocks up to 512K columns, 16 at 2M, never
+  // fewer than 2): the class only serves the few rows no LDS table can hold.
+  int g_blocks = 0;
+  size_t g_cap = 0;  // elements allocated
+  int ensure_global_bin(int64_t n_cols_b) {
+    int64_t blocks = ((int64_t)512 << 20) / ((n_cols_b > 0 ? n_cols_b : 1) * 16);
+    if (blocks > urcco::GLOBAL_BIN_BLOCKS) blocks = urcco::GLOBAL_BIN_BLOCKS;
+    if (blocks < 2) blocks = 2;
+    const size_t n = (size_t)blocks * (size_t)n_cols_b;
+    if (n <= g_cap && g_counts) {
+      // the counters are zero between launches whatever the geometry (every claim walk restores them)
+      g_blocks = (int)(g_cap / (size_t)(n_cols_b > 0 ? n_cols_b : 1) < (size_t)urcco::GLOBAL_BIN_BLOCKS ? g_cap / (size_t)(n_cols_b > 0 ? n_cols_b : 1)
+                                                                                                         : (size_t)urcco::GLOBAL_BIN_BLOCKS);
+      g_cols = n_cols_b;
+      return URCCO_OK;
+    }
+    HIPC(hipStreamSynchronize(stream));
+    if (g_counts) { HIPC(hipFree(g_counts)); HIPC(hipFree(g_cand_key)); HIPC(hipFree(g_cand_col)); }
+    g_counts = nullptr; g_cols = 0; g_cap = 0;
+    HIPC(hipMalloc((void**)&g_counts, n * sizeof(int32_t)));
+    HIPC(hipMalloc((void**)&g_cand_key, n * sizeof(unsigned long long)));
+    HIPC(hipMalloc((void**)&g_cand_col, n * sizeof(int32_t)));
+    HIPC(hipMemsetAsync(g_counts, 0, n * sizeof(int32_t), stream));
+    g_cols = n_cols_b;
+    g_cap = n;
+    g_blocks = (int)blocks;
+    return URCCO_OK;
+  }
+};
+

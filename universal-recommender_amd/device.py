@@ -50,6 +50,9 @@ class DevIndicators:
     sampled_col_idx: Optional[torch.Tensor] = None  # col_idx of the down-sampled B (first nnz' entries live)
 
     def to_host(self):
+        if self.row_ptr.numel() == 0:
+            import numpy as np
+            return np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.float64)
         rp = self.row_ptr.cpu().numpy()
         nnz = int(rp[-1])
         return rp, self.col_idx[:nnz].cpu().numpy(), self.llr[:nnz].cpu().numpy()
@@ -189,92 +192,181 @@ def _to_i32(seed: int) -> int:
     return s - (1 << 32) if s >= (1 << 31) else s
 
 
-class SessionPool:
-    """One urcco_session (own HIP stream + scratch arena) per event type, so that the per-event pipelines -- dozens of
-    short kernels and persistent SpGEMM grids with ragged tails -- overlap on the GPU.  pool[0] runs the primary matrix."""
+_TYPESTR = {torch.int32: "<i4", torch.int64: "<i8", torch.float64: "<f8"}
+_CTYPE = {torch.int32: C.c_int32, torch.int64: C.c_int64, torch.float64: C.c_double}
 
-    def __init__(self, device: torch.device, n: int, library=None, priorities: Optional[Sequence[int]] = None):
+
+class _RawDeviceArray:
+    """Zero-copy handle on context-owned device memory (CUDA array interface, which PyTorch-ROCm honours)."""
+
+    def __init__(self, ptr: int, n: int, dtype: torch.dtype):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": _TYPESTR[dtype], "data": (ptr, False), "version": 2}
+
+
+def _view(ptr: Optional[int], n: int, dtype: torch.dtype, device: torch.device) -> torch.Tensor:
+    """Tensor aliasing n elements at a raw pointer of the context (valid until its next build)."""
+    if not ptr or n <= 0:
+        return torch.empty(0, dtype=dtype, device=device)
+    if device.type == "cuda":
+        return torch.as_tensor(_RawDeviceArray(ptr, n, dtype), device=device)
+    import numpy as np
+    return torch.from_numpy(np.ctypeslib.as_array((_CTYPE[dtype] * n).from_address(ptr)))
+
+
+class Context:
+    """urcco_context (include/urcco.h, CONTEXT level): the persistent, multi-stream, multi-GPU form of the model build.
+
+    One context = this process's GPUs [device, device + n_gpus) as ranks [first_rank, first_rank + n_gpus) of a job of
+    world_size ranks.  Collectives are RCCL inside the library (nccl_unique_id from `unique_id()` on one rank when the
+    ranks are spread over processes) unless `collectives` replaces them (the CPU test-suite: gloo on the simulator)."""
+
+    def __init__(self, device, library=None, n_gpus: int = 1, flags: int = 0, row_rate_mode: int = _lib.ROW_RATE_MAHOUT_INT_DIV,
+                 world_size: int = 0, first_rank: int = 0, unique_id: Optional[bytes] = None, collectives=None):
         self.device = torch.device(device)
+        self.lib = library if library is not None else _lib.lib()
+        index = 0
         if self.device.type == "cuda":
-            pr = list(priorities) if priorities is not None else [0] * n
-            self.sessions = [DeviceSession(self.device, library, torch.cuda.Stream(self.device, priority=pr[i])) for i in range(n)]
-        else:
-            self.sessions = [DeviceSession(self.device, library) for _ in range(n)]
+            index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            self.device = torch.device("cuda", index)
+        self.devices = [torch.device("cuda", index + g) if self.device.type == "cuda" else self.device for g in range(max(n_gpus, 1))]
+        opts = _lib.Options(device=index, row_rate_mode=row_rate_mode, n_gpus=n_gpus, flags=flags)
+        comm = None
+        self._collectives = collectives
+        self._keep = [collectives]
+        if world_size or first_rank or unique_id is not None or collectives is not None:
+            comm = _lib.CommConfig(world_size=world_size, first_rank=first_rank)
+            if unique_id is not None:
+                buf = C.create_string_buffer(bytes(unique_id), _lib.UNIQUE_ID_BYTES)
+                self._keep.append(buf)
+                comm.nccl_unique_id = C.cast(buf, C.c_void_p)
+            if collectives is not None:
+                comm.collectives = C.pointer(collectives.struct)
+        handle = C.c_void_p()
+        _lib.check(self.lib.urcco_context_create(C.byref(opts), C.byref(comm) if comm is not None else None, C.byref(handle)), self.lib)
+        self.handle = handle
+        self.n_local = int(self.lib.urcco_context_local_gpus(handle))
+        self.devices = self.devices[: self.n_local] if len(self.devices) >= self.n_local else [torch.device("cuda", index + g) for g in range(self.n_local)]
+        self._last = None
 
-    def __len__(self):
-        return len(self.sessions)
+    @staticmethod
+    def unique_id(library=None) -> bytes:
+        lib = library if library is not None else _lib.lib()
+        buf = C.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        _lib.check(lib.urcco_comm_unique_id(buf), lib)
+        return buf.raw
 
-    def __getitem__(self, i) -> DeviceSession:
-        return self.sessions[i % len(self.sessions)]
+    def collectives_error(self):
+        return getattr(self._collectives, "error", None)
+
+    def _check(self, status: int):
+        if status != _lib.OK and self.collectives_error() is not None:
+            raise self.collectives_error()      # the Python exception behind a failed collectives callback
+        _lib.check(status, self.lib)
 
     def close(self):
-        for s in self.sessions:
-            s.close()
+        if self.handle:
+            self.lib.urcco_context_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def synchronize(self):
-        for s in self.sessions:
-            s.synchronize()
+        self._check(self.lib.urcco_context_synchronize(self.handle))
 
     def set_timing(self, enable: bool):
-        for s in self.sessions:
-            s.set_timing(enable)
+        self._check(self.lib.urcco_context_set_timing(self.handle, int(enable)))
+
+    def set_debug(self, flags: int):
+        self._check(self.lib.urcco_context_set_debug(self.handle, int(flags)))
+
+    def set_flags(self, flags: int):
+        self._check(self.lib.urcco_context_set_flags(self.handle, int(flags)))
 
     def get_timings(self):
-        out = {}
-        for s in self.sessions:
-            for k, (ms, n) in s.get_timings().items():
-                a, b = out.get(k, (0.0, 0))
-                out[k] = (a + ms, b + n)
+        ms = (C.c_double * _lib.N_STAGES)()
+        n = (C.c_int64 * _lib.N_STAGES)()
+        self._check(self.lib.urcco_context_get_timings(self.handle, ms, n))
+        return {_lib.STAGE_NAMES[i]: (ms[i], n[i]) for i in range(_lib.N_STAGES) if _lib.STAGE_NAMES[i]}
+
+    def build(self, shards: Sequence[Sequence[DevCsr]], params: Sequence[DatasetParams], seed: int, n_users_total: Optional[int] = None,
+              row_bases: Optional[Sequence[int]] = None, input_stream=None):
+        """Enqueue one model build.  shards[d][g] = event type d's user rows held by local GPU g (shards[d] may also be a
+        single DevCsr for a one-GPU context).  Returns immediately (after the one blocking read of ranges / sizes with
+        more than one rank); read the outcome with results()."""
+        n_ds = len(shards)
+        if n_ds == 0 or n_ds != len(params):
+            raise ValueError("need one DatasetParams per matrix and at least the primary matrix")
+        per = [list(sd) if isinstance(sd, (list, tuple)) else [sd] for sd in shards]
+        L = self.n_local
+        if any(len(p) != L for p in per):
+            raise ValueError(f"every event type needs one shard per local GPU ({L})")
+        if row_bases is None:
+            row_bases, acc = [], 0
+            for g in range(L):
+                row_bases.append(acc)
+                acc += per[0][g].n_rows
+        if n_users_total is None:
+            n_users_total = sum(m.n_rows for m in per[0])
+        ds = (_lib.DevDataset * n_ds)()
+        keep = []
+        for d in range(n_ds):
+            arr = (_lib.DevShard * L)()
+            for g, m in enumerate(per[d]):
+                arr[g].n_rows, arr[g].row_base, arr[g].nnz = m.n_rows, row_bases[g], m.nnz_bound
+                arr[g].row_ptr, arr[g].col_idx = m.row_ptr.data_ptr(), m.col_idx.data_ptr()
+            keep.append(arr)
+            p = params[d]
+            ds[d].n_cols = per[d][0].n_cols
+            ds[d].max_elements_per_row, ds[d].max_interesting_elements = p.max_elements_per_row, p.max_interesting_elements
+            ds[d].has_min_llr, ds[d].min_llr = int(p.min_llr is not None), float(p.min_llr) if p.min_llr is not None else 0.0
+            ds[d].shards = arr
+        out = (_lib.DevResult * (n_ds * L))()
+        st = None
+        if input_stream is not None:
+            st = C.c_void_p(input_stream.cuda_stream)
+        elif self.device.type == "cuda" and L == 1:
+            st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._check(self.lib.urcco_context_build_device(self.handle, ds, n_ds, int(n_users_total), _to_i32(seed), st, out))
+        self._last = (out, n_ds, [p.max_interesting_elements for p in params], [per[d][0].n_cols for d in range(n_ds)], (per, keep))
         return out
 
+    def wait(self):
+        """torch's current stream waits (on the device) for the last build (single-GPU contexts)."""
+        if self.device.type == "cuda" and self.n_local == 1:
+            self._check(self.lib.urcco_context_wait_stream(self.handle, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        else:
+            self.synchronize()
 
-def cross_occurrence_streams(pool: SessionPool, mats: Sequence[DevCsr], params: Sequence[DatasetParams], seed: int,
-                             row_rate_mode: int = _lib.ROW_RATE_MAHOUT_INT_DIV) -> List[DevIndicators]:
-    """cross_occurrence_device with one HIP stream per event type: B_i is sampled on its own stream while A is sampled and
-    transposed on stream 0; every A'B_i then runs on stream i behind an event on A's CSC.  Same results, bit for bit."""
-    if len(mats) == 0 or len(mats) != len(params):
-        raise ValueError("need one DatasetParams per matrix and at least the primary matrix")
-    a_raw = mats[0]
-    for m in mats:
-        if m.n_rows != a_raw.n_rows:
-            raise ValueError("all matrices share the user dictionary: row counts differ")
-    n_items_a = a_raw.n_cols
-    if pool.device.type != "cuda":   # host-simulator sessions have no streams: plain sequential pipeline
-        return cross_occurrence_device(pool[0], mats, params, seed, row_rate_mode)
-    main = torch.cuda.current_stream(pool.device)
-    streams = [pool[d].torch_stream for d in range(len(mats))]
-    for st in set(streams):
-        st.wait_stream(main)                       # inputs were produced on the caller's stream
-    sampled = [None] * len(mats)
-    with torch.cuda.stream(streams[0]):
-        s0 = pool[0]
-        raw = s0.column_counts(a_raw.col_idx, a_raw.nnz_bound, a_raw.n_cols)
-        a, cnt_a = s0.downsample(a_raw, a_raw.nnz_bound, raw, seed, params[0].max_elements_per_row, row_rate_mode)
-        a_col_ptr, a_row_idx = s0.transpose(a, cnt_a)
-        a_ready = torch.cuda.Event()
-        a_ready.record(streams[0])
-        sampled[0] = (a, cnt_a)
-    for d in range(1, len(mats)):
-        with torch.cuda.stream(streams[d]):
-            sd, m, p = pool[d], mats[d], params[d]
-            raw_b = sd.column_counts(m.col_idx, m.nnz_bound, m.n_cols)
-            sampled[d] = sd.downsample(m, m.nnz_bound, raw_b, seed, p.max_elements_per_row, row_rate_mode)
-    out = [None] * len(mats)
-    order = sorted(range(len(mats)), key=lambda d: -mats[d].nnz_bound)   # the heaviest event type is enqueued first
-    for d in order:
-        with torch.cuda.stream(streams[d]):
-            if streams[d] is not streams[0]:
-                streams[d].wait_event(a_ready)
-                for t in (a_col_ptr, a_row_idx, cnt_a, a.row_ptr, a.col_idx):
-                    t.record_stream(streams[d])   # produced on stream 0, read here
-            b, cnt_b = sampled[d]
-            ind = pool[d].cco_rows(0, n_items_a, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b, cnt_a, cnt_b, a_raw.n_rows, d == 0, params[d])
-            for t in (ind.row_ptr, ind.col_idx, ind.llr, ind.stats, b.row_ptr, b.col_idx):
-                t.record_stream(main)             # consumed by the caller on its stream
-            out[d] = ind
-    for st in set(streams):
-        main.wait_stream(st)
-    return out
+    def results(self) -> List[List[DevIndicators]]:
+        """Views on the last build's outputs (context-owned memory, valid until the next build): [event type][local GPU].
+        Synchronises."""
+        self.synchronize()
+        out, n_ds, ks, n_cols, _ = self._last
+        L = self.n_local
+        res = []
+        for d in range(n_ds):
+            row = []
+            for g in range(L):
+                r = out[d * L + g]
+                dev = self.devices[g]
+                n = r.item_hi - r.item_lo
+                s_rp = _view(r.sampled_row_ptr, r.sampled_rows + 1, torch.int64, dev)
+                s_nnz = int(s_rp[-1]) if s_rp.numel() else 0
+                row.append(DevIndicators(r.item_lo, r.item_hi, n_cols[d], ks[d], _view(r.row_ptr, n + 1, torch.int64, dev),
+                                         _view(r.col_idx, max(n * ks[d], 1), torch.int32, dev), _view(r.llr, max(n * ks[d], 1), torch.float64, dev),
+                                         _view(r.stats, _lib.STATS_LEN, torch.int64, dev), s_rp, _view(r.sampled_col_idx, max(s_nnz, 1), torch.int32, dev)))
+            res.append(row)
+        return res
+
+
+def cross_occurrence_context(ctx: Context, mats: Sequence[DevCsr], params: Sequence[DatasetParams], seed: int) -> List[DevIndicators]:
+    """SimilarityAnalysis.crossOccurrenceDownsampled on a one-GPU context: one build, results as views."""
+    ctx.build([[m] for m in mats], params, seed)
+    return [r[0] for r in ctx.results()]
 
 
 def cross_occurrence_device(sess: DeviceSession, mats: Sequence[DevCsr], params: Sequence[DatasetParams], seed: int,

@@ -1,250 +1,170 @@
-"""Multi-GPU CCO model build: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+"""Multi-GPU CCO model build, one process per GPU (how bench.py is launched under torch.distributed.run).
 
-The path shards with ONE exchange step:
+The build itself -- user-range input phase, work-balanced item ranges, the exchange, the item-range compute phase
+ -- lives in the library (csrc/urcco_context.hip, urcco_context_build_device) and talks RCCL directly, so
+that a single JVM process reaches every GPU the same way.  This module only wires a process group to it:
 
-  input phase   -- users are range-sharded: rank r holds rows [row_base, row_base + n_local) of every raw matrix.  Per
-                   event type: local column counts -> all-reduce (the raw counts sampleDownAndBinarize needs) ->
-                   down-sampling of the shard (the RNG is keyed by the GLOBAL row, so the result does not depend on
-                   the sharding) -> all-reduce of the post-sampling counts.  Each event type runs on its own HIP stream
-                   when a SessionPool is given; collectives synchronise with that stream only;
-  ranges        -- items of A are split into world_size contiguous ranges of equal summed row work (not equal count:
-                   Zipf skew).  The key is the A'A row work, added up from the user shards by one all-reduce as soon as
-                   A is sampled (the work of A'B_d sums the same users' B_d row lengths and follows it closely), so the
-                   ranges are known before any whole-matrix work and the blocking host read of the build (range bounds
-                   + A's shard sizes) comes after the primary's short chain only; the secondary event types are sampled
-                   afterwards, under the SpGEMM of A'A.  One range set serves every event type, hence ONE
-                   transposition of the rank's slice of A';
-  exchange      -- all-gathers of the down-sampled CSR shards (row lengths + column indices, padded to the largest
-                   shard), issued asynchronously per event type: A first, B_d on stream d behind its own sampling, so
-                   the gathers of the secondaries run under the SpGEMM of A'A;
-  compute phase -- each rank transposes and expands ONLY its item range of A' and emits the indicator rows of that
-                   range -- disjoint rows, no further traffic.
+  * on GPUs: rank 0 asks the library for an RCCL unique id, torch.distributed broadcasts the 128 bytes, every rank
+    creates its urcco_context with (world_size, rank, id) -> ncclCommInitRank inside the library;
+  * on the CPU test-suite (kernel sources on the test-only host simulator, `gloo` group): the context gets
+    `TorchCollectives`, an implementation of the urcco_collectives callbacks on host memory through torch.distributed.
 
-Collectives per model build: per event type 2 all-reduces (int32 counts), 1 tiny all-gather of shard sizes, 1
-all-gather of row lengths + 1 of column indices; plus 1 all-reduce of the int64 work key.  The host blocks once on the
-primary's stream (bounds + sizes of A); the secondaries' shard sizes are read when their gathers are issued, by which time
-the GPU is busy with A'A.  Mahout does the same job with Spark broadcasts of the count vectors and a shuffle inside
-`A.t %*% B` (reference call sites URAlgorithm.scala:323-346).  With world_size == 1 nothing is exchanged.
+Collectives per model build: per event type 2 all-reduces (int32 column counts before / after sampling), 1 tiny
+all-gather of (rows, nnz') records and an all-gather-v of row lengths + column indices (no padding); plus 1 all-reduce of
+the int64 row-work key.  The host blocks once per event type on that event's own stream (shard sizes; for the primary
+also the range bounds).  Mahout does the same job with Spark broadcasts of the count vectors and a shuffle inside
+`A.t %*% B` (reference call sites URAlgorithm.scala:323-346).
 """
 from __future__ import annotations
 
-import contextlib
+import ctypes as C
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import _lib
-from .device import DatasetParams, DevCsr, DevIndicators, DeviceSession
+from .device import Context, DatasetParams, DevCsr, DevIndicators
 
 
 @dataclass
 class ShardedResult:
     indicators: List[DevIndicators]       # this rank's rows, one entry per event type
-    item_ranges: List[List[int]]          # per event type: world_size + 1 bounds
+    item_ranges: List[List[int]]          # per event type: world_size + 1 bounds (filled by gather_item_ranges)
     nnz_sampled: List[int]                # global nnz after down-sampling, per event type
 
 
-def _all_reduce_sum(t: torch.Tensor, group) -> None:
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+class TorchCollectives:
+    """urcco_collectives on HOST memory through a torch.distributed group (the CPU test-suite's stand-in for RCCL).
+    `local_ranks` = the global ranks this process holds (several when one process drives several simulated GPUs).  Calls
+    are recorded between group_start and group_end and executed at group_end: the j-th call of every local rank is one
+    collective."""
+
+    def __init__(self, world: int, local_ranks: Sequence[int], group=None):
+        self.world, self.local, self.group = world, list(local_ranks), group
+        self.multi_process = dist.is_initialized() and dist.get_world_size(group) > 1
+        self.pending = {}
+        self.depth = 0
+        self.error: Optional[BaseException] = None
+        self._gs = _lib.GROUP_FN(self._group_start)
+        self._ge = _lib.GROUP_FN(self._group_end)
+        self._ar = _lib.ALL_REDUCE_FN(self._all_reduce)
+        self._ag = _lib.ALL_GATHER_V_FN(self._all_gather_v)
+        self.struct = _lib.Collectives(None, self._gs, self._ge, self._ar, self._ag)
+
+    def _group_start(self, user):
+        self.depth += 1
+        return 0
+
+    def _all_reduce(self, user, rank, buf, count, dtype, stream):
+        self.pending.setdefault(rank, []).append(("ar", buf, count, dtype))
+        return 0
+
+    def _all_gather_v(self, user, rank, send, recv, offsets, counts, stream):
+        off = [offsets[r] for r in range(self.world)]
+        cnt = [counts[r] for r in range(self.world)]
+        self.pending.setdefault(rank, []).append(("ag", send, recv, off, cnt))
+        return 0
+
+    def _group_end(self, user):
+        self.depth -= 1
+        if self.depth > 0:
+            return 0
+        try:
+            n_ops = {len(v) for v in self.pending.values()}
+            assert len(n_ops) <= 1 and set(self.pending) <= set(self.local), "local ranks issued different collective sequences"
+            for j in range(n_ops.pop() if n_ops else 0):
+                ops = {r: self.pending[r][j] for r in self.local}
+                kind = ops[self.local[0]][0]
+                if kind == "ar":
+                    self._run_all_reduce(ops)
+                else:
+                    self._run_all_gather_v(ops)
+            self.pending = {}
+            return 0
+        except BaseException as e:  # surfaces as URCCO_RCCL_ERROR; the test reads .error
+            self.error = e
+            self.pending = {}
+            return 1
+
+    def _run_all_reduce(self, ops):
+        views = []
+        for r in self.local:
+            _, buf, count, dtype = ops[r]
+            ct = C.c_int32 if dtype == 0 else C.c_int64
+            views.append(np.ctypeslib.as_array((ct * count).from_address(buf)))
+        total = np.sum(views, axis=0, dtype=views[0].dtype)
+        if self.multi_process:
+            t = torch.from_numpy(total)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        for v in views:
+            v[:] = total
+
+    def _run_all_gather_v(self, ops):
+        pieces = {}
+        for r in self.local:
+            _, send, recv, off, cnt = ops[r]
+            pieces[r] = bytes((C.c_char * cnt[r]).from_address(send)) if cnt[r] > 0 else b""
+        if self.multi_process:
+            gathered = [None] * dist.get_world_size(self.group)
+            dist.all_gather_object(gathered, pieces, group=self.group)
+            for g in gathered:
+                pieces.update(g)
+        for r in self.local:
+            _, send, recv, off, cnt = ops[r]
+            for p in range(self.world):
+                assert len(pieces[p]) == cnt[p], f"rank {p} sent {len(pieces[p])} bytes, {cnt[p]} expected"
+                if cnt[p] > 0:
+                    C.memmove(recv + off[p], pieces[p], cnt[p])
 
 
-def _exchange_sizes_start(locals_: Sequence[DevCsr], group) -> torch.Tensor:
-    """(rows, nnz) of every rank's down-sampled shard for ALL event types in one tiny all-gather (device tensor: the
-    caller reads it together with the range bounds, one host sync for both)."""
-    world = dist.get_world_size(group)
-    dev = locals_[0].row_ptr.device
-    mine = torch.stack([v for m in locals_ for v in (torch.tensor(m.n_rows, dtype=torch.int64, device=dev), m.row_ptr[-1])])
-    sizes = torch.empty(world * mine.numel(), dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(sizes, mine, group=group)
-    return sizes
-
-
-def _exchange_sizes_finish(sizes: torch.Tensor, n_ds: int, group) -> List[List[List[int]]]:
-    world = dist.get_world_size(group)
-    sizes = sizes.cpu().view(world, n_ds, 2)
-    return [[[int(sizes[r, d, 0]), int(sizes[r, d, 1])] for r in range(world)] for d in range(n_ds)]
-
-
-@dataclass
-class _PendingGather:
-    local: DevCsr
-    rows: List[int]
-    nnzs: List[int]
-    n_rows_global: int
-    bufs: tuple            # (deg, all_deg, ci, all_ci): kept alive until the collectives have run
-    works: tuple
-
-
-def _gather_start(local: DevCsr, sizes: List[List[int]], n_rows_global: int, group) -> _PendingGather:
-    """Issue the all-gather of a down-sampled row shard (row lengths as int32 + column indices, padded to the largest
-    shard) without waiting for it.  sizes[r] = (rows, nnz) of rank r."""
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    dev = local.row_ptr.device
-    rows = [s[0] for s in sizes]
-    nnzs = [s[1] for s in sizes]
-    if sum(rows) != n_rows_global:
-        raise ValueError(f"row shards sum to {sum(rows)} rows, expected {n_rows_global}")
-    max_rows, max_nnz = max(max(rows), 1), max(max(nnzs), 1)
-    if local.n_rows == max_rows:
-        deg = torch.diff(local.row_ptr).to(torch.int32)
-    else:
-        deg = torch.zeros(max_rows, dtype=torch.int32, device=dev)
-        deg[: local.n_rows] = torch.diff(local.row_ptr).to(torch.int32)
-    all_deg = torch.empty(world * max_rows, dtype=torch.int32, device=dev)
-    w1 = dist.all_gather_into_tensor(all_deg, deg, group=group, async_op=True)
-    if local.col_idx.numel() >= max_nnz:
-        ci = local.col_idx[:max_nnz]              # the shard's buffer is long enough: entries behind its nnz are never read
-    else:
-        ci = torch.zeros(max_nnz, dtype=torch.int32, device=dev)
-        ci[: nnzs[rank]] = local.col_idx[: nnzs[rank]]
-    all_ci = torch.empty(world * max_nnz, dtype=torch.int32, device=dev)
-    w2 = dist.all_gather_into_tensor(all_ci, ci, group=group, async_op=True)
-    return _PendingGather(local, rows, nnzs, n_rows_global, (deg, all_deg, ci, all_ci), (w1, w2))
-
-
-def _gather_finish(p: _PendingGather) -> DevCsr:
-    """Wait for the gather (the CURRENT stream waits, not the host) and assemble the whole matrix, rows in rank order."""
-    for w in p.works:
-        w.wait()
-    _, all_deg, _, all_ci = p.bufs
-    world = len(p.rows)
-    dev = all_deg.device
-    max_rows, max_nnz = all_deg.numel() // world, all_ci.numel() // world
-    if world == 1:
-        deg_cat, col_idx = all_deg[: p.rows[0]], all_ci[: max(p.nnzs[0], 1)]
-    else:
-        deg_cat = torch.cat([all_deg[r * max_rows: r * max_rows + p.rows[r]] for r in range(world)])
-        col_idx = torch.cat([all_ci[r * max_nnz: r * max_nnz + p.nnzs[r]] for r in range(world)])
-    row_ptr = torch.zeros(p.n_rows_global + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(deg_cat, 0, out=row_ptr[1:])
-    total = sum(p.nnzs)
-    if total == 0:
-        col_idx = torch.zeros(1, dtype=torch.int32, device=dev)
-    return DevCsr(p.n_rows_global, p.local.n_cols, row_ptr, col_idx, total)
-
-
-def cross_occurrence_sharded(sess: DeviceSession, shards: Sequence[DevCsr], params: Sequence[DatasetParams], seed: int,
-                             n_rows_global: int, row_base: int, row_rate_mode: int = _lib.ROW_RATE_MAHOUT_INT_DIV,
-                             group=None, force_exchange: bool = False, pool=None) -> ShardedResult:
-    """SimilarityAnalysis.crossOccurrenceDownsampled over world_size GPUs.  shards[d] = this rank's user rows of
-    event type d (shards[0] = primary).  force_exchange runs the collectives and the range logic even in a one-rank
-    group (used to exercise the RCCL path on a single GPU).  pool (device.SessionPool, optional): the A'B_d of each
-    event type runs on its own HIP stream (as the single-GPU driver does), each behind its own gather; same results."""
-    n_ranks = dist.get_world_size(group) if dist.is_initialized() else 1
+def make_context(device, library=None, group=None, flags: int = 0, row_rate_mode: int = _lib.ROW_RATE_MAHOUT_INT_DIV) -> Context:
+    """The urcco_context of THIS rank of a one-process-per-GPU job (`group` = its torch.distributed group)."""
+    device = torch.device(device)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    exchange = n_ranks > 1 or (force_exchange and dist.is_initialized())
-    if len(shards) == 0 or len(shards) != len(params):
-        raise ValueError("need one DatasetParams per matrix and at least the primary matrix")
-    n_items_a = shards[0].n_cols
-    n_ds = len(shards)
+    exchange = world > 1 or (flags & _lib.FLAG_FORCE_EXCHANGE)
+    if not exchange:
+        return Context(device, library, 1, flags, row_rate_mode)
+    if device.type != "cuda":
+        return Context(device, library, 1, flags, row_rate_mode, world, rank, None, TorchCollectives(world, [rank], group))
+    box = [Context.unique_id(library) if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)
+    return Context(device, library, 1, flags, row_rate_mode, world, rank, box[0], None)
 
-    dev = shards[0].row_ptr.device
-    use_streams = pool is not None and dev.type == "cuda"
-    main = torch.cuda.current_stream(dev) if use_streams else None
-    streams = [pool[d].torch_stream for d in range(n_ds)] if use_streams else []
 
-    def on(d):
-        """Event type d's stream (collectives issued inside synchronise with that stream only)."""
-        return torch.cuda.stream(streams[d]) if use_streams else contextlib.nullcontext()
+def cross_occurrence_sharded(ctx: Context, shards: Sequence[DevCsr], params: Sequence[DatasetParams], seed: int, n_rows_global: int,
+                             row_base: int, wait: bool = True) -> ShardedResult:
+    """SimilarityAnalysis.crossOccurrenceDownsampled over the job's GPUs.  shards[d] = this rank's user rows
+    [row_base, row_base + n_rows) of event type d (shards[0] = primary).  Returns this rank's indicator rows as views
+    on context-owned memory (valid until the context's next build)."""
+    ctx.build([[m] for m in shards], params, seed, n_rows_global, [row_base])
+    if not wait:
+        return ShardedResult([], [], [])
+    inds = [r[0] for r in ctx.results()]
+    if ctx.collectives_error() is not None:
+        raise ctx.collectives_error()
+    return ShardedResult(inds, [], [int(i.sampled_row_ptr[-1]) if i.sampled_row_ptr.numel() else 0 for i in inds])
 
-    def worker(d) -> DeviceSession:
-        return pool[d] if use_streams else sess
 
-    def to_main(*tensors):
-        if use_streams:
-            for t in tensors:
-                t.record_stream(main)
-
-    for st in set(streams):
-        st.wait_stream(main)                          # the shards were produced on the caller's stream
-
-    def input_phase(d):
-        """raw counts -> all-reduce -> down-sampling -> all-reduce of the post-sampling counts; nothing waits for the host"""
-        m, p = shards[d], params[d]
-        w = worker(d)
-        raw = w.column_counts(m.col_idx, m.nnz_bound, m.n_cols)
-        if exchange:
-            _all_reduce_sum(raw, group)
-        local, post = w.downsample(m, m.nnz_bound, raw, seed, p.max_elements_per_row, row_rate_mode, row_base)
-        if exchange:
-            _all_reduce_sum(post, group)
-        to_main(local.row_ptr, local.col_idx, post)
-        return local, post
-
-    locals_: List[Optional[DevCsr]] = [None] * n_ds
-    counts: List[Optional[torch.Tensor]] = [None] * n_ds
-
-    if not exchange:  # (kept for callers that pass a plain session; bench.py uses device.cross_occurrence_streams at N = 1)
-        for d in range(n_ds):
-            with on(d):
-                locals_[d], counts[d] = input_phase(d)
-        for st in set(streams):
-            main.wait_stream(st)
-        a = locals_[0]
-        a_col_ptr, a_row_idx = sess.transpose(a, counts[0])
-        out = [sess.cco_rows(0, n_items_a, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, locals_[d], counts[0], counts[d], n_rows_global, d == 0,
-                             params[d]) for d in range(n_ds)]
-        return ShardedResult(out, [[0, n_items_a]] * n_ds, [-1] * n_ds)
-
-    # ---- primary event type first: its input phase, the balance key and the shard sizes of A
-    with on(0):
-        locals_[0], counts[0] = input_phase(0)
-        # Work-balanced item ranges, fixed BEFORE any whole-matrix work and before the secondary event types are even
-        # sampled: the key is the A'A row work, summed from the user shards by one all-reduce.  (The work of A'B_d for
-        # item i is the sum over the same users of their B_d row lengths, so it follows the A'A key closely; using it
-        # as the proxy lets the one blocking host read come right after the primary's short chain.)
-        work = worker(0).row_work_csr(locals_[0], locals_[0].row_ptr)
-        _all_reduce_sum(work, group)
-        sizes_dev: List[Optional[torch.Tensor]] = [None] * n_ds
-        sizes_dev[0] = _exchange_sizes_start([locals_[0]], group)
-    # ---- ranges + exchange + compute of the primary.  (The secondaries are enqueued only afterwards: measured on one
-    #      GPU, sampling them concurrently delays the primary's short dependent chain -- and with it the host read every
-    #      rank blocks on -- by more than it saves; behind A'A they fill the SpGEMM kernels' ragged tails instead.)
-    out: List[Optional[DevIndicators]] = [None] * n_ds
-    nnz_sampled = [0] * n_ds
-    with on(0):
-        bounds = worker(0).partition(work, n_ranks)                  # synchronises stream 0 (the host read)
-        lo, hi = bounds[rank], bounds[rank + 1]
-        sizes0 = _exchange_sizes_finish(sizes_dev[0], 1, group)[0]
-        nnz_sampled[0] = sum(sz[1] for sz in sizes0)
-        a = _gather_finish(_gather_start(locals_[0], sizes0, n_rows_global, group))
-        a_col_ptr, a_row_idx = worker(0).transpose(a, counts[0], lo, hi)
-        if use_streams:
-            a_ready = torch.cuda.Event()
-            a_ready.record(streams[0])
-        out[0] = worker(0).cco_rows(lo, hi, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, a, counts[0], counts[0], n_rows_global, True, params[0])
-        to_main(out[0].row_ptr, out[0].col_idx, out[0].llr, out[0].stats, a.row_ptr, a.col_idx)
-    # ---- secondaries: every input phase is enqueued on its own stream (they run under A'A); then, per event type, the
-    #      shard sizes are read (the host waits for that stream's sampling only, the GPU stays busy), the gather is issued
-    #      and A'B_d runs behind it and behind A's CSC slice
-    for d in range(1, n_ds):
-        with on(d):
-            locals_[d], counts[d] = input_phase(d)
-            sizes_dev[d] = _exchange_sizes_start([locals_[d]], group)
-    for d in range(1, n_ds):
-        with on(d):
-            sizes_d = _exchange_sizes_finish(sizes_dev[d], 1, group)[0]
-            nnz_sampled[d] = sum(sz[1] for sz in sizes_d)
-            pending = _gather_start(locals_[d], sizes_d, n_rows_global, group)
-            if use_streams:
-                streams[d].wait_event(a_ready)
-                for t in (a_col_ptr, a_row_idx, counts[0], a.row_ptr, a.col_idx):
-                    t.record_stream(streams[d])               # produced on stream 0, read here
-            b = _gather_finish(pending)
-            out[d] = worker(d).cco_rows(lo, hi, n_items_a, a_col_ptr, a_row_idx, a.nnz_bound, b, counts[0], counts[d], n_rows_global, False, params[d])
-            to_main(out[d].row_ptr, out[d].col_idx, out[d].llr, out[d].stats, b.row_ptr, b.col_idx)
-    for st in set(streams):
-        main.wait_stream(st)
-    return ShardedResult(out, [list(bounds)] * n_ds, nnz_sampled)
+def gather_item_ranges(res: ShardedResult, n_items_a: int, group=None) -> List[int]:
+    """world_size + 1 range bounds, identical on every rank (each rank contributes its own [lo, hi))."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    mine = (res.indicators[0].item_lo, res.indicators[0].item_hi)
+    if world == 1:
+        return [mine[0], mine[1]]
+    parts = [None] * world
+    dist.all_gather_object(parts, mine, group=group)
+    assert parts[0][0] == 0 and parts[-1][1] == n_items_a and all(parts[r][1] == parts[r + 1][0] for r in range(world - 1)), parts
+    return [p[0] for p in parts] + [parts[-1][1]]
 
 
 def gather_indicators_to_host(res: ShardedResult, group=None):
     """Concatenate every rank's indicator rows on every rank (host numpy): list of (row_ptr, col_idx, llr).
     Not part of the timed model build (the reference hands the rows to URModel.save per partition)."""
-    import numpy as np
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     out = []
     for ind in res.indicators:

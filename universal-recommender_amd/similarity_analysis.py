@@ -47,7 +47,8 @@ def _seed_to_int(seed: int) -> int:
 
 
 def crossOccurrenceDownsampled(datasets: Sequence[DownsamplableCrossOccurrenceDataset], randomSeed: int = 0xdeadbeef,
-                               device: int = 0, rowRateMode: int = _lib.ROW_RATE_MAHOUT_INT_DIV, library=None) -> List[IndexedDataset]:
+                               device: int = 0, rowRateMode: int = _lib.ROW_RATE_MAHOUT_INT_DIV, library=None, numGPUs: int = 1) -> List[IndexedDataset]:
+    """numGPUs: GPUs of this process to use (engine.json `numGPUs`; 0 = every visible one, collectives through RCCL)."""
     global last_stats
     if len(datasets) == 0:
         raise ValueError("crossOccurrenceDownsampled needs at least the primary dataset")
@@ -68,7 +69,7 @@ def crossOccurrenceDownsampled(datasets: Sequence[DownsamplableCrossOccurrenceDa
         arr[d].max_interesting_elements = int(ds.maxInterestingElements)
         arr[d].has_min_llr = int(ds.minLLROpt is not None)
         arr[d].min_llr = float(ds.minLLROpt) if ds.minLLROpt is not None else 0.0
-    opts = _lib.Options(device=device, row_rate_mode=rowRateMode)
+    opts = _lib.Options(device=device, row_rate_mode=rowRateMode, n_gpus=numGPUs)
     out = (_lib.Indicators * n)()
     stats = (_lib.DatasetStats * n)()
     _lib.check(lib.urcco_cross_occurrence_downsampled(arr, n, _seed_to_int(randomSeed), C.byref(opts), out, stats), lib)
@@ -93,6 +94,6 @@ def crossOccurrenceDownsampled(datasets: Sequence[DownsamplableCrossOccurrenceDa
 
 def cooccurrencesIDSs(indexedDatasets: Sequence[IndexedDataset], randomSeed: int = 0xdeadbeef, maxInterestingItemsPerThing: int = 50,
                       maxNumInteractions: int = 500, device: int = 0, rowRateMode: int = _lib.ROW_RATE_MAHOUT_INT_DIV,
-                      library=None) -> List[IndexedDataset]:
+                      library=None, numGPUs: int = 1) -> List[IndexedDataset]:
     ds = [DownsamplableCrossOccurrenceDataset(d, maxNumInteractions, maxInterestingItemsPerThing, None) for d in indexedDatasets]
-    return crossOccurrenceDownsampled(ds, randomSeed, device, rowRateMode, library)
+    return crossOccurrenceDownsampled(ds, randomSeed, device, rowRateMode, library, numGPUs)

@@ -107,3 +107,44 @@ def generate(cfg: SynthConfig, user_lo: int = 0, user_hi: Optional[int] = None):
         rp, ci = generate_event(rng, cfg, ev, primary=(e == 0), user_lo=user_lo, user_hi=user_hi)
         out.append((ev.name, ev.n_items, rp, ci))
     return out
+
+
+def generate_device(cfg: SynthConfig, device, user_lo: int = 0, user_hi: Optional[int] = None):
+    """The same generator evaluated ON THE GPU with torch (device RNG: Philox, so the streams differ from `generate`'s
+    PCG64 -- same distributions, different draws): list of (event name, n_cols, row_ptr int64 tensor, col_idx int32
+    tensor) resident in HBM.  For the 10M x 2M configurations, where the numpy path needs minutes of host time per build
+    of the inputs."""
+    import torch
+    user_hi = cfg.n_users if user_hi is None else user_hi
+    n = user_hi - user_lo
+    out = []
+    for e, ev in enumerate(cfg.events):
+        g = torch.Generator(device=device)
+        g.manual_seed(int(cfg.seed) * 1000003 + e * 7919 + user_lo)
+        deg = torch.poisson(torch.full((n,), float(ev.lam), device=device, dtype=torch.float32), generator=g).to(torch.int64) + (1 if e == 0 else 0)
+        if cfg.heavy_user_frac > 0:
+            heavy = torch.rand(n, device=device, generator=g) < cfg.heavy_user_frac
+            deg = torch.where(heavy, deg * cfg.heavy_user_mult, deg)
+        total = int(deg.sum().item())
+        u = torch.rand(total, device=device, dtype=torch.float64, generator=g)
+        if cfg.skew_top_prob > 0 and ev.n_items >= 1000:
+            n_top = max(int(ev.n_items * cfg.skew_top_frac), 1)
+            from_top = torch.rand(total, device=device, generator=g) < cfg.skew_top_prob
+            cdf = torch.from_numpy(_zipf_cdf(ev.n_items - n_top, ev.zipf_s)).to(device)
+            ranks = torch.where(from_top, (u * n_top).to(torch.int64), n_top + torch.searchsorted(cdf, u))
+        else:
+            cdf = torch.from_numpy(_zipf_cdf(ev.n_items, ev.zipf_s)).to(device)
+            ranks = torch.searchsorted(cdf, u)
+        del u
+        ranks.clamp_(max=ev.n_items - 1)
+        perm = torch.from_numpy(np.random.Generator(np.random.PCG64(cfg.seed * 1000003 + ev.n_items)).permutation(ev.n_items)).to(device)
+        key = torch.repeat_interleave(torch.arange(n, device=device, dtype=torch.int64), deg) * ev.n_items + perm[ranks]
+        del ranks, perm
+        key = torch.unique(key)                               # sorted by (user, item), duplicates collapsed
+        users_u = torch.div(key, ev.n_items, rounding_mode="floor")
+        col = (key - users_u * ev.n_items).to(torch.int32)
+        row_ptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+        torch.cumsum(torch.bincount(users_u, minlength=n), 0, out=row_ptr[1:])
+        del key, users_u
+        out.append((ev.name, ev.n_items, row_ptr, col))
+    return out

@@ -59,6 +59,12 @@ class URAlgorithmParams:
             seed=p.get("seed"))
 
 
+def _get_or_else(v, default):
+    """Scala `Option.getOrElse`: only an ABSENT value takes the default -- an explicit 0 is passed through (and rejected by the
+    library as BAD_ARG, where Mahout would misbehave), it is not silently replaced."""
+    return default if v is None else v
+
+
 class URAlgorithm:
     def __init__(self, ap: URAlgorithmParams, device: int = 0, library=None):
         self.ap = ap
@@ -86,16 +92,16 @@ class URAlgorithm:
         if not ap.indicators:                                                                   # :322
             res = SimilarityAnalysis.cooccurrencesIDSs(
                 ids, randomSeed=seed,
-                maxInterestingItemsPerThing=ap.maxCorrelatorsPerEventType or DefaultURAlgoParams.MaxCorrelatorsPerEventType,
-                maxNumInteractions=ap.maxEventsPerEventType or DefaultURAlgoParams.MaxEventsPerEventType,
+                maxInterestingItemsPerThing=_get_or_else(ap.maxCorrelatorsPerEventType, DefaultURAlgoParams.MaxCorrelatorsPerEventType),
+                maxNumInteractions=_get_or_else(ap.maxEventsPerEventType, DefaultURAlgoParams.MaxEventsPerEventType),
                 device=self.device, library=self.library)
         else:
             if len(ap.indicators) < len(ids):
                 raise IndexError("indicators(i) is matched to the event matrices by position (URAlgorithm.scala:334-340)")
             datasets = [SimilarityAnalysis.DownsamplableCrossOccurrenceDataset(
                 iD,
-                ap.indicators[i].maxItemsPerUser or DefaultURAlgoParams.MaxEventsPerEventType,
-                ap.indicators[i].maxCorrelatorsPerItem or DefaultURAlgoParams.MaxCorrelatorsPerEventType,
+                _get_or_else(ap.indicators[i].maxItemsPerUser, DefaultURAlgoParams.MaxEventsPerEventType),
+                _get_or_else(ap.indicators[i].maxCorrelatorsPerItem, DefaultURAlgoParams.MaxCorrelatorsPerEventType),
                 ap.indicators[i].minLLR) for i, iD in enumerate(ids)]
             res = SimilarityAnalysis.crossOccurrenceDownsampled(datasets, seed, device=self.device, library=self.library)
         return list(zip([n for n, _ in data.actions], res))                                    # :349
@@ -115,13 +121,13 @@ class URAlgorithm:
         pd, dp = Preparator().prepare_on_device(trainingData, sess, keep_on_device=True)
         seed = ap.seed if ap.seed is not None else int(time.time() * 1000)
         if not ap.indicators:
-            params = [DatasetParams(ap.maxEventsPerEventType or DefaultURAlgoParams.MaxEventsPerEventType,
-                                    ap.maxCorrelatorsPerEventType or DefaultURAlgoParams.MaxCorrelatorsPerEventType, None) for _ in dp.events]
+            params = [DatasetParams(_get_or_else(ap.maxEventsPerEventType, DefaultURAlgoParams.MaxEventsPerEventType),
+                                    _get_or_else(ap.maxCorrelatorsPerEventType, DefaultURAlgoParams.MaxCorrelatorsPerEventType), None) for _ in dp.events]
         else:
             if len(ap.indicators) < len(dp.events):
                 raise IndexError("indicators(i) is matched to the event matrices by position (URAlgorithm.scala:334-340)")
-            params = [DatasetParams(ap.indicators[i].maxItemsPerUser or DefaultURAlgoParams.MaxEventsPerEventType,
-                                    ap.indicators[i].maxCorrelatorsPerItem or DefaultURAlgoParams.MaxCorrelatorsPerEventType,
+            params = [DatasetParams(_get_or_else(ap.indicators[i].maxItemsPerUser, DefaultURAlgoParams.MaxEventsPerEventType),
+                                    _get_or_else(ap.indicators[i].maxCorrelatorsPerItem, DefaultURAlgoParams.MaxCorrelatorsPerEventType),
                                     ap.indicators[i].minLLR) for i in range(len(dp.events))]
         res = cross_occurrence_device(sess, [ev.matrix for ev in dp.events], params, _seed_to_int(seed))
         sess.synchronize()
