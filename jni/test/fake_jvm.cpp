@@ -1,0 +1,135 @@
+// TEST-ONLY fake JVM: implements the JNIEnv of jni/stub/jni.h on plain heap objects and drives the shim's native method
+// the way the Scala host does (Native.crossOccurrenceDownsampled).  tests/test_jni_shim.py loads this through ctypes,
+// hands it numpy CSR matrices and compares what comes back with the oracle -- so the marshalling of jni/urcco_jni.cpp is
+// executed, not only type-checked, although this image has no JDK.  It also enforces the JNI critical-section rule: no
+// JNI call may be made while a primitive array is held critically.
+#include <jni.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" jobjectArray Java_com_actionml_urcco_Native_crossOccurrenceDownsampled(JNIEnv*, jclass, jobjectArray, jobjectArray, jlongArray, jintArray,
+                                                                                jintArray, jdoubleArray, jint, jint, jint);
+extern "C" jint Java_com_actionml_urcco_Native_deviceCount(JNIEnv*, jclass);
+extern "C" void Java_com_actionml_urcco_Native_shutdown(JNIEnv*, jclass);
+
+namespace {
+
+struct IntArr : _jintArray { std::vector<jint> v; };
+struct LongArr : _jlongArray { std::vector<jlong> v; };
+struct DoubleArr : _jdoubleArray { std::vector<jdouble> v; };
+struct ObjArr : _jobjectArray { std::vector<jobject> v; };
+struct Cls : _jclass { std::string name; };
+
+struct FakeEnv : JNIEnv {
+  std::vector<_jobject*> heap;
+  int critical = 0;          // primitive arrays currently held critically
+  int violations = 0;        // JNI calls made inside a critical section
+  std::string pending;       // message of the pending exception ("" = none)
+  template <typename T> T* keep(T* o) { heap.push_back(o); return o; }
+  ~FakeEnv() override { for (_jobject* o : heap) delete o; }
+  void call() { if (critical > 0) ++violations; }
+
+  jclass FindClass(const char* name) override { call(); Cls* c = keep(new Cls()); c->name = name; return c; }
+  jint ThrowNew(jclass, const char* msg) override { call(); pending = msg ? msg : "(null)"; return 0; }
+  jsize GetArrayLength(jarray a) override {
+    call();
+    if (auto* x = dynamic_cast<IntArr*>(a)) return (jsize)x->v.size();
+    if (auto* x = dynamic_cast<LongArr*>(a)) return (jsize)x->v.size();
+    if (auto* x = dynamic_cast<DoubleArr*>(a)) return (jsize)x->v.size();
+    if (auto* x = dynamic_cast<ObjArr*>(a)) return (jsize)x->v.size();
+    return -1;
+  }
+  jobject GetObjectArrayElement(jobjectArray a, jsize i) override { call(); return static_cast<ObjArr*>(a)->v.at((size_t)i); }
+  void SetObjectArrayElement(jobjectArray a, jsize i, jobject v) override { call(); static_cast<ObjArr*>(a)->v.at((size_t)i) = v; }
+  jobjectArray NewObjectArray(jsize n, jclass, jobject init) override { call(); ObjArr* o = keep(new ObjArr()); o->v.assign((size_t)n, init); return o; }
+  jintArray NewIntArray(jsize n) override { call(); IntArr* o = keep(new IntArr()); o->v.assign((size_t)n, 0); return o; }
+  jlongArray NewLongArray(jsize n) override { call(); LongArr* o = keep(new LongArr()); o->v.assign((size_t)n, 0); return o; }
+  jdoubleArray NewDoubleArray(jsize n) override { call(); DoubleArr* o = keep(new DoubleArr()); o->v.assign((size_t)n, 0.0); return o; }
+  jint* GetIntArrayElements(jintArray a, jboolean* c) override { call(); if (c) *c = 0; return static_cast<IntArr*>(a)->v.data(); }
+  jlong* GetLongArrayElements(jlongArray a, jboolean* c) override { call(); if (c) *c = 0; return static_cast<LongArr*>(a)->v.data(); }
+  jdouble* GetDoubleArrayElements(jdoubleArray a, jboolean* c) override { call(); if (c) *c = 0; return static_cast<DoubleArr*>(a)->v.data(); }
+  void ReleaseIntArrayElements(jintArray, jint*, jint) override { call(); }
+  void ReleaseLongArrayElements(jlongArray, jlong*, jint) override { call(); }
+  void ReleaseDoubleArrayElements(jdoubleArray, jdouble*, jint) override { call(); }
+  void SetIntArrayRegion(jintArray a, jsize s, jsize n, const jint* b) override { call(); memcpy(static_cast<IntArr*>(a)->v.data() + s, b, sizeof(jint) * (size_t)n); }
+  void SetLongArrayRegion(jlongArray a, jsize s, jsize n, const jlong* b) override { call(); memcpy(static_cast<LongArr*>(a)->v.data() + s, b, sizeof(jlong) * (size_t)n); }
+  void SetDoubleArrayRegion(jdoubleArray a, jsize s, jsize n, const jdouble* b) override {
+    call();
+    memcpy(static_cast<DoubleArr*>(a)->v.data() + s, b, sizeof(jdouble) * (size_t)n);
+  }
+  void* GetPrimitiveArrayCritical(jarray a, jboolean* c) override {  // allowed inside a critical section
+    ++critical;
+    if (c) *c = 0;
+    if (auto* x = dynamic_cast<IntArr*>(a)) return x->v.data();
+    if (auto* x = dynamic_cast<LongArr*>(a)) return x->v.data();
+    if (auto* x = dynamic_cast<DoubleArr*>(a)) return x->v.data();
+    return nullptr;
+  }
+  void ReleasePrimitiveArrayCritical(jarray, void*, jint) override { --critical; }
+};
+
+}  // namespace
+
+extern "C" {
+
+// Runs Native.crossOccurrenceDownsampled on n datasets.  Outputs are malloc'ed (release with fake_jvm_free):
+// out_row_ptr[d] (n_items_a + 1), out_col_idx[d], out_llr[d] (out_nnz[d] entries).  Returns 0, or 1 with the pending
+// RuntimeException's message in err, or 2 on a JNI rule violation.
+int fake_jvm_cross_occurrence(int n, const int64_t* n_rows, const int64_t* n_cols, const int64_t* const* row_ptr, const int32_t* const* col_idx,
+                              const int32_t* max_rows, const int32_t* max_int, const double* min_llr, int seed, int device, int n_gpus,
+                              int64_t** out_row_ptr, int32_t** out_col_idx, double** out_llr, int64_t* out_nnz, int64_t* out_rows, char* err,
+                              int err_cap) {
+  FakeEnv env;
+  ObjArr* rps = env.keep(new ObjArr());
+  ObjArr* cis = env.keep(new ObjArr());
+  LongArr* nc = env.keep(new LongArr());
+  IntArr* mr = env.keep(new IntArr());
+  IntArr* mi = env.keep(new IntArr());
+  DoubleArr* ml = env.keep(new DoubleArr());
+  for (int d = 0; d < n; ++d) {
+    LongArr* rp = env.keep(new LongArr());
+    rp->v.assign(row_ptr[d], row_ptr[d] + n_rows[d] + 1);
+    IntArr* ci = env.keep(new IntArr());
+    ci->v.assign(col_idx[d], col_idx[d] + row_ptr[d][n_rows[d]]);
+    rps->v.push_back(rp);
+    cis->v.push_back(ci);
+    nc->v.push_back(n_cols[d]);
+    mr->v.push_back(max_rows[d]);
+    mi->v.push_back(max_int[d]);
+    ml->v.push_back(min_llr[d]);
+  }
+  jobjectArray res = Java_com_actionml_urcco_Native_crossOccurrenceDownsampled(&env, nullptr, rps, cis, nc, mr, mi, ml, seed, device, n_gpus);
+  if (env.violations > 0 || env.critical != 0) {
+    snprintf(err, (size_t)err_cap, "JNI rule violated: %d call(s) inside a critical section, %d array(s) still held", env.violations, env.critical);
+    return 2;
+  }
+  if (!env.pending.empty() || !res) {
+    snprintf(err, (size_t)err_cap, "%s", env.pending.empty() ? "null result without exception" : env.pending.c_str());
+    return 1;
+  }
+  ObjArr* r = static_cast<ObjArr*>(res);
+  for (int d = 0; d < n; ++d) {
+    LongArr* rp = static_cast<LongArr*>(r->v.at((size_t)3 * d));
+    IntArr* ci = static_cast<IntArr*>(r->v.at((size_t)3 * d + 1));
+    DoubleArr* ll = static_cast<DoubleArr*>(r->v.at((size_t)3 * d + 2));
+    out_rows[d] = (int64_t)rp->v.size() - 1;
+    out_nnz[d] = (int64_t)ci->v.size();
+    out_row_ptr[d] = (int64_t*)malloc(sizeof(int64_t) * rp->v.size());
+    out_col_idx[d] = (int32_t*)malloc(sizeof(int32_t) * (ci->v.size() + 1));
+    out_llr[d] = (double*)malloc(sizeof(double) * (ll->v.size() + 1));
+    memcpy(out_row_ptr[d], rp->v.data(), sizeof(int64_t) * rp->v.size());
+    memcpy(out_col_idx[d], ci->v.data(), sizeof(int32_t) * ci->v.size());
+    memcpy(out_llr[d], ll->v.data(), sizeof(double) * ll->v.size());
+  }
+  return 0;
+}
+
+void fake_jvm_free(void* p) { free(p); }
+int fake_jvm_device_count(void) { return Java_com_actionml_urcco_Native_deviceCount(nullptr, nullptr); }
+void fake_jvm_shutdown(void) { Java_com_actionml_urcco_Native_shutdown(nullptr, nullptr); }
+
+}  // extern "C"

@@ -8,6 +8,7 @@ for s in "$@"; do
   case $s in
     tests)      timeout 1500 python -m pytest tests -m gpu -x -q --durations=8 > $O/pytest.log 2>&1; tail -15 $O/pytest.log ;;
     tests_fast) timeout 900 python -m pytest tests -m gpu -x -q --ignore=tests/test_gpu_scale.py > $O/pytest_fast.log 2>&1; tail -5 $O/pytest_fast.log ;;
+    tests_k)    timeout 900 python -m pytest tests -m gpu -x -q -k "$TESTS_K" > $O/pytest_k.log 2>&1; tail -8 $O/pytest_k.log ;;
     ablate)     timeout 600 python tools/ablate.py 1.0 ${ABLATE:-0,1024,2048,4096,8192,15360} > $O/ablate.log 2>&1; cat $O/ablate.log ;;
     rowscan)    timeout 600 python tools/rowscan_bench.py 1.0 ${ROWSCAN:-0,32,64,128,224,4096} > $O/rowscan.log 2>&1; cat $O/rowscan.log ;;
     bench)      timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.log 2>&1; tail -c 9000 $O/bench.log ;;
