@@ -283,3 +283,25 @@ def test_many_ties_at_the_cut_after_skipped_column_passes(sim_session):
         a = _tied_block(n_users, 40000, 2, np.arange(30000, 30400), extra_rows=[(0, np.arange(20000, 20040))] + extra)
         _, _, st = compare_with_oracle(sim_session, [a, a], [P(100000, 50), P(100000, 50)], 3, exact_ids=True)
         assert st[1][0][3] + st[1][0][4] > 0
+
+
+def test_row_scan_threshold_table_forms(sim_session):
+    """sampleDownAndBinarize, the three ways the per-column thresholds reach the keep decision: (a) LDS tables of the hot
+    columns (bitmap + rank + 16-bit prefix, the full threshold on a prefix tie -- with ~10^6 sampled interactions a few
+    dozen ties occur), (b) more hot columns than the LDS pool holds -> global gather decided on the device, (c) a matrix
+    too wide for the bitmap -> global gather decided on the host.  Both row-rate modes."""
+    rng = np.random.default_rng(33)
+    dev = sim_session.device
+    cases = [(rand_csr(rng, 60000, 30000, 25, zipf_s=1.0), 20),        # (a) ~2K hot columns carrying most interactions
+             (rand_csr(rng, 20000, 60000, 60, zipf_s=0.3), 3),          # (b) nearly every one of 60K columns is hot
+             (rand_csr(rng, 30000, 400000, 40, zipf_s=0.9), 5)]         # (c) 400K columns: bitmap does not fit
+    for m, max_n in cases:
+        raw_ref = O.column_counts(m)
+        raw = torch.from_numpy(raw_ref).to(dev)
+        for mode in (0, 1):
+            out, post = sim_session.downsample(to_dev(m, dev), m.nnz, raw, 1234, max_n, mode)
+            sim_session.synchronize()
+            ref = O.downsample(m, raw_ref, 1234, max_n, mode)
+            assert np.array_equal(out.row_ptr.cpu().numpy(), ref.row_ptr)
+            assert np.array_equal(out.col_idx.cpu().numpy()[:ref.nnz], ref.col_idx)
+            assert np.array_equal(post.cpu().numpy()[:m.n_cols], O.column_counts(ref))

@@ -63,7 +63,7 @@ hipError_t launch_column_counts(hipStream_t st, int n_cu, const int32_t* col_idx
 constexpr int64_t PH_MIN_NNZ = 1 << 20;
 int64_t column_counts_scratch_bytes(int64_t nnz, int32_t n_cols);
 hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_idx, int64_t nnz, const int64_t* nnz_dev, int32_t n_cols,
-                                            int32_t* counts, char* scratch, int debug);
+                                            int32_t* counts, char* scratch);
 
 // scans: out[i] = sum_{t<i} in[t], out[n] = total.  tile_sums scratch: ceil(n / SCAN_TILE) + 1 int64.
 hipError_t launch_scan_i32(hipStream_t st, const int32_t* in, int64_t n, int64_t* out, int64_t* tile_sums);
@@ -73,7 +73,9 @@ hipError_t launch_scan_i32(hipStream_t st, const int32_t* in, int64_t n, int64_t
 hipError_t launch_downsample_flags(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
                                    int32_t n_cols, const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n,
                                    int row_rate_mode, int64_t row_base, int64_t* tile_rows, unsigned long long* flags, int64_t* tile_count,
-                                   int32_t* post_counts, int debug);
+                                   int32_t* post_counts, char* hot_scratch, int debug);
+// scratch for the LDS-resident thresholds of the sampled ("hot") columns; 0 = the matrix is too wide, pass nullptr
+int64_t downsample_hot_scratch_bytes(int32_t n_cols);
 hipError_t launch_downsample_scan(hipStream_t st, int64_t nnz, int64_t* tile_count);
 hipError_t launch_downsample_compact(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
                                      const int64_t* tile_rows, const unsigned long long* flags, const int64_t* tile_off, int64_t* out_row_ptr,

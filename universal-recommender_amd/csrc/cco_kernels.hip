@@ -248,9 +248,62 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_downsweep_kernel(Load ld, i
   if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_sums[n_tiles];
 }
 
+// One 1024-thread block scans the whole input, 8 consecutive values per thread and pass: for inputs of a few tens of
+// thousands of values one launch instead of the three of the tiled scan (each of which is a ~5 us kernel plus a boundary).
+constexpr int SB_THREADS = 1024;
+constexpr int SB_ITEMS = 8;
+constexpr int64_t SB_MAX = 32768;
+template <typename Load>
+__global__ __launch_bounds__(SB_THREADS) void scan_block_kernel(Load ld, int64_t n, int64_t* __restrict__ out) {
+  __shared__ long long s_wave[SB_THREADS / WAVE];
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+  long long carry = 0;
+  for (int64_t base = 0; base < n; base += SB_THREADS * SB_ITEMS) {  // block-uniform trip count
+    const int64_t first = base + (int64_t)threadIdx.x * SB_ITEMS;
+    long long x[SB_ITEMS];
+    long long sum = 0;
+    if (first + SB_ITEMS <= n) {
+      ld.load8(first, x);
+    } else {
+#pragma unroll
+      for (int q = 0; q < SB_ITEMS; ++q) x[q] = first + q < n ? ld(first + q) : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < SB_ITEMS; ++q) sum += x[q];
+    long long inc = sum;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const long long o = shfl_up_i64(inc, d);
+      if (lane >= d) inc += o;
+    }
+    if (lane == WAVE - 1) s_wave[wave] = inc;
+    __syncthreads();
+    long long before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SB_THREADS / WAVE; ++w) {
+      const long long sw = s_wave[w];
+      if (w < wave) before += sw;
+      tot += sw;
+    }
+    __syncthreads();
+    long long run = carry + before + inc - sum;
+#pragma unroll
+    for (int q = 0; q < SB_ITEMS; ++q) {
+      if (first + q < n) out[first + q] = run;
+      run += x[q];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) out[n] = carry;
+}
+
 template <typename Load>
 static hipError_t launch_scan(hipStream_t st, Load ld, int64_t n, int64_t* out, int64_t* tile_sums, const int64_t* n_live = nullptr) {
   if (n <= 0) return hipMemsetAsync(out, 0, sizeof(int64_t), st);
+  if (n <= SB_MAX) {
+    hipLaunchKernelGGL((scan_block_kernel<Load>), dim3(1), dim3(SB_THREADS), 0, st, ld, n, out);
+    return hipGetLastError();
+  }
   const int64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   hipLaunchKernelGGL((scan_reduce_kernel<Load>), dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, st, ld, n, tile_sums, n_live);
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, tile_sums, n_tiles);
@@ -307,41 +360,10 @@ __global__ __launch_bounds__(256) void ph_count_kernel(const int32_t* __restrict
   for (int b = threadIdx.x; b < n_buckets; b += 256) part_counts[(int64_t)b * n_parts + blockIdx.x] = s_cnt[b];
 }
 
+// The part's ids are first grouped by bucket in LDS (the (bucket, part) slice lengths are already known from the offsets),
+// then every slice leaves as one run of consecutive 2-byte stores -- whole lines instead of 16384 isolated 2-byte writes
+// (measured on config 3: -4 % on the column-count stage against scattering straight to global memory).
 __global__ __launch_bounds__(256) void ph_scatter_kernel(const int32_t* __restrict__ ci, int64_t nnz_host, const int64_t* __restrict__ nnz_dev,
-                                                         int n_buckets, int64_t n_parts, const int64_t* __restrict__ offsets,
-                                                         unsigned short* __restrict__ bucketed, int vec_ok) {
-  __shared__ long long s_base[PH_MAX_BUCKETS];
-  __shared__ int s_cur[PH_MAX_BUCKETS];
-  const int64_t nnz = nnz_dev ? *nnz_dev : nnz_host;
-  for (int b = threadIdx.x; b < n_buckets; b += 256) {
-    s_base[b] = offsets[(int64_t)b * n_parts + blockIdx.x];
-    s_cur[b] = 0;
-  }
-  __syncthreads();
-  const int64_t e0 = (int64_t)blockIdx.x * PH_PART;
-  const int64_t e1 = e0 + PH_PART < nnz ? e0 + PH_PART : nnz;
-  for (int64_t e = e0 + (int64_t)threadIdx.x * 4; e < e1; e += 256 * 4) {
-    int cols[4];
-    int n = 4;
-    if (vec_ok && e + 3 < e1) {
-      const int4 x = *reinterpret_cast<const int4*>(ci + e);
-      cols[0] = x.x; cols[1] = x.y; cols[2] = x.z; cols[3] = x.w;
-    } else {
-      n = (int)(e1 - e < 4 ? e1 - e : 4);
-      for (int q = 0; q < n; ++q) cols[q] = ci[e + q];
-    }
-    for (int q = 0; q < n; ++q) {
-      const int b = cols[q] >> PH_BITS;
-      const int r = atomicAdd(&s_cur[b], 1);
-      bucketed[s_base[b] + r] = (unsigned short)(cols[q] & (PH_BUCKET - 1));
-    }
-  }
-}
-
-// CANDIDATE (round 2, unmeasured; debug 2048 switches it on): the part's ids are first grouped by bucket in LDS (the
-// (bucket, part) slice lengths are already known from the offsets), then every slice leaves as one run of consecutive
-// 2-byte stores -- whole lines instead of 16384 isolated 2-byte writes.
-__global__ __launch_bounds__(256) void ph_scatter_staged_kernel(const int32_t* __restrict__ ci, int64_t nnz_host, const int64_t* __restrict__ nnz_dev,
                                                                 int n_buckets, int64_t n_parts, const int64_t* __restrict__ offsets,
                                                                 unsigned short* __restrict__ bucketed, int vec_ok) {
   __shared__ long long s_base[PH_MAX_BUCKETS];
@@ -474,7 +496,7 @@ int64_t column_counts_scratch_bytes(int64_t nnz, int32_t n_cols) {
 }
 
 hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_idx, int64_t nnz, const int64_t* nnz_dev, int32_t n_cols,
-                                            int32_t* counts, char* scratch, int debug) {
+                                            int32_t* counts, char* scratch) {
   const int n_buckets = (int)(((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS);
   const int64_t n_parts = (nnz + PH_PART - 1) / PH_PART;
   const int64_t m = (int64_t)n_buckets * n_parts;
@@ -490,11 +512,7 @@ hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_i
   hipLaunchKernelGGL(ph_count_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, part_counts, vec_ok);
   hipError_t e = launch_scan_i32(st, part_counts, m, offsets, tile_sums);
   if (e != hipSuccess) return e;
-  if (debug & 2048)
-    hipLaunchKernelGGL(ph_scatter_staged_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, offsets, bucketed,
-                       vec_ok);
-  else
-    hipLaunchKernelGGL(ph_scatter_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, offsets, bucketed, vec_ok);
+  hipLaunchKernelGGL(ph_scatter_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, offsets, bucketed, vec_ok);
   hipLaunchKernelGGL(ph_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, offsets, n_buckets, n_parts, blk_prefix);
   hipLaunchKernelGGL(ph_hist_kernel, dim3((unsigned)max_blocks), dim3(256), 0, st, bucketed, offsets, n_buckets, n_parts, blk_prefix, partial);
   hipLaunchKernelGGL(ph_reduce_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, partial, blk_prefix, n_cols, counts);
@@ -524,15 +542,8 @@ static_assert((DS_TILE & (DS_TILE - 1)) == 0, "tile index by shift");
 
 constexpr unsigned long long RATE_ONE = 1ull << 53;  // threshold of a sample rate of 1.0 (every 53-bit hash passes)
 
-// perThingSampleRate = min(max, n) / n of sampleDownAndBinarize, as the integer threshold floor(rate * 2^53)
-__global__ __launch_bounds__(256) void sample_threshold_kernel(const int32_t* __restrict__ raw_counts, int32_t n_cols, int32_t max_n,
-                                                               unsigned long long* __restrict__ thresholds) {
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= n_cols) return;
-  const double n_thing = (double)raw_counts[j];
-  const double dmax = (double)max_n;
-  thresholds[j] = n_thing <= dmax ? RATE_ONE : (unsigned long long)((dmax / n_thing) * 9007199254740992.0);
-}
+// perThingSampleRate = min(max, n) / n of sampleDownAndBinarize is kept as the integer threshold floor(rate * 2^53)
+// (sample_prepare_kernel below): u01 = m * 2^-53 with integer m, so  u01 <= rate  <=>  m <= floor(rate * 2^53).
 
 // first idx in [lo, hi] with rp[idx] > e   (rp[hi] > e guaranteed by the caller)
 __device__ __forceinline__ int64_t upper_bound_i64(const int64_t* __restrict__ rp, int64_t lo, int64_t hi, int64_t e) {
@@ -585,9 +596,8 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_
   // slice rp[r_s .. r_e]: r_s = the last row known to start at or before e0, r_e = the first row starting at or after e1
   const int64_t gp0 = g[tile];
   const int64_t g0 = gp0 >> 1, g1 = g[tile + 1] >> 1;
-  // CANDIDATE (round 2, unmeasured; debug 4096): the "row starts at the tile start" bit travels in the tile table, which
-  // takes one dependent global load out of every tile's prologue
-  const int64_t r_s = (debug & 4096) ? ((gp0 & 1) ? g0 : g0 - 1) : (rp[g0] == e0 ? g0 : g0 - 1);
+  // the "row starts exactly at the tile start" bit travels in the tile table: one dependent global load less per tile
+  const int64_t r_s = (gp0 & 1) ? g0 : g0 - 1;
   const int64_t r_e = g1 < n_rows ? g1 : n_rows;
   const int64_t n_slice = r_e - r_s + 1;
   const bool in_lds = n_slice <= DS_SLICE;
@@ -742,21 +752,283 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_compact_kernel(int64_t 
   }
 }
 
+// --------------------------------------------------------------------------------------------
+// Flags, second form: persistent 512-thread blocks (two 256-thread teams, one tile each per round) that keep the sample
+// thresholds of the HOT columns in LDS.  Only columns with more than `max` interactions have a rate below 1.0 -- a few
+// thousand under a Zipf catalogue, yet they carry most of the interactions -- so the per-interaction 8-byte threshold
+// gather from L2 (one address per clock per CU: a third of the first form's time) becomes three LDS reads:
+//     hot bitmap word (64 columns)  ->  rank of the column among the hot ones  ->  16-bit threshold prefix
+// The 16-bit prefix decides unless the hash's top 16 bits tie with it (one interaction in 65 536), in which case the full
+// threshold is fetched.  Tables: HOT_POOL bytes of LDS carved at run time (8 + 2 bytes per 64 columns, 2 per hot column);
+// matrices whose tables do not fit (more than ~290K columns, or too many hot ones: decided on the device, the hot count
+// is only known there) keep the global gather inside the same kernel.
+// --------------------------------------------------------------------------------------------
+constexpr int FL_TEAMS = 2;
+constexpr int FL_THREADS = FL_TEAMS * DS_THREADS;
+constexpr int HOT_POOL = 45056;  // bytes: with two row_ptr slices (32.8 KB) a block stays under 80 KB -> two blocks per CU
+
+// per 64 columns: hot_bits[w] bit c = column 64 w + c is sampled (raw count > max); hot_cnt[w] = popcount
+__global__ __launch_bounds__(256) void sample_prepare_kernel(const int32_t* __restrict__ raw_counts, int32_t n_cols, int32_t max_n,
+                                                             unsigned long long* __restrict__ thresholds, int32_t n_words,
+                                                             unsigned long long* __restrict__ hot_bits, int32_t* __restrict__ hot_cnt) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;  // the grid covers n_cols rounded up to 64: whole waves
+  bool hot = false;
+  if (j < n_cols) {
+    const double n_thing = (double)raw_counts[j];
+    const double dmax = (double)max_n;
+    hot = n_thing > dmax;
+    thresholds[j] = hot ? (unsigned long long)((dmax / n_thing) * 9007199254740992.0) : RATE_ONE;
+  }
+  const unsigned long long word = __ballot(hot);
+  if ((threadIdx.x & (WAVE - 1)) == 0 && hot_bits && (j >> 6) < n_words) {
+    hot_bits[j >> 6] = word;
+    hot_cnt[j >> 6] = __popcll(word);
+  }
+}
+
+// hot_thr16[rank of column j among the hot columns] = top 16 bits of its 53-bit threshold
+__global__ __launch_bounds__(256) void hot_compact_kernel(int32_t n_cols, const unsigned long long* __restrict__ thresholds,
+                                                          const unsigned long long* __restrict__ hot_bits, const int64_t* __restrict__ hot_rank,
+                                                          unsigned short* __restrict__ hot_thr16, int64_t cap) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_cols) return;
+  const unsigned long long word = hot_bits[j >> 6];
+  const int c = (int)(j & 63);
+  if ((word >> c) & 1ull) {
+    const int64_t idx = hot_rank[j >> 6] + __popcll(c == 0 ? 0ull : (word & ((1ull << c) - 1ull)));
+    if (idx < cap) hot_thr16[idx] = (unsigned short)(thresholds[j] >> 37);
+  }
+}
+
+__global__ __launch_bounds__(FL_THREADS, 4) void downsample_flags_lds_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                                             int64_t nnz, int64_t n_tiles, const int64_t* __restrict__ g,
+                                                                             const unsigned long long* __restrict__ thresholds, int32_t n_words,
+                                                                             const unsigned long long* __restrict__ hot_bits,
+                                                                             const int64_t* __restrict__ hot_rank,
+                                                                             const unsigned short* __restrict__ hot_thr16, uint32_t seed, int32_t max_n,
+                                                                             int row_rate_mode, int64_t row_base, unsigned long long* __restrict__ flags,
+                                                                             int64_t* __restrict__ tile_count, int32_t* __restrict__ post_counts,
+                                                                             int vec_ok) {
+  __shared__ int s_rel[FL_TEAMS][DS_SLICE];
+  __shared__ int s_cnt[FL_TEAMS][DS_THREADS / WAVE];
+  __shared__ __attribute__((aligned(16))) unsigned char s_pool[HOT_POOL];
+  const int team = threadIdx.x / DS_THREADS;
+  const int tl = threadIdx.x % DS_THREADS;
+  const int lane = threadIdx.x & (WAVE - 1);
+  // ---- tables of the hot columns (block-uniform decision; hot_rank[n_words] = number of hot columns)
+  const int words_pad = (n_words + 3) & ~3;
+  unsigned long long* s_bits = reinterpret_cast<unsigned long long*>(s_pool);
+  unsigned short* s_rank = reinterpret_cast<unsigned short*>(s_pool + (size_t)words_pad * 8);
+  unsigned short* s_thr = reinterpret_cast<unsigned short*>(s_pool + (size_t)words_pad * 10);
+  bool lds_tables = false;
+  if (hot_bits != nullptr && (int64_t)words_pad * 10 + 64 <= HOT_POOL) {
+    const int64_t n_hot = hot_rank[n_words];
+    const int64_t cap = (HOT_POOL - (int64_t)words_pad * 10) / 2;
+    if (n_hot <= cap && n_hot < 65536) {
+      lds_tables = true;
+      for (int w = threadIdx.x; w < n_words; w += FL_THREADS) {
+        s_bits[w] = hot_bits[w];
+        s_rank[w] = (unsigned short)hot_rank[w];
+      }
+      for (int t = threadIdx.x; t < (int)n_hot; t += FL_THREADS) s_thr[t] = hot_thr16[t];
+    }
+  }
+  __syncthreads();
+  const double dmax = (double)max_n;
+  const int64_t tiles_per_round = (int64_t)gridDim.x * FL_TEAMS;
+  const int64_t rounds = (n_tiles + tiles_per_round - 1) / tiles_per_round;  // block-uniform trip count
+  for (int64_t round = 0; round < rounds; ++round) {
+    const int64_t tile = (round * gridDim.x + blockIdx.x) * FL_TEAMS + team;
+    const bool live = tile < n_tiles;  // team-uniform
+    const int64_t e0 = tile * DS_TILE;
+    const int64_t e1 = live ? ((e0 + DS_TILE < nnz) ? e0 + DS_TILE : nnz) : e0;
+    int cols[DS_ITERS][4];
+#pragma unroll
+    for (int it = 0; it < DS_ITERS; ++it) {
+      const int64_t e = e0 + ((int64_t)it * DS_THREADS + tl) * 4;
+      if (live && vec_ok && e + 3 < nnz) {
+        const int4 x = *reinterpret_cast<const int4*>(ci + e);
+        cols[it][0] = x.x; cols[it][1] = x.y; cols[it][2] = x.z; cols[it][3] = x.w;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cols[it][q] = (live && e + q < nnz) ? ci[e + q] : 0;
+      }
+    }
+    int64_t r_s = 0, r_e = 0, n_slice = 1;
+    bool in_lds = true;
+    if (live) {
+      const int64_t gp0 = g[tile];
+      const int64_t g0 = gp0 >> 1, g1 = g[tile + 1] >> 1;
+      r_s = (gp0 & 1) ? g0 : g0 - 1;
+      r_e = g1 < n_rows ? g1 : n_rows;
+      n_slice = r_e - r_s + 1;
+      in_lds = n_slice <= DS_SLICE;
+      if (in_lds)
+        for (int64_t t = tl; t < n_slice; t += DS_THREADS) s_rel[team][t] = (int)(rp[r_s + t] - e0);
+    }
+    __syncthreads();
+    int rrel[DS_ITERS];
+#pragma unroll
+    for (int it = 0; it < DS_ITERS; ++it) rrel[it] = 0;
+    if (live && in_lds) {
+      const int last = (int)n_slice - 1;
+      int top = 1;
+      while (top < last) top <<= 1;
+      for (int sft = top >> 1; sft > 0; sft >>= 1) {
+#pragma unroll
+        for (int it = 0; it < DS_ITERS; ++it) {
+          const int el = (it * DS_THREADS + tl) * 4;
+          const int idx = rrel[it] + sft;
+          if (idx < last && s_rel[team][idx] <= el) rrel[it] = idx;
+        }
+      }
+    }
+    int kept = 0;
+#pragma unroll
+    for (int it = 0; it < DS_ITERS; ++it) {  // block-uniform trip count: the wave ops below are legal
+      const int64_t e = e0 + ((int64_t)it * DS_THREADS + tl) * 4;
+      unsigned nib = 0;
+      if (e < e1) {
+        const int el = (int)(e - e0);
+        int64_t r;
+        int64_t r_beg, r_end;
+        if (in_lds) {
+          r = r_s + rrel[it];
+          r_beg = s_rel[team][rrel[it]];
+          r_end = s_rel[team][rrel[it] + 1];
+        } else {
+          r = upper_bound_i64(rp, r_s, r_e, e) - 1;
+          r_beg = rp[r] - e0;
+          r_end = rp[r + 1] - e0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t rel = el + q;
+          if (e + q < e1) {
+            while (rel >= r_end) {  // next non-empty row
+              ++r;
+              r_beg = r_end;
+              r_end = in_lds ? (int64_t)s_rel[team][r + 1 - r_s] : rp[r + 1] - e0;
+            }
+            const int j = cols[it][q];
+            const int64_t n_row = r_end - r_beg;
+            // keep  <=>  hash <= perRow threshold  &&  hash <= perThing threshold   (a rate of 1.0 always passes)
+            bool keep = true;
+            bool need_hash = false;
+            unsigned long long thr_row = RATE_ONE;
+            if (n_row > (int64_t)max_n) {
+              if (row_rate_mode == 0) keep = false;  // Int / Int = 0
+              else {
+                thr_row = (unsigned long long)((dmax / (double)n_row) * 9007199254740992.0);
+                need_hash = true;
+              }
+            }
+            int hot_idx = -1;
+            bool hot = false;
+            if (keep) {
+              if (lds_tables) {
+                const unsigned long long word = s_bits[j >> 6];
+                const int c = j & 63;
+                if ((word >> c) & 1ull) {
+                  hot = true;
+                  hot_idx = (int)s_rank[j >> 6] + __popcll(c == 0 ? 0ull : (word & ((1ull << c) - 1ull)));
+                }
+              } else {
+                hot = true;  // gather form: every column consults its threshold
+              }
+            }
+            if (keep && (hot || need_hash)) {
+              const unsigned long long h = hash53(seed, (uint32_t)(row_base + r), (uint32_t)j);
+              if (h > thr_row) keep = false;
+              if (keep && hot) {
+                if (lds_tables) {
+                  const unsigned h16 = (unsigned)(h >> 37), t16 = (unsigned)s_thr[hot_idx];
+                  if (h16 > t16) keep = false;
+                  else if (h16 == t16 && h > thresholds[j]) keep = false;  // prefix tie: the full threshold decides
+                } else if (h > thresholds[j]) {
+                  keep = false;
+                }
+              }
+            }
+            if (keep) {
+              nib |= 1u << q;
+              if (post_counts) atomicAdd(&post_counts[j], 1);
+            }
+          }
+        }
+      }
+      kept += __popc(nib);
+      unsigned long long m = (unsigned long long)nib << ((lane & 15) * 4);
+      m |= shfl_xor_u64(m, 1);
+      m |= shfl_xor_u64(m, 2);
+      m |= shfl_xor_u64(m, 4);
+      m |= shfl_xor_u64(m, 8);
+      if (live && (lane & 15) == 0) flags[tile * DS_WORDS + ((it * DS_THREADS + tl) >> 4)] = m;
+    }
+    for (int msk = 1; msk < WAVE; msk <<= 1) kept += __shfl_xor(kept, msk);
+    if (lane == 0) s_cnt[team][tl / WAVE] = kept;
+    __syncthreads();  // also: every read of this round's row_ptr slice precedes the next round's fill
+    if (live && tl == 0) {
+      int tot = 0;
+#pragma unroll
+      for (int w = 0; w < DS_THREADS / WAVE; ++w) tot += s_cnt[team][w];
+      tile_count[tile] = tot;
+    }
+  }
+}
+
 hipError_t launch_downsample_flags(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
                                    int32_t n_cols, const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n,
                                    int row_rate_mode, int64_t row_base, int64_t* tile_rows, unsigned long long* flags, int64_t* tile_count,
-                                   int32_t* post_counts, int debug) {
+                                   int32_t* post_counts, char* hot_scratch, int debug) {
   if (nnz == 0) return hipSuccess;
-  hipLaunchKernelGGL(sample_threshold_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, raw_counts, n_cols, max_n, thresholds);
   const int64_t tiles = (nnz + DS_TILE - 1) / DS_TILE;
+  const int n_words = (int)(((int64_t)n_cols + 63) >> 6);
+  // hot-column tables (second form) only when the bitmap + ranks fit the LDS pool; debug 16384 forces the first form
+  const bool tables = hot_scratch != nullptr && !(debug & 16384) && (int64_t)((n_words + 3) & ~3) * 10 + 64 <= HOT_POOL;
+  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  unsigned long long* hot_bits = nullptr;
+  int32_t* hot_cnt = nullptr;
+  int64_t* hot_rank = nullptr;
+  unsigned short* hot_thr16 = nullptr;
+  if (tables) {
+    char* p = hot_scratch;
+    hot_bits = reinterpret_cast<unsigned long long*>(p); p += al((int64_t)n_words * 8);
+    hot_cnt = reinterpret_cast<int32_t*>(p); p += al((int64_t)n_words * 4);
+    hot_rank = reinterpret_cast<int64_t*>(p); p += al(((int64_t)n_words + 1) * 8);
+    hot_thr16 = reinterpret_cast<unsigned short*>(p);
+  }
+  hipLaunchKernelGGL(sample_prepare_kernel, dim3((unsigned)(((int64_t)n_words * 64 + 255) / 256)), dim3(256), 0, st, raw_counts, n_cols, max_n, thresholds,
+                     n_words, hot_bits, hot_cnt);
   int64_t rblocks = (n_rows + 1 + 255) / 256;
   const int64_t rcap = (int64_t)n_cu * 8;
   if (rblocks > rcap) rblocks = rcap;
   hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, n_rows, row_ptr, tiles, tile_rows);
   const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
-  hipLaunchKernelGGL(downsample_flags_kernel, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds,
-                     seed, max_n, row_rate_mode, row_base, flags, tile_count, post_counts, vec_ok, debug);
+  if (debug & 16384) {
+    hipLaunchKernelGGL(downsample_flags_kernel, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds,
+                       seed, max_n, row_rate_mode, row_base, flags, tile_count, post_counts, vec_ok, debug);
+    return hipGetLastError();
+  }
+  if (tables) {
+    hipLaunchKernelGGL((scan_block_kernel<LoadI32>), dim3(1), dim3(SB_THREADS), 0, st, LoadI32{hot_cnt}, (int64_t)n_words, hot_rank);  // n_words <= 4500
+    hipLaunchKernelGGL(hot_compact_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, n_cols, thresholds, hot_bits, hot_rank, hot_thr16,
+                       (int64_t)(HOT_POOL / 2));
+  }
+  int64_t blocks = (tiles + FL_TEAMS - 1) / FL_TEAMS;
+  const int64_t cap = (int64_t)n_cu * 2;  // two resident blocks per CU (LDS)
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(downsample_flags_lds_kernel, dim3((unsigned)blocks), dim3(FL_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tiles, tile_rows, thresholds,
+                     n_words, hot_bits, hot_rank, hot_thr16, seed, max_n, row_rate_mode, row_base, flags, tile_count, post_counts, vec_ok);
   return hipGetLastError();
+}
+
+// bytes of scratch for the hot-column tables of launch_downsample_flags (0: the matrix is too wide for them)
+int64_t downsample_hot_scratch_bytes(int32_t n_cols) {
+  const int64_t n_words = ((int64_t)n_cols + 63) >> 6;
+  if (((n_words + 3) & ~(int64_t)3) * 10 + 64 > HOT_POOL) return 0;
+  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  return al(n_words * 8) + al(n_words * 4) + al((n_words + 1) * 8) + al(HOT_POOL);
 }
 
 // single block of 1024 threads, 8 consecutive values each: in-place exclusive scan of v[0..n), v[n] = total.  The tile
@@ -1303,32 +1575,13 @@ __device__ __forceinline__ bool best_before(unsigned long long ka, int ca, unsig
   return ka > kb || (ka == kb && ca < cb);
 }
 
-// Returns false only if every slot was probed without finding the key or a free slot -- impossible while the binning
-// rule holds (the table always has room for the row's distinct columns); the bound keeps a broken invariant from
-// turning into a hung GPU and is reported through stats[17].
+// Claim-first insert into the packed open-addressing table: one CAS per probe (a new column costs one LDS round trip, a
+// known one two), a single rolled loop with one exit (an unrolled probe loop compiles to more exec-mask bookkeeping than
+// useful work; measured -4 % on the one-wave class against load-then-CAS).  Returns false only if every slot was probed
+// without finding the key or a free slot -- impossible while the binning rule holds (the table always has room for the
+// row's distinct columns); the bound keeps a broken invariant from turning into a hung GPU and is reported through
+// stats[1 + 4 * NBINS].
 __device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int count_bits, unsigned mask, int hshift, bool ident) {
-  unsigned h = ident ? (key - 1u) : ((key * 0x9E3779B1u) >> hshift);
-  const unsigned tagged = key << count_bits;
-  for (unsigned probe = 0; probe <= mask; ++probe) {
-    unsigned v = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (v == 0u) {
-      v = atomicCAS(&tab[h], 0u, tagged | 1u);
-      if (v == 0u) return true;
-    }
-    if ((v >> count_bits) == key) {
-      atomicAdd(&tab[h], 1u);
-      return true;
-    }
-    h = (h + 1u) & mask;
-  }
-  return false;
-}
-
-// CANDIDATE (round 2, unmeasured; debug 8192 selects the kernels instantiated with it): claim-first insert.  One CAS per
-// probe instead of a relaxed load followed by a CAS (a new column costs 1 LDS round trip instead of 2, a known one 2
-// as before), a single rolled loop with one exit -- the unrolled probe loop of tab_insert compiles to more exec-mask
-// bookkeeping (SALU) than useful work.
-__device__ __forceinline__ bool tab_insert_claim_first(unsigned* tab, unsigned key, int count_bits, unsigned mask, int hshift, bool ident) {
   unsigned h = ident ? (key - 1u) : ((key * 0x9E3779B1u) >> hshift);
   const unsigned fresh = (key << count_bits) | 1u;
   bool ok = false;
@@ -1387,7 +1640,7 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
   return base + inc - v;
 }
 
-template <int T, int E, int U, int INS = 0>
+template <int T, int E, int U>
 __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T == 64 ? 6 : 1)) void cco_rows_kernel(CcoArgs a, int bin) {
   constexpr int BLOCK = T < 256 ? 256 : T;
   constexpr int TEAMS = BLOCK / T;
@@ -1520,8 +1773,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
               if ((unsigned)x < nb) {
                 if (a.debug & 1) {  // ablation: gather only
                   if (jj[x] == 0xffffffffu) tab[0] = 1u;
-                } else if (!(INS ? tab_insert_claim_first(tab, jj[x] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)
-                                 : tab_insert(tab, jj[x] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident))) {
+                } else if (!tab_insert(tab, jj[x] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) {
                   atomicAdd(a.err, 1ull);
                 }
               }
@@ -1778,39 +2030,13 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
       }
       team_sync<T>();
       const unsigned n = (a.debug & 16) ? 0u : *nsel;  // ablation 16: no ranking / output
-      if (n <= (unsigned)WAVE && (a.debug & 1024)) {
-        // CANDIDATE (round 2, unmeasured; debug 1024 switches it on): the <= 64 survivors are put in output order by a
-        // bitonic network in the registers of the team's first wave (21 compare-exchange steps of 3 shuffles) instead
-        // of n rounds of LDS-broadcast counting, and leave as contiguous stores.
-        if (tl < WAVE) {  // wave-uniform
-          unsigned long long mk = (unsigned)lane < n ? selk[lane] : 0ull;
-          int mc = (unsigned)lane < n ? (int)selc[lane] : 0x7fffffff;
-          for (int k2 = 2; k2 <= WAVE; k2 <<= 1) {
-            for (int j = k2 >> 1; j > 0; j >>= 1) {
-              const unsigned long long ok = shfl_xor_u64(mk, j);
-              const int oc = __shfl_xor(mc, j);
-              const bool keep_better = ((lane & j) == 0) == ((lane & k2) == 0);  // lower lane of a descending block
-              const bool take = keep_better ? best_before(ok, oc, mk, mc) : best_before(mk, mc, ok, oc);
-              if (take) {
-                mk = ok;
-                mc = oc;
-              }
-            }
-          }
-          if ((unsigned)lane < n) {
-            a.out_idx[obase + lane] = mc;
-            a.out_llr[obase + lane] = __longlong_as_double((long long)mk);
-          }
-        }
-      } else {
-        for (unsigned t = (unsigned)tl; t < n; t += T) {
-          const unsigned long long mk = selk[t];
-          const int mc = (int)selc[t];
-          unsigned rank = 0;
-          for (unsigned u = 0; u < n; ++u) rank += best_before(selk[u], (int)selc[u], mk, mc) ? 1u : 0u;
-          a.out_idx[obase + rank] = mc;
-          a.out_llr[obase + rank] = __longlong_as_double((long long)mk);
-        }
+      for (unsigned t = (unsigned)tl; t < n; t += T) {
+        const unsigned long long mk = selk[t];
+        const int mc = (int)selc[t];
+        unsigned rank = 0;
+        for (unsigned u = 0; u < n; ++u) rank += best_before(selk[u], (int)selc[u], mk, mc) ? 1u : 0u;
+        a.out_idx[obase + rank] = mc;
+        a.out_llr[obase + rank] = __longlong_as_double((long long)mk);
       }
       if (tl == 0) a.out_count[i - a.item_lo] = (int)n;
     }
@@ -2094,26 +2320,11 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
   // so no host synchronisation sits between binning and the SpGEMM.
   switch (bin) {
     case 0: hipLaunchKernelGGL(cco_rows_micro_kernel, dim3((unsigned)(n_cu * blocks_per_cu(0))), dim3(256), 0, st, args); break;
-    case 1:
-      if (args.debug & 8192) hipLaunchKernelGGL((cco_rows_kernel<64, E0, 1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1);
-      else hipLaunchKernelGGL((cco_rows_kernel<64, E0, 1>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1);
-      break;
-    case 2:
-      if (args.debug & 8192) hipLaunchKernelGGL((cco_rows_kernel<256, E1S, 1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(256), 0, st, args, 2);
-      else hipLaunchKernelGGL((cco_rows_kernel<256, E1S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(256), 0, st, args, 2);
-      break;
-    case 3:
-      if (args.debug & 8192) hipLaunchKernelGGL((cco_rows_kernel<256, E1, 1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(3))), dim3(256), 0, st, args, 3);
-      else hipLaunchKernelGGL((cco_rows_kernel<256, E1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(3))), dim3(256), 0, st, args, 3);
-      break;
-    case 4:
-      if (args.debug & 8192) hipLaunchKernelGGL((cco_rows_kernel<512, E2S, 1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(4))), dim3(512), 0, st, args, 4);
-      else hipLaunchKernelGGL((cco_rows_kernel<512, E2S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(4))), dim3(512), 0, st, args, 4);
-      break;
-    case 5:
-      if (args.debug & 8192) hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5);
-      else hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 1>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5);
-      break;
+    case 1: hipLaunchKernelGGL((cco_rows_kernel<64, E0, 1>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1); break;
+    case 2: hipLaunchKernelGGL((cco_rows_kernel<256, E1S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(256), 0, st, args, 2); break;
+    case 3: hipLaunchKernelGGL((cco_rows_kernel<256, E1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(3))), dim3(256), 0, st, args, 3); break;
+    case 4: hipLaunchKernelGGL((cco_rows_kernel<512, E2S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(4))), dim3(512), 0, st, args, 4); break;
+    case 5: hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 1>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5); break;
     default: hipLaunchKernelGGL(cco_rows_global_kernel, dim3((unsigned)(args.g_blocks > 0 ? args.g_blocks : 1)), dim3(GB_THREADS), 0, st, args); break;
   }
   return hipGetLastError();
