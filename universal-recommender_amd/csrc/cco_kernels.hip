@@ -27,6 +27,12 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
   hi = __shfl_xor(hi, m);
   return ((unsigned long long)hi << 32) | lo;
 }
+__device__ __forceinline__ long long shfl_i64(long long v, int src) {
+  unsigned lo = (unsigned)v, hi = (unsigned)((unsigned long long)v >> 32);
+  lo = __shfl(lo, src);
+  hi = __shfl(hi, src);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ long long shfl_up_i64(long long v, unsigned d) {
   unsigned lo = (unsigned)v, hi = (unsigned)((unsigned long long)v >> 32);
   lo = __shfl_up(lo, d);
@@ -144,9 +150,10 @@ struct LoadI64 {
     }
   }
 };
-// inclusive scan of one value per thread over the block; returns the exclusive prefix, *total = block sum.
-// All 256 threads must call it.
-__device__ __forceinline__ long long block_exclusive_scan(long long v, long long* s_wave /*[SCAN_THREADS/WAVE]*/, long long* total) {
+// inclusive scan of one value per thread over a block of NT threads; returns the exclusive prefix, *total = block sum.
+// All NT threads must call it.
+template <int NT = SCAN_THREADS>
+__device__ __forceinline__ long long block_exclusive_scan(long long v, long long* s_wave /*[NT / WAVE]*/, long long* total) {
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
   long long inc = v;
 #pragma unroll
@@ -158,7 +165,7 @@ __device__ __forceinline__ long long block_exclusive_scan(long long v, long long
   __syncthreads();
   long long base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < SCAN_THREADS / WAVE; ++w) {
+  for (int w = 0; w < NT / WAVE; ++w) {
     const long long sw = s_wave[w];
     if (w < wave) base += sw;
     tot += sw;
@@ -337,43 +344,53 @@ constexpr int PH_PART = 16384;
 constexpr int PH_CHUNK = 32768;
 constexpr int PH_MAX_BUCKETS = 1024;
 
+// Eight private copies of the bucket counters, chosen by lane: with a few dozen buckets (25 for a 200K-column matrix) the 64
+// lanes of a wave would otherwise queue on a handful of LDS addresses.
+constexpr int PH_COPIES = 8;
 __global__ __launch_bounds__(256) void ph_count_kernel(const int32_t* __restrict__ ci, int64_t nnz_host, const int64_t* __restrict__ nnz_dev,
                                                        int n_buckets, int64_t n_parts, int32_t* __restrict__ part_counts, int vec_ok) {
-  __shared__ int s_cnt[PH_MAX_BUCKETS];
+  __shared__ int s_cnt[PH_COPIES * PH_MAX_BUCKETS];
   const int64_t nnz = nnz_dev ? *nnz_dev : nnz_host;
-  for (int b = threadIdx.x; b < n_buckets; b += 256) s_cnt[b] = 0;
+  for (int b = threadIdx.x; b < PH_COPIES * n_buckets; b += 256) s_cnt[b] = 0;
   __syncthreads();
+  int* mine = s_cnt + (threadIdx.x & (PH_COPIES - 1)) * n_buckets;
   const int64_t e0 = (int64_t)blockIdx.x * PH_PART;
   const int64_t e1 = e0 + PH_PART < nnz ? e0 + PH_PART : nnz;
   for (int64_t e = e0 + (int64_t)threadIdx.x * 4; e < e1; e += 256 * 4) {
     if (vec_ok && e + 3 < e1) {
       const int4 x = *reinterpret_cast<const int4*>(ci + e);
-      atomicAdd(&s_cnt[x.x >> PH_BITS], 1);
-      atomicAdd(&s_cnt[x.y >> PH_BITS], 1);
-      atomicAdd(&s_cnt[x.z >> PH_BITS], 1);
-      atomicAdd(&s_cnt[x.w >> PH_BITS], 1);
+      atomicAdd(&mine[x.x >> PH_BITS], 1);
+      atomicAdd(&mine[x.y >> PH_BITS], 1);
+      atomicAdd(&mine[x.z >> PH_BITS], 1);
+      atomicAdd(&mine[x.w >> PH_BITS], 1);
     } else {
-      for (int q = 0; q < 4 && e + q < e1; ++q) atomicAdd(&s_cnt[ci[e + q] >> PH_BITS], 1);
+      for (int q = 0; q < 4 && e + q < e1; ++q) atomicAdd(&mine[ci[e + q] >> PH_BITS], 1);
     }
   }
   __syncthreads();
-  for (int b = threadIdx.x; b < n_buckets; b += 256) part_counts[(int64_t)b * n_parts + blockIdx.x] = s_cnt[b];
+  for (int b = threadIdx.x; b < n_buckets; b += 256) {
+    int tot = 0;
+#pragma unroll
+    for (int c = 0; c < PH_COPIES; ++c) tot += s_cnt[c * n_buckets + b];
+    part_counts[(int64_t)b * n_parts + blockIdx.x] = tot;
+  }
 }
 
 // The part's ids are first grouped by bucket in LDS (the (bucket, part) slice lengths are already known from the offsets),
 // then every slice leaves as one run of consecutive 2-byte stores -- whole lines instead of 16384 isolated 2-byte writes
 // (measured on config 3: -4 % on the column-count stage against scattering straight to global memory).
-__global__ __launch_bounds__(256) void ph_scatter_kernel(const int32_t* __restrict__ ci, int64_t nnz_host, const int64_t* __restrict__ nnz_dev,
+constexpr int PHS_THREADS = 512;  // 48 KB of LDS per block: three blocks per CU, so 512 threads keep 24 waves per CU in flight
+__global__ __launch_bounds__(PHS_THREADS) void ph_scatter_kernel(const int32_t* __restrict__ ci, int64_t nnz_host, const int64_t* __restrict__ nnz_dev,
                                                                 int n_buckets, int64_t n_parts, const int64_t* __restrict__ offsets,
                                                                 unsigned short* __restrict__ bucketed, int vec_ok) {
   __shared__ long long s_base[PH_MAX_BUCKETS];
   __shared__ int s_loc[PH_MAX_BUCKETS + 1];  // where the bucket's run starts inside the staging array
   __shared__ int s_cur[PH_MAX_BUCKETS];
   __shared__ unsigned short s_stage[PH_PART];
-  __shared__ long long s_wave[SCAN_THREADS / WAVE];
+  __shared__ long long s_wave[PHS_THREADS / WAVE];
   const int64_t nnz = nnz_dev ? *nnz_dev : nnz_host;
   int carry = 0;
-  for (int base = 0; base < n_buckets; base += 256) {  // block-uniform: exclusive prefix of this part's slice lengths
+  for (int base = 0; base < n_buckets; base += PHS_THREADS) {  // block-uniform: exclusive prefix of this part's slice lengths
     const int b = base + threadIdx.x;
     long long len = 0;
     if (b < n_buckets) {
@@ -384,7 +401,7 @@ __global__ __launch_bounds__(256) void ph_scatter_kernel(const int32_t* __restri
       s_cur[b] = 0;
     }
     long long tot;
-    const long long ex = block_exclusive_scan(len, s_wave, &tot);
+    const long long ex = block_exclusive_scan<PHS_THREADS>(len, s_wave, &tot);
     if (b < n_buckets) s_loc[b] = carry + (int)ex;
     carry += (int)tot;
   }
@@ -392,7 +409,7 @@ __global__ __launch_bounds__(256) void ph_scatter_kernel(const int32_t* __restri
   __syncthreads();
   const int64_t e0 = (int64_t)blockIdx.x * PH_PART;
   const int64_t e1 = e0 + PH_PART < nnz ? e0 + PH_PART : nnz;
-  for (int64_t e = e0 + (int64_t)threadIdx.x * 4; e < e1; e += 256 * 4) {
+  for (int64_t e = e0 + (int64_t)threadIdx.x * 4; e < e1; e += PHS_THREADS * 4) {
     int cols[4];
     int n = 4;
     if (vec_ok && e + 3 < e1) {
@@ -410,7 +427,7 @@ __global__ __launch_bounds__(256) void ph_scatter_kernel(const int32_t* __restri
   __syncthreads();
   // one wave per bucket run, lanes on consecutive ids
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-  for (int b = wave; b < n_buckets; b += 256 / WAVE) {
+  for (int b = wave; b < n_buckets; b += PHS_THREADS / WAVE) {
     const int l0 = s_loc[b], len = s_loc[b + 1] - l0;
     const long long dst = s_base[b];
     for (int t = lane; t < len; t += WAVE) bucketed[dst + t] = s_stage[l0 + t];
@@ -512,7 +529,7 @@ hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_i
   hipLaunchKernelGGL(ph_count_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, part_counts, vec_ok);
   hipError_t e = launch_scan_i32(st, part_counts, m, offsets, tile_sums);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(ph_scatter_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, offsets, bucketed, vec_ok);
+  hipLaunchKernelGGL(ph_scatter_kernel, dim3((unsigned)n_parts), dim3(PHS_THREADS), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, offsets, bucketed, vec_ok);
   hipLaunchKernelGGL(ph_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, offsets, n_buckets, n_parts, blk_prefix);
   hipLaunchKernelGGL(ph_hist_kernel, dim3((unsigned)max_blocks), dim3(256), 0, st, bucketed, offsets, n_buckets, n_parts, blk_prefix, partial);
   hipLaunchKernelGGL(ph_reduce_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, partial, blk_prefix, n_cols, counts);
@@ -890,69 +907,80 @@ __global__ __launch_bounds__(FL_THREADS, 4) void downsample_flags_lds_kernel(int
       unsigned nib = 0;
       if (e < e1) {
         const int el = (int)(e - e0);
-        int64_t r;
-        int64_t r_beg, r_end;
-        if (in_lds) {
-          r = r_s + rrel[it];
-          r_beg = s_rel[team][rrel[it]];
-          r_end = s_rel[team][rrel[it] + 1];
-        } else {
-          r = upper_bound_i64(rp, r_s, r_e, e) - 1;
-          r_beg = rp[r] - e0;
-          r_end = rp[r + 1] - e0;
+        // The four column lookups of the vector are independent of the row walk: all their LDS reads (bitmap word, rank,
+        // threshold prefix) are issued up front, level by level, so that their latencies overlap.
+        unsigned t16[4];   // threshold prefix of a hot column; 0x10000 = not sampled (rate 1.0)
+        if (lds_tables) {
+          unsigned long long word[4];
+          unsigned rk[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            word[q] = s_bits[cols[it][q] >> 6];
+            rk[q] = s_rank[cols[it][q] >> 6];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c = cols[it][q] & 63;
+            const bool hot = (word[q] >> c) & 1ull;
+            const unsigned idx = rk[q] + (unsigned)__popcll(c == 0 ? 0ull : (word[q] & ((1ull << c) - 1ull)));
+            t16[q] = hot ? (unsigned)s_thr[idx] : 0x10000u;
+          }
         }
+        unsigned long long thr_col[4];
+        if (!lds_tables) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) thr_col[q] = thresholds[cols[it][q]];
+        }
+        int r_rel;          // slice-relative row of the current entry
+        int r_beg, r_end;   // its extent relative to e0 (a row has < 2^31 entries)
+        int64_t r_glob = 0;
+        if (in_lds) {
+          r_rel = rrel[it];
+          r_beg = s_rel[team][r_rel];
+          r_end = s_rel[team][r_rel + 1];
+        } else {
+          r_glob = upper_bound_i64(rp, r_s, r_e, e) - 1;
+          r_rel = (int)(r_glob - r_s);
+          r_beg = (int)(rp[r_glob] - e0);
+          r_end = (int)(rp[r_glob + 1] - e0);
+        }
+        uint32_t row_of[4];
+        int n_row_of[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int64_t rel = el + q;
+          const int rel = el + q;
           if (e + q < e1) {
             while (rel >= r_end) {  // next non-empty row
-              ++r;
+              ++r_rel;
               r_beg = r_end;
-              r_end = in_lds ? (int64_t)s_rel[team][r + 1 - r_s] : rp[r + 1] - e0;
+              r_end = in_lds ? s_rel[team][r_rel + 1] : (int)(rp[r_s + r_rel + 1] - e0);
             }
-            const int j = cols[it][q];
-            const int64_t n_row = r_end - r_beg;
+          }
+          row_of[q] = (uint32_t)(row_base + r_s + r_rel);
+          n_row_of[q] = r_end - r_beg;
+        }
+        unsigned long long h[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = hash53(seed, row_of[q], (uint32_t)cols[it][q]);  // four independent multiply chains
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (e + q < e1) {
             // keep  <=>  hash <= perRow threshold  &&  hash <= perThing threshold   (a rate of 1.0 always passes)
             bool keep = true;
-            bool need_hash = false;
-            unsigned long long thr_row = RATE_ONE;
-            if (n_row > (int64_t)max_n) {
+            if (n_row_of[q] > max_n) {
               if (row_rate_mode == 0) keep = false;  // Int / Int = 0
-              else {
-                thr_row = (unsigned long long)((dmax / (double)n_row) * 9007199254740992.0);
-                need_hash = true;
-              }
+              else keep = h[q] <= (unsigned long long)((dmax / (double)n_row_of[q]) * 9007199254740992.0);
             }
-            int hot_idx = -1;
-            bool hot = false;
-            if (keep) {
-              if (lds_tables) {
-                const unsigned long long word = s_bits[j >> 6];
-                const int c = j & 63;
-                if ((word >> c) & 1ull) {
-                  hot = true;
-                  hot_idx = (int)s_rank[j >> 6] + __popcll(c == 0 ? 0ull : (word & ((1ull << c) - 1ull)));
-                }
-              } else {
-                hot = true;  // gather form: every column consults its threshold
-              }
-            }
-            if (keep && (hot || need_hash)) {
-              const unsigned long long h = hash53(seed, (uint32_t)(row_base + r), (uint32_t)j);
-              if (h > thr_row) keep = false;
-              if (keep && hot) {
-                if (lds_tables) {
-                  const unsigned h16 = (unsigned)(h >> 37), t16 = (unsigned)s_thr[hot_idx];
-                  if (h16 > t16) keep = false;
-                  else if (h16 == t16 && h > thresholds[j]) keep = false;  // prefix tie: the full threshold decides
-                } else if (h > thresholds[j]) {
-                  keep = false;
-                }
-              }
+            if (lds_tables) {
+              const unsigned h16 = (unsigned)(h[q] >> 37);
+              if (h16 > t16[q]) keep = false;
+              else if (h16 == t16[q] && h[q] > thresholds[cols[it][q]]) keep = false;  // prefix tie: the full threshold decides
+            } else if (h[q] > thr_col[q]) {
+              keep = false;
             }
             if (keep) {
               nib |= 1u << q;
-              if (post_counts) atomicAdd(&post_counts[j], 1);
+              if (post_counts) atomicAdd(&post_counts[cols[it][q]], 1);
             }
           }
         }
@@ -1358,30 +1386,45 @@ hipError_t launch_xlx_table(hipStream_t st, double* tab) {
 // ============================================================================================
 __global__ __launch_bounds__(256) void expand_prepare_kernel(const int64_t* __restrict__ a_cp, int32_t n_items_a, const int32_t* __restrict__ a_ri,
                                                              const int64_t* __restrict__ b_rp, int64_t cap, int64_t* __restrict__ pstart,
-                                                             int32_t* __restrict__ plen) {
+                                                             int32_t* __restrict__ plen, int vec_ok) {
   const int64_t nnz = a_cp[n_items_a];
   int64_t lim = (nnz / SCAN_TILE + 1) * SCAN_TILE;  // the scan skips tiles that start at or beyond nnz
   if (lim > cap) lim = cap;
-  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < lim; p += (int64_t)gridDim.x * 256) {
-    int32_t len = 0;
-    int64_t s = 0;
-    if (p < nnz) {
-      const int u = a_ri[p];
-      s = b_rp[u];
-      len = (int32_t)(b_rp[u + 1] - s);
+  // Four consecutive CSC entries per thread: one 16-byte load of the user ids, then all eight row_ptr gathers in flight
+  // together (the kernel is a chain of two dependent random loads; with one entry per thread the memory system holds too
+  // few of them to cover the ~2 us latency of a gather that misses L2).
+  for (int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; p0 < lim; p0 += (int64_t)gridDim.x * 256 * 4) {
+    int u[4];
+    if (vec_ok && p0 + 3 < nnz) {
+      const int4 x = *reinterpret_cast<const int4*>(a_ri + p0);
+      u[0] = x.x; u[1] = x.y; u[2] = x.z; u[3] = x.w;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) u[q] = p0 + q < nnz ? a_ri[p0 + q] : -1;
     }
-    pstart[p] = s;
-    plen[p] = len;
+    int64_t s[4], e[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s[q] = u[q] >= 0 ? b_rp[u[q]] : 0;
+      e[q] = u[q] >= 0 ? b_rp[u[q] + 1] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (p0 + q < lim) {
+        pstart[p0 + q] = s[q];
+        plen[p0 + q] = (int32_t)(e[q] - s[q]);
+      }
   }
 }
 
 hipError_t launch_expand_prepare(hipStream_t st, int n_cu, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx,
                                  const int64_t* b_row_ptr, int64_t cap, int64_t* pstart, int32_t* plen, int64_t* wp, int64_t* tile_sums) {
   if (cap > 0) {
-    int64_t blocks = (cap + 255) / 256;
+    int64_t blocks = (cap + 1023) / 1024;
     const int64_t lim = (int64_t)n_cu * 16;
     if (blocks > lim) blocks = lim;
-    hipLaunchKernelGGL(expand_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, cap, pstart, plen);
+    const int vec_ok = (reinterpret_cast<uintptr_t>(a_row_idx) & 15) == 0;
+    hipLaunchKernelGGL(expand_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, cap, pstart, plen, vec_ok);
   }
   return launch_scan(st, LoadI32{plen}, cap, wp, tile_sums, a_col_ptr + n_items_a);
 }
@@ -1476,22 +1519,28 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo,
   if (threadIdx.x < BIN_COLS) tile_counts[(int64_t)blockIdx.x * BIN_COLS + threadIdx.x] = s_acc[threadIdx.x];
 }
 
-// single block: per-bin exclusive scan over tiles (in place), totals -> bin_off / stats
-__global__ __launch_bounds__(BIN_THREADS) void bin_scan_kernel(int64_t* __restrict__ tile_counts, int64_t n_tiles, int32_t* __restrict__ bin_off,
-                                                               int64_t* __restrict__ stats) {
-  __shared__ long long s_wave[SCAN_THREADS / WAVE];
+// single block: per-column exclusive scan over the tiles (in place), totals -> bin_off / stats.  One wave per column of
+// the tile table (rows / pairs / users per bin, total pairs), 16 columns at a time.
+constexpr int BS_THREADS = 1024;
+__global__ __launch_bounds__(BS_THREADS) void bin_scan_kernel(int64_t* __restrict__ tile_counts, int64_t n_tiles, int32_t* __restrict__ bin_off,
+                                                              int64_t* __restrict__ stats) {
   __shared__ long long s_tot[BIN_COLS];
-  for (int k = 0; k < BIN_COLS; ++k) {
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+  for (int k = wave; k < BIN_COLS; k += BS_THREADS / WAVE) {  // wave-uniform
     long long carry = 0;
-    for (int64_t base = 0; base < n_tiles; base += BIN_THREADS) {
-      const int64_t i = base + threadIdx.x;
+    for (int64_t base = 0; base < n_tiles; base += WAVE) {
+      const int64_t i = base + lane;
       const long long v = i < n_tiles ? tile_counts[i * BIN_COLS + k] : 0;
-      long long tot;
-      const long long ex = block_exclusive_scan(v, s_wave, &tot);
-      if (i < n_tiles) tile_counts[i * BIN_COLS + k] = carry + ex;
-      carry += tot;
+      long long inc = v;
+#pragma unroll
+      for (int d = 1; d < WAVE; d <<= 1) {
+        const long long o = shfl_up_i64(inc, d);
+        if (lane >= d) inc += o;
+      }
+      if (i < n_tiles) tile_counts[i * BIN_COLS + k] = carry + inc - v;
+      carry += shfl_i64(inc, WAVE - 1);
     }
-    if (threadIdx.x == 0) s_tot[k] = carry;
+    if (lane == 0) s_tot[k] = carry;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1542,7 +1591,7 @@ hipError_t launch_binning(hipStream_t st, int32_t item_lo, int32_t n, const int6
   }
   const int64_t n_tiles = ((int64_t)n + BIN_TILE - 1) / BIN_TILE;
   hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)n_tiles), dim3(BIN_THREADS), 0, st, item_lo, n, work, cnt_a, n_cols_b, count_bits, k, tile_counts);
-  hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(BIN_THREADS), 0, st, tile_counts, n_tiles, bin_off, stats);
+  hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(BS_THREADS), 0, st, tile_counts, n_tiles, bin_off, stats);
   hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)n_tiles), dim3(BIN_THREADS), 0, st, item_lo, n, work, cnt_a, n_cols_b, count_bits, k,
                      tile_counts, bin_off, bin_rows);
   return hipGetLastError();
