@@ -73,9 +73,7 @@ hipError_t launch_scan_i32(hipStream_t st, const int32_t* in, int64_t n, int64_t
 hipError_t launch_downsample_flags(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
                                    int32_t n_cols, const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n,
                                    int row_rate_mode, int64_t row_base, int64_t* tile_rows, unsigned long long* flags, int64_t* tile_count,
-                                   int32_t* post_counts, char* hot_scratch, int debug);
-// scratch for the LDS-resident thresholds of the sampled ("hot") columns; 0 = the matrix is too wide, pass nullptr
-int64_t downsample_hot_scratch_bytes(int32_t n_cols);
+                                   int32_t* post_counts, int debug);
 hipError_t launch_downsample_scan(hipStream_t st, int64_t nnz, int64_t* tile_count);
 hipError_t launch_downsample_compact(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
                                      const int64_t* tile_rows, const unsigned long long* flags, const int64_t* tile_off, int64_t* out_row_ptr,

@@ -559,9 +559,6 @@ static_assert((DS_TILE & (DS_TILE - 1)) == 0, "tile index by shift");
 
 constexpr unsigned long long RATE_ONE = 1ull << 53;  // threshold of a sample rate of 1.0 (every 53-bit hash passes)
 
-// perThingSampleRate = min(max, n) / n of sampleDownAndBinarize is kept as the integer threshold floor(rate * 2^53)
-// (sample_prepare_kernel below): u01 = m * 2^-53 with integer m, so  u01 <= rate  <=>  m <= floor(rate * 2^53).
-
 // first idx in [lo, hi] with rp[idx] > e   (rp[hi] > e guaranteed by the caller)
 __device__ __forceinline__ int64_t upper_bound_i64(const int64_t* __restrict__ rp, int64_t lo, int64_t hi, int64_t e) {
   while (lo < hi) {
@@ -769,294 +766,31 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_compact_kernel(int64_t 
   }
 }
 
-// --------------------------------------------------------------------------------------------
-// Flags, second form: persistent 512-thread blocks (two 256-thread teams, one tile each per round) that keep the sample
-// thresholds of the HOT columns in LDS.  Only columns with more than `max` interactions have a rate below 1.0 -- a few
-// thousand under a Zipf catalogue, yet they carry most of the interactions -- so the per-interaction 8-byte threshold
-// gather from L2 (one address per clock per CU: a third of the first form's time) becomes three LDS reads:
-//     hot bitmap word (64 columns)  ->  rank of the column among the hot ones  ->  16-bit threshold prefix
-// The 16-bit prefix decides unless the hash's top 16 bits tie with it (one interaction in 65 536), in which case the full
-// threshold is fetched.  Tables: HOT_POOL bytes of LDS carved at run time (8 + 2 bytes per 64 columns, 2 per hot column);
-// matrices whose tables do not fit (more than ~290K columns, or too many hot ones: decided on the device, the hot count
-// is only known there) keep the global gather inside the same kernel.
-// --------------------------------------------------------------------------------------------
-constexpr int FL_TEAMS = 2;
-constexpr int FL_THREADS = FL_TEAMS * DS_THREADS;
-constexpr int HOT_POOL = 45056;  // bytes: with two row_ptr slices (32.8 KB) a block stays under 80 KB -> two blocks per CU
-
-// per 64 columns: hot_bits[w] bit c = column 64 w + c is sampled (raw count > max); hot_cnt[w] = popcount
-__global__ __launch_bounds__(256) void sample_prepare_kernel(const int32_t* __restrict__ raw_counts, int32_t n_cols, int32_t max_n,
-                                                             unsigned long long* __restrict__ thresholds, int32_t n_words,
-                                                             unsigned long long* __restrict__ hot_bits, int32_t* __restrict__ hot_cnt) {
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;  // the grid covers n_cols rounded up to 64: whole waves
-  bool hot = false;
-  if (j < n_cols) {
-    const double n_thing = (double)raw_counts[j];
-    const double dmax = (double)max_n;
-    hot = n_thing > dmax;
-    thresholds[j] = hot ? (unsigned long long)((dmax / n_thing) * 9007199254740992.0) : RATE_ONE;
-  }
-  const unsigned long long word = __ballot(hot);
-  if ((threadIdx.x & (WAVE - 1)) == 0 && hot_bits && (j >> 6) < n_words) {
-    hot_bits[j >> 6] = word;
-    hot_cnt[j >> 6] = __popcll(word);
-  }
-}
-
-// hot_thr16[rank of column j among the hot columns] = top 16 bits of its 53-bit threshold
-__global__ __launch_bounds__(256) void hot_compact_kernel(int32_t n_cols, const unsigned long long* __restrict__ thresholds,
-                                                          const unsigned long long* __restrict__ hot_bits, const int64_t* __restrict__ hot_rank,
-                                                          unsigned short* __restrict__ hot_thr16, int64_t cap) {
+// perThingSampleRate = min(max, n) / n of sampleDownAndBinarize as the integer threshold floor(rate * 2^53)
+__global__ __launch_bounds__(256) void sample_threshold_kernel(const int32_t* __restrict__ raw_counts, int32_t n_cols, int32_t max_n,
+                                                               unsigned long long* __restrict__ thresholds) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= n_cols) return;
-  const unsigned long long word = hot_bits[j >> 6];
-  const int c = (int)(j & 63);
-  if ((word >> c) & 1ull) {
-    const int64_t idx = hot_rank[j >> 6] + __popcll(c == 0 ? 0ull : (word & ((1ull << c) - 1ull)));
-    if (idx < cap) hot_thr16[idx] = (unsigned short)(thresholds[j] >> 37);
-  }
-}
-
-__global__ __launch_bounds__(FL_THREADS, 4) void downsample_flags_lds_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
-                                                                             int64_t nnz, int64_t n_tiles, const int64_t* __restrict__ g,
-                                                                             const unsigned long long* __restrict__ thresholds, int32_t n_words,
-                                                                             const unsigned long long* __restrict__ hot_bits,
-                                                                             const int64_t* __restrict__ hot_rank,
-                                                                             const unsigned short* __restrict__ hot_thr16, uint32_t seed, int32_t max_n,
-                                                                             int row_rate_mode, int64_t row_base, unsigned long long* __restrict__ flags,
-                                                                             int64_t* __restrict__ tile_count, int32_t* __restrict__ post_counts,
-                                                                             int vec_ok) {
-  __shared__ int s_rel[FL_TEAMS][DS_SLICE];
-  __shared__ int s_cnt[FL_TEAMS][DS_THREADS / WAVE];
-  __shared__ __attribute__((aligned(16))) unsigned char s_pool[HOT_POOL];
-  const int team = threadIdx.x / DS_THREADS;
-  const int tl = threadIdx.x % DS_THREADS;
-  const int lane = threadIdx.x & (WAVE - 1);
-  // ---- tables of the hot columns (block-uniform decision; hot_rank[n_words] = number of hot columns)
-  const int words_pad = (n_words + 3) & ~3;
-  unsigned long long* s_bits = reinterpret_cast<unsigned long long*>(s_pool);
-  unsigned short* s_rank = reinterpret_cast<unsigned short*>(s_pool + (size_t)words_pad * 8);
-  unsigned short* s_thr = reinterpret_cast<unsigned short*>(s_pool + (size_t)words_pad * 10);
-  bool lds_tables = false;
-  if (hot_bits != nullptr && (int64_t)words_pad * 10 + 64 <= HOT_POOL) {
-    const int64_t n_hot = hot_rank[n_words];
-    const int64_t cap = (HOT_POOL - (int64_t)words_pad * 10) / 2;
-    if (n_hot <= cap && n_hot < 65536) {
-      lds_tables = true;
-      for (int w = threadIdx.x; w < n_words; w += FL_THREADS) {
-        s_bits[w] = hot_bits[w];
-        s_rank[w] = (unsigned short)hot_rank[w];
-      }
-      for (int t = threadIdx.x; t < (int)n_hot; t += FL_THREADS) s_thr[t] = hot_thr16[t];
-    }
-  }
-  __syncthreads();
+  const double n_thing = (double)raw_counts[j];
   const double dmax = (double)max_n;
-  const int64_t tiles_per_round = (int64_t)gridDim.x * FL_TEAMS;
-  const int64_t rounds = (n_tiles + tiles_per_round - 1) / tiles_per_round;  // block-uniform trip count
-  for (int64_t round = 0; round < rounds; ++round) {
-    const int64_t tile = (round * gridDim.x + blockIdx.x) * FL_TEAMS + team;
-    const bool live = tile < n_tiles;  // team-uniform
-    const int64_t e0 = tile * DS_TILE;
-    const int64_t e1 = live ? ((e0 + DS_TILE < nnz) ? e0 + DS_TILE : nnz) : e0;
-    int cols[DS_ITERS][4];
-#pragma unroll
-    for (int it = 0; it < DS_ITERS; ++it) {
-      const int64_t e = e0 + ((int64_t)it * DS_THREADS + tl) * 4;
-      if (live && vec_ok && e + 3 < nnz) {
-        const int4 x = *reinterpret_cast<const int4*>(ci + e);
-        cols[it][0] = x.x; cols[it][1] = x.y; cols[it][2] = x.z; cols[it][3] = x.w;
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cols[it][q] = (live && e + q < nnz) ? ci[e + q] : 0;
-      }
-    }
-    int64_t r_s = 0, r_e = 0, n_slice = 1;
-    bool in_lds = true;
-    if (live) {
-      const int64_t gp0 = g[tile];
-      const int64_t g0 = gp0 >> 1, g1 = g[tile + 1] >> 1;
-      r_s = (gp0 & 1) ? g0 : g0 - 1;
-      r_e = g1 < n_rows ? g1 : n_rows;
-      n_slice = r_e - r_s + 1;
-      in_lds = n_slice <= DS_SLICE;
-      if (in_lds)
-        for (int64_t t = tl; t < n_slice; t += DS_THREADS) s_rel[team][t] = (int)(rp[r_s + t] - e0);
-    }
-    __syncthreads();
-    int rrel[DS_ITERS];
-#pragma unroll
-    for (int it = 0; it < DS_ITERS; ++it) rrel[it] = 0;
-    if (live && in_lds) {
-      const int last = (int)n_slice - 1;
-      int top = 1;
-      while (top < last) top <<= 1;
-      for (int sft = top >> 1; sft > 0; sft >>= 1) {
-#pragma unroll
-        for (int it = 0; it < DS_ITERS; ++it) {
-          const int el = (it * DS_THREADS + tl) * 4;
-          const int idx = rrel[it] + sft;
-          if (idx < last && s_rel[team][idx] <= el) rrel[it] = idx;
-        }
-      }
-    }
-    int kept = 0;
-#pragma unroll
-    for (int it = 0; it < DS_ITERS; ++it) {  // block-uniform trip count: the wave ops below are legal
-      const int64_t e = e0 + ((int64_t)it * DS_THREADS + tl) * 4;
-      unsigned nib = 0;
-      if (e < e1) {
-        const int el = (int)(e - e0);
-        // The four column lookups of the vector are independent of the row walk: all their LDS reads (bitmap word, rank,
-        // threshold prefix) are issued up front, level by level, so that their latencies overlap.
-        unsigned t16[4];   // threshold prefix of a hot column; 0x10000 = not sampled (rate 1.0)
-        if (lds_tables) {
-          unsigned long long word[4];
-          unsigned rk[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            word[q] = s_bits[cols[it][q] >> 6];
-            rk[q] = s_rank[cols[it][q] >> 6];
-          }
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c = cols[it][q] & 63;
-            const bool hot = (word[q] >> c) & 1ull;
-            const unsigned idx = rk[q] + (unsigned)__popcll(c == 0 ? 0ull : (word[q] & ((1ull << c) - 1ull)));
-            t16[q] = hot ? (unsigned)s_thr[idx] : 0x10000u;
-          }
-        }
-        unsigned long long thr_col[4];
-        if (!lds_tables) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) thr_col[q] = thresholds[cols[it][q]];
-        }
-        int r_rel;          // slice-relative row of the current entry
-        int r_beg, r_end;   // its extent relative to e0 (a row has < 2^31 entries)
-        int64_t r_glob = 0;
-        if (in_lds) {
-          r_rel = rrel[it];
-          r_beg = s_rel[team][r_rel];
-          r_end = s_rel[team][r_rel + 1];
-        } else {
-          r_glob = upper_bound_i64(rp, r_s, r_e, e) - 1;
-          r_rel = (int)(r_glob - r_s);
-          r_beg = (int)(rp[r_glob] - e0);
-          r_end = (int)(rp[r_glob + 1] - e0);
-        }
-        uint32_t row_of[4];
-        int n_row_of[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int rel = el + q;
-          if (e + q < e1) {
-            while (rel >= r_end) {  // next non-empty row
-              ++r_rel;
-              r_beg = r_end;
-              r_end = in_lds ? s_rel[team][r_rel + 1] : (int)(rp[r_s + r_rel + 1] - e0);
-            }
-          }
-          row_of[q] = (uint32_t)(row_base + r_s + r_rel);
-          n_row_of[q] = r_end - r_beg;
-        }
-        unsigned long long h[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) h[q] = hash53(seed, row_of[q], (uint32_t)cols[it][q]);  // four independent multiply chains
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (e + q < e1) {
-            // keep  <=>  hash <= perRow threshold  &&  hash <= perThing threshold   (a rate of 1.0 always passes)
-            bool keep = true;
-            if (n_row_of[q] > max_n) {
-              if (row_rate_mode == 0) keep = false;  // Int / Int = 0
-              else keep = h[q] <= (unsigned long long)((dmax / (double)n_row_of[q]) * 9007199254740992.0);
-            }
-            if (lds_tables) {
-              const unsigned h16 = (unsigned)(h[q] >> 37);
-              if (h16 > t16[q]) keep = false;
-              else if (h16 == t16[q] && h[q] > thresholds[cols[it][q]]) keep = false;  // prefix tie: the full threshold decides
-            } else if (h[q] > thr_col[q]) {
-              keep = false;
-            }
-            if (keep) {
-              nib |= 1u << q;
-              if (post_counts) atomicAdd(&post_counts[cols[it][q]], 1);
-            }
-          }
-        }
-      }
-      kept += __popc(nib);
-      unsigned long long m = (unsigned long long)nib << ((lane & 15) * 4);
-      m |= shfl_xor_u64(m, 1);
-      m |= shfl_xor_u64(m, 2);
-      m |= shfl_xor_u64(m, 4);
-      m |= shfl_xor_u64(m, 8);
-      if (live && (lane & 15) == 0) flags[tile * DS_WORDS + ((it * DS_THREADS + tl) >> 4)] = m;
-    }
-    for (int msk = 1; msk < WAVE; msk <<= 1) kept += __shfl_xor(kept, msk);
-    if (lane == 0) s_cnt[team][tl / WAVE] = kept;
-    __syncthreads();  // also: every read of this round's row_ptr slice precedes the next round's fill
-    if (live && tl == 0) {
-      int tot = 0;
-#pragma unroll
-      for (int w = 0; w < DS_THREADS / WAVE; ++w) tot += s_cnt[team][w];
-      tile_count[tile] = tot;
-    }
-  }
+  thresholds[j] = n_thing <= dmax ? RATE_ONE : (unsigned long long)((dmax / n_thing) * 9007199254740992.0);
 }
 
 hipError_t launch_downsample_flags(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
                                    int32_t n_cols, const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n,
                                    int row_rate_mode, int64_t row_base, int64_t* tile_rows, unsigned long long* flags, int64_t* tile_count,
-                                   int32_t* post_counts, char* hot_scratch, int debug) {
+                                   int32_t* post_counts, int debug) {
   if (nnz == 0) return hipSuccess;
+  hipLaunchKernelGGL(sample_threshold_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, raw_counts, n_cols, max_n, thresholds);
   const int64_t tiles = (nnz + DS_TILE - 1) / DS_TILE;
-  const int n_words = (int)(((int64_t)n_cols + 63) >> 6);
-  // hot-column tables (second form) only when the bitmap + ranks fit the LDS pool; debug 16384 forces the first form
-  const bool tables = hot_scratch != nullptr && !(debug & 16384) && (int64_t)((n_words + 3) & ~3) * 10 + 64 <= HOT_POOL;
-  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
-  unsigned long long* hot_bits = nullptr;
-  int32_t* hot_cnt = nullptr;
-  int64_t* hot_rank = nullptr;
-  unsigned short* hot_thr16 = nullptr;
-  if (tables) {
-    char* p = hot_scratch;
-    hot_bits = reinterpret_cast<unsigned long long*>(p); p += al((int64_t)n_words * 8);
-    hot_cnt = reinterpret_cast<int32_t*>(p); p += al((int64_t)n_words * 4);
-    hot_rank = reinterpret_cast<int64_t*>(p); p += al(((int64_t)n_words + 1) * 8);
-    hot_thr16 = reinterpret_cast<unsigned short*>(p);
-  }
-  hipLaunchKernelGGL(sample_prepare_kernel, dim3((unsigned)(((int64_t)n_words * 64 + 255) / 256)), dim3(256), 0, st, raw_counts, n_cols, max_n, thresholds,
-                     n_words, hot_bits, hot_cnt);
   int64_t rblocks = (n_rows + 1 + 255) / 256;
   const int64_t rcap = (int64_t)n_cu * 8;
   if (rblocks > rcap) rblocks = rcap;
   hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, n_rows, row_ptr, tiles, tile_rows);
   const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
-  if (debug & 16384) {
-    hipLaunchKernelGGL(downsample_flags_kernel, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds,
-                       seed, max_n, row_rate_mode, row_base, flags, tile_count, post_counts, vec_ok, debug);
-    return hipGetLastError();
-  }
-  if (tables) {
-    hipLaunchKernelGGL((scan_block_kernel<LoadI32>), dim3(1), dim3(SB_THREADS), 0, st, LoadI32{hot_cnt}, (int64_t)n_words, hot_rank);  // n_words <= 4500
-    hipLaunchKernelGGL(hot_compact_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, n_cols, thresholds, hot_bits, hot_rank, hot_thr16,
-                       (int64_t)(HOT_POOL / 2));
-  }
-  int64_t blocks = (tiles + FL_TEAMS - 1) / FL_TEAMS;
-  const int64_t cap = (int64_t)n_cu * 2;  // two resident blocks per CU (LDS)
-  if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(downsample_flags_lds_kernel, dim3((unsigned)blocks), dim3(FL_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tiles, tile_rows, thresholds,
-                     n_words, hot_bits, hot_rank, hot_thr16, seed, max_n, row_rate_mode, row_base, flags, tile_count, post_counts, vec_ok);
+  hipLaunchKernelGGL(downsample_flags_kernel, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds,
+                     seed, max_n, row_rate_mode, row_base, flags, tile_count, post_counts, vec_ok, debug);
   return hipGetLastError();
-}
-
-// bytes of scratch for the hot-column tables of launch_downsample_flags (0: the matrix is too wide for them)
-int64_t downsample_hot_scratch_bytes(int32_t n_cols) {
-  const int64_t n_words = ((int64_t)n_cols + 63) >> 6;
-  if (((n_words + 3) & ~(int64_t)3) * 10 + 64 > HOT_POOL) return 0;
-  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
-  return al(n_words * 8) + al(n_words * 4) + al((n_words + 1) * 8) + al(HOT_POOL);
 }
 
 // single block of 1024 threads, 8 consecutive values each: in-place exclusive scan of v[0..n), v[n] = total.  The tile
@@ -1386,21 +1120,19 @@ hipError_t launch_xlx_table(hipStream_t st, double* tab) {
 // ============================================================================================
 __global__ __launch_bounds__(256) void expand_prepare_kernel(const int64_t* __restrict__ a_cp, int32_t n_items_a, const int32_t* __restrict__ a_ri,
                                                              const int64_t* __restrict__ b_rp, int64_t cap, int64_t* __restrict__ pstart,
-                                                             int32_t* __restrict__ plen, int vec_ok) {
+                                                             int32_t* __restrict__ plen) {
   const int64_t nnz = a_cp[n_items_a];
   int64_t lim = (nnz / SCAN_TILE + 1) * SCAN_TILE;  // the scan skips tiles that start at or beyond nnz
   if (lim > cap) lim = cap;
-  // Four consecutive CSC entries per thread: one 16-byte load of the user ids, then all eight row_ptr gathers in flight
-  // together (the kernel is a chain of two dependent random loads; with one entry per thread the memory system holds too
-  // few of them to cover the ~2 us latency of a gather that misses L2).
-  for (int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; p0 < lim; p0 += (int64_t)gridDim.x * 256 * 4) {
+  // Four grid-stride steps at a time: the four user ids are loaded first, then all eight row_ptr gathers are in flight
+  // together (the kernel is a chain of two dependent random loads); every access stays coalesced across the wave.
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t p0 = (int64_t)blockIdx.x * 256 + threadIdx.x; p0 < lim; p0 += stride * 4) {
     int u[4];
-    if (vec_ok && p0 + 3 < nnz) {
-      const int4 x = *reinterpret_cast<const int4*>(a_ri + p0);
-      u[0] = x.x; u[1] = x.y; u[2] = x.z; u[3] = x.w;
-    } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) u[q] = p0 + q < nnz ? a_ri[p0 + q] : -1;
+    for (int q = 0; q < 4; ++q) {
+      const int64_t p = p0 + q * stride;
+      u[q] = p < nnz ? a_ri[p] : -1;
     }
     int64_t s[4], e[4];
 #pragma unroll
@@ -1409,11 +1141,13 @@ __global__ __launch_bounds__(256) void expand_prepare_kernel(const int64_t* __re
       e[q] = u[q] >= 0 ? b_rp[u[q] + 1] : 0;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (p0 + q < lim) {
-        pstart[p0 + q] = s[q];
-        plen[p0 + q] = (int32_t)(e[q] - s[q]);
+    for (int q = 0; q < 4; ++q) {
+      const int64_t p = p0 + q * stride;
+      if (p < lim) {
+        pstart[p] = s[q];
+        plen[p] = (int32_t)(e[q] - s[q]);
       }
+    }
   }
 }
 
@@ -1423,8 +1157,7 @@ hipError_t launch_expand_prepare(hipStream_t st, int n_cu, const int64_t* a_col_
     int64_t blocks = (cap + 1023) / 1024;
     const int64_t lim = (int64_t)n_cu * 16;
     if (blocks > lim) blocks = lim;
-    const int vec_ok = (reinterpret_cast<uintptr_t>(a_row_idx) & 15) == 0;
-    hipLaunchKernelGGL(expand_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, cap, pstart, plen, vec_ok);
+    hipLaunchKernelGGL(expand_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, cap, pstart, plen);
   }
   return launch_scan(st, LoadI32{plen}, cap, wp, tile_sums, a_col_ptr + n_items_a);
 }

@@ -141,18 +141,16 @@ int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_pt
   const int64_t ph_bytes = post_counts ? urcco::column_counts_scratch_bytes(nnz, n_cols) : 0;
   const int64_t ds_tiles = (nnz + urcco::DS_TILE - 1) / urcco::DS_TILE;
   const size_t n_words = (size_t)ds_tiles * (urcco::DS_TILE / 64);
-  const int64_t hot_bytes = urcco::downsample_hot_scratch_bytes(n_cols);
   URC(s->reserve(urcco_session::need((size_t)n_cols, 8) + urcco_session::need((size_t)ds_tiles + 1, 8) * 2 + urcco_session::need(n_words, 8) +
-                 (size_t)ph_bytes + (size_t)hot_bytes + 512));
+                 (size_t)ph_bytes + 256));
   unsigned long long* thresholds = s->take<unsigned long long>((size_t)n_cols);
   int64_t* tile_rows = s->take<int64_t>((size_t)ds_tiles + 1);
   int64_t* tile_count = s->take<int64_t>((size_t)ds_tiles + 1);
   unsigned long long* flags = s->take<unsigned long long>(n_words);
-  char* hot_scratch = hot_bytes > 0 ? s->take<char>((size_t)hot_bytes) : nullptr;
   s->begin(URCCO_STAGE_DOWNSAMPLE_FLAGS);
   HIPC(urcco::launch_downsample_flags(s->stream, s->n_cu, n_rows, row_ptr, col_idx, nnz, n_cols, raw_counts, thresholds, (uint32_t)seed,
                                       max_elements_per_row, row_rate_mode, row_base, tile_rows, flags, tile_count,
-                                      ph_bytes > 0 ? nullptr : post_counts, hot_scratch, s->debug));
+                                      ph_bytes > 0 ? nullptr : post_counts, s->debug));
   s->end();
   s->begin(URCCO_STAGE_DOWNSAMPLE_SCAN);
   HIPC(urcco::launch_downsample_scan(s->stream, nnz, tile_count));
