@@ -316,6 +316,16 @@ int urcco_dev_compact_indicators(urcco_session* s, int32_t n_rows, int32_t k, co
                                  const int32_t* idx, const double* llr, int64_t* out_row_ptr,
                                  int32_t* out_col_idx, double* out_llr);
 
+/* PopModel.calcPopular / calcTrending / calcHot (reference src/main/scala/PopModel.scala:113-179, consumed by
+ * URAlgorithm.getRanksRDD, URAlgorithm.scala:537-560): per-item counts of the events whose time (ms since the epoch) lies in
+ * one of n_intervals (1..3) consecutive half-open intervals [bounds_host[b], bounds_host[b + 1]) -- PEventStore.find's
+ * startTime (inclusive) / untilTime (exclusive).  item_ids[e] < 0 = no target item / other event name: skipped.
+ * counts (device): int32[n_intervals * n_items], overwritten; counts[b * n_items + i].  The host derives the ranks:
+ * popular = counts, trending = newer - older, hot = (newer - middle) - (middle - older), each over the items present in
+ * every interval it joins (universal-recommender_amd/pop_model.py). */
+int urcco_dev_pop_counts(urcco_session* s, int64_t n_events, const int32_t* item_ids, const int64_t* times_ms, int32_t n_items,
+                         int32_t n_intervals, const int64_t* bounds_host, int32_t* counts);
+
 /* Test hooks (device level): LLR of SimilarityAnalysis.logLikelihoodRatio evaluated by the device code for
  * n argument tuples; u01 of the down-sampling RNG.  All pointers device. */
 int urcco_dev_llr(urcco_session* s, int64_t n, const int64_t* with_a, const int64_t* with_b, const int64_t* with_ab,

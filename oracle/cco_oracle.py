@@ -386,3 +386,81 @@ def read_events(lines: Iterable[str], delimiter: str = ",") -> "OrderedDict[str,
 def split_actions(by_event: Dict[str, List[Tuple[str, str]]], event_names: Sequence[str]):
     """DataSource.readTraining :79-89: one (name, pairs) per configured event name, in engine.json order."""
     return [(n, by_event.get(n, [])) for n in event_names]
+
+
+# =====================================================================================================================
+# PopModel (reference src/main/scala/PopModel.scala:55-179) and its consumer URAlgorithm.getRanksRDD / calcAll's
+# propertiesRDD (src/main/scala/URAlgorithm.scala:351-358, :537-560).  Pure-Python restatement; times are integer
+# milliseconds since the epoch.  PEventStore.find(startTime, untilTime) is start-inclusive / end-exclusive.
+# Reference-unpinned beyond data/rank-test-query-expected.txt's "popular item recs only" order: the interval arithmetic
+# (Joda Interval, integer millisecond halves / thirds) is restated as written.
+# =====================================================================================================================
+def pop_calc_popular(events, event_names, start_ms: int, end_ms: int) -> Dict[str, float]:
+    """PopModel.calcPopular :113-122.  events = iterable of (event name, target item or None, time ms)."""
+    out: Dict[str, float] = {}
+    for name, item, t in events:
+        if name in event_names and item is not None and start_ms <= t < end_ms:
+            out[item] = out.get(item, 0.0) + 1.0
+    return out
+
+
+def pop_calc_trending(events, event_names, start_ms: int, end_ms: int) -> Dict[str, float]:
+    """PopModel.calcTrending :128-147: newer half minus older half, over the items present in both."""
+    half = (end_ms - start_ms) // 2
+    older = pop_calc_popular(events, event_names, start_ms, start_ms + half)
+    if not older:
+        return {}
+    newer = pop_calc_popular(events, event_names, start_ms + half, end_ms)
+    return {i: newer[i] - older[i] for i in newer if i in older}
+
+
+def pop_calc_hot(events, event_names, start_ms: int, end_ms: int) -> Dict[str, float]:
+    """PopModel.calcHot :152-179: change of velocity over three consecutive intervals."""
+    third = (end_ms - start_ms) // 3
+    older = pop_calc_popular(events, event_names, start_ms, start_ms + third)
+    if not older:
+        return {}
+    middle = pop_calc_popular(events, event_names, start_ms + third, start_ms + 2 * third)
+    if not middle:
+        return {}
+    newer = pop_calc_popular(events, event_names, start_ms + 2 * third, end_ms)
+    new_v = {i: newer[i] - middle[i] for i in newer if i in middle}
+    old_v = {i: middle[i] - older[i] for i in middle if i in older}
+    return {i: new_v[i] - old_v[i] for i in new_v if i in old_v}
+
+
+def pop_calc(model_name: str, events, event_names, duration_s: int, end_ms: int) -> Dict[str, float]:
+    """PopModel.calc :59-97 for the deterministic ranking types (random is `Random.nextDouble` per item, userDefined empty)."""
+    start_ms = end_ms - duration_s * 1000
+    if model_name == "popular":
+        return pop_calc_popular(events, event_names, start_ms, end_ms)
+    if model_name == "trending":
+        return pop_calc_trending(events, event_names, start_ms, end_ms)
+    if model_name == "hot":
+        return pop_calc_hot(events, event_names, start_ms, end_ms)
+    return {}
+
+
+def get_ranks(rankings: Sequence[dict], events, model_event_names: Sequence[str], now_ms: int) -> Dict[str, Dict[str, float]]:
+    """URAlgorithm.getRanksRDD :537-560: fold of full outer joins -> item -> {ranking field name: rank}.
+    rankings = [{name?, type?, eventNames?, duration_s?, end_ms?}] (durations already in seconds)."""
+    name_by_type = {"popular": "popRank", "trending": "trendRank", "hot": "hotRank", "userDefined": "userRank", "random": "uniqueRank"}
+    out: Dict[str, Dict[str, float]] = {}
+    for r in rankings:
+        rtype = r.get("type") or "popular"
+        field = r.get("name") or name_by_type.get(rtype, "unknownRank")
+        names = r.get("eventNames") or list(model_event_names[:1])
+        ranks = pop_calc(rtype, events, names, int(r.get("duration_s", 3650 * 86400)), int(r.get("end_ms", now_ms)))
+        for item, v in ranks.items():
+            out.setdefault(item, {})[field] = v
+    return out
+
+
+def properties_with_ranks(fields: Dict[str, dict], ranks: Dict[str, Dict[str, float]]) -> Dict[str, dict]:
+    """calcAll's propertiesRDD :351-358: fields fullOuterJoin ranks, the rank map laid over the field map."""
+    out = {}
+    for item in list(fields) + [i for i in ranks if i not in fields]:
+        m = dict(fields.get(item, {}))
+        m.update(ranks.get(item, {}))
+        out[item] = m
+    return out

@@ -13,6 +13,9 @@
                            (minEventsPerUser = 6): the reference ships no expected output for it -- an input-only fixture that
                            exercises the Preparator's user filter on the reference's own data
 
+  rank.json                data/sample-rank-data.txt with the event times examples/rank/import_rank.py assigns, the `rankings` of
+                           examples/rank/rank-engine.json and the popularity order data/rank-test-query-expected.txt holds
+
 Usage: python tests/golden/make_golden.py [/root/reference]
 """
 import json
@@ -98,6 +101,35 @@ def inputs_only(name, data, engine):
     print(name, len(events), "events (no reference golden)")
 
 
+def rank():
+    """data/sample-rank-data.txt as examples/rank/import_rank.py posts it: line k gets event time now - 0.8 days * k
+    (import_rank.py:22-26,71; `$set` lines advance the clock too), stored here as day offsets so that the fixture does not
+    depend on the day it is used.  Golden: the "popular item recs only" query of data/rank-test-query-expected.txt -- with
+    no user and no item the result order is the popRank order of examples/rank/rank-engine.json (popular over show + like,
+    3650 days)."""
+    import re as _re
+    events = []
+    k = 0
+    for line in open(os.path.join(REF, "data", "sample-rank-data.txt")):
+        line = line.rstrip("\r\n")
+        if not line:
+            continue
+        d = line.split(",")
+        if d[1] != "$set":
+            events.append([d[0], d[1], d[2], -0.8 * k])
+        k += 1
+    engine = json.load(open(os.path.join(REF, "examples", "rank", "rank-engine.json")))
+    algo = [a for a in engine["algorithms"] if a["name"] == "ur"][0]["params"]
+    text = open(os.path.join(REF, "data", "rank-test-query-expected.txt")).read()
+    m = _re.search(r"query with no item or user id, ordered by popularity\s*\n\s*\n(\{.*?\})\s*\n", text, _re.S)
+    expected = [x["item"] for x in json.loads(m.group(1))["itemScores"]]
+    doc = {"source": {"data": "data/sample-rank-data.txt", "importer": "examples/rank/import_rank.py", "engine": "examples/rank/rank-engine.json",
+                      "expected": "data/rank-test-query-expected.txt (popular item recs only)"},
+           "rankings": algo["rankings"], "eventNames": algo["eventNames"], "events": events, "popular_order_expected": expected}
+    json.dump(doc, open(os.path.join(HERE, "rank.json"), "w"), indent=1)
+    print("rank.json", len(events), "events; expected popular order", expected)
+
+
 def movielens():
     random.seed(3)                                   # import_movielens_eventserver.py:10,14
     events = []
@@ -118,3 +150,4 @@ if __name__ == "__main__":
              "integration-test-item-set-expected.txt")
     inputs_only("downsample.json", "sample-downsamplable-data.txt", "handmade-engine-downsample.json")
     movielens()
+    rank()

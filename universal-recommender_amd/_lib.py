@@ -125,6 +125,7 @@ SYMBOLS = {
     "urcco_dev_cco_rows": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, C.c_int64, _p, _p, C.c_int32, _p, _p, C.c_int64, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_double, _p, _p, _p, _p]),
     "urcco_dev_compact_indicators": (C.c_int, [_p, C.c_int32, C.c_int32, _p, _p, _p, _p, _p, _p]),
+    "urcco_dev_pop_counts": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), _p]),
     "urcco_dev_llr": (C.c_int, [_p, C.c_int64, _p, _p, _p, _p, _p]),
     "urcco_dev_u01": (C.c_int, [_p, C.c_int64, C.c_int32, _p, _p, _p]),
     "urcco_dev_dictionary_build": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int32, _p, C.POINTER(_p), C.POINTER(C.c_int64)]),

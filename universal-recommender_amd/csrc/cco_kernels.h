@@ -116,6 +116,10 @@ hipError_t launch_validate_csr(hipStream_t st, int n_cu, int64_t n_rows, const i
                                int g_log2, int64_t rp0, unsigned long long* err);
 hipError_t launch_rebase_i64(hipStream_t st, int n_cu, int64_t* p, int64_t n, int64_t delta);
 
+// PopModel interval histograms: counts[b * n_items + i] = events of item i with bounds[b] <= t < bounds[b + 1], b < n_buckets <= 3
+hipError_t launch_pop_counts(hipStream_t st, int n_cu, int64_t n, const int32_t* item, const int64_t* t_ms, int32_t n_items, int n_buckets,
+                             const int64_t* bounds, int32_t* counts);
+
 hipError_t launch_xlx_table(hipStream_t st, double* tab);
 hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, double* xlx_n);
 

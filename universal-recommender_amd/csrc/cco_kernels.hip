@@ -2255,6 +2255,51 @@ hipError_t launch_rebase_i64(hipStream_t st, int n_cu, int64_t* p, int64_t n, in
 }
 
 // ============================================================================================
+// PopModel.calcPopular / calcTrending / calcHot (reference src/main/scala/PopModel.scala:113-179): per-item counts of the
+// events whose time lies in one of up to three consecutive half-open intervals [bounds[b], bounds[b + 1]) -- the reference
+// counts each interval with its own PEventStore.find(startTime, untilTime) + groupByKey; here one pass over the event
+// stream fills all the interval histograms.  item < 0 = event without a target item (or of another event name): skipped.
+// Hot items take millions of increments, so the block-level LDS cache of K1 sits in front of the L2 atomics.
+// ============================================================================================
+struct PopBounds { long long b[4]; };
+__global__ __launch_bounds__(CC_THREADS) void pop_counts_kernel(int64_t n, const int32_t* __restrict__ item, const int64_t* __restrict__ t_ms,
+                                                              int32_t n_items, int n_buckets, PopBounds bounds, int32_t* __restrict__ counts) {
+  __shared__ int s_key[CC_SLOTS];
+  __shared__ int s_cnt[CC_SLOTS];
+  for (int s = threadIdx.x; s < CC_SLOTS; s += CC_THREADS) {
+    s_key[s] = 0;
+    s_cnt[s] = 0;
+  }
+  __syncthreads();
+  for (int64_t e = (int64_t)blockIdx.x * CC_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * CC_THREADS) {
+    const int i = item[e];
+    if (i < 0 || i >= n_items) continue;
+    const long long t = t_ms[e];
+    int b = -1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k < n_buckets && t >= bounds.b[k] && t < bounds.b[k + 1]) b = k;
+    if (b >= 0) cc_insert(s_key, s_cnt, counts, b * n_items + i);
+  }
+  __syncthreads();
+  for (int s = threadIdx.x; s < CC_SLOTS; s += CC_THREADS)
+    if (s_key[s] != 0) atomicAdd(&counts[s_key[s] - 1], s_cnt[s]);
+}
+hipError_t launch_pop_counts(hipStream_t st, int n_cu, int64_t n, const int32_t* item, const int64_t* t_ms, int32_t n_items, int n_buckets,
+                             const int64_t* bounds, int32_t* counts) {
+  hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)n_items * (size_t)n_buckets, st);
+  if (e != hipSuccess || n == 0) return e;
+  PopBounds pb;
+  for (int k = 0; k < 4; ++k) pb.b[k] = k <= n_buckets ? bounds[k] : bounds[n_buckets];
+  int64_t blocks = (n + (int64_t)CC_THREADS * 8 - 1) / ((int64_t)CC_THREADS * 8);
+  const int64_t cap = (int64_t)n_cu * 4;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(pop_counts_kernel, dim3((unsigned)blocks), dim3(CC_THREADS), 0, st, n, item, t_ms, n_items, n_buckets, pb, counts);
+  return hipGetLastError();
+}
+
+// ============================================================================================
 // test hooks
 // ============================================================================================
 __global__ void llr_test_kernel(int64_t n, const int64_t* a, const int64_t* b, const int64_t* ab, const int64_t* nu, double* out) {

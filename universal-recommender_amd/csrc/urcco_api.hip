@@ -413,6 +413,19 @@ int urcco_dev_csr_from_pairs(urcco_session* s, int64_t n, const int32_t* rows, c
   return URCCO_OK;
 }
 
+int urcco_dev_pop_counts(urcco_session* s, int64_t n_events, const int32_t* item_ids, const int64_t* times_ms, int32_t n_items, int32_t n_intervals,
+                         const int64_t* bounds_host, int32_t* counts) {
+  if (!s || n_events < 0 || n_items < 0 || n_intervals < 1 || n_intervals > 3 || !bounds_host || (n_events > 0 && (!item_ids || !times_ms)) ||
+      (n_items > 0 && !counts))
+    return fail(URCCO_BAD_ARG, "urcco_dev_pop_counts: bad argument");
+  for (int k = 0; k < n_intervals; ++k)
+    if (bounds_host[k + 1] < bounds_host[k]) return fail(URCCO_BAD_ARG, "urcco_dev_pop_counts: interval bounds must not decrease");
+  if ((int64_t)n_items * n_intervals > 0x7ffffff0ll) return fail(URCCO_BAD_ARG, "urcco_dev_pop_counts: too many items");
+  if (n_items == 0) return URCCO_OK;
+  HIPC(urcco::launch_pop_counts(s->stream, s->n_cu, n_events, item_ids, times_ms, n_items, n_intervals, bounds_host, counts));
+  return URCCO_OK;
+}
+
 int urcco_dev_llr(urcco_session* s, int64_t n, const int64_t* with_a, const int64_t* with_b, const int64_t* with_ab, const int64_t* n_users,
                   double* out) {
   if (!s || n < 0) return fail(URCCO_BAD_ARG, "urcco_dev_llr: bad argument");
