@@ -42,9 +42,9 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 LDS_ATOMIC_PEAK_GOPS = 16 * 256 * 2.4
 
 BIN_STAGES = ["cco_rows_micro", "cco_rows_wave", "cco_rows_block_small", "cco_rows_block", "cco_rows_cu_half", "cco_rows_cu", "cco_rows_global"]
-STAGE_TO_KERNEL = {"cco_rows_micro": "cco_rows_micro_kernel", "cco_rows_wave": "cco_rows_kernel<64, 1024, 1, 0>",
-                   "cco_rows_block_small": "cco_rows_kernel<256, 4096, 1, 0>", "cco_rows_block": "cco_rows_kernel<256, 8192, 1, 0>",
-                   "cco_rows_cu_half": "cco_rows_kernel<512, 16384, 1, 0>", "cco_rows_cu": "cco_rows_kernel<1024, 32768, 1, 0>",
+STAGE_TO_KERNEL = {"cco_rows_micro": "cco_rows_micro_kernel", "cco_rows_wave": "cco_rows_kernel<64, 1024, 1>",
+                   "cco_rows_block_small": "cco_rows_kernel<256, 4096, 1>", "cco_rows_block": "cco_rows_kernel<256, 8192, 1>",
+                   "cco_rows_cu_half": "cco_rows_kernel<512, 16384, 1>", "cco_rows_cu": "cco_rows_kernel<1024, 32768, 1>",
                    "downsample_flags": "downsample_flags_kernel", "compact_indicators": "compact_indicators_kernel"}
 
 
@@ -144,6 +144,52 @@ def rowscan_hbm_leg(lib, dev, seed):
             "ms": round(ms, 4), "parts_ms": {k: round(v, 4) for k, v in parts.items()}, "alg_MB": round(alg / 1e6, 1),
             "GBps": round(alg / 1e9 / (ms / 1e3), 1), "frac_of_hbm_peak": round(alg / 1e9 / (ms / 1e3) / HBM_PEAK_GBS, 4),
             "label": "HBM-resident (working set >> 256 MiB Infinity Cache)"}
+
+
+def ingest_leg(lib, dev, data, cfg, seed):
+    """end-to-end events/s INCLUDING the copies -- the event streams of config 3 (every interaction once, in
+    random stream order, plus ~10 % repeated events; 64-bit keys as the host's string hashing produces them) start in
+    pageable host memory, go through the device Preparator (dictionaries by first appearance, CSR builders) and straight
+    into the CCO build; the timed region ends when the indicator rows are back on the host."""
+    from universal_recommender_amd import ingest
+    from universal_recommender_amd.device import DatasetParams, DeviceSession, cross_occurrence_device
+    rng = np.random.default_rng(1)
+    host_actions, total = [], 0
+    for (name, n_cols, rp, ci) in data:
+        rows = np.repeat(np.arange(cfg.n_users, dtype=np.int64), np.diff(rp))
+        cols = ci.astype(np.int64)
+        dup = rng.integers(0, rows.size, rows.size // 10)
+        rows, cols = np.concatenate([rows, rows[dup]]), np.concatenate([cols, cols[dup]])
+        order = rng.permutation(rows.size)
+        uk = rows[order] * np.int64(0x9E3779B97F4A7C15 - (1 << 64)) + 11      # injective stand-ins for 64-bit string hashes
+        ik = cols[order] * np.int64(0xC2B2AE3D27D4EB4F - (1 << 64)) + 5
+        host_actions.append((name, uk, ik))
+        total += rows.size
+    sess = DeviceSession(dev, lib)
+    params = [DatasetParams(500, 50, None)] * len(data)
+    times, pairs, parts = [], 0, None
+    for it in range(3):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        actions = [(n, torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev)) for (n, u, i) in host_actions]
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        dp = ingest.prepare_device(sess, actions, 1)
+        sess.synchronize()
+        t2 = time.perf_counter()
+        res = cross_occurrence_device(sess, [ev.matrix for ev in dp.events], params, seed)
+        host = [r.to_host() for r in res]
+        t3 = time.perf_counter()
+        pairs = sum(int(r.stats[0]) for r in res)
+        if it > 0:
+            times.append(t3 - t0)
+            parts = {"h2d_ms": round((t1 - t0) * 1e3, 2), "ingest_ms": round((t2 - t1) * 1e3, 2), "model_build_and_d2h_ms": round((t3 - t2) * 1e3, 2)}
+        del actions, dp, res, host
+    sess.close()
+    s = statistics.median(times)
+    return {"events": total, "ms": round(s * 1e3, 2), "events_per_s": round(total / s, 1), "parts_last_run": parts, "pairs": pairs,
+            "what": "pageable host key streams (16 B per event) -> H2D -> device Preparator (2 dictionary builds + 2 lookups + CSR build per event type) -> "
+                    "CCO model build -> indicator rows D2H; median of 2 after 1 warm-up; string hashing (urcco_hash_strings on the host) not included"}
 
 
 def cpu_legs(data, cfg, seed, pairs_gpu):
@@ -401,6 +447,7 @@ def main():
         if not args.no_extras:
             extras["host_level"] = host_level_leg(library, host_data, cfg, args.seed, pairs)
             extras["csr_row_scan_hbm_resident"] = rowscan_hbm_leg(library, dev, args.seed)
+            extras["ingest_to_model"] = ingest_leg(library, dev, host_data, cfg, args.seed)
         if not args.no_cpu_baseline:
             cpu_baseline, cpu_scipy = cpu_legs(host_data, cfg, args.seed, pairs)
 

@@ -338,6 +338,11 @@ int urcco_dev_u01(urcco_session* s, int64_t n, int32_t seed, const int32_t* row,
  * (oracle decision D8), so the host recovers the id -> string dictionary from `first_pos` alone. */
 typedef struct urcco_key_table urcco_key_table;
 
+/* Host helper: keys[i] = XXH64(bytes[offsets[i] .. offsets[i + 1]), seed) for n strings laid end to end (UTF-8); the value ~0
+ * is remapped to 0 (reserved by the device dictionary).  A few host threads for large n.  The same function with a
+ * second seed gives the independent check keys of urcco_dev_dictionary_verify. */
+int urcco_hash_strings(const uint8_t* bytes, const int64_t* offsets, int64_t n, uint64_t seed, uint64_t* keys);
+
 /* BiDictionary over keys[0..n): id = rank of the key's first position among the first positions of the keys that
  * occur at least min_count times (`minEventsPerUser` counts RAW events, Preparator.scala:129-132); other keys get no id.
  * select (nullable, device int32[n]): positions with select[p] < 0 do not take part (events of dropped users,
@@ -348,6 +353,12 @@ int urcco_dev_dictionary_build(urcco_session* s, int64_t n, const uint64_t* keys
 /* ids[p] = dense id of keys[p], or -1 (key without id, or select[p] < 0).  No host synchronisation. */
 int urcco_dev_dictionary_lookup(urcco_session* s, const urcco_key_table* table, int64_t n, const uint64_t* keys,
                                 const int32_t* select, int32_t* ids);
+/* Collision check of a dictionary built from 64-bit hashes: check_keys[p] = a SECOND, independent hash of the same string
+ * (another seed).  Counts the positions whose check key differs from the check key of their id's first occurrence, i.e. two
+ * different strings that the first hash merged into one id (probability ~n^2 / 2^65 per dictionary); *n_mismatch is written
+ * on the host (synchronises).  first_pos = the array urcco_dev_dictionary_build filled. */
+int urcco_dev_dictionary_verify(urcco_session* s, const urcco_key_table* table, int64_t n, const uint64_t* keys, const int32_t* select,
+                                const uint64_t* check_keys, const int64_t* first_pos, int64_t* n_mismatch);
 /* Frees the table (hipFree: waits for device work still using it). */
 void urcco_key_table_destroy(urcco_key_table* table);
 /* IndexedDatasetSpark's row assembly: (row id, column id) pairs (pairs with a negative id are skipped) -> binary CSR

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "universal-recommender_amd", "csrc")
 OUT = os.path.join(HERE, "_build", "liburcco_hostsim.so")
-SOURCES = [os.path.join(CSRC, "cco_kernels.hip"), os.path.join(CSRC, "ingest_kernels.hip"), os.path.join(CSRC, "urcco_api.hip"), os.path.join(CSRC, "urcco_context.hip"),
+SOURCES = [os.path.join(CSRC, "cco_kernels.hip"), os.path.join(CSRC, "ingest_kernels.hip"), os.path.join(CSRC, "urcco_api.hip"), os.path.join(CSRC, "urcco_context.hip"), os.path.join(CSRC, "urcco_hash.hip"),
            os.path.join(HERE, "hipsim.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, "cco_kernels.h"), os.path.join(CSRC, "cco_device.h"), os.path.join(CSRC, "urcco_internal.h"),
                   os.path.join(ROOT, "include", "urcco.h"), os.path.join(HERE, "include", "hip", "hip_runtime.h")]

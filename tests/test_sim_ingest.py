@@ -198,3 +198,37 @@ def test_reference_downsample_fixture_user_filter(sim_session, sim_lib):
         for item, m in PO.to_string_map(ev, ind).items():
             ref_model.setdefault(item, {}).update(m)
     assert model == ref_model
+
+
+def test_native_string_hash_known_answers_and_collision_check(sim_session, sim_lib):
+    """urcco_hash_strings = XXH64 (known answers of the public algorithm, seed 0 and the check seed); a dictionary in which
+    two different strings share the 64-bit key is detected through the second hash (urcco_dev_dictionary_verify)."""
+    import torch
+    from universal_recommender_amd import ingest
+    from universal_recommender_amd.preparator import CHECK_SEED, hash_keys
+    strs = ["", "a", "user-1", "Iphone 6", "x" * 40]
+    got = hash_keys(strs, 0, sim_lib).view(np.uint64).tolist()
+    assert got == [0xef46db3751d8e999, 0xd24ec4f1a98c6e5b, 0xa173746b114c6be8, 0x4ae1af7e7ed5ca3b, 0x926f564e1b3e18d5]
+    got2 = hash_keys(strs, CHECK_SEED, sim_lib).view(np.uint64).tolist()
+    assert got2 == [0xc4349fc93c010000, 0x9a7c6d2ea45568c9, 0xf45ce0957975e277, 0x2d02c0058280b236, 0x5c39218a651d07bb]
+    try:
+        import xxhash
+        assert got == [xxhash.xxh64_intdigest(s.encode()) for s in strs]
+        assert got2 == [xxhash.xxh64_intdigest(s.encode(), seed=CHECK_SEED) for s in strs]
+    except ImportError:
+        pass
+    dev = sim_session.device
+    t = lambda x: torch.from_numpy(np.asarray(x, np.int64)).to(dev)
+    users, items = [f"u{i % 7}" for i in range(40)], [f"i{i % 11}" for i in range(40)]
+    uk, ik = hash_keys(users, 0, sim_lib), hash_keys(items, 0, sim_lib)
+    uc, ic = hash_keys(users, CHECK_SEED, sim_lib), hash_keys(items, CHECK_SEED, sim_lib)
+    ok = ingest.prepare_device(sim_session, [("buy", t(uk), t(ik), t(uc), t(ic))], 1)
+    assert ok.user_first_pos.numel() == 7 and ok.events[0].matrix.n_cols == 11
+    ik_bad = ik.copy()
+    ik_bad[np.asarray(items) == "i3"] = ik[items.index("i5")]          # "i3" and "i5" now share a key, their check keys differ
+    with pytest.raises(ingest.HashCollision):
+        ingest.prepare_device(sim_session, [("buy", t(uk), t(ik_bad), t(uc), t(ic))], 1)
+    uk_bad = uk.copy()
+    uk_bad[np.asarray(users) == "u1"] = uk[users.index("u2")]
+    with pytest.raises(ingest.HashCollision):
+        ingest.prepare_device(sim_session, [("buy", t(uk_bad), t(ik), t(uc), t(ic))], 1)

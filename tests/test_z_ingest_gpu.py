@@ -31,3 +31,7 @@ def test_preparator_mirror_device_equals_host_on_gpu(gpu_session):
 
 def test_events_to_model_without_leaving_the_device_on_gpu(gpu_session):
     logic.test_events_to_model_without_leaving_the_device(gpu_session, gpu_session.lib)
+
+
+def test_native_hash_and_collision_check_on_gpu(gpu_session):
+    logic.test_native_string_hash_known_answers_and_collision_check(gpu_session, gpu_session.lib)

@@ -111,6 +111,30 @@ hipError_t launch_dictionary_build(hipStream_t st, int n_cu, KeyTable t, int64_t
   return hipGetLastError();
 }
 
+// collision check: the check key (a second, independent hash of the same string) of every position must equal the check key
+// of its id's first occurrence; err[0] counts the positions where it does not
+__global__ __launch_bounds__(256) void ig_verify_kernel(KeyTable t, int64_t n, const unsigned long long* __restrict__ keys, const int32_t* __restrict__ select,
+                                                        const unsigned long long* __restrict__ check, const int64_t* __restrict__ first_pos,
+                                                        unsigned long long* __restrict__ err) {
+  unsigned bad = 0;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (int64_t)gridDim.x * 256) {
+    if (select && select[p] < 0) continue;
+    const unsigned long long key = keys[p];
+    const unsigned long long slot = ig_find(t, key);
+    if (t.keys[slot] != key) continue;
+    const int32_t id = t.id[slot];
+    if (id >= 0 && check[p] != check[first_pos[id]]) ++bad;
+  }
+  if (bad) atomicAdd(err, (unsigned long long)bad);
+}
+hipError_t launch_dictionary_verify(hipStream_t st, int n_cu, KeyTable t, int64_t n, const unsigned long long* keys, const int32_t* select,
+                                    const unsigned long long* check, const int64_t* first_pos, unsigned long long* err) {
+  hipError_t e = hipMemsetAsync(err, 0, sizeof(unsigned long long), st);
+  if (e != hipSuccess || n == 0) return e;
+  hipLaunchKernelGGL(ig_verify_kernel, dim3(ig_grid(n, n_cu)), dim3(256), 0, st, t, n, keys, select, check, first_pos, err);
+  return hipGetLastError();
+}
+
 hipError_t launch_dictionary_lookup(hipStream_t st, int n_cu, KeyTable t, int64_t n, const unsigned long long* keys, const int32_t* select,
                                     int32_t* ids) {
   if (n == 0) return hipSuccess;

@@ -60,6 +60,18 @@ def dictionary_lookup(sess: DeviceSession, d: DevDictionary, keys: torch.Tensor,
     return ids[: keys.numel()]
 
 
+class HashCollision(RuntimeError):
+    """Two different id strings share a 64-bit key (detected through the second hash); re-key with another seed."""
+
+
+def dictionary_verify(sess: DeviceSession, d: DevDictionary, keys: torch.Tensor, check_keys: torch.Tensor, select: Optional[torch.Tensor] = None) -> int:
+    """Number of stream positions whose check key differs from the check key of their id's first occurrence (0 = no collision)."""
+    bad = C.c_int64()
+    sess._check(sess.lib.urcco_dev_dictionary_verify(sess.handle, d.handle, keys.numel(), _ptr(keys), _ptr(select), _ptr(check_keys),
+                                                     _ptr(d.first_pos) if d.n_ids else _ptr(sess.empty(1, torch.int64)), C.byref(bad)))
+    return int(bad.value)
+
+
 def csr_from_pairs(sess: DeviceSession, rows: torch.Tensor, cols: torch.Tensor, n_rows: int, n_cols: int) -> DevCsr:
     n = rows.numel()
     out_rp = sess.empty(n_rows + 1, torch.int64)
@@ -84,22 +96,29 @@ class DevPreparedData:
 
 def prepare_device(sess: DeviceSession, actions: Sequence[Tuple[str, torch.Tensor, torch.Tensor]],
                    min_events_per_user: Optional[int] = None) -> DevPreparedData:
-    """Preparator.prepare.  actions[d] = (event name, user keys, item keys) with the keys as int64 tensors (uint64 bit
-    patterns) resident on the session's device; actions[0] is the primary event type."""
+    """Preparator.prepare.  actions[d] = (event name, user keys, item keys[, user check keys, item check keys]) with the keys
+    as int64 tensors (uint64 bit patterns) resident on the session's device; actions[0] is the primary event type.  With
+    check keys (a second, independent hash of the same strings) every dictionary is verified: HashCollision if two
+    different strings were merged into one id."""
     if not actions:
         raise ValueError("need at least the primary event type")
-    _, pu, _ = actions[0]
+    pu = actions[0][1]
     users = dictionary_build(sess, pu, None, min_events_per_user if min_events_per_user is not None else 1)
     try:
         n_users = users.n_ids
         user_first = users.first_pos.clone()
+        if len(actions[0]) >= 5 and dictionary_verify(sess, users, pu, actions[0][3]):
+            raise HashCollision("two user ids share a 64-bit key")
         out: List[DevPreparedEvent] = []
-        for name, uk, ik in actions:
+        for act in actions:
+            name, uk, ik = act[0], act[1], act[2]
             if uk.numel() != ik.numel():
                 raise ValueError(f"event type {name}: user and item key streams differ in length")
             rows = dictionary_lookup(sess, users, uk)                      # -1: user not in the dictionary -> event dropped
             items = dictionary_build(sess, ik, rows, 1)                     # column ids over the surviving events only
             try:
+                if len(act) >= 5 and dictionary_verify(sess, items, ik, act[4], rows):
+                    raise HashCollision(f"event type {name}: two item ids share a 64-bit key")
                 cols = dictionary_lookup(sess, items, ik, rows)
                 m = csr_from_pairs(sess, rows, cols, n_users, items.n_ids)
                 out.append(DevPreparedEvent(name, m, items.first_pos.clone()))

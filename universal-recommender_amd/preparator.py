@@ -58,20 +58,28 @@ def _min_events_row_ids(elements: Sequence[Tuple[str, str]], min_events: int) ->
     return BiDictionary([u for u, c in counts.items() if c >= min_events])
 
 
-def hash_keys(strings: Sequence[str]) -> np.ndarray:
-    """64-bit keys of id strings: xxHash64 of the UTF-8 bytes (blake2b-64 when the xxhash module is absent) -- a fixed
-    function of the string, so every rank of a multi-GPU build maps the same id to the same key.  ~0 is the device
-    dictionary's reserved value and is remapped.  Two distinct strings collide with probability ~n^2 / 2^65 (3e-5 for
-    a billion ids)."""
-    try:
-        import xxhash
-        out = np.fromiter(map(xxhash.xxh64_intdigest, strings), dtype=np.uint64, count=len(strings))
-    except ImportError:
-        import hashlib
-        out = np.fromiter((int.from_bytes(hashlib.blake2b(s.encode("utf-8"), digest_size=8).digest(), "little") for s in strings),
-                          dtype=np.uint64, count=len(strings))
-    out[out == np.uint64(0xFFFFFFFFFFFFFFFF)] = 0
-    return out.view(np.int64)
+HASH_SEED = 0
+CHECK_SEED = 0x9E3779B97F4A7C15      # second, independent hash of the same string: the collision check
+
+
+def hash_keys(strings: Sequence[str], seed: int = HASH_SEED, library=None) -> np.ndarray:
+    """64-bit keys of id strings: XXH64(seed) of the UTF-8 bytes, evaluated by the library's host helper
+    (urcco_hash_strings: native, multi-threaded) -- a fixed function of the string, so every rank of a multi-GPU build maps
+    the same id to the same key.  ~0 is the device dictionary's reserved value and is remapped to 0.  Two distinct strings
+    collide with probability ~n^2 / 2^65 (3e-5 for a billion ids); `prepare_on_device` detects that with a second hash."""
+    import ctypes as C
+    from . import _lib
+    lib = library if library is not None else _lib.lib()
+    enc = [x.encode("utf-8") for x in strings]
+    n = len(enc)
+    offsets = np.zeros(n + 1, np.int64)
+    if n:
+        np.cumsum(np.fromiter(map(len, enc), np.int64, count=n), out=offsets[1:])
+    blob = b"".join(enc)
+    out = np.empty(max(n, 1), np.uint64)
+    buf = np.frombuffer(blob, np.uint8) if blob else np.zeros(1, np.uint8)
+    _lib.check(lib.urcco_hash_strings(buf.ctypes.data, offsets.ctypes.data, n, C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), out.ctypes.data), lib)
+    return out[:n].view(np.int64)
 
 
 class Preparator:
@@ -86,10 +94,10 @@ class Preparator:
             raise ValueError("no event type with events")
         dev_actions = []
         for name, elements in trainingData.actions:
-            uk = torch.from_numpy(hash_keys([u for u, _ in elements])).to(sess.device)
-            ik = torch.from_numpy(hash_keys([i for _, i in elements])).to(sess.device)
-            dev_actions.append((name, uk, ik))
-        dp = ingest.prepare_device(sess, dev_actions, trainingData.minEventsPerUser)
+            users, items = [u for u, _ in elements], [i for _, i in elements]
+            keys = [torch.from_numpy(hash_keys(x, sd, sess.lib)).to(sess.device) for x in (users, items) for sd in (HASH_SEED, CHECK_SEED)]
+            dev_actions.append((name, keys[0], keys[2], keys[1], keys[3]))      # (user keys, item keys, user check keys, item check keys)
+        dp = ingest.prepare_device(sess, dev_actions, trainingData.minEventsPerUser)   # raises on a hash collision
         primary = trainingData.actions[0][1]
         row_ids = BiDictionary([primary[p][0] for p in dp.user_first_pos.cpu().numpy()])
         out: List[Tuple[str, IndexedDataset]] = []
