@@ -74,10 +74,18 @@ constexpr int XLX_TABLE = 4096;
 __device__ __forceinline__ double x_log_x_tab(long long x, const double* __restrict__ xlx_tab) {
   return x < (long long)XLX_TABLE ? xlx_tab[x] : (double)x * log_pos((double)x);
 }
+// k22 = N - cA - cB + k11 sits within a few hundred of N once the interaction cut has capped cA and cB, so its xLogX comes
+// from a second table, xlx_hi[d] = x_log_x(N - d) (filled by the same device function for the N of the build): with it the
+// common case evaluates no logarithm at all -- four table reads -- and the value stays bit-identical.
+__device__ __forceinline__ double x_log_x_hi(long long x, long long n_users, const double* __restrict__ xlx_hi, const double* __restrict__ xlx_tab) {
+  const long long d = n_users - x;
+  return (d >= 0 && d < (long long)XLX_TABLE) ? xlx_hi[d] : x_log_x_tab(x, xlx_tab);
+}
 __device__ __forceinline__ double llr_from_entropies_tab(double row_entropy, double column_entropy, double xlx_n, long long k11, long long k12,
-                                                         long long k21, long long k22, const double* __restrict__ xlx_tab) {
+                                                         long long k21, long long k22, const double* __restrict__ xlx_tab,
+                                                         long long n_users, const double* __restrict__ xlx_hi) {
   const double matrix_entropy =
-      (((xlx_n - x_log_x_tab(k11, xlx_tab)) - x_log_x_tab(k12, xlx_tab)) - x_log_x_tab(k21, xlx_tab)) - x_log_x_tab(k22, xlx_tab);
+      (((xlx_n - x_log_x_tab(k11, xlx_tab)) - x_log_x_tab(k12, xlx_tab)) - x_log_x_tab(k21, xlx_tab)) - x_log_x_hi(k22, n_users, xlx_hi, xlx_tab);
   const double s = row_entropy + column_entropy;
   if (s < matrix_entropy) return 0.0; /* round off error */
   return 2.0 * (s - matrix_entropy);

@@ -34,6 +34,7 @@ struct CcoArgs {
   const double* ent_b;       // columnEntropy per item of B
   const double* xlx_n;       // [1] xLogX(N)
   const double* xlx_tab;     // [XLX_TABLE_HOST] xLogX of small integers
+  const double* xlx_hi;      // [XLX_TABLE_HOST] xLogX(n_users - d): the k22 term without a logarithm
   int32_t debug;             // ablation switches for profiling (0 in production): 1 = gather only, 2 = no LLR, 4 = no top-k
   long long n_users;
   int32_t n_cols_b;
@@ -123,6 +124,7 @@ hipError_t launch_pop_counts(hipStream_t st, int n_cu, int64_t n, const int32_t*
                              const int64_t* bounds, int32_t* counts);
 
 hipError_t launch_xlx_table(hipStream_t st, double* tab);
+hipError_t launch_xlx_hi_table(hipStream_t st, double* tab, long long n_users);
 hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, double* xlx_n);
 
 // pstart[cap], plen[cap] (scratch), wp[cap + 1]; cap >= nnz(A'); tile_sums scratch as for scans over cap elements

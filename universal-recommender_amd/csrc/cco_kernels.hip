@@ -1108,6 +1108,15 @@ hipError_t launch_xlx_table(hipStream_t st, double* tab) {
   hipLaunchKernelGGL(xlx_table_kernel, dim3(XLX_TABLE / 256), dim3(256), 0, st, tab);
   return hipGetLastError();
 }
+// tab[d] = xLogX(n_users - d), d < XLX_TABLE (entries with n_users - d < 0 are never read)
+__global__ __launch_bounds__(256) void xlx_hi_table_kernel(double* __restrict__ tab, long long n_users) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d < XLX_TABLE) tab[d] = n_users - d >= 0 ? x_log_x(n_users - (long long)d) : 0.0;
+}
+hipError_t launch_xlx_hi_table(hipStream_t st, double* tab, long long n_users) {
+  hipLaunchKernelGGL(xlx_hi_table_kernel, dim3(XLX_TABLE / 256), dim3(256), 0, st, tab, n_users);
+  return hipGetLastError();
+}
 
 // ============================================================================================
 // Expand preparation.  For every entry p of the CSC of A' (user u of some item) it records where u's B' row starts
@@ -1617,7 +1626,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
             if (!(a.exclude_self && j == i)) {
               const double llr = (a.debug & 2) ? (double)k11
                                                : llr_from_entropies_tab(row_entropy, eb[x], xlx_n, k11, ca - k11, (long long)cbj[x] - k11,
-                                                                        a.n_users - ca - (long long)cbj[x] + k11, a.xlx_tab);
+                                                                        a.n_users - ca - (long long)cbj[x] + k11, a.xlx_tab, a.n_users, a.xlx_hi);
               if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
             }
             kk[t] = key;
@@ -1812,13 +1821,29 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
       }
       team_sync<T>();
       const unsigned n = (a.debug & 16) ? 0u : *nsel;  // ablation 16: no ranking / output
+      // Rank by counting.  Up to SEL_M survivors are put in order in LDS first (the arrays of the select's ambiguous set
+      // are free again) and leave as contiguous stores: one element per lane scattered straight to its rank made every
+      // store a partial-line write (measured 4x write amplification on the one-wave class).
+      const bool staged = n <= (unsigned)SEL_M;
       for (unsigned t = (unsigned)tl; t < n; t += T) {
         const unsigned long long mk = selk[t];
         const int mc = (int)selc[t];
         unsigned rank = 0;
         for (unsigned u = 0; u < n; ++u) rank += best_before(selk[u], (int)selc[u], mk, mc) ? 1u : 0u;
-        a.out_idx[obase + rank] = mc;
-        a.out_llr[obase + rank] = __longlong_as_double((long long)mk);
+        if (staged) {
+          amb_key[rank] = mk;
+          amb_col[rank] = (unsigned)mc;
+        } else {
+          a.out_idx[obase + rank] = mc;
+          a.out_llr[obase + rank] = __longlong_as_double((long long)mk);
+        }
+      }
+      if (staged) {
+        team_sync<T>();
+        for (unsigned t = (unsigned)tl; t < n; t += T) {
+          a.out_idx[obase + t] = (int)amb_col[t];
+          a.out_llr[obase + t] = __longlong_as_double((long long)amb_key[t]);
+        }
       }
       if (tl == 0) a.out_count[i - a.item_lo] = (int)n;
     }
@@ -1937,7 +1962,7 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
         const long long cbj = a.cnt_b[j];
         const double llr = (a.debug & 2) ? (double)k11
                                          : llr_from_entropies_tab(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11,
-                                                                  a.xlx_tab);
+                                                                  a.xlx_tab, a.n_users, a.xlx_hi);
         if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
           mk = (unsigned long long)__double_as_longlong(llr);
           mc = j;
@@ -2015,7 +2040,7 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
         const long long k11 = atomicExch(&cnt[j], 0);  // exactly one lane claims (and clears) each column
         if (k11 > 0 && !(a.exclude_self && j == i)) {
           const long long cbj = a.cnt_b[j];
-          const double llr = llr_from_entropies_tab(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11, a.xlx_tab);
+          const double llr = llr_from_entropies_tab(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11, a.xlx_tab, a.n_users, a.xlx_hi);
           if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
             const int pos = atomicAdd(&s_ncand, 1);
             ckey[pos] = (unsigned long long)__double_as_longlong(llr);

@@ -70,6 +70,7 @@ void urcco_session_destroy(urcco_session* s) {
   (void)hipStreamSynchronize(s->stream);
   if (s->arena) (void)hipFree(s->arena);
   if (s->xlx_tab) (void)hipFree(s->xlx_tab);
+  if (s->xlx_hi) (void)hipFree(s->xlx_hi);
   if (s->g_counts) { (void)hipFree(s->g_counts); (void)hipFree(s->g_cand_key); (void)hipFree(s->g_cand_col); }
   s->collect();
   for (hipEvent_t e : s->free_events) (void)hipEventDestroy(e);
@@ -268,6 +269,11 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
     HIPC(hipMalloc((void**)&s->xlx_tab, sizeof(double) * urcco::XLX_TABLE_HOST));
     HIPC(urcco::launch_xlx_table(s->stream, s->xlx_tab));
   }
+  if (!s->xlx_hi) HIPC(hipMalloc((void**)&s->xlx_hi, sizeof(double) * urcco::XLX_TABLE_HOST));
+  if (s->xlx_hi_n != n_users) {
+    HIPC(urcco::launch_xlx_hi_table(s->stream, s->xlx_hi, n_users));
+    s->xlx_hi_n = n_users;
+  }
   const int64_t n_tiles = ((int64_t)n + urcco::BIN_TILE - 1) / urcco::BIN_TILE;
   const bool same = (counts_a == counts_b) && (n_items_a == n_cols_b);
   const int64_t cap = nnz_a_bound;
@@ -306,7 +312,7 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   urcco::CcoArgs a;
   a.bin_rows = bin_rows; a.bin_off = bin_off;
   a.a_col_ptr = a_col_ptr; a.pstart = pstart; a.wp = wp; a.b_col_idx = b_col_idx;
-  a.cnt_a = counts_a; a.cnt_b = counts_b; a.ent_a = ent_a; a.ent_b = ent_b; a.xlx_n = xlx_n; a.xlx_tab = s->xlx_tab; a.debug = s->debug;
+  a.cnt_a = counts_a; a.cnt_b = counts_b; a.ent_a = ent_a; a.ent_b = ent_b; a.xlx_n = xlx_n; a.xlx_tab = s->xlx_tab; a.xlx_hi = s->xlx_hi; a.debug = s->debug;
   a.n_users = n_users; a.n_cols_b = n_cols_b; a.item_lo = item_lo; a.exclude_self = exclude_self ? 1 : 0; a.k = k;
   a.has_min_llr = has_min_llr ? 1 : 0; a.min_llr = min_llr; a.count_bits = count_bits;
   a.col_bytes = n_cols_b <= (1 << 8) ? 1 : (n_cols_b <= (1 << 16) ? 2 : (n_cols_b <= (1 << 24) ? 3 : 4));

@@ -81,6 +81,8 @@ struct urcco_session {
   int32_t* g_cand_col = nullptr;
   int64_t g_cols = 0;
   double* xlx_tab = nullptr;  // xLogX of small integers (N-independent), filled once
+  double* xlx_hi = nullptr;   // xLogX(N - d) for the N of the last build
+  long long xlx_hi_n = -1;
   int debug = 0;              // kernel ablation switches (profiling only)
   // optional per-stage HIP-event timing (bench.py's roofline numbers)
   bool timing = false;
