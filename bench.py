@@ -353,6 +353,22 @@ def main():
         ctx.set_timing(False)
         ctx.set_flags(base_flags)
         kernel_timing_mode = f"separate single-stream pass of the same steps (the timed region overlaps the event types on {len(shards)} HIP streams)"
+    # the same steps with URCCO_FLAG_UNORDERED_ROWS (rows = top-k sets without the in-kernel ranking pass: what a JNI host,
+    # which re-inserts by column index anyway, would ask for) -- reported beside `value`, never as `value`
+    unordered = None
+    if world == 1 and not args.single_stream and not args.force_exchange:
+        ctx.set_flags(base_flags | _lib.FLAG_UNORDERED_ROWS)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0u = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        unordered = (time.perf_counter() - t0u) / args.steps
+        ctx.set_flags(base_flags)
+        step()          # leave the ordered result in the context's buffers for the facts below
+        barrier()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -468,6 +484,9 @@ def main():
         "roofline": roofline, "roofline_lds": roofline_lds, "kernels": kernels, "kernel_timing": kernel_timing_mode, "cpu_baseline": cpu_baseline,
         "cpu_baseline_scipy": cpu_scipy, "gpu_over_cpu": round(value / cpu_baseline["value"], 1) if cpu_baseline else None,
         "input_generation_s": round(gen_s, 1),
+        "unordered_rows": None if unordered is None else {"flag": "URCCO_FLAG_UNORDERED_ROWS", "ms_per_step": round(unordered * 1e3, 4),
+                                                           "pairs_per_s": round(pairs / unordered, 1),
+                                                           "note": "same build, indicator rows as unordered top-k sets (no ranking pass); not the headline value"},
     }
     line.update(extras)
     print(json.dumps(line))

@@ -75,6 +75,10 @@ typedef struct urcco_options {
 } urcco_options;
 #define URCCO_FLAG_SINGLE_STREAM 1  /* run the event types back to back on one HIP stream per GPU (profiling) */
 #define URCCO_FLAG_FORCE_EXCHANGE 2 /* run the multi-GPU exchange path (collectives, work-balanced ranges) even with one rank */
+#define URCCO_FLAG_UNORDERED_ROWS 4 /* indicator rows carry their top-k SET in unspecified (run-dependent) order: what Mahout's
+                                       computeSimilarities returns -- a sparse vector has no score order, the reference sorts
+                                       later (toStringMapRDD, package.scala:102) and a JNI host re-inserts by index anyway.
+                                       Saves the in-kernel ranking pass.  Default off: rows ordered (llr desc, col asc). */
 
 /* One returned IndexedDataset: rows = items of the primary matrix A (rowIDs = A.columnIDs), columns = items
  * of B_i (columnIDs = B_i.columnIDs), values = raw LLR.  Inside a row entries are ordered (llr desc, col asc)

@@ -118,3 +118,12 @@ def compare_with_oracle_large(sess, mats, params, seed, mode=0, threads=None):
         res.append((st.copy(), ties))
         del ref, b
     return out, res
+
+
+def sort_rows(got):
+    """(row_ptr, col_idx, llr) with every row re-ordered to the canonical (llr desc, col asc) -- for outputs produced under
+    URCCO_FLAG_UNORDERED_ROWS, whose rows carry the right SET in arbitrary order."""
+    rp, ci, llr = got
+    rows = np.repeat(np.arange(rp.size - 1), np.diff(rp))
+    order = np.lexsort((ci, -llr, rows))
+    return rp, ci[order], llr[order]

@@ -197,3 +197,10 @@ def test_stream_per_event_type_is_bit_identical(gpu_session):
     from universal_recommender_amd import _lib
     import test_sim_context as ctx_cases
     ctx_cases.context_reuse_case(_lib.load(_lib.DEFAULT_PATH), gpu_session.device)
+
+
+def test_unordered_rows_flag_on_gpu(gpu_session):
+    """URCCO_FLAG_UNORDERED_ROWS on hardware: rows hold exactly the oracle's top-k sets."""
+    from universal_recommender_amd import _lib
+    import test_sim_context as ctx_cases
+    ctx_cases.unordered_rows_case(_lib.load(_lib.DEFAULT_PATH), gpu_session.device)

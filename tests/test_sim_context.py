@@ -161,3 +161,31 @@ def test_one_process_drives_several_gpus(sim_lib, n_gpus, monkeypatch):
         assert coll.error is None
     finally:
         ctx.close()
+
+
+def unordered_rows_case(lib, device):
+    """URCCO_FLAG_UNORDERED_ROWS: every row holds exactly the oracle's top-k set (ids and scores), in arbitrary order --
+    all accumulator classes, k boundary with ties, minLLR."""
+    from universal_recommender_amd import _lib
+    from universal_recommender_amd.device import Context, cross_occurrence_context
+    from helpers import sort_rows
+    import test_sim_kernel_logic as logic
+    rng = np.random.default_rng(2)
+    cases = [([rand_csr(rng, 4000, 20000, 12, zipf_s=1.2), rand_csr(rng, 4000, 30000, 25, zipf_s=1.1)], [P(10000, 50), P(10000, 20)]),
+             ([rand_csr(rng, 300, 80, 6), rand_csr(rng, 300, 40, 9), rand_csr(rng, 300, 7, 2)], [P(20, 5), P(30, 7, 0.5), P(500, 3)]),
+             ([logic._tied_block(13, 150, 2, np.arange(150))] * 2, [P(100000, 20), P(100000, 20)]),
+             ([rand_csr(rng, 1500, 40, 6, zipf_s=1.5), rand_csr(rng, 1500, 17000, 40, zipf_s=0.3)], [P(100000, 10), P(100000, 60)])]
+    ctx = Context(device, lib, flags=_lib.FLAG_UNORDERED_ROWS)
+    try:
+        for mats, ps in cases:
+            ref = O.cross_occurrence_downsampled(mats, ps, 5)
+            out = cross_occurrence_context(ctx, [to_dev(m, device) for m in mats], to_params(ps), 5)
+            for o, r in zip(out, ref):
+                assert int(o.stats[0]) == r.pairs
+                check_indicators(sort_rows(o.to_host()), r)
+    finally:
+        ctx.close()
+
+
+def test_unordered_rows_flag(sim_lib):
+    unordered_rows_case(sim_lib, torch.device("cpu"))

@@ -16,6 +16,7 @@ DEFAULT_PATH = os.path.join(_HERE, "lib", "liburcco.so")
 OK, BAD_ARG, OOM_HOST, OOM_DEVICE, HIP_ERROR, INTERNAL, NO_DEVICE, RCCL_ERROR = range(8)
 FLAG_SINGLE_STREAM = 1
 FLAG_FORCE_EXCHANGE = 2
+FLAG_UNORDERED_ROWS = 4
 UNIQUE_ID_BYTES = 128
 ROW_RATE_MAHOUT_INT_DIV = 0
 ROW_RATE_FRACTIONAL = 1

@@ -46,6 +46,7 @@ struct CcoArgs {
   int32_t count_bits;        // packed LDS entry = ((col+1) << count_bits) | count
   int32_t col_bytes;         // bytes needed for a column index of B (1..4): digits of the top-k tie break
   int32_t g_log2;            // lanes cooperating on one user's B row = 1 << g_log2
+  int32_t unordered;         // 1: rows carry their top-k set in arbitrary order (no ranking pass)
   // outputs (strided by k)
   int32_t* out_count;
   int32_t* out_idx;

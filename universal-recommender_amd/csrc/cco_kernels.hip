@@ -1809,6 +1809,25 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
       team_sync<T>();
       unsigned long long* selk = kk + D;                                  // [k]
       unsigned* selc = reinterpret_cast<unsigned*>(selk + a.k);          // [k]
+      if (a.unordered) {
+        // URCCO_FLAG_UNORDERED_ROWS: the top-k SET of the row, in whatever order the lanes claim output slots -- what
+        // Mahout's computeSimilarities returns (a sparse vector has no score order; the reference sorts later, in
+        // toStringMapRDD, package.scala:102).  No ranking pass.
+        for (unsigned t = (unsigned)tl; t < D; t += T) {
+          const unsigned long long key = kk[t];
+          if (key == 0ull) continue;
+          const unsigned col = (unsigned)((int)(tab[t] >> cb) - 1);
+          if (key > thr_key || (key == thr_key && ~col >= thr_ncol)) {
+            const unsigned pos = atomicAdd(nsel, 1u);
+            a.out_idx[obase + pos] = (int)col;
+            a.out_llr[obase + pos] = __longlong_as_double((long long)key);
+          }
+        }
+        team_sync<T>();
+        if (tl == 0) a.out_count[i - a.item_lo] = (int)*nsel;
+        team_sync<T>();
+        continue;
+      }
       for (unsigned t = (unsigned)tl; t < D; t += T) {
         const unsigned long long key = kk[t];
         if (key == 0ull) continue;
@@ -1971,8 +1990,17 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
       kkm[lane] = mk;
     }
     wave_sync();
-    const int n_valid = __popcll(__ballot(mk != 0ull));
-    if (!(a.debug & 4)) {
+    const unsigned long long valid_mask = __ballot(mk != 0ull);
+    const int n_valid = __popcll(valid_mask);
+    if (a.unordered && n_valid <= a.k && !(a.debug & 4)) {  // every candidate is emitted: no ranking needed (wave-uniform)
+      const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
+      if (mk != 0ull) {
+        const int pos = __popcll(valid_mask & lt);
+        a.out_idx[obase + pos] = mc;
+        a.out_llr[obase + pos] = __longlong_as_double((long long)mk);
+      }
+      if (lane == 0) a.out_count[i - a.item_lo] = n_valid;
+    } else if (!(a.debug & 4)) {
       const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
       unsigned rank = 0;
       for (unsigned u = 0; u < D; ++u) {  // broadcast LDS reads

@@ -280,12 +280,14 @@ int ensure_events(urcco_context* c, DevState& D, int n_ds) {
     URC(urcco_session_create(D.device, nullptr, &s));
     s->debug = c->debug;
     s->timing = c->timing;
+    s->unordered_rows = (c->flags & URCCO_FLAG_UNORDERED_ROWS) ? 1 : 0;
     D.sessions.push_back(s);
   }
   if ((int)D.ev.size() < n_ds) D.ev.resize((size_t)n_ds);
   for (int d = 0; d < n_ds; ++d) {
     EvState& E = D.ev[(size_t)d];
     E.s = sess_of(c, D, d);
+    E.s->unordered_rows = (c->flags & URCCO_FLAG_UNORDERED_ROWS) ? 1 : 0;
     if (!E.ev_sampled) HIPC(hipEventCreateWithFlags(&E.ev_sampled, hipEventDisableTiming));
     if (!E.ev_done) HIPC(hipEventCreateWithFlags(&E.ev_done, hipEventDisableTiming));
     if (!E.ev_rp) HIPC(hipEventCreateWithFlags(&E.ev_rp, hipEventDisableTiming));

@@ -84,6 +84,7 @@ struct urcco_session {
   double* xlx_hi = nullptr;   // xLogX(N - d) for the N of the last build
   long long xlx_hi_n = -1;
   int debug = 0;              // kernel ablation switches (profiling only)
+  int unordered_rows = 0;     // URCCO_FLAG_UNORDERED_ROWS of the owning context
   // optional per-stage HIP-event timing (bench.py's roofline numbers)
   bool timing = false;
   struct Rec { int stage; hipEvent_t e0, e1; };
