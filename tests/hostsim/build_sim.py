@@ -32,3 +32,31 @@ def build(force: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+
+
+OUT_ASAN = os.path.join(HERE, "_build", "liburcco_hostsim_asan.so")
+ORACLE_ASAN = os.path.join(HERE, "_build", "liburcco_oracle_asan.so")
+
+
+def build_asan(force: bool = False):
+    """The C-ABI translation units (urcco_api / urcco_context / urcco_hash: sessions, contexts, staging, validation, error
+    paths) and the C oracle compiled with AddressSanitizer + UndefinedBehaviorSanitizer; the kernel sources and the fiber
+    runtime stay uninstrumented (the simulator switches stacks by hand, which ASan's stack instrumentation cannot follow).
+    Loaded by tests/test_sanitizers.py in a subprocess that preloads libasan."""
+    os.makedirs(os.path.dirname(OUT_ASAN), exist_ok=True)
+    if force or not os.path.exists(OUT_ASAN) or any(os.path.getmtime(OUT_ASAN) < os.path.getmtime(d) for d in DEPS):
+        base = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-fopenmp", "-ffp-contract=off", "-fno-strict-aliasing", "-pthread",
+                "-I", os.path.join(HERE, "include"), "-Wno-unknown-pragmas"]
+        san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"]
+        objs = []
+        for s in SOURCES:
+            o = os.path.join(HERE, "_build", "asan_" + os.path.basename(s) + ".o")
+            instrument = os.path.basename(s) in ("urcco_api.hip", "urcco_context.hip", "urcco_hash.hip")
+            subprocess.check_call(base + (san if instrument else []) + ["-x", "c++", "-c", s, "-o", o])
+            objs.append(o)
+        subprocess.check_call(["g++", "-shared", "-fopenmp", "-pthread"] + san + objs + ["-ldl", "-o", OUT_ASAN])
+    osrc = os.path.join(ROOT, "oracle", "cco_oracle.c")
+    if force or not os.path.exists(ORACLE_ASAN) or os.path.getmtime(ORACLE_ASAN) < os.path.getmtime(osrc):
+        subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-std=c11", "-fopenmp", "-ffp-contract=off", "-fsanitize=address,undefined",
+                               "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined", "-shared", osrc, "-lm", "-o", ORACLE_ASAN])
+    return OUT_ASAN, ORACLE_ASAN

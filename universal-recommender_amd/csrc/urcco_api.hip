@@ -316,7 +316,7 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   a.n_users = n_users; a.n_cols_b = n_cols_b; a.item_lo = item_lo; a.exclude_self = exclude_self ? 1 : 0; a.k = k;
   a.has_min_llr = has_min_llr ? 1 : 0; a.min_llr = min_llr; a.count_bits = count_bits;
   a.col_bytes = n_cols_b <= (1 << 8) ? 1 : (n_cols_b <= (1 << 16) ? 2 : (n_cols_b <= (1 << 24) ? 3 : 4));
-  a.unordered = s->unordered_rows;
+  a.unordered = (s->unordered_rows || (s->debug & 32768)) ? 1 : 0;  // debug 32768: per-class measurement of the flag
   a.g_log2 = 4;  // 16 lanes stream one user's B' row: 64 B segments, matches the ~10-40 item rows the cut leaves
   a.out_count = out_count; a.out_idx = out_idx; a.out_llr = out_llr;
   a.err = reinterpret_cast<unsigned long long*>(stats + 1 + 4 * urcco::NBINS);
@@ -365,7 +365,8 @@ int urcco_dev_dictionary_build(urcco_session* s, int64_t n, const uint64_t* keys
   if (!s || n < 0 || (n > 0 && (!keys || !first_pos)) || !table || !n_ids) return fail(URCCO_BAD_ARG, "urcco_dev_dictionary_build: bad argument");
   if (n >= ((int64_t)1 << 32) - 1) return fail(URCCO_BAD_ARG, "urcco_dev_dictionary_build: at most 2^32 - 2 events per stream, got %lld", (long long)n);
   *table = nullptr;
-  std::unique_ptr<urcco_key_table, void (*)(urcco_key_table*)> tab(new urcco_key_table(), urcco_key_table_destroy);
+  std::unique_ptr<urcco_key_table, void (*)(urcco_key_table*)> tab(new (std::nothrow) urcco_key_table(), urcco_key_table_destroy);
+  if (!tab) return fail(URCCO_OOM_HOST, "key table alloc");
   tab->device = s->device;
   int64_t cap = 1024;
   while (cap < 2 * n) cap <<= 1;

@@ -93,21 +93,33 @@ struct urcco_session {
   double acc_ms[URCCO_N_STAGES] = {0};
   int64_t acc_n[URCCO_N_STAGES] = {0};
 
-  hipEvent_t get_event() {
+  // Timing bookkeeping never throws across the C ABI: an allocation failure just drops the sample.
+  hipEvent_t get_event() noexcept {
     if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
     hipEvent_t e = nullptr;
     (void)hipEventCreate(&e);
     return e;
   }
-  void begin(int stage) {
+  void begin(int stage) noexcept {
     if (!timing) return;
+    try {
+      recs.reserve(recs.size() + 1);
+      free_events.reserve(free_events.size() + 2 * (recs.size() + 1));
+    } catch (...) {
+      open_rec = false;
+      return;
+    }
     Rec r{stage, get_event(), get_event()};
+    if (!r.e0 || !r.e1) { open_rec = false; return; }
     (void)hipEventRecord(r.e0, stream);
     recs.push_back(r);
+    open_rec = true;
   }
-  void end() {
-    if (!timing) return;
+  bool open_rec = false;
+  void end() noexcept {
+    if (!timing || !open_rec || recs.empty()) return;
     (void)hipEventRecord(recs.back().e1, stream);
+    open_rec = false;
   }
   void collect() {
     (void)hipStreamSynchronize(stream);
