@@ -580,7 +580,13 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(int64_t n_rows, const in
   if (blockIdx.x == 0 && threadIdx.x == 0) g[n_tiles] = (n_rows + 1) << 1;
 }
 
+// Each thread owns two runs of EIGHT consecutive entries (two 16-byte loads each): a run's keep bits are one byte of the
+// tile's keep words, written straight from the lane -- no cross-lane assembly -- and one entry -> row search serves eight
+// entries.  Index arithmetic inside the tile is 32-bit.  The eight threshold gathers of a run are issued before the row
+// walk; the hashes are evaluated four at a time (independent multiply chains).
 // `debug` (profiling only, results meaningless): 32 = cheap hash, 64 = no threshold gather, 128 = no row lookup
+constexpr int DS_RUN = 8;
+constexpr int DS_RUNS = DS_TILE / (DS_THREADS * DS_RUN);  // 2
 __global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_rows, const int64_t* __restrict__ rp,
                                                                       const int32_t* __restrict__ ci, int64_t nnz,
                                                                       const int64_t* __restrict__ g,
@@ -593,18 +599,20 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_
   __shared__ int s_cnt[DS_THREADS / WAVE];
   const int64_t tile = blockIdx.x;
   const int64_t e0 = tile * DS_TILE;
-  const int64_t e1 = (e0 + DS_TILE < nnz) ? e0 + DS_TILE : nnz;
-  // all four 16-byte column vectors of this thread are requested before anything else (independent of the row lookup)
-  int cols[DS_ITERS][4];
+  const int n_live = (int)((e0 + DS_TILE < nnz) ? DS_TILE : nnz - e0);  // entries of this tile
+  // all column loads of the thread are requested before anything else (independent of the row lookup)
+  int cols[DS_RUNS][DS_RUN];
 #pragma unroll
-  for (int it = 0; it < DS_ITERS; ++it) {
-    const int64_t e = e0 + ((int64_t)it * DS_THREADS + threadIdx.x) * 4;
-    if (vec_ok && e + 3 < nnz) {
-      const int4 x = *reinterpret_cast<const int4*>(ci + e);
-      cols[it][0] = x.x; cols[it][1] = x.y; cols[it][2] = x.z; cols[it][3] = x.w;
+  for (int gq = 0; gq < DS_RUNS; ++gq) {
+    const int el0 = (gq * DS_THREADS + (int)threadIdx.x) * DS_RUN;
+    const int64_t e = e0 + el0;
+    if (vec_ok && el0 + DS_RUN <= n_live) {
+      const int4 x = *reinterpret_cast<const int4*>(ci + e), y = *reinterpret_cast<const int4*>(ci + e + 4);
+      cols[gq][0] = x.x; cols[gq][1] = x.y; cols[gq][2] = x.z; cols[gq][3] = x.w;
+      cols[gq][4] = y.x; cols[gq][5] = y.y; cols[gq][6] = y.z; cols[gq][7] = y.w;
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) cols[it][q] = (e + q < nnz) ? ci[e + q] : 0;
+      for (int q = 0; q < DS_RUN; ++q) cols[gq][q] = (el0 + q < n_live) ? ci[e + q] : 0;
     }
   }
   // slice rp[r_s .. r_e]: r_s = the last row known to start at or before e0, r_e = the first row starting at or after e1
@@ -619,82 +627,86 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_
     for (int64_t t = threadIdx.x; t < n_slice; t += DS_THREADS) s_rel[t] = (int)(rp[r_s + t] - e0);
   __syncthreads();
   const int lane = threadIdx.x & (WAVE - 1);
-  // slice-relative row of the first entry of each of the thread's four vectors = the last slice index whose start is
-  // <= the entry (empty rows in front of it are skipped by construction); the four binary searches advance in lock
-  // step so that their LDS reads overlap
-  int rrel[DS_ITERS];
+  // slice-relative row of the first entry of each run = the last slice index whose start is <= the entry (empty rows in
+  // front of it are skipped by construction); the searches of a thread advance in lock step so that their LDS reads overlap
+  int rrel[DS_RUNS];
 #pragma unroll
-  for (int it = 0; it < DS_ITERS; ++it) rrel[it] = 0;
+  for (int gq = 0; gq < DS_RUNS; ++gq) rrel[gq] = 0;
   if (in_lds && !(debug & 128)) {
     const int last = (int)n_slice - 1;  // s_rel[last] = rp[r_e] - e0 >= the tile length
     int top = 1;
     while (top < last) top <<= 1;
     for (int sft = top >> 1; sft > 0; sft >>= 1) {
 #pragma unroll
-      for (int it = 0; it < DS_ITERS; ++it) {
-        const int el = (it * DS_THREADS + (int)threadIdx.x) * 4;
-        const int idx = rrel[it] + sft;
-        if (idx < last && s_rel[idx] <= el) rrel[it] = idx;
+      for (int gq = 0; gq < DS_RUNS; ++gq) {
+        const int el0 = (gq * DS_THREADS + (int)threadIdx.x) * DS_RUN;
+        const int idx = rrel[gq] + sft;
+        if (idx < last && s_rel[idx] <= el0) rrel[gq] = idx;
       }
     }
   }
   const double dmax = (double)max_n;
+  const uint32_t row0 = (uint32_t)(row_base + r_s);
   int kept = 0;
 #pragma unroll
-  for (int it = 0; it < DS_ITERS; ++it) {  // block-uniform trip count: wave ops below are legal
-    const int64_t e = e0 + ((int64_t)it * DS_THREADS + threadIdx.x) * 4;
-    unsigned nib = 0;
-    if (e < e1) {
-      unsigned long long thr_col[4];  // the four threshold gathers travel together
+  for (int gq = 0; gq < DS_RUNS; ++gq) {
+    const int el0 = (gq * DS_THREADS + (int)threadIdx.x) * DS_RUN;
+    unsigned keep_byte = 0;
+    if (el0 < n_live) {
+      unsigned long long thr_col[DS_RUN];  // the eight threshold gathers travel together
 #pragma unroll
-      for (int q = 0; q < 4; ++q) thr_col[q] = (debug & 64) ? RATE_ONE - 1 : thresholds[cols[it][q]];
-      const int el = (int)(e - e0);
-      int64_t r;
-      int64_t r_beg, r_end;  // relative to e0
+      for (int q = 0; q < DS_RUN; ++q) thr_col[q] = (debug & 64) ? RATE_ONE - 1 : thresholds[cols[gq][q]];
+      int r_rel, r_beg, r_end;  // slice-relative row of the current entry and its extent relative to e0
       if (in_lds) {
-        r = r_s + rrel[it];
-        r_beg = s_rel[rrel[it]];
-        r_end = s_rel[rrel[it] + 1];
+        r_rel = rrel[gq];
+        r_beg = s_rel[r_rel];
+        r_end = s_rel[r_rel + 1];
       } else {
-        r = upper_bound_i64(rp, r_s, r_e, e) - 1;
-        r_beg = rp[r] - e0;
-        r_end = rp[r + 1] - e0;
+        const int64_t r = upper_bound_i64(rp, r_s, r_e, e0 + el0) - 1;
+        r_rel = (int)(r - r_s);
+        r_beg = (int)(rp[r] - e0);
+        r_end = (int)(rp[r + 1] - e0);
       }
+      int r_of[DS_RUN], n_of[DS_RUN];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int64_t rel = el + q;
-        if (e + q < e1) {
-          while (rel >= r_end && !(debug & 128)) {  // next non-empty row
-            ++r;
+      for (int q = 0; q < DS_RUN; ++q) {
+        if (el0 + q < n_live) {
+          while (el0 + q >= r_end && !(debug & 128)) {  // next non-empty row
+            ++r_rel;
             r_beg = r_end;
-            r_end = in_lds ? (int64_t)s_rel[r + 1 - r_s] : rp[r + 1] - e0;
+            r_end = in_lds ? s_rel[r_rel + 1] : (int)(rp[r_s + r_rel + 1] - e0);
           }
-          // u01 = m * 2^-53 with integer m < 2^53, so  u01 <= rate  <=>  m <= floor(rate * 2^53)  (the scaling is exact):
-          // the per-column threshold is precomputed (one division per column, not per interaction) and entries whose
-          // rate is 1.0 are kept without evaluating the hash.
-          const int64_t n_row = r_end - r_beg;
-          unsigned long long thr_row = RATE_ONE;
-          if (n_row > (int64_t)max_n)
-            thr_row = row_rate_mode == 0 ? 0ull /* Int / Int = 0 */ : (unsigned long long)((dmax / (double)n_row) * 9007199254740992.0);
-          const int j = cols[it][q];
-          const unsigned long long thr = thr_row < thr_col[q] ? thr_row : thr_col[q];
-          const unsigned long long h =
-              (debug & 32) ? ((unsigned long long)((unsigned)j * 0x9E3779B1u) << 21) : hash53(seed, (uint32_t)(row_base + r), (uint32_t)j);
-          if (thr == RATE_ONE || h <= thr) {
-            nib |= 1u << q;
-            if (post_counts) atomicAdd(&post_counts[j], 1);
+        }
+        r_of[q] = r_rel;
+        n_of[q] = r_end - r_beg;
+      }
+      // keep  <=>  hash <= perRow threshold  &&  hash <= perThing threshold: u01 = m * 2^-53 with integer m < 2^53, so
+      // u01 <= rate  <=>  m <= floor(rate * 2^53) (the scaling is exact); a rate of 1.0 (threshold 2^53) always passes
+#pragma unroll
+      for (int half = 0; half < DS_RUN; half += 4) {
+        unsigned long long h[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          h[q] = (debug & 32) ? ((unsigned long long)((unsigned)cols[gq][half + q] * 0x9E3779B1u) << 21)
+                              : hash53(seed, row0 + (uint32_t)r_of[half + q], (uint32_t)cols[gq][half + q]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int qq = half + q;
+          if (el0 + qq < n_live) {
+            bool keep = h[q] <= thr_col[qq];
+            if (n_of[qq] > max_n)  // rare: a user with more interactions than the cap (Int / Int = 0: only a hash of exactly 0 passes)
+              keep = keep && h[q] <= (row_rate_mode == 0 ? 0ull : (unsigned long long)((dmax / (double)n_of[qq]) * 9007199254740992.0));
+            if (keep) {
+              keep_byte |= 1u << qq;
+              if (post_counts) atomicAdd(&post_counts[cols[gq][qq]], 1);
+            }
           }
         }
       }
     }
-    kept += __popc(nib);
-    // keep word of 16 neighbouring lanes (64 consecutive entries); words behind the last entry are written as zero
-    unsigned long long m = (unsigned long long)nib << ((lane & 15) * 4);
-    m |= shfl_xor_u64(m, 1);
-    m |= shfl_xor_u64(m, 2);
-    m |= shfl_xor_u64(m, 4);
-    m |= shfl_xor_u64(m, 8);
-    if ((lane & 15) == 0) flags[tile * DS_WORDS + ((it * DS_THREADS + (int)threadIdx.x) >> 4)] = m;
+    kept += __popc(keep_byte);
+    // byte b of keep word w covers entries 64 w + 8 b ..: this run's byte; runs behind the last entry are written as zero
+    reinterpret_cast<unsigned char*>(flags + tile * DS_WORDS)[gq * DS_THREADS + (int)threadIdx.x] = (unsigned char)keep_byte;
   }
   for (int msk = 1; msk < WAVE; msk <<= 1) kept += __shfl_xor(kept, msk);
   if (lane == 0) s_cnt[threadIdx.x / WAVE] = kept;
