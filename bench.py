@@ -332,6 +332,20 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    # the same steps with URCCO_FLAG_UNORDERED_ROWS (rows = top-k sets without the in-kernel ranking pass: what a JNI host,
+    # which re-inserts by column index anyway, would ask for) -- reported beside `value`, never as `value`
+    unordered = None
+    if world == 1 and not args.single_stream and not args.force_exchange:
+        ctx.set_flags(base_flags | _lib.FLAG_UNORDERED_ROWS)
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0u = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        unordered = (time.perf_counter() - t0u) / args.steps
+        ctx.set_flags(base_flags)
     if args.single_stream:
         timings = ctx.get_timings()
         ctx.set_timing(False)
@@ -353,22 +367,6 @@ def main():
         ctx.set_timing(False)
         ctx.set_flags(base_flags)
         kernel_timing_mode = f"separate single-stream pass of the same steps (the timed region overlaps the event types on {len(shards)} HIP streams)"
-    # the same steps with URCCO_FLAG_UNORDERED_ROWS (rows = top-k sets without the in-kernel ranking pass: what a JNI host,
-    # which re-inserts by column index anyway, would ask for) -- reported beside `value`, never as `value`
-    unordered = None
-    if world == 1 and not args.single_stream and not args.force_exchange:
-        ctx.set_flags(base_flags | _lib.FLAG_UNORDERED_ROWS)
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        t0u = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        unordered = (time.perf_counter() - t0u) / args.steps
-        ctx.set_flags(base_flags)
-        step()          # leave the ordered result in the context's buffers for the facts below
-        barrier()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

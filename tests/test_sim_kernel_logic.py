@@ -305,3 +305,21 @@ def test_row_scan_threshold_table_forms(sim_session):
             assert np.array_equal(out.row_ptr.cpu().numpy(), ref.row_ptr)
             assert np.array_equal(out.col_idx.cpu().numpy()[:ref.nnz], ref.col_idx)
             assert np.array_equal(post.cpu().numpy()[:m.n_cols], O.column_counts(ref))
+
+
+def test_global_class_ties_at_the_cut(sim_session):
+    """The global-accumulator class (here reached through the packed-count overflow: 3M columns leave 10 count bits, the
+    item has 1100 users) selects its top k by radix select over candidates in global scratch: 200 candidates with exactly
+    equal LLR, so the cut falls in the column digits (3 column bytes).  Exact ids."""
+    n_users, n_b = 1300, 3_000_000
+    a_rows = [np.array([0], np.int64) if u < 1100 else np.array([1], np.int64) for u in range(n_users)]
+    cols = 70000 + 3 * np.arange(200)
+    b_rows = [cols if u < 1100 else np.array([5, 2_999_999], np.int64) for u in range(n_users)]
+    def csr(rows, n_cols):
+        rp = np.zeros(len(rows) + 1, np.int64)
+        np.cumsum([len(r) for r in rows], out=rp[1:])
+        return O.Csr(len(rows), n_cols, rp, np.concatenate(rows).astype(np.int32))
+    a, b = csr(a_rows, 2), csr(b_rows, n_b)
+    for k in (7, 50, 150):
+        _, _, st = compare_with_oracle(sim_session, [a, b], [P(1000000, k), P(1000000, k)], 3, exact_ids=True)
+        assert st[1][0][7] > 0          # global class used

@@ -2046,12 +2046,18 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
 // top-k by k strictly-descending argmax sweeps.  Correct for any row; only meant for the rare heavy ones.
 // --------------------------------------------------------------------------------------------
 constexpr int GB_THREADS = 1024;
+constexpr int GSEL_K = 1024;  // survivors held in LDS by the radix-select form of the top-k
 
 __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) {
   constexpr int NW = GB_THREADS / WAVE;
   __shared__ unsigned long long s_pkey[2][NW];
   __shared__ int s_pcol[2][NW];
   __shared__ int s_ncand;
+  __shared__ unsigned s_hist[256];
+  __shared__ unsigned s_sel[4];
+  __shared__ int s_nsel;
+  __shared__ unsigned long long s_selk[GSEL_K];
+  __shared__ unsigned s_selc[GSEL_K];
   const int bin = NBINS - 1;
   const int list_start = a.bin_off[bin];
   const int list_n = a.bin_off[bin + 1] - list_start;
@@ -2091,10 +2097,90 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
     }
     __syncthreads();
     const int ncand = s_ncand;
+    const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
+    if (a.k <= GSEL_K) {
+      // ---- top-k: MSB-first radix select (8-bit digits, one 256-bin LDS histogram) of the k-th (llr, ~col) composite over
+      // the candidates in global scratch -- at most twelve coalesced sweeps instead of k argmax sweeps (these rows have
+      // tens of thousands of candidates: under config 5's skew the k = 50 sweeps were 60 % of a 330 us row)
+      unsigned long long thr_key = 0ull;
+      unsigned thr_ncol = 0u;
+      if (ncand > a.k) {  // block-uniform
+        unsigned need = (unsigned)a.k;
+        if (a.col_bytes < 4) thr_ncol = 0xffffffffu << (8 * a.col_bytes);  // digits of ~col above the highest used byte are all ones
+        const int first_col_pass = 8 + (3 - (a.col_bytes - 1));
+        for (int p = 0; p < 12; ++p) {  // block-uniform trip count (the break below is on a value every thread agrees on)
+          if (p >= 8 && p < first_col_pass) continue;
+          if (threadIdx.x < 256) s_hist[threadIdx.x] = 0u;
+          __syncthreads();
+          const int shk = p < 8 ? 56 - 8 * p : 0, shc = p < 8 ? 0 : 24 - 8 * (p - 8);
+          for (int t = threadIdx.x; t < ncand; t += GB_THREADS) {
+            const unsigned long long key = ckey[t];
+            bool match;
+            unsigned dig;
+            if (p < 8) {
+              match = p == 0 || (key >> (shk + 8)) == (thr_key >> (shk + 8));
+              dig = (unsigned)(key >> shk) & 255u;
+            } else {
+              const unsigned ncol = ~(unsigned)ccol[t];
+              match = key == thr_key && (p == first_col_pass || (ncol >> (shc + 8)) == (thr_ncol >> (shc + 8)));
+              dig = (ncol >> shc) & 255u;
+            }
+            if (match) atomicAdd(&s_hist[dig], 1u);
+          }
+          __syncthreads();
+          if (threadIdx.x == 0) {  // the digit that holds the cut, scanning from the top
+            unsigned above = 0u, d = 255u;
+            for (;; --d) {
+              if (above + s_hist[d] >= need || d == 0u) break;
+              above += s_hist[d];
+            }
+            s_sel[0] = d;
+            s_sel[1] = s_hist[d];
+            s_sel[2] = above;
+          }
+          __syncthreads();
+          const unsigned d = s_sel[0], cnt_d = s_sel[1];
+          need -= s_sel[2];
+          if (p < 8) thr_key |= (unsigned long long)d << shk;
+          else thr_ncol |= d << shc;
+          if (cnt_d == need) break;  // the whole bin is wanted: every composite >= the prefix (low bits zero) is selected
+        }
+      }
+      if (threadIdx.x == 0) s_nsel = 0;
+      __syncthreads();
+      for (int t = threadIdx.x; t < ncand; t += GB_THREADS) {
+        const unsigned long long key = ckey[t];
+        const unsigned col = (unsigned)ccol[t];
+        if (key > thr_key || (key == thr_key && ~col >= thr_ncol)) {
+          const int pos = atomicAdd(&s_nsel, 1);
+          if (a.unordered) {
+            a.out_idx[obase + pos] = (int)col;
+            a.out_llr[obase + pos] = __longlong_as_double((long long)key);
+          } else {
+            s_selk[pos] = key;
+            s_selc[pos] = col;
+          }
+        }
+      }
+      __syncthreads();
+      const int n = s_nsel;
+      if (!a.unordered)
+        for (int t = threadIdx.x; t < n; t += GB_THREADS) {  // rank by counting, straight to the output position
+          const unsigned long long mk = s_selk[t];
+          const int mc = (int)s_selc[t];
+          int rank = 0;
+          for (int u = 0; u < n; ++u) rank += best_before(s_selk[u], (int)s_selc[u], mk, mc) ? 1 : 0;
+          a.out_idx[obase + rank] = mc;
+          a.out_llr[obase + rank] = __longlong_as_double((long long)mk);
+        }
+      if (threadIdx.x == 0) a.out_count[i - a.item_lo] = n;
+      __syncthreads();
+      continue;
+    }
+    // k beyond the LDS survivor arrays: k strictly-descending argmax sweeps
     unsigned long long last_key = ~0ull;
     int last_col = -1;
     int emitted = 0;
-    const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
     for (int r = 0; r < a.k; ++r) {
       unsigned long long wk = 0ull;
       int wc = 0x7fffffff;
