@@ -13,7 +13,7 @@ constexpr int NBINS = 7;  // accumulator classes: 0 micro (one wave, <= 64 pairs
 // Geometry the host side needs for scratch sizing.
 constexpr int SCAN_TILE = 2048;          // elements per scan tile (256 threads x 8)
 constexpr int DS_TILE = 4096;            // entries per down-sample tile (256 threads x 4 x 4)
-constexpr int GLOBAL_BIN_BLOCKS = 64;    // persistent blocks of the global-accumulator kernel (upper bound)
+constexpr int GLOBAL_BIN_BLOCKS = 128;    // persistent blocks of the global-accumulator kernel (upper bound)
 constexpr int BIN_TILE = 1024;           // items per binning tile
 constexpr int XLX_TABLE_HOST = 4096;     // entries of the small-integer xLogX table (== XLX_TABLE in cco_device.h)
 constexpr int BIN_COLS_HOST = 3 * NBINS + 1;  // int64 per binning tile

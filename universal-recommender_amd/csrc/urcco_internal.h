@@ -156,13 +156,15 @@ struct urcco_session {
   static size_t need(size_t n, size_t elem) { return align_up((n ? n : 1) * elem, 256); }
 
   // Dense per-block counters of the global-accumulator class: g_blocks x n_cols_b x 16 B.  The block count shrinks with
-  // the width of B so that the scratch stays within ~2 GiB per session (64 blocks up to 2M columns, 13 at 10M, never fewer
+  // the width of B so that the scratch stays within 1 GiB per session (4 GiB from 1M columns on: 128 blocks at 2M, 26 at 10M, never fewer
   // than 2): the class serves the rows no LDS table can hold -- a handful under a Zipf catalogue, thousands under config
   // 5's hot head, where the number of resident blocks is what its throughput scales with.
   int g_blocks = 0;
   size_t g_cap = 0;  // elements allocated
   int ensure_global_bin(int64_t n_cols_b) {
-    int64_t blocks = ((int64_t)2048 << 20) / ((n_cols_b > 0 ? n_cols_b : 1) * 16);
+    // wide column spaces (>= 1M columns: the 10M x 2M configurations) are where thousands of rows land in this class
+    const int64_t budget = n_cols_b >= (1 << 20) ? ((int64_t)4096 << 20) : ((int64_t)1024 << 20);
+    int64_t blocks = budget / ((n_cols_b > 0 ? n_cols_b : 1) * 16);
     if (blocks > urcco::GLOBAL_BIN_BLOCKS) blocks = urcco::GLOBAL_BIN_BLOCKS;
     if (blocks < 2) blocks = 2;
     const size_t n = (size_t)blocks * (size_t)n_cols_b;
