@@ -15,6 +15,9 @@
 // wave-uniform control flow.
 #include "cco_kernels.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "cco_device.h"
 
 namespace urcco {
@@ -2251,13 +2254,30 @@ static int blocks_per_cu(int bin) {
 hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, int bin) {
   // Persistent grids sized to the chip; each kernel reads its own row list length from bin_off on the device,
   // so no host synchronisation sits between binning and the SpGEMM.
+  // Twice as many blocks as fit the chip (tunable per class through URCCO_GRID_FACTORS="f0,f1,..,f5" for measurements):
+  // the second half starts as blocks of the first retire, which evens out the classes' ragged ends and lets short kernels
+  // of the other event types' streams in -- a grid that exactly fills the chip locks them out until it ends (measured:
+  // single-block kernels of another stream waited 0.2 ms).  3.5-3.7 -> 3.2-3.3 ms per build of config 3; 3x, 4x and 8x
+  // measured no better than 1x (profiles/r02_grid_factor_sweep.log).
+  static int factor[6] = {0, 0, 0, 0, 0, 0};
+  if (factor[0] == 0) {
+    const int dflt[6] = {2, 2, 2, 2, 2, 2};
+    for (int b = 0; b < 6; ++b) factor[b] = dflt[b];
+    if (const char* e = getenv("URCCO_GRID_FACTORS")) {
+      int v[6];
+      if (sscanf(e, "%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6)
+        for (int b = 0; b < 6; ++b)
+          if (v[b] >= 1 && v[b] <= 64) factor[b] = v[b];
+    }
+  }
+  auto grid = [&](int b) { return dim3((unsigned)(n_cu * blocks_per_cu(b)) * (unsigned)factor[b]); };
   switch (bin) {
-    case 0: hipLaunchKernelGGL(cco_rows_micro_kernel, dim3((unsigned)(n_cu * blocks_per_cu(0))), dim3(256), 0, st, args); break;
-    case 1: hipLaunchKernelGGL((cco_rows_kernel<64, E0, 1>), dim3((unsigned)(n_cu * blocks_per_cu(1))), dim3(256), 0, st, args, 1); break;
-    case 2: hipLaunchKernelGGL((cco_rows_kernel<256, E1S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(2))), dim3(256), 0, st, args, 2); break;
-    case 3: hipLaunchKernelGGL((cco_rows_kernel<256, E1, 1>), dim3((unsigned)(n_cu * blocks_per_cu(3))), dim3(256), 0, st, args, 3); break;
-    case 4: hipLaunchKernelGGL((cco_rows_kernel<512, E2S, 1>), dim3((unsigned)(n_cu * blocks_per_cu(4))), dim3(512), 0, st, args, 4); break;
-    case 5: hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 1>), dim3((unsigned)(n_cu * blocks_per_cu(5))), dim3(1024), 0, st, args, 5); break;
+    case 0: hipLaunchKernelGGL(cco_rows_micro_kernel, grid(0), dim3(256), 0, st, args); break;
+    case 1: hipLaunchKernelGGL((cco_rows_kernel<64, E0, 1>), grid(1), dim3(256), 0, st, args, 1); break;
+    case 2: hipLaunchKernelGGL((cco_rows_kernel<256, E1S, 1>), grid(2), dim3(256), 0, st, args, 2); break;
+    case 3: hipLaunchKernelGGL((cco_rows_kernel<256, E1, 1>), grid(3), dim3(256), 0, st, args, 3); break;
+    case 4: hipLaunchKernelGGL((cco_rows_kernel<512, E2S, 1>), grid(4), dim3(512), 0, st, args, 4); break;
+    case 5: hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 1>), grid(5), dim3(1024), 0, st, args, 5); break;
     default: hipLaunchKernelGGL(cco_rows_global_kernel, dim3((unsigned)(args.g_blocks > 0 ? args.g_blocks : 1)), dim3(GB_THREADS), 0, st, args); break;
   }
   return hipGetLastError();

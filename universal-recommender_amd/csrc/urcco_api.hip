@@ -321,7 +321,11 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   a.out_count = out_count; a.out_idx = out_idx; a.out_llr = out_llr;
   a.err = reinterpret_cast<unsigned long long*>(stats + 1 + 4 * urcco::NBINS);
   a.g_counts = s->g_counts; a.g_cand_key = s->g_cand_key; a.g_cand_col = s->g_cand_col; a.g_blocks = s->g_blocks;
-  for (int bin = 0; bin < urcco::NBINS; ++bin) {
+  // Heaviest classes first (global, whole-CU, half-CU, ...): they have few, long rows and end raggedly; the fine-grained
+  // one-wave and micro classes run last and finish sharply -- and, with a stream per event type, fill the heavy classes'
+  // tails of the other event types instead of leaving a tail of their own.  debug 65536 restores the ascending order.
+  for (int step = 0; step < urcco::NBINS; ++step) {
+    const int bin = (s->debug & 65536) ? step : urcco::NBINS - 1 - step;
     s->begin(URCCO_STAGE_CCO_BIN0 + bin);
     HIPC(urcco::launch_cco_rows_bin(s->stream, s->n_cu, a, bin));
     s->end();

@@ -13,7 +13,9 @@
 #include <algorithm>
 #include <atomic>
 #include <memory>
+#include <future>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <unordered_map>
 
@@ -339,29 +341,59 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
   EvState& A = D.ev[0];
   D.item_lo = 0;
   D.item_hi = (int32_t)ps[0].n_cols;
-  URC(stage_raw_counts(D, A, sh[0], ps[0]));
-  URC(stage_downsample(c, D, A, sh[0], ps[0], seed));
   URC(D.a_cp.ensure((size_t)ps[0].n_cols + 2));
   URC(D.a_ri.ensure((size_t)sh[0].nnz + 4));
-  URC(urcco_dev_transpose(A.s, sh[0].n_rows, A.s_rp.p, A.s_ci.p, sh[0].nnz, (int32_t)ps[0].n_cols, A.post.p, 0, (int32_t)ps[0].n_cols, D.a_cp.p, D.a_ri.p));
-  HIPC(hipEventRecord(D.a_ready, A.s->stream));
-  for (int d = 1; d < n_ds; ++d) {
+  // A build is ~150 launches of mostly short kernels: enqueued by ONE host thread the first ~0.5 ms of every build are
+  // launch-bound (measured: the primary's stream idles 0.4 ms between its transposition and its SpGEMM while the host is
+  // still enqueueing the other event types).  With a stream per event type each secondary gets its own enqueueing thread:
+  // B_d's chain (counts, sampling) -> wait for A's CSC event -> A'B_d.  The event must have been recorded before a
+  // stream is told to wait for it, hence the host-side hand-off.
+  const bool threaded = n_ds > 1 && !c->single_stream();
+  std::promise<void> a_recorded;
+  std::shared_future<void> a_recorded_f = a_recorded.get_future().share();
+  auto secondary = [&](int d, bool wait_host) -> int {
+    URC(set_dev(D));
     EvState& E = D.ev[(size_t)d];
     URC(stage_raw_counts(D, E, sh[(size_t)d], ps[(size_t)d]));
     URC(stage_downsample(c, D, E, sh[(size_t)d], ps[(size_t)d], seed));
-  }
-  std::vector<int> order((size_t)n_ds);
-  for (int d = 0; d < n_ds; ++d) order[(size_t)d] = d;
-  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return sh[(size_t)x].nnz > sh[(size_t)y].nnz; });
-  for (int d : order) {
-    EvState& E = D.ev[(size_t)d];
+    if (wait_host) a_recorded_f.wait();
     if (E.s != A.s) HIPC(hipStreamWaitEvent(E.s->stream, D.a_ready, 0));
     E.b_rp = E.s_rp.p;
     E.b_ci = E.s_ci.p;
     E.b_rows = sh[(size_t)d].n_rows;
     E.b_nnz_bound = sh[(size_t)d].nnz;
-    URC(stage_rows(D, E, A, d, ps[0], ps[(size_t)d], n_users, sh[0].nnz));
+    return stage_rows(D, E, A, d, ps[0], ps[(size_t)d], n_users, sh[0].nnz);
+  };
+  std::vector<std::thread> workers;
+  std::vector<int> status((size_t)n_ds, URCCO_OK);
+  std::vector<std::string> message((size_t)n_ds);
+  if (threaded)
+    for (int d = 1; d < n_ds; ++d)
+      workers.emplace_back([&, d] {
+        status[(size_t)d] = guarded([&] { return secondary(d, true); });
+        if (status[(size_t)d] != URCCO_OK) message[(size_t)d] = err_buf();  // the message lives in the worker's thread-local buffer
+      });
+  int st = [&]() -> int {
+    URC(stage_raw_counts(D, A, sh[0], ps[0]));
+    URC(stage_downsample(c, D, A, sh[0], ps[0], seed));
+    URC(urcco_dev_transpose(A.s, sh[0].n_rows, A.s_rp.p, A.s_ci.p, sh[0].nnz, (int32_t)ps[0].n_cols, A.post.p, 0, (int32_t)ps[0].n_cols, D.a_cp.p, D.a_ri.p));
+    HIPC(hipEventRecord(D.a_ready, A.s->stream));
+    return URCCO_OK;
+  }();
+  a_recorded.set_value();  // also on failure: the workers must not wait forever
+  if (st == URCCO_OK) {
+    A.b_rp = A.s_rp.p;
+    A.b_ci = A.s_ci.p;
+    A.b_rows = sh[0].n_rows;
+    A.b_nnz_bound = sh[0].nnz;
+    st = stage_rows(D, A, A, 0, ps[0], ps[0], n_users, sh[0].nnz);
   }
+  for (std::thread& t : workers) t.join();
+  if (st != URCCO_OK) return st;
+  if (!threaded)
+    for (int d = 1; d < n_ds; ++d) URC(secondary(d, false));
+  for (int d = 1; d < n_ds; ++d)
+    if (status[(size_t)d] != URCCO_OK) return fail(status[(size_t)d], "%s", message[(size_t)d].c_str());
   return URCCO_OK;
 }
 
