@@ -12,6 +12,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <future>
 #include <mutex>
@@ -175,6 +177,8 @@ struct EvState {
   DBuf<int64_t> stats;
   DBuf<unsigned long long> verr;
   hipEvent_t ev_sampled = nullptr, ev_done = nullptr, ev_rp = nullptr;
+  hipEvent_t ev_cons[2] = {nullptr, nullptr};  // A'B_d of the build that used A's buffer set 0 / 1 has finished
+  bool cons_valid[2] = {false, false};
   // facts of the current build
   const int64_t* b_rp = nullptr;  // the B this GPU multiplies with
   const int32_t* b_ci = nullptr;
@@ -186,6 +190,11 @@ struct EvState {
     if (ev_sampled) (void)hipEventDestroy(ev_sampled);
     if (ev_done) (void)hipEventDestroy(ev_done);
     if (ev_rp) (void)hipEventDestroy(ev_rp);
+    for (int q = 0; q < 2; ++q) {
+      if (ev_cons[q]) (void)hipEventDestroy(ev_cons[q]);
+      ev_cons[q] = nullptr;
+      cons_valid[q] = false;
+    }
     ev_sampled = ev_done = ev_rp = nullptr;
   }
 };
@@ -196,8 +205,13 @@ struct DevState {
   int n_cu = 256;
   std::vector<urcco_session*> sessions;
   std::vector<EvState> ev;
-  DBuf<int64_t> a_cp;
-  DBuf<int32_t> a_ri;
+  // What every event type's stream reads of the primary -- its CSC and its post-sampling column counts -- exists twice:
+  // consecutive builds alternate, so the next build's primary chain (stream 0) may overwrite one set while the A'B_d of the
+  // previous build (streams 1..) still read the other.  A set is reused two builds later, behind the ev_cons events.
+  DBuf<int64_t> a_cp[2];
+  DBuf<int32_t> a_ri[2];
+  DBuf<int32_t> a_post[2];
+  int par = 0;
   DBuf<int64_t> work;
   DBuf<int32_t> bounds;
   hipEvent_t a_ready = nullptr, in_ready = nullptr;
@@ -216,9 +230,79 @@ struct DsParams {
   double min_llr = 0.0;
 };
 
+// One enqueueing thread per local GPU.  A build is a few hundred launches per GPU; issued by one host thread for eight GPUs
+// the launch rate (~4 us each) would exceed the build itself, so the phases that only enqueue kernels run on all GPUs at
+// once; the collective phases stay on the calling thread (one thread owning several ranks must group them anyway).
+struct DevWorkers {
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable start_cv, done_cv;
+  const std::function<int(size_t)>* job = nullptr;
+  uint64_t generation = 0;
+  size_t pending = 0;
+  bool stop = false;
+  std::vector<int> status;
+  std::vector<std::string> message;
+
+  void start(size_t n) {
+    status.assign(n, URCCO_OK);
+    message.assign(n, std::string());
+    if (n <= 1) return;
+    for (size_t g = 0; g < n; ++g)
+      threads.emplace_back([this, g] {
+        uint64_t seen = 0;
+        for (;;) {
+          const std::function<int(size_t)>* f = nullptr;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            start_cv.wait(lk, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+            f = job;
+          }
+          const int st = guarded([&] { return (*f)(g); });
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            status[g] = st;
+            if (st != URCCO_OK) message[g] = err_buf();
+            if (--pending == 0) done_cv.notify_all();
+          }
+        }
+      });
+  }
+  // f(g) for every local GPU g; returns the first failure (its message copied into the caller's error buffer)
+  int run(const std::function<int(size_t)>& f) {
+    const size_t n = status.size();
+    if (n <= 1) return n == 1 ? f(0) : URCCO_OK;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      job = &f;
+      pending = n;
+      ++generation;
+    }
+    start_cv.notify_all();
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      done_cv.wait(lk, [&] { return pending == 0; });
+    }
+    for (size_t g = 0; g < n; ++g)
+      if (status[g] != URCCO_OK) return fail(status[g], "%s", message[g].c_str());
+    return URCCO_OK;
+  }
+  ~DevWorkers() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    start_cv.notify_all();
+    for (std::thread& t : threads) t.join();
+  }
+};
+
 }  // namespace
 
 struct urcco_context {
+  std::unique_ptr<DevWorkers> workers{new DevWorkers()};
   std::vector<DevState> devs;
   int world = 1, first_rank = 0;
   int row_rate_mode = URCCO_ROW_RATE_MAHOUT_INT_DIV;
@@ -292,6 +376,8 @@ int ensure_events(urcco_context* c, DevState& D, int n_ds) {
     E.s->unordered_rows = (c->flags & URCCO_FLAG_UNORDERED_ROWS) ? 1 : 0;
     if (!E.ev_sampled) HIPC(hipEventCreateWithFlags(&E.ev_sampled, hipEventDisableTiming));
     if (!E.ev_done) HIPC(hipEventCreateWithFlags(&E.ev_done, hipEventDisableTiming));
+    for (int q = 0; q < 2; ++q)
+      if (!E.ev_cons[q]) HIPC(hipEventCreateWithFlags(&E.ev_cons[q], hipEventDisableTiming));
     if (!E.ev_rp) HIPC(hipEventCreateWithFlags(&E.ev_rp, hipEventDisableTiming));
   }
   if (!D.a_ready) HIPC(hipEventCreateWithFlags(&D.a_ready, hipEventDisableTiming));
@@ -305,12 +391,16 @@ int stage_raw_counts(DevState& D, EvState& E, const Shard& sh, const DsParams& p
   URC(E.raw.ensure((size_t)p.n_cols + 1));
   return urcco_dev_column_counts(E.s, sh.nnz, sh.ci, (int32_t)p.n_cols, E.raw.p);
 }
-int stage_downsample(urcco_context* c, DevState& D, EvState& E, const Shard& sh, const DsParams& p, int32_t seed) {
+// post-sampling column counts of event type d: the primary's live in the build's buffer set (read by every stream)
+DBuf<int32_t>& post_of(DevState& D, int d) { return d == 0 ? D.a_post[D.par] : D.ev[(size_t)d].post; }
+
+int stage_downsample(urcco_context* c, DevState& D, int d, const Shard& sh, const DsParams& p, int32_t seed) {
+  EvState& E = D.ev[(size_t)d];
   URC(E.s_rp.ensure((size_t)sh.n_rows + 1));
   URC(E.s_ci.ensure((size_t)sh.nnz + 4));
-  URC(E.post.ensure((size_t)p.n_cols + 1));
+  URC(post_of(D, d).ensure((size_t)p.n_cols + 1));
   return urcco_dev_downsample(E.s, sh.n_rows, sh.rp, sh.ci, sh.nnz, (int32_t)p.n_cols, E.raw.p, seed, p.max_rows, c->row_rate_mode, sh.row_base, E.s_rp.p,
-                              E.s_ci.p, E.post.p);
+                              E.s_ci.p, post_of(D, d).p);
 }
 
 // A'B_d for the GPU's item range + strided -> CSR, on event d's stream
@@ -324,10 +414,13 @@ int stage_rows(DevState& D, EvState& E, EvState& A, int d, const DsParams& pa, c
   URC(E.c_idx.ensure(strided));
   URC(E.c_llr.ensure(strided));
   URC(E.stats.ensure(URCCO_STATS_LEN));
-  URC(urcco_dev_cco_rows(E.s, D.item_lo, D.item_hi, (int32_t)pa.n_cols, D.a_cp.p, D.a_ri.p, a_nnz_bound, E.b_rp, E.b_ci, (int32_t)p.n_cols, A.post.p, E.post.p,
+  URC(urcco_dev_cco_rows(E.s, D.item_lo, D.item_hi, (int32_t)pa.n_cols, D.a_cp[D.par].p, D.a_ri[D.par].p, a_nnz_bound, E.b_rp, E.b_ci, (int32_t)p.n_cols,
+                         post_of(D, 0).p, post_of(D, d).p,
                          n_users, d == 0 ? 1 : 0, p.k, p.has_min_llr, p.min_llr, E.o_count.p, E.o_idx.p, E.o_llr.p, E.stats.p));
   URC(urcco_dev_compact_indicators(E.s, n, p.k, E.o_count.p, E.o_idx.p, E.o_llr.p, E.c_rp.p, E.c_idx.p, E.c_llr.p));
   HIPC(hipEventRecord(E.ev_done, E.s->stream));
+  HIPC(hipEventRecord(E.ev_cons[D.par], E.s->stream));
+  E.cons_valid[D.par] = true;
   return URCCO_OK;
 }
 
@@ -341,8 +434,8 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
   EvState& A = D.ev[0];
   D.item_lo = 0;
   D.item_hi = (int32_t)ps[0].n_cols;
-  URC(D.a_cp.ensure((size_t)ps[0].n_cols + 2));
-  URC(D.a_ri.ensure((size_t)sh[0].nnz + 4));
+  URC(D.a_cp[D.par].ensure((size_t)ps[0].n_cols + 2));
+  URC(D.a_ri[D.par].ensure((size_t)sh[0].nnz + 4));
   // A build is ~150 launches of mostly short kernels: enqueued by ONE host thread the first ~0.5 ms of every build are
   // launch-bound (measured: the primary's stream idles 0.4 ms between its transposition and its SpGEMM while the host is
   // still enqueueing the other event types).  With a stream per event type each secondary gets its own enqueueing thread:
@@ -355,7 +448,7 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
     URC(set_dev(D));
     EvState& E = D.ev[(size_t)d];
     URC(stage_raw_counts(D, E, sh[(size_t)d], ps[(size_t)d]));
-    URC(stage_downsample(c, D, E, sh[(size_t)d], ps[(size_t)d], seed));
+    URC(stage_downsample(c, D, d, sh[(size_t)d], ps[(size_t)d], seed));
     if (wait_host) a_recorded_f.wait();
     if (E.s != A.s) HIPC(hipStreamWaitEvent(E.s->stream, D.a_ready, 0));
     E.b_rp = E.s_rp.p;
@@ -375,8 +468,9 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
       });
   int st = [&]() -> int {
     URC(stage_raw_counts(D, A, sh[0], ps[0]));
-    URC(stage_downsample(c, D, A, sh[0], ps[0], seed));
-    URC(urcco_dev_transpose(A.s, sh[0].n_rows, A.s_rp.p, A.s_ci.p, sh[0].nnz, (int32_t)ps[0].n_cols, A.post.p, 0, (int32_t)ps[0].n_cols, D.a_cp.p, D.a_ri.p));
+    URC(stage_downsample(c, D, 0, sh[0], ps[0], seed));
+    URC(urcco_dev_transpose(A.s, sh[0].n_rows, A.s_rp.p, A.s_ci.p, sh[0].nnz, (int32_t)ps[0].n_cols, post_of(D, 0).p, 0, (int32_t)ps[0].n_cols,
+                            D.a_cp[D.par].p, D.a_ri[D.par].p));
     HIPC(hipEventRecord(D.a_ready, A.s->stream));
     return URCCO_OK;
   }();
@@ -402,24 +496,26 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
 // ---------------------------------------------------------------------------------------------------------
 int input_phase(urcco_context* c, int d, const std::vector<std::vector<Shard>>& sh, const std::vector<DsParams>& ps, int32_t seed) {
   const DsParams& p = ps[(size_t)d];
-  for (DevState& D : c->devs) {
+  URC(c->workers->run([&](size_t g) -> int {
+    DevState& D = c->devs[g];
     URC(set_dev(D));
-    URC(stage_raw_counts(D, D.ev[(size_t)d], sh[(size_t)d][(size_t)(&D - c->devs.data())], p));
-  }
+    return stage_raw_counts(D, D.ev[(size_t)d], sh[(size_t)d][g], p);
+  }));
   URC(c->group_start());
   for (DevState& D : c->devs) {
     URC(set_dev(D));
     URC(c->all_reduce(D, D.ev[(size_t)d].raw.p, p.n_cols, 0, D.ev[(size_t)d].s->stream));
   }
   URC(c->group_end());
-  for (DevState& D : c->devs) {
+  URC(c->workers->run([&](size_t g) -> int {
+    DevState& D = c->devs[g];
     URC(set_dev(D));
-    URC(stage_downsample(c, D, D.ev[(size_t)d], sh[(size_t)d][(size_t)(&D - c->devs.data())], p, seed));
-  }
+    return stage_downsample(c, D, d, sh[(size_t)d][g], p, seed);
+  }));
   URC(c->group_start());
   for (DevState& D : c->devs) {
     URC(set_dev(D));
-    URC(c->all_reduce(D, D.ev[(size_t)d].post.p, p.n_cols, 0, D.ev[(size_t)d].s->stream));
+    URC(c->all_reduce(D, post_of(D, d).p, p.n_cols, 0, D.ev[(size_t)d].s->stream));
   }
   URC(c->group_end());
   // row lengths (what travels) + the (rows, nnz') record of the shard, gathered over the ranks
@@ -502,13 +598,14 @@ int build_sharded(urcco_context* c, const std::vector<std::vector<Shard>>& sh, c
   // work of A'B_d sums the same users' B_d row lengths and follows it closely), so the ranges are fixed before any
   // whole-matrix work and the one blocking host read comes right after the primary's short chain.
   URC(input_phase(c, 0, sh, ps, seed));
-  for (DevState& D : c->devs) {
+  URC(c->workers->run([&](size_t g) -> int {
+    DevState& D = c->devs[g];
     URC(set_dev(D));
     EvState& A = D.ev[0];
-    const Shard& s = sh[0][(size_t)(&D - c->devs.data())];
+    const Shard& s = sh[0][g];
     URC(D.work.ensure((size_t)n_items_a + 1));
-    URC(urcco_dev_row_work_csr(A.s, s.n_rows, A.s_rp.p, A.s_ci.p, s.nnz, A.s_rp.p, n_items_a, D.work.p));
-  }
+    return urcco_dev_row_work_csr(A.s, s.n_rows, A.s_rp.p, A.s_ci.p, s.nnz, A.s_rp.p, n_items_a, D.work.p);
+  }));
   URC(c->group_start());
   for (DevState& D : c->devs) {
     URC(set_dev(D));
@@ -530,15 +627,16 @@ int build_sharded(urcco_context* c, const std::vector<std::vector<Shard>>& sh, c
   int64_t a_nnz = 0;
   for (int r = 0; r < W; ++r) a_nnz += sizes[(size_t)2 * r + 1];
   c->h_sizes[0] = a_nnz;
-  for (DevState& D : c->devs) {
+  URC(c->workers->run([&](size_t g) -> int {
+    DevState& D = c->devs[g];
     URC(set_dev(D));
     EvState& A = D.ev[0];
-    URC(D.a_cp.ensure((size_t)n_items_a + 2));
-    URC(D.a_ri.ensure((size_t)a_nnz + 4));
-    URC(urcco_dev_transpose(A.s, n_users, A.f_rp.p, A.f_ci.p, a_nnz, n_items_a, A.post.p, D.item_lo, D.item_hi, D.a_cp.p, D.a_ri.p));
+    URC(D.a_cp[D.par].ensure((size_t)n_items_a + 2));
+    URC(D.a_ri[D.par].ensure((size_t)a_nnz + 4));
+    URC(urcco_dev_transpose(A.s, n_users, A.f_rp.p, A.f_ci.p, a_nnz, n_items_a, post_of(D, 0).p, D.item_lo, D.item_hi, D.a_cp[D.par].p, D.a_ri[D.par].p));
     HIPC(hipEventRecord(D.a_ready, A.s->stream));
-    URC(stage_rows(D, A, A, 0, ps[0], ps[0], n_users, a_nnz));
-  }
+    return stage_rows(D, A, A, 0, ps[0], ps[0], n_users, a_nnz);
+  }));
   // ---- secondaries: every input phase is enqueued on its own stream (they run under A'A); then per event type the shard
   // sizes are read (the host waits for that stream's sampling only), the exchange is issued and A'B_d runs behind it
   for (int d = 1; d < n_ds; ++d) URC(input_phase(c, d, sh, ps, seed));
@@ -547,12 +645,13 @@ int build_sharded(urcco_context* c, const std::vector<std::vector<Shard>>& sh, c
     int64_t b_nnz = 0;
     for (int r = 0; r < W; ++r) b_nnz += sizes[(size_t)2 * r + 1];
     c->h_sizes[(size_t)d] = b_nnz;
-    for (DevState& D : c->devs) {
+    URC(c->workers->run([&](size_t g) -> int {
+      DevState& D = c->devs[g];
       URC(set_dev(D));
       EvState& E = D.ev[(size_t)d];
       if (E.s != D.ev[0].s) HIPC(hipStreamWaitEvent(E.s->stream, D.a_ready, 0));
-      URC(stage_rows(D, E, D.ev[0], d, ps[0], ps[(size_t)d], n_users, a_nnz));
-    }
+      return stage_rows(D, E, D.ev[0], d, ps[0], ps[(size_t)d], n_users, a_nnz);
+    }));
   }
   return URCCO_OK;
 }
@@ -568,6 +667,10 @@ int run_build(urcco_context* c, const std::vector<std::vector<Shard>>& sh, const
   const int n_ds = (int)ps.size();
   for (DevState& D : c->devs) {
     URC(ensure_events(c, D, n_ds));
+    // this build's set of the primary's shared buffers was last read by the A'B_d of the build before the previous one
+    D.par ^= 1;
+    for (size_t d = 1; d < D.ev.size(); ++d)
+      if (D.ev[d].cons_valid[D.par] && D.ev[d].s != D.ev[0].s) HIPC(hipStreamWaitEvent(D.ev[0].s->stream, D.ev[d].ev_cons[D.par], 0));
     if (input_stream && c->devs.size() == 1) {
       HIPC(hipEventRecord(D.in_ready, input_stream));
       for (int d = 0; d < n_ds; ++d) HIPC(hipStreamWaitEvent(D.ev[(size_t)d].s->stream, D.in_ready, 0));
@@ -612,7 +715,7 @@ struct Stager {
     for (auto& s : slots)
       if (s->ev) (void)hipEventDestroy(s->ev);
   }
-  int copy(int device, hipStream_t st, void* dst, const void* src, size_t bytes) {
+  int copy(int device, hipStream_t st, void* dst, const void* src, size_t bytes, int max_threads) {
     if (bytes == 0) return URCCO_OK;
     const size_t n_chunks = (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK;
     const long long base = next_chunk.fetch_add((long long)n_chunks);
@@ -636,7 +739,7 @@ struct Stager {
         s.gen.store(gen + 1, std::memory_order_release);
       }
     };
-    const int nt = (int)std::min<size_t>((size_t)c->copy_threads, n_chunks);
+    const int nt = (int)std::min<size_t>((size_t)(max_threads > 0 ? max_threads : 1), n_chunks);
     std::vector<std::thread> th;
     for (int t = 1; t < nt; ++t) th.emplace_back(worker);
     worker();
@@ -671,7 +774,8 @@ void urcco_context_destroy(urcco_context* c) {
     for (urcco_session* s : D.sessions) (void)hipStreamSynchronize(s->stream);
     if (D.comm && c->rccl) (void)c->rccl->CommDestroy(D.comm);
     for (EvState& E : D.ev) E.release();
-    D.a_cp.release(); D.a_ri.release(); D.work.release(); D.bounds.release();
+    for (int q = 0; q < 2; ++q) { D.a_cp[q].release(); D.a_ri[q].release(); D.a_post[q].release(); }
+    D.work.release(); D.bounds.release();
     if (D.a_ready) (void)hipEventDestroy(D.a_ready);
     if (D.in_ready) (void)hipEventDestroy(D.in_ready);
     for (urcco_session* s : D.sessions) urcco_session_destroy(s);
@@ -713,6 +817,7 @@ int urcco_context_create(const urcco_options* options, const urcco_comm_config* 
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, D.device) == hipSuccess && prop.multiProcessorCount > 0) D.n_cu = prop.multiProcessorCount;
     }
+    c->workers->start((size_t)n_local);
     const unsigned hc = std::thread::hardware_concurrency();
     c->copy_threads = hc >= 32 ? 8 : (hc >= 8 ? 4 : 2);
     if (!c->have_cb && (c->world > 1 || (c->flags & URCCO_FLAG_FORCE_EXCHANGE))) {
@@ -886,9 +991,10 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
     Stager stager{c};
     URC(stager.ensure(24));
     std::vector<std::vector<Shard>> sh((size_t)n_ds, std::vector<Shard>(L));
+    const int threads_each = L > 1 ? std::max(1, c->copy_threads / 2) : c->copy_threads;  // every GPU has its own link: all stage at once
     for (int d = 0; d < n_ds; ++d) {
       const urcco_csr& m = datasets[d].matrix;
-      for (size_t g = 0; g < L; ++g) {
+      URC(c->workers->run([&](size_t g) -> int {
         DevState& D = c->devs[g];
         URC(set_dev(D));
         EvState& E = D.ev[(size_t)d];
@@ -898,15 +1004,16 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
         URC(E.in_rp.ensure((size_t)rows + 1));
         URC(E.in_ci.ensure((size_t)nnz + 4));
         URC(E.verr.ensure(1));
-        URC(stager.copy(D.device, E.s->stream, E.in_rp.p, m.row_ptr + u0, sizeof(int64_t) * ((size_t)rows + 1)));
-        URC(stager.copy(D.device, E.s->stream, E.in_ci.p, m.col_idx + e0, sizeof(int32_t) * (size_t)nnz));
+        URC(stager.copy(D.device, E.s->stream, E.in_rp.p, m.row_ptr + u0, sizeof(int64_t) * ((size_t)rows + 1), threads_each));
+        URC(stager.copy(D.device, E.s->stream, E.in_ci.p, m.col_idx + e0, sizeof(int32_t) * (size_t)nnz, threads_each));
         HIPC(hipMemsetAsync(E.verr.p, 0, sizeof(unsigned long long), E.s->stream));
         int gl = rows > 0 ? ceil_log2_i64((nnz + rows - 1) / rows) : 1;
         gl = gl < 1 ? 1 : (gl > 6 ? 6 : gl);
         HIPC(urcco::launch_validate_csr(E.s->stream, D.n_cu, rows, E.in_rp.p, E.in_ci.p, nnz, (int32_t)m.n_cols, gl, e0, E.verr.p));
         HIPC(urcco::launch_rebase_i64(E.s->stream, D.n_cu, E.in_rp.p, rows + 1, e0));
         sh[(size_t)d][g] = Shard{rows, u0, nnz, E.in_rp.p, E.in_ci.p};
-      }
+        return URCCO_OK;
+      }));
     }
     // the boundary check must have passed before any kernel consumes the matrices
     for (int d = 0; d < n_ds; ++d)
