@@ -261,6 +261,7 @@ def main():
     ap.add_argument("--single-stream", action="store_true", help="run the event types back to back on one HIP stream")
     ap.add_argument("--force-exchange", action="store_true",
                     help="debug: run the N > 1 code path (RCCL collectives, range-restricted transpose) in a one-rank communicator")
+    ap.add_argument("--timed-only", action="store_true", help="stop after the timed region (timeline captures)")
     ap.add_argument("--seed", type=int, default=20260925)
     args = ap.parse_args()
 
@@ -288,7 +289,7 @@ def main():
             __graft_entry__.build_hip()
         if world > 1:
             dist.barrier()
-    library = _lib.load(_lib.DEFAULT_PATH)
+    library = _lib.load(os.environ.get("URCCO_LIB", _lib.DEFAULT_PATH))   # URCCO_LIB: A/B runs of two builds on one box
 
     # ---- workload -------------------------------------------------------------------------------------
     workload = args.workload if args.workload != "auto" else ("config3" if world == 1 else "config4")
@@ -332,6 +333,9 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if args.timed_only:
+        print(json.dumps({"ms_per_step": round(elapsed / args.steps * 1e3, 4)}))
+        return
     # the same steps with URCCO_FLAG_UNORDERED_ROWS (rows = top-k sets without the in-kernel ranking pass: what a JNI host,
     # which re-inserts by column index anyway, would ask for) -- reported beside `value`, never as `value`
     unordered = None

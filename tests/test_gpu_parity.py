@@ -204,3 +204,10 @@ def test_unordered_rows_flag_on_gpu(gpu_session):
     from universal_recommender_amd import _lib
     import test_sim_context as ctx_cases
     ctx_cases.unordered_rows_case(_lib.load(_lib.DEFAULT_PATH), gpu_session.device)
+
+
+def test_back_to_back_builds_on_gpu(gpu_session):
+    """Builds enqueued without a wait in between: the primary's shared products alternate between two buffer sets."""
+    from universal_recommender_amd import _lib
+    import test_sim_context as ctx_cases
+    ctx_cases.back_to_back_builds_case(_lib.load(_lib.DEFAULT_PATH), gpu_session.device, 150000)

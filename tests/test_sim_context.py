@@ -97,6 +97,42 @@ def context_reuse_case(lib, device):
         sess.close()
 
 
+def back_to_back_builds_case(lib, device, n_users):
+    """Builds enqueued back to back WITHOUT waiting in between (what bench.py's timed region does): the next build's primary
+    chain runs on stream 0 while the previous build's A'B_d still read the primary's CSC and counts on their own streams,
+    so those live in alternating buffer sets.  The secondaries are made much heavier than the primary so that their
+    streams lag; shapes alternate so that a clobbered CSC would index out of range.  The last build must equal the
+    one-session driver bit for bit."""
+    from universal_recommender_amd.device import Context, DeviceSession, cross_occurrence_context, cross_occurrence_device
+    rng = np.random.default_rng(43)
+    x = ([rand_csr(rng, n_users, 300, 4), rand_csr(rng, n_users, 2500, 40, zipf_s=1.05), rand_csr(rng, n_users, 1200, 25)], [P(60, 20), P(60, 30), P(60, 30)])
+    y = ([rand_csr(rng, n_users // 3, 5000, 9), rand_csr(rng, n_users // 3, 700, 30)], [P(100, 10), P(100, 10)])
+    sess = DeviceSession(device, lib)
+    ctx = Context(device, lib)
+    try:
+        refs = []
+        for mats, ps in (x, y):
+            refs.append([r.to_host() for r in cross_occurrence_device(sess, [to_dev(m, device) for m in mats], to_params(ps), 23)])
+            sess.synchronize()
+        dev = [([to_dev(m, device) for m in mats], to_params(ps)) for mats, ps in (x, y)]
+        for last in (0, 1):
+            for i in range(7):
+                mats, ps = dev[(i + last) % 2]
+                ctx.build([[m] for m in mats], ps, 23)           # enqueue only
+            out = [r[0] for r in ctx.results()]                    # waits for the last build
+            assert len(out) == len(refs[last])
+            for a, b in zip(out, refs[last]):
+                for u, v in zip(a.to_host(), b):
+                    assert np.array_equal(u, v)
+    finally:
+        ctx.close()
+        sess.close()
+
+
+def test_back_to_back_builds(sim_lib):
+    back_to_back_builds_case(sim_lib, torch.device("cpu"), 3000)
+
+
 def test_context_reuse_and_stream_modes(sim_lib):
     context_reuse_case(sim_lib, torch.device("cpu"))
 

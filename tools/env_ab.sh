@@ -1,0 +1,13 @@
+#!/bin/bash
+# A/B of environment settings of the library on ONE box: tools/env_ab.sh TAG reps "NAME=VAL ..." "NAME=VAL ..." ...   ("-" = no setting)
+TAG=$1; REPS=$2; shift 2
+O=gpurun_out/$TAG; mkdir -p $O
+for i in $(seq 1 $REPS); do
+  j=0
+  for v in "$@"; do
+    j=$((j+1))
+    if [ "$v" = "-" ]; then e=""; else e="$v"; fi
+    env $e timeout 600 python bench.py --steps ${STEPS:-40} --warmup 5 --no-cpu-baseline --no-extras ${BENCH_ARGS} > $O/ab_${j}_$i.log 2>&1
+    echo "[$v] $i rc=$? $(grep -o '"ms_per_step": [0-9.]*' $O/ab_${j}_$i.log | head -1)"
+  done
+done

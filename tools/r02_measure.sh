@@ -13,6 +13,7 @@ for s in "$@"; do
     rowscan)    timeout 600 python tools/rowscan_bench.py 1.0 ${ROWSCAN:-0,32,64,128,224,4096} > $O/rowscan.log 2>&1; cat $O/rowscan.log ;;
     bench)      timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.log 2>&1; tail -c 9000 $O/bench.log ;;
     bench_fx)   timeout 900 python bench.py --steps 20 --warmup 5 --force-exchange --no-cpu-baseline --no-extras > $O/bench_fx.log 2>&1; tail -c 1500 $O/bench_fx.log ;;
+    bench_fx5)  for i in 1 2 3 4 5; do timeout 600 python bench.py --steps 40 --warmup 5 --force-exchange --no-cpu-baseline --no-extras > $O/bench_fx_$i.log 2>&1; echo "rc=$?"; tail -c 400 $O/bench_fx_$i.log; done ;;
     bench_c4)   timeout 1200 python bench.py --steps 5 --warmup 2 --workload config4 --no-cpu-baseline --no-extras > $O/bench_c4.log 2>&1; tail -c 6000 $O/bench_c4.log ;;
     bench_c5)   timeout 1200 python bench.py --steps 5 --warmup 2 --workload config5 --no-cpu-baseline --no-extras > $O/bench_c5.log 2>&1; tail -c 3000 $O/bench_c5.log ;;
     bench_ss)   timeout 900 python bench.py --steps 20 --warmup 5 --single-stream --no-cpu-baseline --no-extras > $O/bench_ss.log 2>&1; tail -c 3000 $O/bench_ss.log ;;

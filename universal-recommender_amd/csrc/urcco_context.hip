@@ -157,6 +157,9 @@ PinnedPool& pinned_pool() {
 // ---------------------------------------------------------------------------------------------------------
 // per event type, per GPU
 // ---------------------------------------------------------------------------------------------------------
+// buffer sets of the primary's shared products (see DevState); measured: 2, 3 and 4 sets give the same back-to-back build rate
+constexpr int A_SETS = 2;
+
 struct EvState {
   urcco_session* s = nullptr;   // own stream + arena (borrowed from DevState::sessions)
   DBuf<int64_t> in_rp;          // host level: the staged raw shard
@@ -177,8 +180,8 @@ struct EvState {
   DBuf<int64_t> stats;
   DBuf<unsigned long long> verr;
   hipEvent_t ev_sampled = nullptr, ev_done = nullptr, ev_rp = nullptr;
-  hipEvent_t ev_cons[2] = {nullptr, nullptr};  // A'B_d of the build that used A's buffer set 0 / 1 has finished
-  bool cons_valid[2] = {false, false};
+  hipEvent_t ev_cons[A_SETS] = {};  // ev_cons[q]: the A'B_d of the last build that used the primary's buffer set q has finished
+  bool cons_valid[A_SETS] = {};
   // facts of the current build
   const int64_t* b_rp = nullptr;  // the B this GPU multiplies with
   const int32_t* b_ci = nullptr;
@@ -190,7 +193,7 @@ struct EvState {
     if (ev_sampled) (void)hipEventDestroy(ev_sampled);
     if (ev_done) (void)hipEventDestroy(ev_done);
     if (ev_rp) (void)hipEventDestroy(ev_rp);
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < A_SETS; ++q) {
       if (ev_cons[q]) (void)hipEventDestroy(ev_cons[q]);
       ev_cons[q] = nullptr;
       cons_valid[q] = false;
@@ -208,9 +211,9 @@ struct DevState {
   // What every event type's stream reads of the primary -- its CSC and its post-sampling column counts -- exists twice:
   // consecutive builds alternate, so the next build's primary chain (stream 0) may overwrite one set while the A'B_d of the
   // previous build (streams 1..) still read the other.  A set is reused two builds later, behind the ev_cons events.
-  DBuf<int64_t> a_cp[2];
-  DBuf<int32_t> a_ri[2];
-  DBuf<int32_t> a_post[2];
+  DBuf<int64_t> a_cp[A_SETS];
+  DBuf<int32_t> a_ri[A_SETS];
+  DBuf<int32_t> a_post[A_SETS];
   int par = 0;
   DBuf<int64_t> work;
   DBuf<int32_t> bounds;
@@ -376,7 +379,7 @@ int ensure_events(urcco_context* c, DevState& D, int n_ds) {
     E.s->unordered_rows = (c->flags & URCCO_FLAG_UNORDERED_ROWS) ? 1 : 0;
     if (!E.ev_sampled) HIPC(hipEventCreateWithFlags(&E.ev_sampled, hipEventDisableTiming));
     if (!E.ev_done) HIPC(hipEventCreateWithFlags(&E.ev_done, hipEventDisableTiming));
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < A_SETS; ++q)
       if (!E.ev_cons[q]) HIPC(hipEventCreateWithFlags(&E.ev_cons[q], hipEventDisableTiming));
     if (!E.ev_rp) HIPC(hipEventCreateWithFlags(&E.ev_rp, hipEventDisableTiming));
   }
@@ -668,7 +671,7 @@ int run_build(urcco_context* c, const std::vector<std::vector<Shard>>& sh, const
   for (DevState& D : c->devs) {
     URC(ensure_events(c, D, n_ds));
     // this build's set of the primary's shared buffers was last read by the A'B_d of the build before the previous one
-    D.par ^= 1;
+    D.par = (D.par + 1) % A_SETS;
     for (size_t d = 1; d < D.ev.size(); ++d)
       if (D.ev[d].cons_valid[D.par] && D.ev[d].s != D.ev[0].s) HIPC(hipStreamWaitEvent(D.ev[0].s->stream, D.ev[d].ev_cons[D.par], 0));
     if (input_stream && c->devs.size() == 1) {
@@ -774,7 +777,7 @@ void urcco_context_destroy(urcco_context* c) {
     for (urcco_session* s : D.sessions) (void)hipStreamSynchronize(s->stream);
     if (D.comm && c->rccl) (void)c->rccl->CommDestroy(D.comm);
     for (EvState& E : D.ev) E.release();
-    for (int q = 0; q < 2; ++q) { D.a_cp[q].release(); D.a_ri[q].release(); D.a_post[q].release(); }
+    for (int q = 0; q < A_SETS; ++q) { D.a_cp[q].release(); D.a_ri[q].release(); D.a_post[q].release(); }
     D.work.release(); D.bounds.release();
     if (D.a_ready) (void)hipEventDestroy(D.a_ready);
     if (D.in_ready) (void)hipEventDestroy(D.in_ready);
