@@ -186,6 +186,36 @@ static inline void __builtin_amdgcn_s_sleep(int) {}
 static inline void hipsim_wave_barrier(int line) { hipsim::wave_op(hipsim::OP_BALLOT, 0, 0, HIPSIM_SITE(line)); }
 #define __builtin_amdgcn_wave_barrier() hipsim_wave_barrier(__LINE__)
 
+// DPP (data-parallel primitives) of GFX9: row_shr:n (0x110 + n), row_shl:n (0x100 + n) inside rows of 16 lanes, row_bcast15
+// (0x142: lane 15 of a row -> the next row) and row_bcast31 (0x143: lane 31 -> rows 2 and 3).  A lane that is masked off
+// by row_mask / bank_mask keeps `old`; a lane whose source falls outside its row gets 0 (bound_ctrl) or `old`.
+static inline int hipsim_update_dpp(int line, int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+  const int lane = hipsim::lane_id();
+  const int row = lane >> 4, bank = (lane >> 2) & 3;
+  int s = -1;
+  if (ctrl > 0x110 && ctrl <= 0x11f) { const int n = ctrl - 0x110; s = (lane & 15) >= n ? lane - n : -1; }
+  else if (ctrl > 0x100 && ctrl <= 0x10f) { const int n = ctrl - 0x100; s = (lane & 15) + n < 16 ? lane + n : -1; }
+  else if (ctrl == 0x142) s = row >= 1 ? row * 16 - 1 : -1;
+  else if (ctrl == 0x143) s = lane >= 32 ? 31 : -1;
+  else abort();
+  uint64_t p = (uint32_t)src;
+  const uint64_t r = hipsim::wave_op(hipsim::OP_SHFL, p, s < 0 ? lane : s, HIPSIM_SITE(line));
+  if (!((row_mask >> row) & 1) || !((bank_mask >> bank) & 1)) return old;
+  if (s < 0) return bound_ctrl ? 0 : old;
+  return (int)(uint32_t)r;
+}
+#define __builtin_amdgcn_update_dpp(...) hipsim_update_dpp(__LINE__, __VA_ARGS__)
+#define __builtin_amdgcn_readlane(v, l) hipsim_shfl(__LINE__, (int)(v), (int)(l))
+#define __builtin_amdgcn_readfirstlane(v) (v)  /* only ever applied to wave-uniform values */
+static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned base) {
+  const int lane = hipsim::lane_id();
+  return base + (unsigned)__builtin_popcount(mask & (lane >= 32 ? 0xffffffffu : ((1u << lane) - 1u)));
+}
+static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned base) {
+  const int lane = hipsim::lane_id();
+  return base + (unsigned)__builtin_popcount(mask & (lane <= 32 ? 0u : ((1u << (lane - 32)) - 1u)));
+}
+
 // ---- runtime API ---------------------------------------------------------------------------
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess(sim)" : "hipError(sim)"; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }

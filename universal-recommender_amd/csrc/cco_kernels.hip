@@ -1381,6 +1381,27 @@ __device__ __forceinline__ bool best_before(unsigned long long ka, int ca, unsig
   return ka > kb || (ka == kb && ca < cb);
 }
 
+// Rank of (mk, mc) among keys[0 .. n) (columns through col_of) in the order key desc, column asc, by counting.  `n` must be
+// wave-uniform and is moved to a scalar register: the trip count, the element index and the LDS offsets then live in the
+// scalar unit and the loop unrolls with immediate offsets -- with a lane-valued trip count half of the vector instructions of
+// this loop were bookkeeping (three address/counter increments and an exec-mask test per element), and the ranking loops were
+// ~45 % of the VALU instructions of a typical one-wave row.  Equal keys are COMMON (an LLR is a function of four small integer
+// counts), so the column comparison cannot be left to a rare path (measured: a key-only loop with a second pass for lanes that
+// saw their key twice was 8 % slower than the plain loop).
+template <class ColOf>
+__device__ __forceinline__ unsigned rank_by_counting(const unsigned long long* keys, unsigned n_uniform, unsigned long long mk, int mc, ColOf col_of) {
+  const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)n_uniform);
+  unsigned r0 = 0, r1 = 0, r2 = 0, r3 = 0, u = 0;  // four chains: each comparison ends in one add-with-carry
+  for (; u + 4 <= n; u += 4) {
+    r0 += best_before(keys[u], col_of(u), mk, mc) ? 1u : 0u;
+    r1 += best_before(keys[u + 1], col_of(u + 1), mk, mc) ? 1u : 0u;
+    r2 += best_before(keys[u + 2], col_of(u + 2), mk, mc) ? 1u : 0u;
+    r3 += best_before(keys[u + 3], col_of(u + 3), mk, mc) ? 1u : 0u;
+  }
+  for (; u < n; ++u) r0 += best_before(keys[u], col_of(u), mk, mc) ? 1u : 0u;
+  return (r0 + r1) + (r2 + r3);
+}
+
 // Claim-first insert into the packed open-addressing table: one CAS per probe (a new column costs one LDS round trip, a
 // known one two), a single rolled loop with one exit (an unrolled probe loop compiles to more exec-mask bookkeeping than
 // useful work; measured -4 % on the one-wave class against load-then-CAS).  Returns false only if every slot was probed
@@ -1417,18 +1438,34 @@ __device__ __forceinline__ void team_sync() {
   if (T == WAVE) wave_sync(); else __syncthreads();
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave, entirely in the VALU: four DPP row shifts inside the rows of 16 lanes,
+// then the two row broadcasts that carry the row totals upwards.  (A __shfl_up ladder is six dependent ds_bpermute round
+// trips through the LDS pipe, each with its own lane-bound bookkeeping; a row of the SpGEMM ran ~5 such ladders.)  Every lane
+// of the wave must be active.  One DPP per source line: the test simulator keys wave operations by line.
+__device__ __forceinline__ unsigned wave_inclusive_sum(unsigned v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return (unsigned)x;
+}
+// value of lane l (wave-uniform l): one v_readlane, no LDS
+__device__ __forceinline__ unsigned wave_read_lane(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+// number of set bits of m below this lane
+__device__ __forceinline__ unsigned lanes_below(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
 // exclusive scan of one unsigned per thread across a team of T threads; *total = team sum.  Every thread must call.
 template <int T>
 __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_wsum /*[T / WAVE]*/, unsigned* total) {
   const int lane = threadIdx.x & (WAVE - 1);
-  unsigned inc = v;
-#pragma unroll
-  for (int d = 1; d < WAVE; d <<= 1) {
-    const unsigned o = __shfl_up(inc, d);
-    if (lane >= d) inc += o;
-  }
+  const unsigned inc = wave_inclusive_sum(v);
   if (T == WAVE) {
-    *total = __shfl(inc, WAVE - 1);
+    *total = wave_read_lane(inc, WAVE - 1);
     return inc - v;
   }
   const int wave = (threadIdx.x % T) / WAVE;
@@ -1593,7 +1630,18 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
     // ---- 3. compact the occupied slots to tab[0 .. D); candidate keys will live behind them in the same LDS:
     //         words [kb, kb + 2 D) with kb = D rounded up to even.  The binning rule keeps 3 D + 1 <= E.
     unsigned D;
-    {
+    if (T == WAVE) {  // one wave: positions from ballots (no scan); all SPT reads are issued before the first write
+      unsigned v[SPT];
+#pragma unroll
+      for (int q = 0; q < SPT; ++q) v[q] = tab[tl + q * T];
+      D = 0;
+#pragma unroll
+      for (int q = 0; q < SPT; ++q) {
+        const unsigned long long m = __ballot(v[q] != 0u);
+        if (v[q] != 0u) tab[D + lanes_below(m)] = v[q];
+        D += (unsigned)__popcll(m);
+      }
+    } else {
       unsigned v[SPT];
       unsigned occ = 0;
 #pragma unroll
@@ -1752,28 +1800,25 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
             list_n = sel_res[0];
           }
           first_pass = false;
-          {  // every wave locates the digit that holds the cut (lanes own 4 bins each, higher lanes = higher digits)
+          {  // every wave locates the digit that holds the cut: lane l owns the four bins of digit group 63 - l (the highest
+             // digits sit in the lowest lanes, so that the count of everything above a group is a PREFIX sum over lanes)
             unsigned* Hz = hist + ((q + NH - 1) % NH) * 128;
             for (int b = tl; b < 128; b += T) Hz[b] = 0u;  // the previous pass's buffer: every wave is past its reads of it
-            const unsigned w01 = H[2 * lane], w23 = H[2 * lane + 1];
+            const int grp = WAVE - 1 - lane;
+            const unsigned w01 = H[2 * grp], w23 = H[2 * grp + 1];
             const unsigned h0 = w01 & 0xffffu, h1 = w01 >> 16, h2 = w23 & 0xffffu, h3 = w23 >> 16;
             const unsigned v4 = h0 + h1 + h2 + h3;
-            unsigned S = v4;  // inclusive suffix sum over lanes
-#pragma unroll
-            for (int dd = 1; dd < WAVE; dd <<= 1) {
-              const unsigned o = __shfl_down(S, dd);
-              if (lane + dd < WAVE) S += o;
-            }
+            const unsigned S = wave_inclusive_sum(v4);  // members of this digit group and of every higher one
             const unsigned long long ge = __ballot(S >= need);
-            const int L = 63 - __clzll((long long)ge);
+            const int L = __ffsll((unsigned long long)ge) - 1;  // the highest group that reaches the cut (ge != 0: S of lane 63 is the whole set)
             unsigned above = S - v4;
             unsigned d, cnt;
             if (above + h3 >= need) { d = 3; cnt = h3; }
             else if (above + h3 + h2 >= need) { d = 2; cnt = h2; above += h3; }
             else if (above + h3 + h2 + h1 >= need) { d = 1; cnt = h1; above += h3 + h2; }
             else { d = 0; cnt = h0; above += h3 + h2 + h1; }
-            const unsigned packed = (unsigned)__shfl((int)(((4u * (unsigned)lane + d) << 16) | cnt), L);  // cnt < 2^16
-            above = (unsigned)__shfl((int)above, L);
+            const unsigned packed = wave_read_lane(((4u * (unsigned)grp + d) << 16) | cnt, L);  // cnt < 2^16
+            above = wave_read_lane(above, L);
             d = packed >> 16;
             cnt = packed & 0xffffu;
             need -= above;
@@ -1805,9 +1850,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
             for (unsigned x = (unsigned)tl; x < m; x += T) {
               const unsigned long long mk = amb_key[x];
               const int mc = (int)amb_col[x];
-              unsigned rank = 0;
-#pragma unroll 4
-              for (unsigned u = 0; u < m; ++u) rank += best_before(amb_key[u], (int)amb_col[u], mk, mc) ? 1u : 0u;
+              const unsigned rank = rank_by_counting(amb_key, m, mk, mc, [&](unsigned u) { return (int)amb_col[u]; });
               if (rank + 1u == need) {
                 sel_thr[0] = mk;
                 sel_thr[1] = (unsigned long long)(~(unsigned)mc);
@@ -1862,8 +1905,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
       for (unsigned t = (unsigned)tl; t < n; t += T) {
         const unsigned long long mk = selk[t];
         const int mc = (int)selc[t];
-        unsigned rank = 0;
-        for (unsigned u = 0; u < n; ++u) rank += best_before(selk[u], (int)selc[u], mk, mc) ? 1u : 0u;
+        const unsigned rank = rank_by_counting(selk, n, mk, mc, [&](unsigned u) { return (int)selc[u]; });
         if (staged) {
           amb_key[rank] = mk;
           amb_col[rank] = (unsigned)mc;
@@ -2017,11 +2059,7 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
       if (lane == 0) a.out_count[i - a.item_lo] = n_valid;
     } else if (!(a.debug & 4)) {
       const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
-      unsigned rank = 0;
-      for (unsigned u = 0; u < D; ++u) {  // broadcast LDS reads
-        const unsigned long long ok = kkm[u];
-        rank += (ok != 0ull && best_before(ok, (int)(cand[u] >> cb) - 1, mk, mc)) ? 1u : 0u;
-      }
+      const unsigned rank = mk == 0ull ? 0u : rank_by_counting(kkm, D, mk, mc, [&](unsigned u) { return (int)(cand[u] >> cb) - 1; });  // broadcast LDS reads
       // the row is put in order in LDS (the accumulator words are free again) and leaves as contiguous stores
       wave_sync();
       unsigned* srt_col = tab;                                                    // [64]
@@ -2171,8 +2209,7 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
         for (int t = threadIdx.x; t < n; t += GB_THREADS) {  // rank by counting, straight to the output position
           const unsigned long long mk = s_selk[t];
           const int mc = (int)s_selc[t];
-          int rank = 0;
-          for (int u = 0; u < n; ++u) rank += best_before(s_selk[u], (int)s_selc[u], mk, mc) ? 1 : 0;
+          const int rank = (int)rank_by_counting(s_selk, (unsigned)n, mk, mc, [&](unsigned u) { return (int)s_selc[u]; });
           a.out_idx[obase + rank] = mc;
           a.out_llr[obase + rank] = __longlong_as_double((long long)mk);
         }
