@@ -1452,6 +1452,17 @@ __device__ __forceinline__ unsigned wave_inclusive_sum(unsigned v) {
   x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
   return (unsigned)x;
 }
+// A value every lane of the wave agrees on, moved to a scalar register.  The compiler cannot tell that threadIdx.x / T, or
+// anything loaded through it (the row id, its CSC bounds, the chunk's work bounds, counts read back from LDS), is uniform, and
+// keeps all arithmetic, addressing and loop control that derives from it in the vector unit -- where every instruction costs a
+// wave four issue cycles and the SpGEMM classes are bound by exactly that.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int64_t uni(int64_t v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((int64_t)hi << 32) | (int64_t)lo;
+}
 // value of lane l (wave-uniform l): one v_readlane, no LDS
 __device__ __forceinline__ unsigned wave_read_lane(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
 // number of set bits of m below this lane
@@ -1511,7 +1522,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
   constexpr bool SKIP_SHARED = T == 256;
   __shared__ unsigned long long s_kbits[2 * NW];  // per wave: AND / OR over its valid keys
 
-  const int team = threadIdx.x / T;
+  const int team = TEAMS == 1 ? 0 : uni((int)threadIdx.x / T);  // a team is one wave (T == 64) or the whole block
   const int tl = threadIdx.x % T;
   const int lane = threadIdx.x & (WAVE - 1);
   unsigned* tab = s_tab + team * E;
@@ -1537,16 +1548,16 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
   int i_nx = 0;
   int64_t cs_nx = 0, ce_nx = 0;
   if (li < list_n) {
-    i_nx = a.bin_rows[list_start + li];
-    cs_nx = a.a_col_ptr[i_nx];
-    ce_nx = a.a_col_ptr[i_nx + 1];
+    i_nx = uni(a.bin_rows[list_start + li]);
+    cs_nx = uni(a.a_col_ptr[i_nx]);
+    ce_nx = uni(a.a_col_ptr[i_nx + 1]);
   }
   // first-chunk operands of the row about to be processed (loaded one row ahead, see the end of step 4)
   int64_t pf_w0 = 0, pf_w1 = 0, pf_wp = 0, pf_start = 0;
   if (li < list_n) {
     const int64_t c1 = cs_nx + T < ce_nx ? cs_nx + T : ce_nx;
-    pf_w0 = a.wp[cs_nx];
-    pf_w1 = a.wp[c1];
+    pf_w0 = uni(a.wp[cs_nx]);
+    pf_w1 = uni(a.wp[c1]);
     if (cs_nx + tl < c1) {
       pf_wp = a.wp[cs_nx + tl];
       pf_start = a.pstart[cs_nx + tl];
@@ -1557,9 +1568,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
     const int64_t cs = cs_nx, ce = ce_nx;
     const bool has_next = li + total_teams < list_n;
     if (has_next) {  // the next row's row id and CSC bounds travel while this row is processed
-      i_nx = a.bin_rows[list_start + li + total_teams];
-      cs_nx = a.a_col_ptr[i_nx];
-      ce_nx = a.a_col_ptr[i_nx + 1];
+      i_nx = uni(a.bin_rows[list_start + li + total_teams]);
+      cs_nx = uni(a.a_col_ptr[i_nx]);
+      ce_nx = uni(a.a_col_ptr[i_nx + 1]);
     }
 #pragma unroll
     for (int q = 0; q < SPT; ++q) tab[tl + q * T] = 0u;
@@ -1568,8 +1579,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
     for (int64_t c0 = cs; c0 < ce; c0 += T) {  // team-uniform
       const int64_t c1 = c0 + T < ce ? c0 + T : ce;
       const bool pre = c0 == cs;  // the first chunk's operands were prefetched
-      const int64_t w0 = pre ? pf_w0 : a.wp[c0];
-      const unsigned total = (unsigned)((pre ? pf_w1 : a.wp[c1]) - w0);
+      const int64_t w0 = pre ? pf_w0 : uni(a.wp[c0]);
+      const unsigned total = (unsigned)((pre ? pf_w1 : uni(a.wp[c1])) - w0);
       const int64_t p = c0 + tl;
       if (p < c1) {
         ustart[tl] = pre ? pf_start : a.pstart[p];
@@ -1592,36 +1603,24 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
           int o = lo - 1;
           int64_t pos = ustart[o] + (first - uoff[o]);
           unsigned uend = uoff[o + 1];
-          unsigned t = first;
-          // U column gathers are issued before the first insert.  Measured on config 3: U = 2 / 4 are 2-7 % SLOWER than
-          // U = 1 in every accumulator class (the other resident waves already cover the gather latency; the extra
-          // instructions cost more), so every class is instantiated with U = 1.
-          while (t < last) {
-            const unsigned nb = last - t < (unsigned)U ? last - t : (unsigned)U;
-            unsigned jj[U];
-#pragma unroll
-            for (int x = 0; x < U; ++x) {
-              jj[x] = 0u;
-              if ((unsigned)x < nb) {
-                if (t + (unsigned)x >= uend) {  // next user with a non-empty B' row
-                  do { ++o; } while (uoff[o + 1] <= t + (unsigned)x);
-                  pos = ustart[o];
-                  uend = uoff[o + 1];
-                }
-                jj[x] = (unsigned)a.b_col_idx[pos++];
+          // `per` is team-uniform: the loop counter and its bound live in the scalar unit.  (Gathering U > 1 columns before
+          // the first insert was measured 2-7 % SLOWER in every accumulator class on config 3: the other resident waves
+          // already cover the gather latency and the extra instructions cost more.)
+          for (unsigned x = 0; x < per; ++x) {
+            const unsigned t = first + x;
+            if (t < last) {
+              if (t >= uend) {  // next user with a non-empty B' row
+                do { ++o; } while (uoff[o + 1] <= t);
+                pos = ustart[o];
+                uend = uoff[o + 1];
+              }
+              const unsigned jj = (unsigned)a.b_col_idx[pos++];
+              if (a.debug & 1) {  // ablation: gather only
+                if (jj == 0xffffffffu) tab[0] = 1u;
+              } else if (!tab_insert(tab, jj + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) {
+                atomicAdd(a.err, 1ull);
               }
             }
-#pragma unroll
-            for (int x = 0; x < U; ++x) {
-              if ((unsigned)x < nb) {
-                if (a.debug & 1) {  // ablation: gather only
-                  if (jj[x] == 0xffffffffu) tab[0] = 1u;
-                } else if (!tab_insert(tab, jj[x] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) {
-                  atomicAdd(a.err, 1ull);
-                }
-              }
-            }
-            t += nb;
           }
         }
       }
@@ -1650,6 +1649,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
         occ += v[q] != 0u;
       }
       unsigned wpos = team_exclusive_scan<T>(occ, s_wsum, &D);
+      D = uni(D);
       team_sync<T>();  // every read of the table precedes every write below
 #pragma unroll
       for (int q = 0; q < SPT; ++q)
@@ -1663,7 +1663,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
     {
       const long long ca = a.cnt_a[i];
       const double row_entropy = a.ent_a[i];
-      for (unsigned t0 = (unsigned)tl; t0 < D; t0 += U * T) {  // the column-info gathers of U candidates travel together
+      for (unsigned base = 0; base < D; base += U * T) {  // scalar loop control; the column-info gathers of U candidates travel together
+        const unsigned t0 = base + (unsigned)tl;
         unsigned vv[U];
         int cbj[U];
         double eb[U];
@@ -1726,6 +1727,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
     }
     unsigned C;
     team_exclusive_scan<T>(n_valid, s_wsum, &C);
+    C = uni(C);
     team_sync<T>();
     // ---- 5. top-k.  Order: key desc, then column asc == (key, ~col) desc as one 96-bit composite.
     //   a. C > k: MSB-first radix select (8-bit digits, LDS histogram) of the k-th composite; stops as soon as the digit
@@ -1775,7 +1777,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
           const bool build = SEL_CAP > 0 && !have_list && !first_pass && prev_cnt <= (unsigned)SEL_CAP;  // this sweep also records the survivors
           const unsigned n_scan = have_list ? list_n : D;
           const int shk = p < 8 ? 56 - 8 * p : 0, shc = p < 8 ? 0 : 24 - 8 * (p - 8);
-          for (unsigned idx = (unsigned)tl; idx < n_scan; idx += T) {
+          for (unsigned base = 0; base < n_scan; base += T) {  // scalar loop control
+            const unsigned idx = base + (unsigned)tl;
+            if (idx >= n_scan) continue;
             const unsigned t = have_list ? (unsigned)lst[idx] : idx;
             const unsigned long long key = kk[t];
             if (key == 0ull) continue;
@@ -1797,7 +1801,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
           team_sync<T>();
           if (build) {
             have_list = true;
-            list_n = sel_res[0];
+            list_n = uni(sel_res[0]);
           }
           first_pass = false;
           {  // every wave locates the digit that holds the cut: lane l owns the four bins of digit group 63 - l (the highest
@@ -1832,7 +1836,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
           if (prev_cnt <= (unsigned)SEL_M) {
             // finish: copy out the members of the cut bin (they match the prefix through digit p) ...
             const unsigned n_scan2 = have_list ? list_n : D;
-            for (unsigned idx = (unsigned)tl; idx < n_scan2; idx += T) {
+            for (unsigned base = 0; base < n_scan2; base += T) {
+              const unsigned idx = base + (unsigned)tl;
+              if (idx >= n_scan2) continue;
               const unsigned t = have_list ? (unsigned)lst[idx] : idx;
               const unsigned long long key = kk[t];
               if (key == 0ull) continue;
@@ -1846,8 +1852,10 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
             }
             team_sync<T>();
             // ... and rank them by counting; the need-th best composite is the exact threshold
-            const unsigned m = sel_res[1];
-            for (unsigned x = (unsigned)tl; x < m; x += T) {
+            const unsigned m = uni(sel_res[1]);
+            for (unsigned base = 0; base < m; base += T) {
+              const unsigned x = base + (unsigned)tl;
+              if (x >= m) continue;
               const unsigned long long mk = amb_key[x];
               const int mc = (int)amb_col[x];
               const unsigned rank = rank_by_counting(amb_key, m, mk, mc, [&](unsigned u) { return (int)amb_col[u]; });
@@ -1871,7 +1879,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
         // URCCO_FLAG_UNORDERED_ROWS: the top-k SET of the row, in whatever order the lanes claim output slots -- what
         // Mahout's computeSimilarities returns (a sparse vector has no score order; the reference sorts later, in
         // toStringMapRDD, package.scala:102).  No ranking pass.
-        for (unsigned t = (unsigned)tl; t < D; t += T) {
+        for (unsigned base = 0; base < D; base += T) {
+          const unsigned t = base + (unsigned)tl;
+          if (t >= D) continue;
           const unsigned long long key = kk[t];
           if (key == 0ull) continue;
           const unsigned col = (unsigned)((int)(tab[t] >> cb) - 1);
@@ -1886,7 +1896,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
         team_sync<T>();
         continue;
       }
-      for (unsigned t = (unsigned)tl; t < D; t += T) {
+      for (unsigned base = 0; base < D; base += T) {
+        const unsigned t = base + (unsigned)tl;
+        if (t >= D) continue;
         const unsigned long long key = kk[t];
         if (key == 0ull) continue;
         const unsigned col = (unsigned)((int)(tab[t] >> cb) - 1);
@@ -1897,12 +1909,14 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
         }
       }
       team_sync<T>();
-      const unsigned n = (a.debug & 16) ? 0u : *nsel;  // ablation 16: no ranking / output
+      const unsigned n = (a.debug & 16) ? 0u : uni(*nsel);  // ablation 16: no ranking / output
       // Rank by counting.  Up to SEL_M survivors are put in order in LDS first (the arrays of the select's ambiguous set
       // are free again) and leave as contiguous stores: one element per lane scattered straight to its rank made every
       // store a partial-line write (measured 4x write amplification on the one-wave class).
       const bool staged = n <= (unsigned)SEL_M;
-      for (unsigned t = (unsigned)tl; t < n; t += T) {
+      for (unsigned base = 0; base < n; base += T) {
+        const unsigned t = base + (unsigned)tl;
+        if (t >= n) continue;
         const unsigned long long mk = selk[t];
         const int mc = (int)selc[t];
         const unsigned rank = rank_by_counting(selk, n, mk, mc, [&](unsigned u) { return (int)selc[u]; });
@@ -1916,7 +1930,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
       }
       if (staged) {
         team_sync<T>();
-        for (unsigned t = (unsigned)tl; t < n; t += T) {
+        for (unsigned base = 0; base < n; base += T) {
+          const unsigned t = base + (unsigned)tl;
+          if (t >= n) continue;
           a.out_idx[obase + t] = (int)amb_col[t];
           a.out_llr[obase + t] = __longlong_as_double((long long)amb_key[t]);
         }
