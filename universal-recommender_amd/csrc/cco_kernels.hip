@@ -1495,7 +1495,7 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 }
 
 template <int T, int E, int U>
-__global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T == 64 ? 6 : 1)) void cco_rows_kernel(CcoArgs a, int bin) {
+__global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? 8 : (T == 256 && E == 4096 ? 6 : 1))) void cco_rows_kernel(CcoArgs a, int bin) {
   constexpr int BLOCK = T < 256 ? 256 : T;
   constexpr int TEAMS = BLOCK / T;
   constexpr int SPT = E / T;
@@ -1503,17 +1503,27 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
   constexpr int LOG2E = E == 1024 ? 10 : (E == 4096 ? 12 : (E == 8192 ? 13 : (E == 16384 ? 14 : 15)));
   static_assert((1 << LOG2E) == E, "table size");
   __shared__ unsigned s_tab[TEAMS * E];
-  __shared__ long long s_ustart[TEAMS * T];
-  __shared__ unsigned s_uoff[TEAMS * (T + 1)];
+  // One-wave teams: the chunk operands (insert phase), the select histogram (select passes) and the ambiguous / staged
+  // survivors (after the passes) are never live together and share ONE region of SHARE_WORDS 64-bit words per team --
+  // 19.6 KB of LDS per block instead of 26.8, which with 64 VGPRs lets eight blocks (32 waves) share a CU instead of six.
+  constexpr bool SHARE = T == WAVE;
+  constexpr int SHARE_WORDS = 98;  // 64 x 8 B (ustart | amb_key | the histogram) + 65 x 4 B (uoff | amb_col), rounded up
+  __shared__ unsigned long long s_share[SHARE ? TEAMS * SHARE_WORDS : 1];
+  __shared__ long long s_ustart[SHARE ? 1 : TEAMS * T];
+  __shared__ unsigned s_uoff[SHARE ? 1 : TEAMS * (T + 1)];
   __shared__ unsigned s_wsum[NW];
-  constexpr int NH = T == WAVE ? 2 : 3;  // rotating histograms (a one-wave team can afford the extra wave-level sync of two)
-  __shared__ unsigned s_hist[TEAMS * NH * 128];  // 256 bins of 16-bit counters, two per word
+  // select histograms: 256 bins of 16-bit counters, two per word.  Teams of several waves rotate three (pass p counts into
+  // one while the previous one is cleared: one team barrier per pass); a one-wave team needs one -- every lane zeroes the
+  // two words it has just read.
+  constexpr int NH = T == WAVE ? 1 : 3;
+  __shared__ unsigned s_hist[SHARE ? 1 : TEAMS * NH * 128];
   __shared__ unsigned s_selres[TEAMS * 4];
   constexpr int SEL_CAP = T == WAVE ? 0 : (T == 256 ? 512 : 2048);  // explicit survivor list (16-bit indices); a wave sweeps its <= 341 candidates directly
   constexpr int SEL_M = T == WAVE ? 64 : 128;                        // ambiguous set ranked directly
   __shared__ unsigned short s_lst[TEAMS * (SEL_CAP > 0 ? SEL_CAP : 1)];
-  __shared__ unsigned long long s_ambkey[TEAMS * SEL_M];
-  __shared__ unsigned s_ambcol[TEAMS * SEL_M];
+  __shared__ unsigned long long s_ambkey[SHARE ? 1 : TEAMS * SEL_M];
+  __shared__ unsigned s_ambcol[SHARE ? 1 : TEAMS * SEL_M];
+  static_assert(!SHARE || (T * 8 + (T + 1) * 4 <= SHARE_WORDS * 8 && NH * 128 * 4 <= SHARE_WORDS * 8 && SEL_M * 12 <= SHARE_WORDS * 8), "shared region");
   __shared__ unsigned long long s_selthr[TEAMS * 2];
   // The leading key bytes shared by every candidate of a row need no select pass (LLRs of one row share sign and high
   // exponent bits: typically the whole first pass).  Measured on config 3: -7..9 % for the 256-thread classes, but the
@@ -1526,14 +1536,15 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
   const int tl = threadIdx.x % T;
   const int lane = threadIdx.x & (WAVE - 1);
   unsigned* tab = s_tab + team * E;
-  long long* ustart = s_ustart + team * T;
-  unsigned* uoff = s_uoff + team * (T + 1);
-  unsigned* hist = s_hist + team * NH * 128;
+  unsigned long long* share = s_share + (SHARE ? team * SHARE_WORDS : 0);
+  long long* ustart = SHARE ? reinterpret_cast<long long*>(share) : s_ustart + team * T;
+  unsigned* uoff = SHARE ? reinterpret_cast<unsigned*>(share + T) : s_uoff + team * (T + 1);
+  unsigned* hist = SHARE ? reinterpret_cast<unsigned*>(share) : s_hist + team * NH * 128;
   unsigned* sel_res = s_selres + team * 4;
   unsigned* nsel = sel_res + 3;
   unsigned short* lst = s_lst + team * (SEL_CAP > 0 ? SEL_CAP : 1);
-  unsigned long long* amb_key = s_ambkey + team * SEL_M;
-  unsigned* amb_col = s_ambcol + team * SEL_M;
+  unsigned long long* amb_key = SHARE ? share : s_ambkey + team * SEL_M;
+  unsigned* amb_col = SHARE ? reinterpret_cast<unsigned*>(share + SEL_M) : s_ambcol + team * SEL_M;
   unsigned long long* sel_thr = s_selthr + team * 2;
   const int list_start = a.bin_off[bin];
   const int list_n = a.bin_off[bin + 1] - list_start;
@@ -1806,10 +1817,15 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
           first_pass = false;
           {  // every wave locates the digit that holds the cut: lane l owns the four bins of digit group 63 - l (the highest
              // digits sit in the lowest lanes, so that the count of everything above a group is a PREFIX sum over lanes)
-            unsigned* Hz = hist + ((q + NH - 1) % NH) * 128;
-            for (int b = tl; b < 128; b += T) Hz[b] = 0u;  // the previous pass's buffer: every wave is past its reads of it
             const int grp = WAVE - 1 - lane;
             const unsigned w01 = H[2 * grp], w23 = H[2 * grp + 1];
+            if (NH == 1) {  // one wave: the words just read are this lane's to clear
+              H[2 * grp] = 0u;
+              H[2 * grp + 1] = 0u;
+            } else {
+              unsigned* Hz = hist + ((q + NH - 1) % NH) * 128;
+              for (int b = tl; b < 128; b += T) Hz[b] = 0u;  // the previous pass's buffer: every wave is past its reads of it
+            }
             const unsigned h0 = w01 & 0xffffu, h1 = w01 >> 16, h2 = w23 & 0xffffu, h3 = w23 >> 16;
             const unsigned v4 = h0 + h1 + h2 + h3;
             const unsigned S = wave_inclusive_sum(v4);  // members of this digit group and of every higher one
@@ -1830,7 +1846,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), ((T == 256 && E == 4096) || T 
             else thr_ncol |= d << shc;
             prev_cnt = cnt;
             if (cnt == need) break;  // the whole bin is wanted: every composite >= the prefix (low bits zero) is selected
-            if (NH == 2) team_sync<T>();  // the buffer just cleared is the next pass's target
+            if (NH == 1) team_sync<T>();  // the histogram just cleared is the next pass's target
             ++q;
           }
           if (prev_cnt <= (unsigned)SEL_M) {
