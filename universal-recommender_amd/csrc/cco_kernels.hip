@@ -1495,7 +1495,7 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 }
 
 template <int T, int E, int U>
-__global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? 8 : (T == 256 && E == 4096 ? 6 : 1))) void cco_rows_kernel(CcoArgs a, int bin) {
+__global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? 8 : (T == 256 && E == 4096 ? 7 : 1))) void cco_rows_kernel(CcoArgs a, int bin) {
   constexpr int BLOCK = T < 256 ? 256 : T;
   constexpr int TEAMS = BLOCK / T;
   constexpr int SPT = E / T;
@@ -1503,27 +1503,30 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? 8 : (T == 256 && E 
   constexpr int LOG2E = E == 1024 ? 10 : (E == 4096 ? 12 : (E == 8192 ? 13 : (E == 16384 ? 14 : 15)));
   static_assert((1 << LOG2E) == E, "table size");
   __shared__ unsigned s_tab[TEAMS * E];
-  // One-wave teams: the chunk operands (insert phase), the select histogram (select passes) and the ambiguous / staged
-  // survivors (after the passes) are never live together and share ONE region of SHARE_WORDS 64-bit words per team --
-  // 19.6 KB of LDS per block instead of 26.8, which with 64 VGPRs lets eight blocks (32 waves) share a CU instead of six.
-  constexpr bool SHARE = T == WAVE;
-  constexpr int SHARE_WORDS = 98;  // 64 x 8 B (ustart | amb_key | the histogram) + 65 x 4 B (uoff | amb_col), rounded up
-  __shared__ unsigned long long s_share[SHARE ? TEAMS * SHARE_WORDS : 1];
-  __shared__ long long s_ustart[SHARE ? 1 : TEAMS * T];
-  __shared__ unsigned s_uoff[SHARE ? 1 : TEAMS * (T + 1)];
-  __shared__ unsigned s_wsum[NW];
+  // One-wave teams and the small block class: the chunk operands (insert phase), the select histograms + survivor list (select
+  // passes) and the ambiguous / staged survivors (after the passes; they overlay the histograms) are never live together and
+  // share ONE region per team.  One-wave class: 19.6 KB of LDS per block instead of 26.8, which with <= 64 VGPRs lets eight
+  // blocks (32 waves) share a CU instead of six.
   // select histograms: 256 bins of 16-bit counters, two per word.  Teams of several waves rotate three (pass p counts into
   // one while the previous one is cleared: one team barrier per pass); a one-wave team needs one -- every lane zeroes the
   // two words it has just read.
   constexpr int NH = T == WAVE ? 1 : 3;
-  __shared__ unsigned s_hist[SHARE ? 1 : TEAMS * NH * 128];
-  __shared__ unsigned s_selres[TEAMS * 4];
   constexpr int SEL_CAP = T == WAVE ? 0 : (T == 256 ? 512 : 2048);  // explicit survivor list (16-bit indices); a wave sweeps its <= 341 candidates directly
   constexpr int SEL_M = T == WAVE ? 64 : 128;                        // ambiguous set ranked directly
-  __shared__ unsigned short s_lst[TEAMS * (SEL_CAP > 0 ? SEL_CAP : 1)];
+  constexpr bool SHARE = T == WAVE || (T == 256 && E == 4096);
+  constexpr int SH_INS = T * 8 + (T + 1) * 4;                                                     // ustart | uoff
+  constexpr int SH_LST = ((NH * 128 * 4 > SEL_M * 12 ? NH * 128 * 4 : SEL_M * 12) + 7) / 8 * 8;  // histograms or amb_key | amb_col, then the list
+  constexpr int SH_SEL = SH_LST + SEL_CAP * 2;
+  constexpr int SHARE_WORDS = ((SH_INS > SH_SEL ? SH_INS : SH_SEL) + 7) / 8;
+  __shared__ unsigned long long s_share[SHARE ? TEAMS * SHARE_WORDS : 1];
+  __shared__ long long s_ustart[SHARE ? 1 : TEAMS * T];
+  __shared__ unsigned s_uoff[SHARE ? 1 : TEAMS * (T + 1)];
+  __shared__ unsigned s_wsum[NW];
+  __shared__ unsigned s_hist[SHARE ? 1 : TEAMS * NH * 128];
+  __shared__ unsigned s_selres[TEAMS * 4];
+  __shared__ unsigned short s_lst[SHARE ? 1 : TEAMS * (SEL_CAP > 0 ? SEL_CAP : 1)];
   __shared__ unsigned long long s_ambkey[SHARE ? 1 : TEAMS * SEL_M];
   __shared__ unsigned s_ambcol[SHARE ? 1 : TEAMS * SEL_M];
-  static_assert(!SHARE || (T * 8 + (T + 1) * 4 <= SHARE_WORDS * 8 && NH * 128 * 4 <= SHARE_WORDS * 8 && SEL_M * 12 <= SHARE_WORDS * 8), "shared region");
   __shared__ unsigned long long s_selthr[TEAMS * 2];
   // The leading key bytes shared by every candidate of a row need no select pass (LLRs of one row share sign and high
   // exponent bits: typically the whole first pass).  Measured on config 3: -7..9 % for the 256-thread classes, but the
@@ -1542,7 +1545,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? 8 : (T == 256 && E 
   unsigned* hist = SHARE ? reinterpret_cast<unsigned*>(share) : s_hist + team * NH * 128;
   unsigned* sel_res = s_selres + team * 4;
   unsigned* nsel = sel_res + 3;
-  unsigned short* lst = s_lst + team * (SEL_CAP > 0 ? SEL_CAP : 1);
+  unsigned short* lst = SHARE ? reinterpret_cast<unsigned short*>(share) + SH_LST / 2 : s_lst + team * (SEL_CAP > 0 ? SEL_CAP : 1);
   unsigned long long* amb_key = SHARE ? share : s_ambkey + team * SEL_M;
   unsigned* amb_col = SHARE ? reinterpret_cast<unsigned*>(share + SEL_M) : s_ambcol + team * SEL_M;
   unsigned long long* sel_thr = s_selthr + team * 2;
@@ -1972,6 +1975,8 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
   __shared__ unsigned s_tab[TEAMS * MICRO_WORDS];
   __shared__ long long s_ustart[TEAMS * WAVE];
   __shared__ unsigned s_uoff[TEAMS * (WAVE + 1)];
+  // (moving the row id, bounds and counts to scalar registers as in cco_rows_kernel was measured 12 % SLOWER here: the kernel
+  // argument block alone keeps ~60 SGPRs live and the extra scalars spill to VGPR lanes)
   const int team = threadIdx.x / WAVE;
   const int lane = threadIdx.x & (WAVE - 1);
   unsigned* tab = s_tab + team * MICRO_WORDS;
@@ -2056,7 +2061,7 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
     for (int q = 0; q < 4; ++q) {
       const unsigned v = tab[lane + q * WAVE];
       const unsigned long long m = __ballot(v != 0u);
-      if (v != 0u) cand[D + (unsigned)__popcll(m & lt)] = v;
+      if (v != 0u) cand[D + lanes_below(m)] = v;
       D += (unsigned)__popcll(m);
     }
     wave_sync();
