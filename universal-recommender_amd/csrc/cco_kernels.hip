@@ -1494,12 +1494,22 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
   return base + inc - v;
 }
 
+#ifndef URCCO_G_WAVE
+#define URCCO_G_WAVE 1
+#endif
+#ifndef URCCO_G_BLOCK
+#define URCCO_G_BLOCK 1
+#endif
+#ifndef URCCO_G_CU
+#define URCCO_G_CU 1
+#endif
 template <int T, int E, int U>
 __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? 8 : (T == 256 && E == 4096 ? 7 : 1))) void cco_rows_kernel(CcoArgs a, int bin) {
   constexpr int BLOCK = T < 256 ? 256 : T;
   constexpr int TEAMS = BLOCK / T;
   constexpr int SPT = E / T;
   constexpr int NW = T / WAVE;  // waves per team
+  constexpr int G = T == WAVE ? URCCO_G_WAVE : (T == 256 ? URCCO_G_BLOCK : URCCO_G_CU);  // column gathers in flight per lane
   constexpr int LOG2E = E == 1024 ? 10 : (E == 4096 ? 12 : (E == 8192 ? 13 : (E == 16384 ? 14 : 15)));
   static_assert((1 << LOG2E) == E, "table size");
   __shared__ unsigned s_tab[TEAMS * E];
@@ -1617,22 +1627,33 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? 8 : (T == 256 && E 
           int o = lo - 1;
           int64_t pos = ustart[o] + (first - uoff[o]);
           unsigned uend = uoff[o + 1];
-          // `per` is team-uniform: the loop counter and its bound live in the scalar unit.  (Gathering U > 1 columns before
-          // the first insert was measured 2-7 % SLOWER in every accumulator class on config 3: the other resident waves
-          // already cover the gather latency and the extra instructions cost more.)
-          for (unsigned x = 0; x < per; ++x) {
-            const unsigned t = first + x;
-            if (t < last) {
-              if (t >= uend) {  // next user with a non-empty B' row
-                do { ++o; } while (uoff[o + 1] <= t);
-                pos = ustart[o];
-                uend = uoff[o + 1];
+          // `per` is team-uniform: the loop counter and its bound live in the scalar unit.  G column gathers are issued
+          // before the first of their inserts (a gather that misses L2 costs 1-2 us and a lane's pairs are a chain of them).
+          for (unsigned x = 0; x < per; x += G) {
+            unsigned jj[G];
+            bool on[G];
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+              const unsigned t = first + x + (unsigned)q;
+              on[q] = t < last;
+              jj[q] = 0u;
+              if (on[q]) {
+                if (t >= uend) {  // next user with a non-empty B' row
+                  do { ++o; } while (uoff[o + 1] <= t);
+                  pos = ustart[o];
+                  uend = uoff[o + 1];
+                }
+                jj[q] = (unsigned)a.b_col_idx[pos++];
               }
-              const unsigned jj = (unsigned)a.b_col_idx[pos++];
-              if (a.debug & 1) {  // ablation: gather only
-                if (jj == 0xffffffffu) tab[0] = 1u;
-              } else if (!tab_insert(tab, jj + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) {
-                atomicAdd(a.err, 1ull);
+            }
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+              if (on[q]) {
+                if (a.debug & 1) {  // ablation: gather only
+                  if (jj[q] == 0xffffffffu) tab[0] = 1u;
+                } else if (!tab_insert(tab, jj[q] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) {
+                  atomicAdd(a.err, 1ull);
+                }
               }
             }
           }
