@@ -1494,6 +1494,22 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
   return base + inc - v;
 }
 
+// candidates scored together per lane (their column-info gathers travel together), per class
+#ifndef URCCO_U_WAVE
+#define URCCO_U_WAVE 1
+#endif
+#ifndef URCCO_U_BS
+#define URCCO_U_BS 1
+#endif
+#ifndef URCCO_U_B
+#define URCCO_U_B 1
+#endif
+#ifndef URCCO_U_H
+#define URCCO_U_H 1
+#endif
+#ifndef URCCO_U_C
+#define URCCO_U_C 1
+#endif
 #ifndef URCCO_G_WAVE
 #define URCCO_G_WAVE 1
 #endif
@@ -2336,11 +2352,11 @@ static int blocks_per_cu(int bin) {
     int n = 0;
     hipError_t e = hipErrorUnknown;
     if (bin == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_micro_kernel, 256, 0);
-    if (bin == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<64, E0, 1>, 256, 0);
-    if (bin == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1S, 1>, 256, 0);
-    if (bin == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1, 1>, 256, 0);
-    if (bin == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<512, E2S, 1>, 512, 0);
-    if (bin == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2, 1>, 1024, 0);
+    if (bin == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<64, E0, URCCO_U_WAVE>, 256, 0);
+    if (bin == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1S, URCCO_U_BS>, 256, 0);
+    if (bin == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1, URCCO_U_B>, 256, 0);
+    if (bin == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<512, E2S, URCCO_U_H>, 512, 0);
+    if (bin == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2, URCCO_U_C>, 1024, 0);
     cache[bin] = (e == hipSuccess && n > 0) ? n : 1;
   }
   return cache[bin];
@@ -2368,11 +2384,11 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
   auto grid = [&](int b) { return dim3((unsigned)(n_cu * blocks_per_cu(b)) * (unsigned)factor[b]); };
   switch (bin) {
     case 0: hipLaunchKernelGGL(cco_rows_micro_kernel, grid(0), dim3(256), 0, st, args); break;
-    case 1: hipLaunchKernelGGL((cco_rows_kernel<64, E0, 1>), grid(1), dim3(256), 0, st, args, 1); break;
-    case 2: hipLaunchKernelGGL((cco_rows_kernel<256, E1S, 1>), grid(2), dim3(256), 0, st, args, 2); break;
-    case 3: hipLaunchKernelGGL((cco_rows_kernel<256, E1, 1>), grid(3), dim3(256), 0, st, args, 3); break;
-    case 4: hipLaunchKernelGGL((cco_rows_kernel<512, E2S, 1>), grid(4), dim3(512), 0, st, args, 4); break;
-    case 5: hipLaunchKernelGGL((cco_rows_kernel<1024, E2, 1>), grid(5), dim3(1024), 0, st, args, 5); break;
+    case 1: hipLaunchKernelGGL((cco_rows_kernel<64, E0, URCCO_U_WAVE>), grid(1), dim3(256), 0, st, args, 1); break;
+    case 2: hipLaunchKernelGGL((cco_rows_kernel<256, E1S, URCCO_U_BS>), grid(2), dim3(256), 0, st, args, 2); break;
+    case 3: hipLaunchKernelGGL((cco_rows_kernel<256, E1, URCCO_U_B>), grid(3), dim3(256), 0, st, args, 3); break;
+    case 4: hipLaunchKernelGGL((cco_rows_kernel<512, E2S, URCCO_U_H>), grid(4), dim3(512), 0, st, args, 4); break;
+    case 5: hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C>), grid(5), dim3(1024), 0, st, args, 5); break;
     default: hipLaunchKernelGGL(cco_rows_global_kernel, dim3((unsigned)(args.g_blocks > 0 ? args.g_blocks : 1)), dim3(GB_THREADS), 0, st, args); break;
   }
   return hipGetLastError();
