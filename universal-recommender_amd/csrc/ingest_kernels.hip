@@ -38,17 +38,23 @@ __device__ __forceinline__ unsigned long long ig_find(const KeyTable& t, unsigne
 }
 }  // namespace
 
+// Popular keys are hit by millions of events (the top item of a Zipf catalogue by ~1 % of the stream): three atomics per event
+// on the key's slot -- claim, position minimum, count -- serialise on one L2 address each (measured: 6.2 ms per dictionary,
+// two thirds of the whole ingest).  A key never changes once written, the position minimum only decreases and the count only
+// matters up to `need` (min_count), so each of the three is read first and the atomic issued only if it can still change
+// something; a stale read (L1 is not coherent with other CUs' atomics) costs one unnecessary atomic, never a wrong result.
 __global__ __launch_bounds__(256) void ig_insert_kernel(KeyTable t, int64_t n, const unsigned long long* __restrict__ keys,
-                                                        const int32_t* __restrict__ select) {
+                                                        const int32_t* __restrict__ select, unsigned need) {
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (int64_t)gridDim.x * 256) {
     if (select && select[p] < 0) continue;
     const unsigned long long key = keys[p];
     unsigned long long slot = ig_mix(key) & t.mask;
     for (;;) {
-      const unsigned long long cur = atomicCAS(&t.keys[slot], IG_EMPTY, key);
+      unsigned long long cur = t.keys[slot];
+      if (cur == IG_EMPTY) cur = atomicCAS(&t.keys[slot], IG_EMPTY, key);
       if (cur == IG_EMPTY || cur == key) {
-        atomicMin(&t.minpos[slot], (unsigned)p);
-        atomicAdd(&t.count[slot], 1u);
+        if ((unsigned)p < t.minpos[slot]) atomicMin(&t.minpos[slot], (unsigned)p);
+        if (need > 1u && t.count[slot] < need) atomicAdd(&t.count[slot], 1u);  // exact below `need`, at least `need` from there on
         break;
       }
       slot = (slot + 1) & t.mask;
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(256) void ig_first_flags_kernel(KeyTable t, int64_t
     int f = 0;
     if (!(select && select[p] < 0)) {
       const unsigned long long slot = ig_find(t, keys[p]);
-      f = t.minpos[slot] == (unsigned)p && t.count[slot] >= min_count;
+      f = t.minpos[slot] == (unsigned)p && (min_count <= 1u || t.count[slot] >= min_count);
     }
     flag[p] = f;
   }
@@ -103,7 +109,7 @@ static unsigned ig_grid(int64_t n, int n_cu) {
 hipError_t launch_dictionary_build(hipStream_t st, int n_cu, KeyTable t, int64_t n, const unsigned long long* keys, const int32_t* select,
                                    int32_t min_count, int32_t* flag, int64_t* prefix, int64_t* tile_sums, int64_t* first_pos) {
   if (n == 0) return hipMemsetAsync(prefix, 0, sizeof(int64_t), st);
-  hipLaunchKernelGGL(ig_insert_kernel, dim3(ig_grid(n, n_cu)), dim3(256), 0, st, t, n, keys, select);
+  hipLaunchKernelGGL(ig_insert_kernel, dim3(ig_grid(n, n_cu)), dim3(256), 0, st, t, n, keys, select, (unsigned)(min_count < 1 ? 1 : min_count));
   hipLaunchKernelGGL(ig_first_flags_kernel, dim3(ig_grid(n, n_cu)), dim3(256), 0, st, t, n, keys, select, (unsigned)(min_count < 1 ? 1 : min_count), flag);
   hipError_t e = launch_scan_i32(st, flag, n, prefix, tile_sums);
   if (e != hipSuccess) return e;
