@@ -336,6 +336,17 @@ def main():
     if args.timed_only:
         print(json.dumps({"ms_per_step": round(elapsed / args.steps * 1e3, 4)}))
         return
+    # one build at a time (what a single `pio train` sees): every build followed by a wait
+    single_build_ms = None
+    if world == 1 and not args.single_stream and not args.force_exchange:
+        lat = []
+        for _ in range(max(5, args.steps // 2)):
+            barrier()
+            t1 = time.perf_counter()
+            step()
+            ctx.synchronize()
+            lat.append((time.perf_counter() - t1) * 1e3)
+        single_build_ms = statistics.median(lat)
     # the same steps with URCCO_FLAG_UNORDERED_ROWS (rows = top-k sets without the in-kernel ranking pass: what a JNI host,
     # which re-inserts by column index anyway, would ask for) -- reported beside `value`, never as `value`
     unordered = None
@@ -486,6 +497,8 @@ def main():
         "roofline": roofline, "roofline_lds": roofline_lds, "kernels": kernels, "kernel_timing": kernel_timing_mode, "cpu_baseline": cpu_baseline,
         "cpu_baseline_scipy": cpu_scipy, "gpu_over_cpu": round(value / cpu_baseline["value"], 1) if cpu_baseline else None,
         "input_generation_s": round(gen_s, 1),
+        "single_build_latency_ms": None if single_build_ms is None else round(single_build_ms, 4),
+        "single_build_latency_note": "median wall time of one build followed by a wait (the timed region enqueues its builds back to back: consecutive builds overlap)",
         "unordered_rows": None if unordered is None else {"flag": "URCCO_FLAG_UNORDERED_ROWS", "ms_per_step": round(unordered * 1e3, 4),
                                                            "pairs_per_s": round(pairs / unordered, 1),
                                                            "note": "same build, indicator rows as unordered top-k sets (no ranking pass); not the headline value"},
