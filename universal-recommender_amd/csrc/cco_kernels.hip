@@ -996,7 +996,10 @@ __global__ __launch_bounds__(256) void tr_prefix_kernel(const unsigned* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void tr_place_kernel(const unsigned short* __restrict__ bk_col, const int32_t* __restrict__ bk_row,
+// 1024 threads per chunk of 32768 entries: a matrix of a few million entries yields only ~150 chunks, and with 256 threads each
+// block walked its chunk in 128 dependent rounds of (LDS atomic -> scattered store) on less than one wave per SIMD.
+constexpr int TRP_THREADS = 1024;
+__global__ __launch_bounds__(TRP_THREADS) void tr_place_kernel(const unsigned short* __restrict__ bk_col, const int32_t* __restrict__ bk_row,
                                                        const int64_t* __restrict__ offsets, int n_buckets, int64_t n_parts,
                                                        const int32_t* __restrict__ blk_prefix, const unsigned* __restrict__ prefix,
                                                        const int64_t* __restrict__ col_ptr, int32_t n_cols, int32_t* __restrict__ out_rows) {
@@ -1011,13 +1014,13 @@ __global__ __launch_bounds__(256) void tr_place_kernel(const unsigned short* __r
   const int b = lo;
   const int64_t col0 = (int64_t)b << PH_BITS;
   const int64_t base = col_ptr[col0];  // where the bucket's CSC segment starts (a bucket holds < 2^32 entries)
-  for (int c = threadIdx.x; c < PH_BUCKET; c += 256)
+  for (int c = threadIdx.x; c < PH_BUCKET; c += TRP_THREADS)
     s_cur[c] = (col0 + c < n_cols ? (unsigned)(col_ptr[col0 + c] - base) : 0u) + prefix[(int64_t)blk * PH_BUCKET + c];
   __syncthreads();
   const int64_t bs = offsets[(int64_t)b * n_parts], be = offsets[(int64_t)(b + 1) * n_parts];
   const int64_t e0 = bs + (int64_t)(blk - blk_prefix[b]) * PH_CHUNK;
   const int64_t e1 = e0 + PH_CHUNK < be ? e0 + PH_CHUNK : be;
-  for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+  for (int64_t e = e0 + threadIdx.x; e < e1; e += TRP_THREADS) {
     const unsigned p = atomicAdd(&s_cur[bk_col[e]], 1u);
     out_rows[base + p] = bk_row[e];
   }
@@ -1058,7 +1061,7 @@ hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const in
   hipLaunchKernelGGL(ph_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, offsets, n_buckets, n_parts, blk_prefix);
   hipLaunchKernelGGL(ph_hist_kernel, dim3((unsigned)max_blocks), dim3(256), 0, st, bk_col, offsets, n_buckets, n_parts, blk_prefix, partial);
   hipLaunchKernelGGL(tr_prefix_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, partial, blk_prefix, n_cols, prefix);
-  hipLaunchKernelGGL(tr_place_kernel, dim3((unsigned)max_blocks), dim3(256), 0, st, bk_col, bk_row, offsets, n_buckets, n_parts, blk_prefix, prefix,
+  hipLaunchKernelGGL(tr_place_kernel, dim3((unsigned)max_blocks), dim3(TRP_THREADS), 0, st, bk_col, bk_row, offsets, n_buckets, n_parts, blk_prefix, prefix,
                      col_ptr, n_cols, out_row_idx);
   return hipGetLastError();
 }
@@ -1216,6 +1219,12 @@ hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t it
 // ============================================================================================
 constexpr int E0 = 1024, E1S = 4096, E1 = 8192, E2S = 16384, E2 = 32768;  // LDS table words: wave / small block / block / half CU / CU
 
+#ifndef URCCO_WB1
+#define URCCO_WB1 512
+#endif
+#ifndef URCCO_WB2
+#define URCCO_WB2 8192
+#endif
 __device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_cols_b, int32_t count_bits, int32_t k) {
   if (ca <= 0 || w <= 0) return -1;  // no users or no pairs: empty indicator row
   if (count_bits < 31 && ca > ((1ll << count_bits) - 1)) return NBINS - 1;
@@ -1229,7 +1238,7 @@ __device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_c
   else if (dmax <= E1) cap_bin = 3;
   else if (dmax <= E2S) cap_bin = 4;
   else if (dmax <= E2) cap_bin = 5;
-  const int work_bin = w <= 512 ? 1 : (w <= 8192 ? 2 : 4);
+  const int work_bin = w <= URCCO_WB1 ? 1 : (w <= URCCO_WB2 ? 2 : 4);  // long rows want more lanes even when a small table would hold them
   return cap_bin > work_bin ? cap_bin : work_bin;
 }
 
