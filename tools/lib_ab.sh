@@ -14,7 +14,7 @@ for line in open(sys.argv[1]):
         j = json.loads(line)
         k = j["kernels"]
         rows = sum(v["ms_per_step"] for n, v in k.items() if n.startswith("cco_rows"))
-        print(f'step {j["ms_per_step"]:.3f} unordered {j["unordered_rows"]["ms_per_step"]:.3f} rows {rows:.3f} | ' + " ".join(f'{n.replace("cco_rows_", "")}={v["ms_per_step"]:.3f}' for n, v in k.items() if n.startswith("cco_rows")))
+        print(f'step {j["ms_per_step"]:.3f} unordered {j["unordered_rows"]["ms_per_step"]:.3f} rows {rows:.3f} tr {k["transpose"]["ms_per_step"]:.3f} cc {k["column_counts"]["ms_per_step"]:.3f} rw {k["row_work"]["ms_per_step"]:.3f} | ' + " ".join(f'{n.replace("cco_rows_", "")}={v["ms_per_step"]:.3f}' for n, v in k.items() if n.startswith("cco_rows")))
 PY
 )"
   done

@@ -130,7 +130,8 @@ hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n,
 
 // pstart[cap], plen[cap] (scratch), wp[cap + 1]; cap >= nnz(A'); tile_sums scratch as for scans over cap elements
 hipError_t launch_expand_prepare(hipStream_t st, int n_cu, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx,
-                                 const int64_t* b_row_ptr, int64_t cap, int64_t* pstart, int32_t* plen, int64_t* wp, int64_t* tile_sums);
+                                 const int64_t* b_row_ptr, unsigned* b_rp32_scratch /* nullable: n_rows_b + 1 words */, int64_t n_rows_b, int64_t cap,
+                                 int64_t* pstart, int32_t* plen, int64_t* wp, int64_t* tile_sums);
 hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr, const int64_t* wp, int64_t* work);
 
 // binning: tile_counts scratch [(ceil(n/BIN_TILE)+1) * BIN_COLS_HOST] int64;

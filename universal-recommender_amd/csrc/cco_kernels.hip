@@ -457,7 +457,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void ph_blockmap_kernel(const int64_t
   if (threadIdx.x == 0) blk_prefix[n_buckets] = (int32_t)carry;
 }
 
-__global__ __launch_bounds__(256) void ph_hist_kernel(const unsigned short* __restrict__ bucketed, const int64_t* __restrict__ offsets,
+constexpr int PHH_THREADS = 1024;  // a few-million-entry matrix has only ~150 chunks: four times the waves per chunk
+__global__ __launch_bounds__(PHH_THREADS) void ph_hist_kernel(const unsigned short* __restrict__ bucketed, const int64_t* __restrict__ offsets,
                                                       int n_buckets, int64_t n_parts, const int32_t* __restrict__ blk_prefix,
                                                       unsigned* __restrict__ partial) {
   __shared__ unsigned s_cnt[PH_BUCKET];
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(256) void ph_hist_kernel(const unsigned short* __re
     if (blk_prefix[mid] <= blk) lo = mid; else hi = mid;
   }
   const int b = lo;
-  for (int c = threadIdx.x; c < PH_BUCKET; c += 256) s_cnt[c] = 0u;
+  for (int c = threadIdx.x; c < PH_BUCKET; c += PHH_THREADS) s_cnt[c] = 0u;
   __syncthreads();
   const int64_t bs = offsets[(int64_t)b * n_parts], be = offsets[(int64_t)(b + 1) * n_parts];
   const int64_t e0 = bs + (int64_t)(blk - blk_prefix[b]) * PH_CHUNK;
@@ -477,8 +478,8 @@ __global__ __launch_bounds__(256) void ph_hist_kernel(const unsigned short* __re
   // 16-byte loads of eight 16-bit ids where aligned
   int64_t e = e0 + threadIdx.x;
   const int64_t a0 = (e0 + 7) & ~(int64_t)7;
-  for (; e < e1 && e < a0; e += 256) atomicAdd(&s_cnt[bucketed[e]], 1u);  // unaligned head (< 8 entries: first iteration only)
-  for (int64_t v = a0 + (int64_t)threadIdx.x * 8; v + 7 < e1; v += 256 * 8) {
+  for (; e < e1 && e < a0; e += PHH_THREADS) atomicAdd(&s_cnt[bucketed[e]], 1u);  // unaligned head (< 8 entries: first iteration only)
+  for (int64_t v = a0 + (int64_t)threadIdx.x * 8; v + 7 < e1; v += PHH_THREADS * 8) {
     const uint4 x = *reinterpret_cast<const uint4*>(bucketed + v);
     atomicAdd(&s_cnt[x.x & 0xffffu], 1u); atomicAdd(&s_cnt[x.x >> 16], 1u);
     atomicAdd(&s_cnt[x.y & 0xffffu], 1u); atomicAdd(&s_cnt[x.y >> 16], 1u);
@@ -487,11 +488,11 @@ __global__ __launch_bounds__(256) void ph_hist_kernel(const unsigned short* __re
   }
   {
     const int64_t n_vec = e1 > a0 ? (e1 - a0) / 8 : 0;
-    for (int64_t t = a0 + n_vec * 8 + threadIdx.x; t < e1; t += 256) atomicAdd(&s_cnt[bucketed[t]], 1u);  // tail
+    for (int64_t t = a0 + n_vec * 8 + threadIdx.x; t < e1; t += PHH_THREADS) atomicAdd(&s_cnt[bucketed[t]], 1u);  // tail
   }
   __syncthreads();
   unsigned* out = partial + (int64_t)blk * PH_BUCKET;
-  for (int c = threadIdx.x; c < PH_BUCKET; c += 256) out[c] = s_cnt[c];
+  for (int c = threadIdx.x; c < PH_BUCKET; c += PHH_THREADS) out[c] = s_cnt[c];
 }
 
 __global__ __launch_bounds__(256) void ph_reduce_kernel(const unsigned* __restrict__ partial, const int32_t* __restrict__ blk_prefix, int32_t n_cols,
@@ -534,7 +535,7 @@ hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_i
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(ph_scatter_kernel, dim3((unsigned)n_parts), dim3(PHS_THREADS), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, offsets, bucketed, vec_ok);
   hipLaunchKernelGGL(ph_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, offsets, n_buckets, n_parts, blk_prefix);
-  hipLaunchKernelGGL(ph_hist_kernel, dim3((unsigned)max_blocks), dim3(256), 0, st, bucketed, offsets, n_buckets, n_parts, blk_prefix, partial);
+  hipLaunchKernelGGL(ph_hist_kernel, dim3((unsigned)max_blocks), dim3(PHH_THREADS), 0, st, bucketed, offsets, n_buckets, n_parts, blk_prefix, partial);
   hipLaunchKernelGGL(ph_reduce_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, partial, blk_prefix, n_cols, counts);
   return hipGetLastError();
 }
@@ -1059,7 +1060,7 @@ hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const in
   hipLaunchKernelGGL(tr_scatter_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, n_rows, row_ptr, col_idx, g_log2, n_buckets, n_parts, col_lo, col_hi,
                      offsets, bk_col, bk_row);
   hipLaunchKernelGGL(ph_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, offsets, n_buckets, n_parts, blk_prefix);
-  hipLaunchKernelGGL(ph_hist_kernel, dim3((unsigned)max_blocks), dim3(256), 0, st, bk_col, offsets, n_buckets, n_parts, blk_prefix, partial);
+  hipLaunchKernelGGL(ph_hist_kernel, dim3((unsigned)max_blocks), dim3(PHH_THREADS), 0, st, bk_col, offsets, n_buckets, n_parts, blk_prefix, partial);
   hipLaunchKernelGGL(tr_prefix_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, partial, blk_prefix, n_cols, prefix);
   hipLaunchKernelGGL(tr_place_kernel, dim3((unsigned)max_blocks), dim3(TRP_THREADS), 0, st, bk_col, bk_row, offsets, n_buckets, n_parts, blk_prefix, prefix,
                      col_ptr, n_cols, out_row_idx);
@@ -1145,12 +1146,20 @@ hipError_t launch_xlx_hi_table(hipStream_t st, double* tab, long long n_users) {
 // w_i = wp[cp[i+1]] - wp[cp[i]] (exactly the cooccurrence pairs row i forms) drives binning and work-balanced item
 // ranges, and lanes find "their" pairs by searching that slice.
 // ============================================================================================
+// 32-bit copy of B's row_ptr.  expand_prepare is bound by the fabric traffic of one random row_ptr gather per CSC entry of A'
+// (PMC: 415 MB per launch for 4.6M entries); a table of 4 B per user is half as large and stays closer to the L2s.
+__global__ __launch_bounds__(256) void narrow_row_ptr_kernel(const int64_t* __restrict__ rp, int64_t n, unsigned* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) out[i] = (unsigned)rp[i];
+}
+
+// b_rp32: optional 32-bit copy of b_rp (n_rows_b + 1 entries); used when B holds fewer than 2^32 entries (read on the device)
 __global__ __launch_bounds__(256) void expand_prepare_kernel(const int64_t* __restrict__ a_cp, int32_t n_items_a, const int32_t* __restrict__ a_ri,
-                                                             const int64_t* __restrict__ b_rp, int64_t cap, int64_t* __restrict__ pstart,
-                                                             int32_t* __restrict__ plen) {
+                                                             const int64_t* __restrict__ b_rp, const unsigned* __restrict__ b_rp32, int64_t n_rows_b,
+                                                             int64_t cap, int64_t* __restrict__ pstart, int32_t* __restrict__ plen) {
   const int64_t nnz = a_cp[n_items_a];
   int64_t lim = (nnz / SCAN_TILE + 1) * SCAN_TILE;  // the scan skips tiles that start at or beyond nnz
   if (lim > cap) lim = cap;
+  const bool narrow = b_rp32 != nullptr && b_rp[n_rows_b] < ((int64_t)1 << 32);
   // Four grid-stride steps at a time: the four user ids are loaded first, then all eight row_ptr gathers are in flight
   // together (the kernel is a chain of two dependent random loads); every access stays coalesced across the wave.
   const int64_t stride = (int64_t)gridDim.x * 256;
@@ -1162,10 +1171,18 @@ __global__ __launch_bounds__(256) void expand_prepare_kernel(const int64_t* __re
       u[q] = p < nnz ? a_ri[p] : -1;
     }
     int64_t s[4], e[4];
+    if (narrow) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      s[q] = u[q] >= 0 ? b_rp[u[q]] : 0;
-      e[q] = u[q] >= 0 ? b_rp[u[q] + 1] : 0;
+      for (int q = 0; q < 4; ++q) {
+        s[q] = u[q] >= 0 ? (int64_t)b_rp32[u[q]] : 0;
+        e[q] = u[q] >= 0 ? (int64_t)b_rp32[u[q] + 1] : 0;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s[q] = u[q] >= 0 ? b_rp[u[q]] : 0;
+        e[q] = u[q] >= 0 ? b_rp[u[q] + 1] : 0;
+      }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1179,12 +1196,19 @@ __global__ __launch_bounds__(256) void expand_prepare_kernel(const int64_t* __re
 }
 
 hipError_t launch_expand_prepare(hipStream_t st, int n_cu, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx,
-                                 const int64_t* b_row_ptr, int64_t cap, int64_t* pstart, int32_t* plen, int64_t* wp, int64_t* tile_sums) {
+                                 const int64_t* b_row_ptr, unsigned* b_rp32_scratch, int64_t n_rows_b, int64_t cap, int64_t* pstart, int32_t* plen,
+                                 int64_t* wp, int64_t* tile_sums) {
   if (cap > 0) {
+    if (b_rp32_scratch) {
+      int64_t nb = (n_rows_b + 1 + 255) / 256;
+      if (nb > (int64_t)n_cu * 8) nb = (int64_t)n_cu * 8;
+      hipLaunchKernelGGL(narrow_row_ptr_kernel, dim3((unsigned)nb), dim3(256), 0, st, b_row_ptr, n_rows_b + 1, b_rp32_scratch);
+    }
     int64_t blocks = (cap + 1023) / 1024;
     const int64_t lim = (int64_t)n_cu * 16;
     if (blocks > lim) blocks = lim;
-    hipLaunchKernelGGL(expand_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, cap, pstart, plen);
+    hipLaunchKernelGGL(expand_prepare_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, b_row_ptr,
+                       (const unsigned*)b_rp32_scratch, n_rows_b, cap, pstart, plen);
   }
   return launch_scan(st, LoadI32{plen}, cap, wp, tile_sums, a_col_ptr + n_items_a);
 }

@@ -221,7 +221,7 @@ int urcco_dev_row_work(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   int64_t* wp = s->take<int64_t>((size_t)cap + 1);
   int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
   s->begin(URCCO_STAGE_ROW_WORK);
-  HIPC(urcco::launch_expand_prepare(s->stream, s->n_cu, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, cap, pstart, plen, wp, tile_sums));
+  HIPC(urcco::launch_expand_prepare(s->stream, s->n_cu, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, nullptr, 0, cap, pstart, plen, wp, tile_sums));
   HIPC(urcco::launch_row_work(s->stream, s->n_cu, item_lo, item_hi, a_col_ptr, wp, work));
   s->end();
   return URCCO_OK;
@@ -282,7 +282,8 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
                  urcco_session::need((size_t)p_tiles + 2, 8) +
                  urcco_session::need((size_t)n, 8) + urcco_session::need((size_t)(n_tiles + 1) * urcco::BIN_COLS_HOST, 8) +
                  urcco_session::need(urcco::NBINS + 1, 4) + urcco_session::need((size_t)n, 4) + urcco_session::need((size_t)n_items_a, 8) +
-                 urcco_session::need((size_t)n_cols_b, 8) + urcco_session::need(1, 8) + urcco_session::need(URCCO_STATS_LEN, 8)));
+                 urcco_session::need((size_t)n_cols_b, 8) + urcco_session::need(1, 8) + urcco_session::need(URCCO_STATS_LEN, 8) +
+                 urcco_session::need((size_t)n_users + 1, 4)));
   int64_t* pstart = s->take<int64_t>((size_t)cap);
   int32_t* plen = s->take<int32_t>((size_t)cap);
   int64_t* wp = s->take<int64_t>((size_t)cap + 1);
@@ -295,9 +296,10 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   double* ent_b = same ? ent_a : s->take<double>((size_t)n_cols_b);
   double* xlx_n = s->take<double>(1);
   int64_t* stats = stats_dev ? stats_dev : s->take<int64_t>(URCCO_STATS_LEN);
+  unsigned* b_rp32 = s->take<unsigned>((size_t)n_users + 1);
 
   s->begin(URCCO_STAGE_ROW_WORK);
-  HIPC(urcco::launch_expand_prepare(s->stream, s->n_cu, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, cap, pstart, plen, wp, p_tile_sums));
+  HIPC(urcco::launch_expand_prepare(s->stream, s->n_cu, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, b_rp32, n_users, cap, pstart, plen, wp, p_tile_sums));
   HIPC(urcco::launch_row_work(s->stream, s->n_cu, item_lo, item_hi, a_col_ptr, wp, work));
   s->end();
   s->begin(URCCO_STAGE_BINNING);
