@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -427,11 +428,48 @@ int stage_rows(DevState& D, EvState& E, EvState& A, int d, const DsParams& pa, c
   return URCCO_OK;
 }
 
+// URCCO_TRACE_HOST=1: wall-clock marks of the host-level call on stderr (where the milliseconds of a PCIe-inclusive call go)
+struct HostTrace {
+  bool on = getenv("URCCO_TRACE_HOST") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char* what, int d = -1) const {
+    if (!on) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "[urcco host] %8.3f ms  %s%s\n", ms, what, d >= 0 ? (std::string(" ") + std::to_string(d)).c_str() : "");
+  }
+};
+
+// Host level, one GPU: the build is enqueued WHILE the caller's matrices are still being staged.  The staging thread signals
+// an event type once all of its copies and its boundary check are enqueued on that event type's stream; the thread that
+// enqueues the event type's chain then waits for the stream (the copies have landed), reads the check's verdict and only
+// then lets a kernel consume the matrix.  The primary's chain and A'A thus run under the upload of the larger secondaries.
+struct InputGate {
+  const HostTrace* trace = nullptr;
+  std::vector<std::promise<int>> staged;
+  std::vector<std::shared_future<int>> fut;
+  explicit InputGate(int n) : staged((size_t)n), fut((size_t)n) {
+    for (int d = 0; d < n; ++d) fut[(size_t)d] = staged[(size_t)d].get_future().share();
+  }
+  int wait(DevState& D, int d) {
+    const int st = fut[(size_t)d].get();
+    if (st != URCCO_OK) return fail(st, "dataset %d: staging failed", d);
+    EvState& E = D.ev[(size_t)d];
+    unsigned long long bad = 0;
+    HIPC(hipMemcpyAsync(&bad, E.verr.p, sizeof(bad), hipMemcpyDeviceToHost, E.s->stream));
+    HIPC(hipStreamSynchronize(E.s->stream));
+    if (bad)
+      return fail(URCCO_BAD_ARG, "dataset %d: %llu invalid entries (row_ptr not monotone, or col_idx out of [0, n_cols) / not strictly increasing inside a row)", d, bad);
+    if (trace) trace->mark("matrices landed and checked", d);
+    return URCCO_OK;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // one rank, nothing to exchange: every event type on its own stream; B_d is sampled while A is sampled and transposed,
 // every A'B_d runs behind an event on A's CSC; the heaviest event type is enqueued first
 // ---------------------------------------------------------------------------------------------------------
-int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, const std::vector<DsParams>& ps, int64_t n_users, int32_t seed) {
+int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, const std::vector<DsParams>& ps, int64_t n_users, int32_t seed,
+                 InputGate* gate) {
   const int n_ds = (int)sh.size();
   URC(set_dev(D));
   EvState& A = D.ev[0];
@@ -450,6 +488,7 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
   auto secondary = [&](int d, bool wait_host) -> int {
     URC(set_dev(D));
     EvState& E = D.ev[(size_t)d];
+    if (gate) URC(gate->wait(D, d));
     URC(stage_raw_counts(D, E, sh[(size_t)d], ps[(size_t)d]));
     URC(stage_downsample(c, D, d, sh[(size_t)d], ps[(size_t)d], seed));
     if (wait_host) a_recorded_f.wait();
@@ -458,7 +497,9 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
     E.b_ci = E.s_ci.p;
     E.b_rows = sh[(size_t)d].n_rows;
     E.b_nnz_bound = sh[(size_t)d].nnz;
-    return stage_rows(D, E, A, d, ps[0], ps[(size_t)d], n_users, sh[0].nnz);
+    URC(stage_rows(D, E, A, d, ps[0], ps[(size_t)d], n_users, sh[0].nnz));
+    if (gate && gate->trace) gate->trace->mark("chain enqueued", d);
+    return URCCO_OK;
   };
   std::vector<std::thread> workers;
   std::vector<int> status((size_t)n_ds, URCCO_OK);
@@ -470,6 +511,7 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
         if (status[(size_t)d] != URCCO_OK) message[(size_t)d] = err_buf();  // the message lives in the worker's thread-local buffer
       });
   int st = [&]() -> int {
+    if (gate) URC(gate->wait(D, 0));
     URC(stage_raw_counts(D, A, sh[0], ps[0]));
     URC(stage_downsample(c, D, 0, sh[0], ps[0], seed));
     URC(urcco_dev_transpose(A.s, sh[0].n_rows, A.s_rp.p, A.s_ci.p, sh[0].nnz, (int32_t)ps[0].n_cols, post_of(D, 0).p, 0, (int32_t)ps[0].n_cols,
@@ -484,6 +526,7 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
     A.b_rows = sh[0].n_rows;
     A.b_nnz_bound = sh[0].nnz;
     st = stage_rows(D, A, A, 0, ps[0], ps[0], n_users, sh[0].nnz);
+    if (gate && gate->trace) gate->trace->mark("chain enqueued", 0);
   }
   for (std::thread& t : workers) t.join();
   if (st != URCCO_OK) return st;
@@ -666,10 +709,10 @@ int check_params(const DsParams& p, int d) {
 }
 
 int run_build(urcco_context* c, const std::vector<std::vector<Shard>>& sh, const std::vector<DsParams>& ps, int64_t n_users, int32_t seed,
-              hipStream_t input_stream) {
+              hipStream_t input_stream, InputGate* gate = nullptr) {
   const int n_ds = (int)ps.size();
   for (DevState& D : c->devs) {
-    URC(ensure_events(c, D, n_ds));
+    if (!gate) URC(ensure_events(c, D, n_ds));  // with a gate the caller has done it (its staging thread is using the streams)
     // this build's set of the primary's shared buffers was last read by the A'B_d of the build before the previous one
     D.par = (D.par + 1) % A_SETS;
     for (size_t d = 1; d < D.ev.size(); ++d)
@@ -683,7 +726,7 @@ int run_build(urcco_context* c, const std::vector<std::vector<Shard>>& sh, const
     std::vector<Shard> one((size_t)n_ds);
     for (int d = 0; d < n_ds; ++d) one[(size_t)d] = sh[(size_t)d][0];
     return one;
-  }(), ps, n_users, seed);
+  }(), ps, n_users, seed, gate);
   return build_sharded(c, sh, ps, n_users, seed);
 }
 
@@ -691,6 +734,7 @@ int run_build(urcco_context* c, const std::vector<std::vector<Shard>>& sh, const
 // host level: staging
 // ---------------------------------------------------------------------------------------------------------
 constexpr size_t STAGE_CHUNK = (size_t)8 << 20;
+
 
 // pageable host memory -> device through the context's pinned ring, `threads` copy threads; every chunk's H2D is enqueued
 // on `st` as soon as the chunk sits in pinned memory, so the link is busy while later chunks are still being copied.
@@ -823,6 +867,7 @@ int urcco_context_create(const urcco_options* options, const urcco_comm_config* 
     c->workers->start((size_t)n_local);
     const unsigned hc = std::thread::hardware_concurrency();
     c->copy_threads = hc >= 32 ? 8 : (hc >= 8 ? 4 : 2);
+    if (const char* e = getenv("URCCO_COPY_THREADS")) c->copy_threads = std::max(1, std::min(64, atoi(e)));
     if (!c->have_cb && (c->world > 1 || (c->flags & URCCO_FLAG_FORCE_EXCHANGE))) {
       c->rccl = Rccl::get();
       if (!c->rccl) return fail(URCCO_RCCL_ERROR, "a multi-rank build needs librccl, which could not be loaded");
@@ -991,13 +1036,15 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
     for (DevState& D : c->devs) URC(ensure_events(c, D, n_ds));
     // ---- stage + validate every shard on its event stream (copy threads feed the pinned ring; the link is busy while
     // the next chunks are copied), heaviest transfers last so that the primary starts first
+    HostTrace trace;
     Stager stager{c};
     URC(stager.ensure(24));
     std::vector<std::vector<Shard>> sh((size_t)n_ds, std::vector<Shard>(L));
     const int threads_each = L > 1 ? std::max(1, c->copy_threads / 2) : c->copy_threads;  // every GPU has its own link: all stage at once
+    // buffers and shard descriptors first (everything but the bytes is known from the caller's row_ptr)
     for (int d = 0; d < n_ds; ++d) {
       const urcco_csr& m = datasets[d].matrix;
-      URC(c->workers->run([&](size_t g) -> int {
+      for (size_t g = 0; g < L; ++g) {
         DevState& D = c->devs[g];
         URC(set_dev(D));
         EvState& E = D.ev[(size_t)d];
@@ -1007,32 +1054,80 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
         URC(E.in_rp.ensure((size_t)rows + 1));
         URC(E.in_ci.ensure((size_t)nnz + 4));
         URC(E.verr.ensure(1));
-        URC(stager.copy(D.device, E.s->stream, E.in_rp.p, m.row_ptr + u0, sizeof(int64_t) * ((size_t)rows + 1), threads_each));
-        URC(stager.copy(D.device, E.s->stream, E.in_ci.p, m.col_idx + e0, sizeof(int32_t) * (size_t)nnz, threads_each));
-        HIPC(hipMemsetAsync(E.verr.p, 0, sizeof(unsigned long long), E.s->stream));
-        int gl = rows > 0 ? ceil_log2_i64((nnz + rows - 1) / rows) : 1;
-        gl = gl < 1 ? 1 : (gl > 6 ? 6 : gl);
-        HIPC(urcco::launch_validate_csr(E.s->stream, D.n_cu, rows, E.in_rp.p, E.in_ci.p, nnz, (int32_t)m.n_cols, gl, e0, E.verr.p));
-        HIPC(urcco::launch_rebase_i64(E.s->stream, D.n_cu, E.in_rp.p, rows + 1, e0));
         sh[(size_t)d][g] = Shard{rows, u0, nnz, E.in_rp.p, E.in_ci.p};
-        return URCCO_OK;
-      }));
+      }
     }
-    // the boundary check must have passed before any kernel consumes the matrices
-    for (int d = 0; d < n_ds; ++d)
-      for (size_t g = 0; g < L; ++g) {
+    auto stage_event = [&](int d) -> int {  // copies + boundary check of event type d, enqueued on its stream on every GPU
+      const urcco_csr& m = datasets[d].matrix;
+      return c->workers->run([&](size_t g) -> int {
         DevState& D = c->devs[g];
         URC(set_dev(D));
         EvState& E = D.ev[(size_t)d];
-        unsigned long long bad = 0;
-        HIPC(hipMemcpyAsync(&bad, E.verr.p, sizeof(bad), hipMemcpyDeviceToHost, E.s->stream));
-        HIPC(hipStreamSynchronize(E.s->stream));
-        if (bad) return fail(URCCO_BAD_ARG, "dataset %d: %llu invalid entries (row_ptr not monotone, or col_idx out of [0, n_cols) / not strictly increasing inside a row)", d, bad);
+        const Shard& x = sh[(size_t)d][g];
+        const int64_t e0 = m.row_ptr[x.row_base];
+        URC(stager.copy(D.device, E.s->stream, E.in_rp.p, m.row_ptr + x.row_base, sizeof(int64_t) * ((size_t)x.n_rows + 1), threads_each));
+        URC(stager.copy(D.device, E.s->stream, E.in_ci.p, m.col_idx + e0, sizeof(int32_t) * (size_t)x.nnz, threads_each));
+        HIPC(hipMemsetAsync(E.verr.p, 0, sizeof(unsigned long long), E.s->stream));
+        int gl = x.n_rows > 0 ? ceil_log2_i64((x.nnz + x.n_rows - 1) / x.n_rows) : 1;
+        gl = gl < 1 ? 1 : (gl > 6 ? 6 : gl);
+        HIPC(urcco::launch_validate_csr(E.s->stream, D.n_cu, x.n_rows, E.in_rp.p, E.in_ci.p, x.nnz, (int32_t)m.n_cols, gl, e0, E.verr.p));
+        HIPC(urcco::launch_rebase_i64(E.s->stream, D.n_cu, E.in_rp.p, x.n_rows + 1, e0));
+        return URCCO_OK;
+      });
+    };
+    if (L == 1 && !c->exchange()) {
+      // one GPU: the build is enqueued by its own thread(s) while this thread stages; every event type starts the moment its
+      // own matrices have landed and passed the boundary check (InputGate)
+      InputGate gate(n_ds);
+      gate.trace = &trace;
+      int build_st = URCCO_OK;
+      std::string build_msg;
+      std::thread builder([&] {
+        build_st = guarded([&] { return run_build(c, sh, ps, n_users, seed, nullptr, &gate); });
+        if (build_st != URCCO_OK) build_msg = err_buf();
+      });
+      int stage_st = URCCO_OK;
+      std::string stage_msg;
+      for (int d = 0; d < n_ds; ++d) {
+        if (stage_st == URCCO_OK) {
+          stage_st = guarded([&] { return stage_event(d); });
+          if (stage_st != URCCO_OK) stage_msg = err_buf();
+        }
+        gate.staged[(size_t)d].set_value(stage_st);  // also on failure: the builder must not wait forever
+        trace.mark("staged (copies enqueued)", d);
       }
-    URC(run_build(c, sh, ps, n_users, seed, nullptr));
+      builder.join();
+      trace.mark("build enqueued");
+      if (stage_st != URCCO_OK) return fail(stage_st, "%s", stage_msg.c_str());
+      if (build_st != URCCO_OK) return fail(build_st, "%s", build_msg.c_str());
+    } else {
+      // several GPUs / the exchange path: stage + validate everything, heaviest transfers last so that the primary starts first
+      for (int d = 0; d < n_ds; ++d) URC(stage_event(d));
+      // the boundary check must have passed before any kernel consumes the matrices
+      for (int d = 0; d < n_ds; ++d)
+        for (size_t g = 0; g < L; ++g) {
+          DevState& D = c->devs[g];
+          URC(set_dev(D));
+          EvState& E = D.ev[(size_t)d];
+          unsigned long long bad = 0;
+          HIPC(hipMemcpyAsync(&bad, E.verr.p, sizeof(bad), hipMemcpyDeviceToHost, E.s->stream));
+          HIPC(hipStreamSynchronize(E.s->stream));
+          if (bad) return fail(URCCO_BAD_ARG, "dataset %d: %llu invalid entries (row_ptr not monotone, or col_idx out of [0, n_cols) / not strictly increasing inside a row)", d, bad);
+        }
+      URC(run_build(c, sh, ps, n_users, seed, nullptr));
+    }
     // ---- results: row_ptr of every GPU's slice first (small), then exactly nnz entries each
     const int32_t n_items_a = (int32_t)ps[0].n_cols;
-    std::vector<std::vector<int64_t>> h_stats((size_t)n_ds * L, std::vector<int64_t>(URCCO_STATS_LEN, 0));
+    // per-build statistics land in PINNED memory: an "async" copy into pageable memory blocks the calling thread until the stream
+    // has drained, which serialised the result phase behind the slowest event type
+    struct PinnedBlock {
+      void* p = nullptr;
+      ~PinnedBlock() { if (p) (void)pinned_pool().put(p); }
+    } stats_block;
+    stats_block.p = pinned_pool().get(sizeof(int64_t) * URCCO_STATS_LEN * (size_t)n_ds * L);
+    if (!stats_block.p) return fail(URCCO_OOM_HOST, "pinned statistics block");
+    int64_t* h_stats = static_cast<int64_t*>(stats_block.p);
+    memset(h_stats, 0, sizeof(int64_t) * URCCO_STATS_LEN * (size_t)n_ds * L);
     for (int d = 0; d < n_ds; ++d) {
       urcco_indicators& o = out[d];
       o.n_rows = n_items_a;
@@ -1047,7 +1142,7 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
         const int32_t n = D.item_hi - D.item_lo;
         // slice row_ptr[1..n] lands at out.row_ptr[item_lo + 1 ..]; re-based below once the slices' sizes are known
         if (n > 0) HIPC(hipMemcpyAsync(o.row_ptr + D.item_lo + 1, E.c_rp.p + 1, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, E.s->stream));
-        HIPC(hipMemcpyAsync(h_stats[(size_t)d * L + g].data(), E.stats.p, sizeof(int64_t) * URCCO_STATS_LEN, hipMemcpyDeviceToHost, E.s->stream));
+        HIPC(hipMemcpyAsync(h_stats + ((size_t)d * L + g) * URCCO_STATS_LEN, E.stats.p, sizeof(int64_t) * URCCO_STATS_LEN, hipMemcpyDeviceToHost, E.s->stream));
         HIPC(hipEventRecord(E.ev_rp, E.s->stream));
       }
     }
@@ -1058,6 +1153,7 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
         DevState& D = c->devs[g];
         URC(set_dev(D));
         HIPC(hipEventSynchronize(D.ev[(size_t)d].ev_rp));
+        trace.mark("indicator row_ptr on the host", d);
         const int32_t n = D.item_hi - D.item_lo;
         base[g + 1] = base[g] + (n > 0 ? o.row_ptr[D.item_hi] : 0);
       }
@@ -1079,13 +1175,14 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
       }
     }
     URC(urcco_context_synchronize(c));
+    trace.mark("all indicator entries on the host");
     if (stats)
       for (int d = 0; d < n_ds; ++d) {
         urcco_dataset_stats& st = stats[d];
         st.nnz_raw = datasets[d].matrix.row_ptr[n_users];
         st.nnz_out = out[d].nnz;
         for (size_t g = 0; g < L; ++g) {
-          const std::vector<int64_t>& h = h_stats[(size_t)d * L + g];
+          const int64_t* h = h_stats + ((size_t)d * L + g) * URCCO_STATS_LEN;
           st.pairs += h[0];
           for (int b = 0; b < URCCO_N_BINS; ++b) st.rows_by_bin[b] += h[1 + (size_t)b];
         }
