@@ -995,6 +995,7 @@ int urcco_context_build_device(urcco_context* c, const urcco_dev_dataset* datase
 
 int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datasets, int32_t n_ds, int32_t seed, urcco_indicators* out,
                                    urcco_dataset_stats* stats) {
+  HostTrace trace;
   const int status = guarded([&]() -> int {
     err_buf()[0] = 0;
     if (!c || !datasets || n_ds <= 0 || !out) return fail(URCCO_BAD_ARG, "datasets / out is NULL or n_datasets <= 0");
@@ -1036,7 +1037,7 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
     for (DevState& D : c->devs) URC(ensure_events(c, D, n_ds));
     // ---- stage + validate every shard on its event stream (copy threads feed the pinned ring; the link is busy while
     // the next chunks are copied), heaviest transfers last so that the primary starts first
-    HostTrace trace;
+    trace.mark("arguments checked, streams ready");
     Stager stager{c};
     URC(stager.ensure(24));
     std::vector<std::vector<Shard>> sh((size_t)n_ds, std::vector<Shard>(L));
@@ -1196,6 +1197,7 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
     return URCCO_OK;
   });
   if (status != URCCO_OK && out && n_ds > 0) urcco_free_indicators(out, n_ds);
+  trace.mark("return");
   return status;
 }
 
