@@ -1543,6 +1543,9 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 #ifndef URCCO_U_C
 #define URCCO_U_C 1
 #endif
+#ifndef URCCO_OCC_WAVE
+#define URCCO_OCC_WAVE 8  // blocks of four one-wave teams per CU the one-wave class is compiled for
+#endif
 #ifndef URCCO_G_WAVE
 #define URCCO_G_WAVE 1
 #endif
@@ -1553,7 +1556,7 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 #define URCCO_G_CU 1
 #endif
 template <int T, int E, int U>
-__global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? 8 : (T == 256 && E == 4096 ? 7 : 1))) void cco_rows_kernel(CcoArgs a, int bin) {
+__global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T == 256 && E == 4096 ? 7 : 1))) void cco_rows_kernel(CcoArgs a, int bin) {
   constexpr int BLOCK = T < 256 ? 256 : T;
   constexpr int TEAMS = BLOCK / T;
   constexpr int SPT = E / T;
