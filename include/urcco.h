@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define URCCO_VERSION 200 /* 0.2.0 */
+#define URCCO_VERSION 300 /* 0.3.0 */
 
 typedef enum urcco_status {
   URCCO_OK = 0,
@@ -126,6 +126,17 @@ int urcco_cross_occurrence_downsampled(const urcco_dataset* datasets, int32_t n_
 
 void urcco_free_indicators(urcco_indicators* indicators, int32_t n);
 
+/* The same call in two halves, for a caller whose input arrays are only pinned for a short while -- the JNI shim holds them
+ * between Get/ReleasePrimitiveArrayCritical, which locks the JVM's garbage collector out (jni/urcco_jni.cpp):
+ *   _stage   returns as soon as the library has finished READING datasets[*].matrix (every byte sits in its pinned staging ring
+ *            or in HBM; the model build is already running behind the copies).  The caller may release its arrays.
+ *   _finish  waits for the build and hands out the indicator matrices (n_datasets = the staged count).
+ * Exactly one _finish per successful _stage, from the same thread or another; urcco_shutdown abandons a staged build.
+ * urcco_cross_occurrence_downsampled == _stage followed by _finish.  out[] is zeroed on entry of every function that takes
+ * it, before any fallible step: on failure the caller owns nothing and must free nothing. */
+int urcco_cross_occurrence_stage(const urcco_dataset* datasets, int32_t n_datasets, int32_t random_seed, const urcco_options* options);
+int urcco_cross_occurrence_finish(urcco_indicators* out, int32_t n_datasets, urcco_dataset_stats* stats);
+
 /* ---- CONTEXT level: the persistent form of the host level, and the multi-GPU build ------------------------------
  * A context owns, per GPU, one HIP stream + scratch arena per event type, every intermediate and output buffer (grown
  * on demand, reused by the next build), pinned staging memory and -- with more than one rank -- a communicator.  The
@@ -176,6 +187,9 @@ int32_t urcco_context_local_gpus(const urcco_context* ctx);
  * context's pool; release with urcco_free_indicators).  Single-process contexts only. */
 int urcco_context_cross_occurrence(urcco_context* ctx, const urcco_dataset* datasets, int32_t n_datasets, int32_t random_seed,
                                    urcco_indicators* out, urcco_dataset_stats* stats);
+/* ... and its two halves (see urcco_cross_occurrence_stage): out[n_datasets of the stage call] */
+int urcco_context_stage(urcco_context* ctx, const urcco_dataset* datasets, int32_t n_datasets, int32_t random_seed);
+int urcco_context_finish(urcco_context* ctx, urcco_indicators* out, urcco_dataset_stats* stats);
 
 /* The same build with the matrices already resident in HBM -- what bench.py times.  Per event type and per local GPU
  * one user-range shard (rows [row_base, row_base + n_rows) of the n_users_total x n_cols matrix). */

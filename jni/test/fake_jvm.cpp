@@ -5,6 +5,7 @@
 // JNI call may be made while a primitive array is held critically.
 #include <jni.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -69,7 +70,13 @@ struct FakeEnv : JNIEnv {
     if (auto* x = dynamic_cast<DoubleArr*>(a)) return x->v.data();
     return nullptr;
   }
-  void ReleasePrimitiveArrayCritical(jarray, void*, jint) override { --critical; }
+  // A released array may be moved by the garbage collector at once: the fake JVM overwrites it, so a library that still read
+  // the caller's matrices after the shim released them (the release now comes BEFORE the build is awaited) would compute garbage
+  void ReleasePrimitiveArrayCritical(jarray a, void*, jint) override {
+    --critical;
+    if (auto* x = dynamic_cast<IntArr*>(a)) std::fill(x->v.begin(), x->v.end(), (jint)0x5a5a5a5a);
+    if (auto* x = dynamic_cast<LongArr*>(a)) std::fill(x->v.begin(), x->v.end(), (jlong)0x5a5a5a5a5a5a5a5all);
+  }
 };
 
 }  // namespace

@@ -43,6 +43,7 @@ JNIEXPORT jobjectArray JNICALL Java_com_actionml_urcco_Native_crossOccurrenceDow
   std::vector<urcco_dataset> ds((size_t)n);
   std::vector<jlongArray> rp((size_t)n);
   std::vector<jintArray> ci((size_t)n);
+  std::vector<jsize> ci_len((size_t)n);
   jlong* ncols = env->GetLongArrayElements(nCols, nullptr);
   jint* max_row = env->GetIntArrayElements(maxElementsPerRow, nullptr);
   jint* max_int = env->GetIntArrayElements(maxInterestingElements, nullptr);
@@ -50,6 +51,7 @@ JNIEXPORT jobjectArray JNICALL Java_com_actionml_urcco_Native_crossOccurrenceDow
   for (jsize d = 0; d < n; ++d) {
     rp[(size_t)d] = (jlongArray)env->GetObjectArrayElement(rowPtrs, d);
     ci[(size_t)d] = (jintArray)env->GetObjectArrayElement(colIdxs, d);
+    ci_len[(size_t)d] = env->GetArrayLength(ci[(size_t)d]);
     urcco_dataset& x = ds[(size_t)d];
     x.matrix.n_rows = env->GetArrayLength(rp[(size_t)d]) - 1;
     x.matrix.n_cols = ncols[d];
@@ -63,8 +65,11 @@ JNIEXPORT jobjectArray JNICALL Java_com_actionml_urcco_Native_crossOccurrenceDow
   env->ReleaseIntArrayElements(maxElementsPerRow, max_row, JNI_ABORT);
   env->ReleaseIntArrayElements(maxInterestingElements, max_int, JNI_ABORT);
   env->ReleaseDoubleArrayElements(minLlr, mllr, JNI_ABORT);
-  // The matrices are pinned only for the duration of the call: the library copies them through its own staging ring
-  // before it returns.  No JNI call is made between the first Get...Critical and the last Release...Critical.
+  // The matrices are pinned only while the library READS them: urcco_cross_occurrence_stage returns once every byte sits in the
+  // library's pinned staging ring (the build is already running behind the copies), the critical sections are released, and
+  // only then does the shim wait for the model (urcco_cross_occurrence_finish) -- the JVM's garbage collector is locked out for
+  // the duration of a memcpy-speed pass over the inputs, not for the build and the download of the results.  No JNI call is
+  // made between the first Get...Critical and the last Release...Critical.
   for (jsize d = 0; d < n; ++d) {
     ds[(size_t)d].matrix.row_ptr = (const int64_t*)env->GetPrimitiveArrayCritical(rp[(size_t)d], nullptr);
     ds[(size_t)d].matrix.col_idx = (const int32_t*)env->GetPrimitiveArrayCritical(ci[(size_t)d], nullptr);
@@ -73,12 +78,23 @@ JNIEXPORT jobjectArray JNICALL Java_com_actionml_urcco_Native_crossOccurrenceDow
   opt.device = device;
   opt.row_rate_mode = URCCO_ROW_RATE_MAHOUT_INT_DIV;
   opt.n_gpus = nGpus;
+  // The Scala host re-inserts every row by column index (SequentialAccessSparseVector.setQuick) and the reference sorts by
+  // score later (toStringMapRDD, package.scala:102): the order inside a returned row is never observed, so the library may
+  // skip its ranking pass.
+  opt.flags = URCCO_FLAG_UNORDERED_ROWS;
   std::vector<urcco_indicators> out((size_t)n);
-  const int st = urcco_cross_occurrence_downsampled(ds.data(), n, seed, &opt, out.data(), nullptr);
+  bool null_array = false;
+  for (jsize d = 0; d < n; ++d) null_array = null_array || !ds[(size_t)d].matrix.row_ptr || (!ds[(size_t)d].matrix.col_idx && ci_len[(size_t)d] > 0);
+  int st = null_array ? URCCO_OOM_HOST : urcco_cross_occurrence_stage(ds.data(), n, seed, &opt);
   for (jsize d = n; d-- > 0;) {  // release in reverse order of acquisition
-    env->ReleasePrimitiveArrayCritical(ci[(size_t)d], (void*)ds[(size_t)d].matrix.col_idx, JNI_ABORT);
-    env->ReleasePrimitiveArrayCritical(rp[(size_t)d], (void*)ds[(size_t)d].matrix.row_ptr, JNI_ABORT);
+    if (ds[(size_t)d].matrix.col_idx) env->ReleasePrimitiveArrayCritical(ci[(size_t)d], (void*)ds[(size_t)d].matrix.col_idx, JNI_ABORT);
+    if (ds[(size_t)d].matrix.row_ptr) env->ReleasePrimitiveArrayCritical(rp[(size_t)d], (void*)ds[(size_t)d].matrix.row_ptr, JNI_ABORT);
   }
+  if (null_array) {
+    throw_runtime(env, "urcco: the JVM could not pin an input array");
+    return nullptr;
+  }
+  if (st == URCCO_OK) st = urcco_cross_occurrence_finish(out.data(), n, nullptr);
   if (st != URCCO_OK) {
     throw_runtime(env, urcco_last_error());
     return nullptr;

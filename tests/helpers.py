@@ -94,30 +94,57 @@ def compare_with_oracle(sess, mats, params, seed, mode=0, item_lo=0, item_hi=Non
     return out, ref, stats
 
 
-def compare_with_oracle_large(sess, mats, params, seed, mode=0, threads=None):
+def compare_with_oracle_large(sess, mats, params, seed, mode=0, threads=None, dev_mats=None, via_context=False, flags=0):
     """compare_with_oracle for workloads of 10^8..10^9 pairs: the C oracle runs on every host core, one event type at a
     time (its strided outputs are freed before the next), and the down-sampled matrices themselves -- row_ptr AND
-    col_idx -- are compared bit for bit before the indicator rows (every row) are.  Returns per event
+    col_idx -- are compared bit for bit before the indicator rows (every row) are.  `dev_mats`: the same matrices already
+    resident in HBM (inputs generated on the device).  `via_context`: run the build through urcco_context_build_device (the
+    entry point bench.py times) instead of the session-level stage calls.  Returns per event
     (stats vector, rows needing the k-boundary tie rule)."""
     threads = threads or min(os.cpu_count() or 1, O.lib().orc_max_threads())
-    out = run_device(sess, mats, params, seed, mode)
-    a = O.downsample(mats[0], O.column_counts(mats[0]), seed, params[0].max_elements_per_row, mode)
-    cnt_a = O.column_counts(a)
-    a_cp, a_ri = O.transpose(a)
-    res = []
-    for d, (m, p, o) in enumerate(zip(mats, params, out)):
-        b = a if d == 0 else O.downsample(m, O.column_counts(m), seed, p.max_elements_per_row, mode)
-        cnt_b = cnt_a if d == 0 else O.column_counts(b)
-        assert np.array_equal(o.sampled_row_ptr.cpu().numpy(), b.row_ptr), f"event {d}: down-sampled row_ptr differs"
-        assert np.array_equal(o.sampled_col_idx[:b.nnz].cpu().numpy(), b.col_idx), f"event {d}: down-sampled col_idx differs"
-        ref = O.cco_rows(a_cp, a_ri, b, cnt_a, cnt_b, mats[0].n_rows, d == 0, p.max_interesting_elements, p.min_llr, 0, None, threads)
-        st = o.stats.cpu().numpy()
-        assert int(st[0]) == ref.pairs, f"event {d}: pairs {int(st[0])} vs oracle {ref.pairs}"
-        assert int(st[1 + 4 * 7]) == 0, "LDS accumulator overflow reported"
-        _, ties = check_indicators(o.to_host(), ref)
-        res.append((st.copy(), ties))
-        del ref, b
+    ctx = None
+    if dev_mats is None:
+        dev_mats = [to_dev(m, sess.device) for m in mats]
+    if via_context:
+        ctx = D.Context(sess.device, sess.lib, 1, flags, mode)
+        out = D.cross_occurrence_context(ctx, dev_mats, to_params(params), seed)
+    else:
+        out = D.cross_occurrence_device(sess, dev_mats, to_params(params), seed, mode)
+        sess.synchronize()
+    try:
+        a = O.downsample(mats[0], O.column_counts(mats[0]), seed, params[0].max_elements_per_row, mode)
+        cnt_a = O.column_counts(a)
+        a_cp, a_ri = O.transpose(a)
+        res = []
+        for d, (m, p, o) in enumerate(zip(mats, params, out)):
+            b = a if d == 0 else O.downsample(m, O.column_counts(m), seed, p.max_elements_per_row, mode)
+            cnt_b = cnt_a if d == 0 else O.column_counts(b)
+            assert np.array_equal(o.sampled_row_ptr.cpu().numpy(), b.row_ptr), f"event {d}: down-sampled row_ptr differs"
+            assert np.array_equal(o.sampled_col_idx[:b.nnz].cpu().numpy(), b.col_idx), f"event {d}: down-sampled col_idx differs"
+            ref = O.cco_rows(a_cp, a_ri, b, cnt_a, cnt_b, mats[0].n_rows, d == 0, p.max_interesting_elements, p.min_llr, 0, None, threads)
+            st = o.stats.cpu().numpy()
+            assert int(st[0]) == ref.pairs, f"event {d}: pairs {int(st[0])} vs oracle {ref.pairs}"
+            assert int(st[1 + 4 * 7]) == 0, "LDS accumulator overflow reported"
+            _, ties = check_indicators(o.to_host(), ref)
+            res.append((st.copy(), ties))
+            del ref, b
+    finally:
+        if ctx is not None:
+            out = None
+            ctx.close()
     return out, res
+
+
+def device_generated(cfg, device):
+    """Inputs of a BASELINE configuration generated ON THE GPU (synth.generate_device) and mirrored to the host for the
+    oracle: (device matrices, host matrices)."""
+    from universal_recommender_amd import synth
+    dev_mats, mats = [], []
+    for (_, nc, rp, ci) in synth.generate_device(cfg, device):
+        nnz = int(rp[-1].item())
+        dev_mats.append(D.DevCsr(cfg.n_users, nc, rp, ci, nnz))
+        mats.append(O.Csr(cfg.n_users, nc, rp.cpu().numpy(), ci.cpu().numpy()))
+    return dev_mats, mats
 
 
 def sort_rows(got):

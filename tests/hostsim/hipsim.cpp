@@ -39,6 +39,8 @@ hipsim_switch:
 namespace hipsim {
 
 thread_local Idx tIdx, bIdx, bDim, gDim;
+thread_local int cur_device = 0;
+thread_local int last_error = 0;
 
 namespace {
 

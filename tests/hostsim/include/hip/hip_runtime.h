@@ -47,9 +47,14 @@ static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, 
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorNoDevice = 100, hipErrorUnknown = 999 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorNoDevice = 100, hipErrorInvalidDevice = 101, hipErrorInvalidHandle = 400,
+       hipErrorUnknown = 999 };
+// Devices are modelled as far as the host code can get them wrong: every thread has a current device, streams and events
+// belong to the device that was current when they were created, an event may only be recorded on a stream of its own device
+// and a kernel may only be launched on a stream of the current device (both are errors on real HIP).
+struct hipsimStream { int device; };
 typedef void* hipStream_t;
-struct hipsimEvent { std::chrono::steady_clock::time_point t; };
+struct hipsimEvent { std::chrono::steady_clock::time_point t; int device; };
 typedef hipsimEvent* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
 struct hipDeviceProp_t { int multiProcessorCount; char name[64]; char gcnArchName[64]; size_t totalGlobalMem; };
@@ -58,6 +63,9 @@ namespace hipsim {
 struct Idx { unsigned x, y, z; };
 extern thread_local Idx tIdx, bIdx, bDim, gDim;
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+extern thread_local int cur_device;
+extern thread_local int last_error;  // sticky until read by hipGetLastError
+static inline int stream_device(void* st) { return st ? static_cast<hipsimStream*>(st)->device : cur_device; }
 void sync_threads();
 enum WaveOp { OP_BALLOT = 1, OP_SHFL = 2 };
 uint64_t wave_op(int op, uint64_t payload, int arg, const void* site);
@@ -71,7 +79,10 @@ int lane_id();
 #define warpSize 64
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-  hipsim::launch(dim3(grid), dim3(block), [=]() { kern(__VA_ARGS__); })
+  do {                                                                                                              \
+    if (hipsim::stream_device(stream) != hipsim::cur_device) hipsim::last_error = hipErrorInvalidHandle;             \
+    else hipsim::launch(dim3(grid), dim3(block), [=]() { kern(__VA_ARGS__); });                                      \
+  } while (0)
 
 static inline void __syncthreads() { hipsim::sync_threads(); }
 
@@ -218,11 +229,12 @@ static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned base) {
 
 // ---- runtime API ---------------------------------------------------------------------------
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess(sim)" : "hipError(sim)"; }
-static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipGetLastError() { const int e = hipsim::last_error; hipsim::last_error = hipSuccess; return e; }
 static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+enum { hipHostMallocDefault = 0, hipHostMallocPortable = 1 };
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
@@ -231,13 +243,20 @@ static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, 
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { if (n) memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
-static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = new hipsimStream{hipsim::cur_device}; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { delete static_cast<hipsimStream*>(s); return hipSuccess; }
 enum { hipStreamDefault = 0, hipStreamNonBlocking = 1 };
 static inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = 0; return hipSuccess; }
-static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipSuccess; }
-static inline hipError_t hipSetDevice(int) { return hipSuccess; }
-static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
+static inline hipError_t hipGetDeviceCount(int* n);
+static inline hipError_t hipSetDevice(int d) {
+  int n = 1;
+  hipGetDeviceCount(&n);
+  if (d < 0 || d >= n) return hipErrorInvalidDevice;
+  hipsim::cur_device = d;
+  return hipSuccess;
+}
+static inline hipError_t hipGetDevice(int* d) { *d = hipsim::cur_device; return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) {  // HIPSIM_DEVICE_COUNT: pretend to hold several GPUs (multi-GPU orchestration tests)
   const char* e = getenv("HIPSIM_DEVICE_COUNT");
   *n = e ? atoi(e) : 1;
@@ -253,12 +272,16 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   return hipSuccess;
 }
 template <typename F> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 2; return hipSuccess; }
-static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipsimEvent(); return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipsimEvent(); (*e)->device = hipsim::cur_device; return hipSuccess; }
 enum { hipEventDefault = 0, hipEventDisableTiming = 2 };
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t st = nullptr) {
+  if (e->device != hipsim::stream_device(st)) return hipErrorInvalidHandle;  // an event belongs to the device it was created on
+  e->t = std::chrono::steady_clock::now();
+  return hipSuccess;
+}
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();

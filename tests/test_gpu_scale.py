@@ -60,6 +60,77 @@ def test_config5_tenth_scale_full_item_space_skew(gpu_session):
     compare_with_oracle_large(gpu_session, mats[:2], [P(500, 50), P(500, 50)], 5, mode=1)
 
 
+def test_full_config4_every_row(gpu_session):
+    """BASELINE config 4 at FULL size (10M users x 2M / 2M / 2M / 200K / 2K items, 5 event types, ~784M raw interactions,
+    ~1.06G cooccurrence pairs) -- the workload bench.py's default line is quoted on -- through the entry point it times
+    (urcco_context_build_device): the five down-sampled matrices bit for bit, every one of the 10M indicator rows.  Inputs
+    are generated on the GPU and mirrored to the host for the oracle (all host cores)."""
+    from helpers import device_generated
+    from universal_recommender_amd import synth
+    cfg = synth.config4(1.0)
+    dev_mats, mats = device_generated(cfg, gpu_session.device)
+    assert mats[0].n_rows == 10_000_000 and mats[0].n_cols == 2_000_000 and len(mats) == 5
+    _, res = compare_with_oracle_large(gpu_session, mats, [P()] * 5, 20260925, dev_mats=dev_mats, via_context=True)
+    rows_by_bin = np.sum([st[1:8] for st, _ in res], axis=0)
+    assert sum(int(st[0]) for st, _ in res) > 1_000_000_000 and rows_by_bin[:6].min() > 0, rows_by_bin
+
+
+def test_full_config5_every_row(gpu_session):
+    """BASELINE config 5 at FULL size (config 4's shape with the hot head -- top 0.1 % of the items draw 40 % of the
+    interactions -- and 1 % heavy users x50), engine.json defaults as bench.py --workload config5 runs it: the heavy
+    users' rows are dropped by maxItemsPerUser (Int / Int row rate), the hot items' rows are too heavy for any single-pass
+    LDS accumulator (the multi-pass class)."""
+    from helpers import device_generated
+    from universal_recommender_amd import synth
+    cfg = synth.config5(1.0)
+    dev_mats, mats = device_generated(cfg, gpu_session.device)
+    assert max(int(np.diff(m.row_ptr).max()) for m in mats) > 500
+    _, res = compare_with_oracle_large(gpu_session, mats, [P()] * 5, 20260925, dev_mats=dev_mats, via_context=True)
+    rows_by_bin = np.sum([st[1:8] for st, _ in res], axis=0)
+    assert rows_by_bin[6] > 1000, rows_by_bin                   # the heavy-row class carries real work here
+
+
+def test_host_level_force_exchange_real_rccl(gpu_session):
+    """The JVM-shaped multi-GPU route on a one-GPU box: urcco_cross_occurrence_downsampled with
+    options.flags = URCCO_FLAG_FORCE_EXCHANGE -> the process-wide context creates its communicator with ncclCommInitAll and
+    the build runs the exchange path (all-reduces, all-gather-v, work-balanced ranges, range-restricted transposition)
+    behind the non-gated staging branch.  Config 3 at 1/4 scale, every row against the oracle; then the same call without
+    the flag (the default context is keyed on the flags: it must be rebuilt, not silently reused)."""
+    import ctypes as C
+    import os
+    from helpers import check_indicators
+    from universal_recommender_amd import _lib, synth
+    lib = _lib.load(_lib.DEFAULT_PATH)
+    cfg = synth.config3(0.25)
+    data = synth.generate(cfg)
+    mats = [O.Csr(cfg.n_users, nc, rp, ci) for (_, nc, rp, ci) in data]
+    n = len(mats)
+    threads = min(os.cpu_count() or 1, O.lib().orc_max_threads())
+    ref = O.cross_occurrence_downsampled(mats, [P(), P(), P()], 31, 0, threads)
+    arr = (_lib.Dataset * n)()
+    for d, m in enumerate(mats):
+        arr[d].matrix.n_rows, arr[d].matrix.n_cols = m.n_rows, m.n_cols
+        arr[d].matrix.row_ptr, arr[d].matrix.col_idx = m.row_ptr.ctypes.data, m.col_idx.ctypes.data
+        arr[d].max_elements_per_row, arr[d].max_interesting_elements = 500, 50
+    for flags in (_lib.FLAG_FORCE_EXCHANGE, 0, _lib.FLAG_FORCE_EXCHANGE | _lib.FLAG_UNORDERED_ROWS):
+        opts = _lib.Options(device=0, row_rate_mode=0, n_gpus=1, flags=flags)
+        out = (_lib.Indicators * n)()
+        stats = (_lib.DatasetStats * n)()
+        _lib.check(lib.urcco_cross_occurrence_downsampled(arr, n, 31, C.byref(opts), out, stats), lib)
+        for d, r in enumerate(ref):
+            o = out[d]
+            nnz = int(o.nnz)
+            got = (np.ctypeslib.as_array(o.row_ptr, shape=(o.n_rows + 1,)).copy(), np.ctypeslib.as_array(o.col_idx, shape=(max(nnz, 1),))[:nnz].copy(),
+                   np.ctypeslib.as_array(o.llr, shape=(max(nnz, 1),))[:nnz].copy())
+            if flags & _lib.FLAG_UNORDERED_ROWS:
+                from helpers import sort_rows
+                got = sort_rows(got)
+            check_indicators(got, r)
+            assert stats[d].pairs == r.pairs and stats[d].nnz_out == nnz
+        lib.urcco_free_indicators(out, n)
+    assert lib.urcco_shutdown() == 0
+
+
 def test_host_level_c_abi_config3_size(gpu_session):
     """The host-level entry point a JNI shim binds (urcco_cross_occurrence_downsampled: pageable host CSR in through the
     pinned staging ring, indicator CSR out in pinned host memory) on the FULL config-3 input: every row against the

@@ -1,7 +1,8 @@
 """The JNI shim (jni/urcco_jni.cpp) without a JVM: `make -C jni check` type-checks it against the stub <jni.h>, and a fake
 JNIEnv (jni/test/fake_jvm.cpp) RUNS Native.crossOccurrenceDownsampled on top of the library -- the simulator build here,
-the product library on the GPU box -- so that the marshalling (critical sections, NaN = None, Object[3n] result,
-RuntimeException on failure) is executed and its output compared with the oracle."""
+the product library on the GPU box -- so that the marshalling (critical sections released after the staging half of the
+call -- the fake JVM overwrites a released array, so a library that read it later would fail --, NaN = None, Object[3n]
+result, RuntimeException on failure) is executed and its output compared with the oracle."""
 import ctypes as C
 import os
 import subprocess
@@ -9,7 +10,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from helpers import check_indicators, rand_csr
+from helpers import check_indicators, rand_csr, sort_rows
 from oracle import c_oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -61,7 +62,7 @@ def shim_case(jvm):
         st, msg, out = run_shim(jvm, mats, params, -559038737)
         assert st == 0, msg
         for got, r in zip(out, ref):
-            check_indicators(got, r)
+            check_indicators(sort_rows(got), r)      # the shim asks for URCCO_FLAG_UNORDERED_ROWS: rows are top-k SETS
     # failure -> RuntimeException carrying urcco_last_error, arrays released, no JNI call inside the critical section
     bad = O.Csr(2000, 4, mats[0].row_ptr, mats[0].col_idx)             # columns out of range
     st, msg, _ = run_shim(jvm, [bad], [params[0]], 1)

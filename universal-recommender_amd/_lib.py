@@ -96,6 +96,10 @@ SYMBOLS = {
     "urcco_cross_occurrence_downsampled": (C.c_int, [C.POINTER(Dataset), C.c_int32, C.c_int32, C.POINTER(Options),
                                                      C.POINTER(Indicators), C.POINTER(DatasetStats)]),
     "urcco_free_indicators": (None, [C.POINTER(Indicators), C.c_int32]),
+    "urcco_cross_occurrence_stage": (C.c_int, [C.POINTER(Dataset), C.c_int32, C.c_int32, C.POINTER(Options)]),
+    "urcco_cross_occurrence_finish": (C.c_int, [C.POINTER(Indicators), C.c_int32, C.POINTER(DatasetStats)]),
+    "urcco_context_stage": (C.c_int, [_p, C.POINTER(Dataset), C.c_int32, C.c_int32]),
+    "urcco_context_finish": (C.c_int, [_p, C.POINTER(Indicators), C.POINTER(DatasetStats)]),
     "urcco_shutdown": (C.c_int, []),
     "urcco_comm_unique_id": (C.c_int, [_p]),
     "urcco_context_create": (C.c_int, [C.POINTER(Options), C.POINTER(CommConfig), C.POINTER(_p)]),

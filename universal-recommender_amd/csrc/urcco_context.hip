@@ -303,6 +303,68 @@ struct DevWorkers {
   }
 };
 
+// URCCO_TRACE_HOST=1: wall-clock marks of the host-level call on stderr (where the milliseconds of a PCIe-inclusive call go)
+struct HostTrace {
+  bool on = getenv("URCCO_TRACE_HOST") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void mark(const char* what, int d = -1) const {
+    if (!on) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "[urcco host] %8.3f ms  %s%s\n", ms, what, d >= 0 ? (std::string(" ") + std::to_string(d)).c_str() : "");
+  }
+};
+
+// Pinned staging ring of ONE GPU: pageable host memory -> pinned slot -> H2D on a stream of that GPU.  The slot events are
+// created under hipSetDevice(device): HIP rejects an event recorded on a stream of another device.
+constexpr size_t STAGE_CHUNK = (size_t)8 << 20;
+struct StageRing {
+  struct Slot { hipEvent_t ev = nullptr; std::atomic<long long> gen{0}; };
+  int device = 0;
+  char* base = nullptr;
+  std::vector<std::unique_ptr<Slot>> slots;
+  std::atomic<long long> next_chunk{0};  // global chunk counter: chunk q uses slot q % n_slots in generation q / n_slots
+  int ensure(int dev, size_t n_slots) {
+    device = dev;
+    HIPC(hipSetDevice(dev));
+    if (slots.size() >= n_slots && base) return URCCO_OK;
+    release();
+    HIPC(hipHostMalloc((void**)&base, n_slots * STAGE_CHUNK, hipHostMallocPortable));
+    while (slots.size() < n_slots) {
+      slots.emplace_back(new Slot());
+      HIPC(hipEventCreateWithFlags(&slots.back()->ev, hipEventDisableTiming));
+    }
+    return URCCO_OK;
+  }
+  void release() {
+    if (base || !slots.empty()) (void)hipSetDevice(device);
+    for (auto& s : slots)
+      if (s->ev) (void)hipEventDestroy(s->ev);
+    slots.clear();
+    next_chunk = 0;
+    if (base) (void)hipHostFree(base);
+    base = nullptr;
+  }
+  ~StageRing() { release(); }
+};
+
+struct InputGate;
+// What urcco_context_stage leaves behind for urcco_context_finish: the caller's arrays are not touched again.
+struct PendingBuild {
+  int n_ds = 0;
+  int64_t n_users = 0;
+  int32_t seed = 0;
+  std::vector<DsParams> ps;
+  std::vector<std::vector<Shard>> sh;
+  std::vector<int64_t> nnz_raw;
+  std::unique_ptr<InputGate> gate;
+  std::thread builder;        // one GPU: enqueues the build while the staging goes on
+  int build_st = URCCO_OK;
+  std::string build_msg;
+  bool build_deferred = false;  // several GPUs / exchange path: the build is issued by urcco_context_finish
+  HostTrace trace;
+  ~PendingBuild();
+};
+
 }  // namespace
 
 struct urcco_context {
@@ -317,10 +379,10 @@ struct urcco_context {
   Rccl* rccl = nullptr;
   std::vector<int32_t> h_bounds;                // host copy of the item range bounds of the last multi-rank build
   std::vector<int64_t> h_sizes;
-  // staging (host level)
-  void* stage = nullptr;
-  size_t stage_cap = 0;
+  // staging (host level): one pinned ring per GPU (slot events belong to the device whose stream records them)
+  std::vector<std::unique_ptr<StageRing>> rings;
   int copy_threads = 4;
+  std::unique_ptr<PendingBuild> pending;  // between urcco_context_stage and urcco_context_finish
 
   bool exchange() const { return world > 1 || (flags & URCCO_FLAG_FORCE_EXCHANGE); }
   bool single_stream() const { return (flags & URCCO_FLAG_SINGLE_STREAM) != 0; }
@@ -428,17 +490,6 @@ int stage_rows(DevState& D, EvState& E, EvState& A, int d, const DsParams& pa, c
   return URCCO_OK;
 }
 
-// URCCO_TRACE_HOST=1: wall-clock marks of the host-level call on stderr (where the milliseconds of a PCIe-inclusive call go)
-struct HostTrace {
-  bool on = getenv("URCCO_TRACE_HOST") != nullptr;
-  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-  void mark(const char* what, int d = -1) const {
-    if (!on) return;
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    fprintf(stderr, "[urcco host] %8.3f ms  %s%s\n", ms, what, d >= 0 ? (std::string(" ") + std::to_string(d)).c_str() : "");
-  }
-};
-
 // Host level, one GPU: the build is enqueued WHILE the caller's matrices are still being staged.  The staging thread signals
 // an event type once all of its copies and its boundary check are enqueued on that event type's stream; the thread that
 // enqueues the event type's chain then waits for the stream (the copies have landed), reads the check's verdict and only
@@ -447,8 +498,13 @@ struct InputGate {
   const HostTrace* trace = nullptr;
   std::vector<std::promise<int>> staged;
   std::vector<std::shared_future<int>> fut;
-  explicit InputGate(int n) : staged((size_t)n), fut((size_t)n) {
+  std::vector<char> released;
+  explicit InputGate(int n) : staged((size_t)n), fut((size_t)n), released((size_t)n, 0) {
     for (int d = 0; d < n; ++d) fut[(size_t)d] = staged[(size_t)d].get_future().share();
+  }
+  void release(int d, int status) {
+    released[(size_t)d] = 1;
+    staged[(size_t)d].set_value(status);
   }
   int wait(DevState& D, int d) {
     const int st = fut[(size_t)d].get();
@@ -733,72 +789,52 @@ int run_build(urcco_context* c, const std::vector<std::vector<Shard>>& sh, const
 // ---------------------------------------------------------------------------------------------------------
 // host level: staging
 // ---------------------------------------------------------------------------------------------------------
-constexpr size_t STAGE_CHUNK = (size_t)8 << 20;
+PendingBuild::~PendingBuild() {
+  if (gate)
+    for (size_t d = 0; d < gate->staged.size(); ++d)
+      if (!gate->released[d]) gate->release((int)d, URCCO_INTERNAL);  // a builder still waiting must not wait forever
+  if (builder.joinable()) builder.join();
+}
 
-
-// pageable host memory -> device through the context's pinned ring, `threads` copy threads; every chunk's H2D is enqueued
+// pageable host memory -> device through the GPU's pinned ring, `max_threads` copy threads; every chunk's H2D is enqueued
 // on `st` as soon as the chunk sits in pinned memory, so the link is busy while later chunks are still being copied.
-// Returns after all copies of this array are ENQUEUED.
-struct Stager {
-  urcco_context* c;
-  struct Slot { hipEvent_t ev = nullptr; std::atomic<long long> gen{0}; };
-  std::vector<std::unique_ptr<Slot>> slots;
-  std::atomic<long long> next_chunk{0};  // global chunk counter: chunk q uses slot q % n_slots in generation q / n_slots
-  int ensure(size_t n_slots) {
-    if (c->stage_cap < n_slots * STAGE_CHUNK) {
-      if (c->stage) (void)hipHostFree(c->stage);
-      c->stage = nullptr;
-      c->stage_cap = 0;
-      HIPC(hipHostMalloc(&c->stage, n_slots * STAGE_CHUNK, 0));
-      c->stage_cap = n_slots * STAGE_CHUNK;
+// Returns once the caller's bytes have all been READ (every chunk sits in pinned memory, its H2D enqueued).
+int stage_copy(StageRing& ring, hipStream_t st, void* dst, const void* src, size_t bytes, int max_threads) {
+  if (bytes == 0) return URCCO_OK;
+  const size_t n_chunks = (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK;
+  const long long base = ring.next_chunk.fetch_add((long long)n_chunks);
+  const size_t n_slots = ring.slots.size();
+  std::atomic<size_t> take{0};
+  std::atomic<int> status{URCCO_OK};
+  auto worker = [&]() {
+    if (hipSetDevice(ring.device) != hipSuccess) { status = URCCO_HIP_ERROR; return; }
+    for (;;) {
+      const size_t k = take.fetch_add(1);
+      if (k >= n_chunks) break;
+      const long long q = base + (long long)k;
+      StageRing::Slot& s = *ring.slots[(size_t)(q % (long long)n_slots)];
+      const long long gen = q / (long long)n_slots;
+      while (s.gen.load(std::memory_order_acquire) != gen) std::this_thread::yield();  // the slot's previous user has recorded its event
+      if (gen > 0 && hipEventSynchronize(s.ev) != hipSuccess) status = URCCO_HIP_ERROR;  // ... and its H2D has left the slot
+      const size_t o = k * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - o);
+      char* pin = ring.base + (size_t)(q % (long long)n_slots) * STAGE_CHUNK;
+      memcpy(pin, (const char*)src + o, len);
+      if (hipMemcpyAsync((char*)dst + o, pin, len, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(s.ev, st) != hipSuccess) status = URCCO_HIP_ERROR;
+      s.gen.store(gen + 1, std::memory_order_release);
     }
-    while (slots.size() < n_slots) {
-      slots.emplace_back(new Slot());
-      HIPC(hipEventCreateWithFlags(&slots.back()->ev, hipEventDisableTiming));
-    }
-    return URCCO_OK;
-  }
-  ~Stager() {
-    for (auto& s : slots)
-      if (s->ev) (void)hipEventDestroy(s->ev);
-  }
-  int copy(int device, hipStream_t st, void* dst, const void* src, size_t bytes, int max_threads) {
-    if (bytes == 0) return URCCO_OK;
-    const size_t n_chunks = (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK;
-    const long long base = next_chunk.fetch_add((long long)n_chunks);
-    const size_t n_slots = slots.size();
-    std::atomic<size_t> take{0};
-    std::atomic<int> status{URCCO_OK};
-    auto worker = [&]() {
-      if (hipSetDevice(device) != hipSuccess) { status = URCCO_HIP_ERROR; return; }
-      for (;;) {
-        const size_t k = take.fetch_add(1);
-        if (k >= n_chunks) break;
-        const long long q = base + (long long)k;
-        Slot& s = *slots[(size_t)(q % (long long)n_slots)];
-        const long long gen = q / (long long)n_slots;
-        while (s.gen.load(std::memory_order_acquire) != gen) std::this_thread::yield();  // the slot's previous user has recorded its event
-        if (gen > 0 && hipEventSynchronize(s.ev) != hipSuccess) status = URCCO_HIP_ERROR;  // ... and its H2D has left the slot
-        const size_t o = k * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - o);
-        char* pin = (char*)c->stage + (size_t)(q % (long long)n_slots) * STAGE_CHUNK;
-        memcpy(pin, (const char*)src + o, len);
-        if (hipMemcpyAsync((char*)dst + o, pin, len, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(s.ev, st) != hipSuccess) status = URCCO_HIP_ERROR;
-        s.gen.store(gen + 1, std::memory_order_release);
-      }
-    };
-    const int nt = (int)std::min<size_t>((size_t)(max_threads > 0 ? max_threads : 1), n_chunks);
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(worker);
-    worker();
-    for (auto& t : th) t.join();
-    if (status != URCCO_OK) return fail(URCCO_HIP_ERROR, "host -> device staging failed");
-    return URCCO_OK;
-  }
-};
+  };
+  const int nt = (int)std::min<size_t>((size_t)(max_threads > 0 ? max_threads : 1), n_chunks);
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; ++t) th.emplace_back(worker);
+  worker();
+  for (auto& t : th) t.join();
+  if (status != URCCO_OK) return fail(URCCO_HIP_ERROR, "host -> device staging failed");
+  return URCCO_OK;
+}
 
 std::mutex g_default_mu;
 urcco_context* g_default_ctx = nullptr;
-int g_default_n_gpus = -1, g_default_device = -1, g_default_mode = -1;
+int g_default_n_gpus = -1, g_default_device = -1, g_default_mode = -1, g_default_flags = 0;
 
 }  // namespace
 
@@ -816,6 +852,7 @@ int urcco_comm_unique_id(void* out) {
 
 void urcco_context_destroy(urcco_context* c) {
   if (!c) return;
+  c->pending.reset();  // joins a builder thread of a staged build nobody finished
   for (DevState& D : c->devs) {
     (void)hipSetDevice(D.device);
     for (urcco_session* s : D.sessions) (void)hipStreamSynchronize(s->stream);
@@ -827,7 +864,7 @@ void urcco_context_destroy(urcco_context* c) {
     if (D.in_ready) (void)hipEventDestroy(D.in_ready);
     for (urcco_session* s : D.sessions) urcco_session_destroy(s);
   }
-  if (c->stage) (void)hipHostFree(c->stage);
+  c->rings.clear();
   delete c;
 }
 
@@ -993,20 +1030,23 @@ int urcco_context_build_device(urcco_context* c, const urcco_dev_dataset* datase
   });
 }
 
-int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datasets, int32_t n_ds, int32_t seed, urcco_indicators* out,
-                                   urcco_dataset_stats* stats) {
-  HostTrace trace;
-  const int status = guarded([&]() -> int {
+// ---- host level, split: stage (reads the caller's arrays) / finish (waits for the build, hands out the results) ----
+int urcco_context_stage(urcco_context* c, const urcco_dataset* datasets, int32_t n_ds, int32_t seed) {
+  return guarded([&]() -> int {
     err_buf()[0] = 0;
-    if (!c || !datasets || n_ds <= 0 || !out) return fail(URCCO_BAD_ARG, "datasets / out is NULL or n_datasets <= 0");
+    if (!c || !datasets || n_ds <= 0) return fail(URCCO_BAD_ARG, "datasets is NULL or n_datasets <= 0");
+    if (c->pending) return fail(URCCO_BAD_ARG, "urcco_context_stage: the previous staged build has not been finished");
     const size_t L = c->devs.size();
     if ((int)L != c->world) return fail(URCCO_BAD_ARG, "the host-level build needs every rank in this process");
-    for (int d = 0; d < n_ds; ++d) {
-      memset(&out[d], 0, sizeof(urcco_indicators));
-      if (stats) memset(&stats[d], 0, sizeof(urcco_dataset_stats));
-    }
-    std::vector<DsParams> ps((size_t)n_ds);
+    std::unique_ptr<PendingBuild> P(new PendingBuild());
+    HostTrace& trace = P->trace;
+    P->n_ds = n_ds;
+    P->seed = seed;
+    P->ps.resize((size_t)n_ds);
+    P->nnz_raw.resize((size_t)n_ds);
+    std::vector<DsParams>& ps = P->ps;
     const int64_t n_users = datasets[0].matrix.n_rows;
+    P->n_users = n_users;
     for (int d = 0; d < n_ds; ++d) {
       const urcco_csr& m = datasets[d].matrix;
       if (m.n_rows < 0 || m.n_cols < 0 || m.n_rows > 0x7fffffffll) return fail(URCCO_BAD_ARG, "dataset %d: bad shape", d);
@@ -1016,6 +1056,7 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
         return fail(URCCO_BAD_ARG, "dataset %d has %lld rows, the primary has %lld: all matrices share the user dictionary", d, (long long)m.n_rows, (long long)n_users);
       const int64_t nnz = m.row_ptr[m.n_rows];
       if (nnz < 0 || (nnz > 0 && !m.col_idx)) return fail(URCCO_BAD_ARG, "dataset %d: bad nnz / col_idx", d);
+      P->nnz_raw[(size_t)d] = nnz;
       DsParams& p = ps[(size_t)d];
       p.n_cols = m.n_cols; p.max_rows = datasets[d].max_elements_per_row; p.k = datasets[d].max_interesting_elements;
       p.has_min_llr = datasets[d].has_min_llr; p.min_llr = datasets[d].min_llr;
@@ -1033,14 +1074,22 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
         while (lo < hi) { const int64_t mid = lo + (hi - lo) / 2; if (total_at(mid) >= target) hi = mid; else lo = mid + 1; }
         cut[g] = lo;
       }
+      // the copy ranges below come from the caller's row_ptr at the cuts, BEFORE the device-side check has seen it: they must
+      // at least be ordered and inside the arrays (a non-monotone row_ptr would otherwise become an out-of-bounds host read)
+      for (int d = 0; d < n_ds; ++d) {
+        const int64_t* rp = datasets[d].matrix.row_ptr;
+        for (size_t g = 0; g < L; ++g)
+          if (rp[cut[g]] < 0 || rp[cut[g]] > rp[cut[g + 1]] || rp[cut[g + 1]] > rp[n_users]) return fail(URCCO_BAD_ARG, "dataset %d: row_ptr not monotone", d);
+      }
     }
     for (DevState& D : c->devs) URC(ensure_events(c, D, n_ds));
     // ---- stage + validate every shard on its event stream (copy threads feed the pinned ring; the link is busy while
     // the next chunks are copied), heaviest transfers last so that the primary starts first
     trace.mark("arguments checked, streams ready");
-    Stager stager{c};
-    URC(stager.ensure(24));
-    std::vector<std::vector<Shard>> sh((size_t)n_ds, std::vector<Shard>(L));
+    while (c->rings.size() < L) c->rings.emplace_back(new StageRing());
+    for (size_t g = 0; g < L; ++g) URC(c->rings[g]->ensure(c->devs[g].device, L > 1 ? 12 : 24));
+    P->sh.assign((size_t)n_ds, std::vector<Shard>(L));
+    std::vector<std::vector<Shard>>& sh = P->sh;
     const int threads_each = L > 1 ? std::max(1, c->copy_threads / 2) : c->copy_threads;  // every GPU has its own link: all stage at once
     // buffers and shard descriptors first (everything but the bytes is known from the caller's row_ptr)
     for (int d = 0; d < n_ds; ++d) {
@@ -1066,8 +1115,8 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
         EvState& E = D.ev[(size_t)d];
         const Shard& x = sh[(size_t)d][g];
         const int64_t e0 = m.row_ptr[x.row_base];
-        URC(stager.copy(D.device, E.s->stream, E.in_rp.p, m.row_ptr + x.row_base, sizeof(int64_t) * ((size_t)x.n_rows + 1), threads_each));
-        URC(stager.copy(D.device, E.s->stream, E.in_ci.p, m.col_idx + e0, sizeof(int32_t) * (size_t)x.nnz, threads_each));
+        URC(stage_copy(*c->rings[g], E.s->stream, E.in_rp.p, m.row_ptr + x.row_base, sizeof(int64_t) * ((size_t)x.n_rows + 1), threads_each));
+        URC(stage_copy(*c->rings[g], E.s->stream, E.in_ci.p, m.col_idx + e0, sizeof(int32_t) * (size_t)x.nnz, threads_each));
         HIPC(hipMemsetAsync(E.verr.p, 0, sizeof(unsigned long long), E.s->stream));
         int gl = x.n_rows > 0 ? ceil_log2_i64((x.nnz + x.n_rows - 1) / x.n_rows) : 1;
         gl = gl < 1 ? 1 : (gl > 6 ? 6 : gl);
@@ -1079,13 +1128,12 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
     if (L == 1 && !c->exchange()) {
       // one GPU: the build is enqueued by its own thread(s) while this thread stages; every event type starts the moment its
       // own matrices have landed and passed the boundary check (InputGate)
-      InputGate gate(n_ds);
-      gate.trace = &trace;
-      int build_st = URCCO_OK;
-      std::string build_msg;
-      std::thread builder([&] {
-        build_st = guarded([&] { return run_build(c, sh, ps, n_users, seed, nullptr, &gate); });
-        if (build_st != URCCO_OK) build_msg = err_buf();
+      P->gate.reset(new InputGate(n_ds));
+      P->gate->trace = &trace;
+      PendingBuild* pb = P.get();
+      pb->builder = std::thread([c, pb] {
+        pb->build_st = guarded([&] { return run_build(c, pb->sh, pb->ps, pb->n_users, pb->seed, nullptr, pb->gate.get()); });
+        if (pb->build_st != URCCO_OK) pb->build_msg = err_buf();
       });
       int stage_st = URCCO_OK;
       std::string stage_msg;
@@ -1094,17 +1142,42 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
           stage_st = guarded([&] { return stage_event(d); });
           if (stage_st != URCCO_OK) stage_msg = err_buf();
         }
-        gate.staged[(size_t)d].set_value(stage_st);  // also on failure: the builder must not wait forever
+        P->gate->release(d, stage_st);  // also on failure: the builder must not wait forever
         trace.mark("staged (copies enqueued)", d);
       }
-      builder.join();
-      trace.mark("build enqueued");
-      if (stage_st != URCCO_OK) return fail(stage_st, "%s", stage_msg.c_str());
-      if (build_st != URCCO_OK) return fail(build_st, "%s", build_msg.c_str());
+      if (stage_st != URCCO_OK) {
+        P.reset();  // joins the builder
+        return fail(stage_st, "%s", stage_msg.c_str());
+      }
     } else {
-      // several GPUs / the exchange path: stage + validate everything, heaviest transfers last so that the primary starts first
+      // several GPUs / the exchange path: stage + validate everything; the boundary check must have passed before any kernel
+      // consumes the matrices, and the build itself (blocking host reads between its collectives) is issued by finish
       for (int d = 0; d < n_ds; ++d) URC(stage_event(d));
-      // the boundary check must have passed before any kernel consumes the matrices
+      P->build_deferred = true;
+    }
+    trace.mark("caller arrays released");
+    c->pending = std::move(P);
+    return URCCO_OK;
+  });
+}
+
+int urcco_context_finish(urcco_context* c, urcco_indicators* out, urcco_dataset_stats* stats) {
+  if (out && c && c->pending)
+    for (int d = 0; d < c->pending->n_ds; ++d) memset(&out[d], 0, sizeof(urcco_indicators));
+  int n_ds = 0;
+  const int status = guarded([&]() -> int {
+    err_buf()[0] = 0;
+    if (!c || !out) return fail(URCCO_BAD_ARG, "context / out is NULL");
+    if (!c->pending) return fail(URCCO_BAD_ARG, "urcco_context_finish: nothing staged");
+    std::unique_ptr<PendingBuild> P = std::move(c->pending);
+    HostTrace& trace = P->trace;
+    n_ds = P->n_ds;
+    const size_t L = c->devs.size();
+    const std::vector<DsParams>& ps = P->ps;
+    const int64_t n_users = P->n_users;
+    if (stats)
+      for (int d = 0; d < n_ds; ++d) memset(&stats[d], 0, sizeof(urcco_dataset_stats));
+    if (P->build_deferred) {
       for (int d = 0; d < n_ds; ++d)
         for (size_t g = 0; g < L; ++g) {
           DevState& D = c->devs[g];
@@ -1115,7 +1188,11 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
           HIPC(hipStreamSynchronize(E.s->stream));
           if (bad) return fail(URCCO_BAD_ARG, "dataset %d: %llu invalid entries (row_ptr not monotone, or col_idx out of [0, n_cols) / not strictly increasing inside a row)", d, bad);
         }
-      URC(run_build(c, sh, ps, n_users, seed, nullptr));
+      URC(run_build(c, P->sh, ps, n_users, P->seed, nullptr));
+    } else {
+      if (P->builder.joinable()) P->builder.join();
+      trace.mark("build enqueued");
+      if (P->build_st != URCCO_OK) return fail(P->build_st, "%s", P->build_msg.c_str());
     }
     // ---- results: row_ptr of every GPU's slice first (small), then exactly nnz entries each
     const int32_t n_items_a = (int32_t)ps[0].n_cols;
@@ -1125,10 +1202,11 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
       void* p = nullptr;
       ~PinnedBlock() { if (p) (void)pinned_pool().put(p); }
     } stats_block;
-    stats_block.p = pinned_pool().get(sizeof(int64_t) * URCCO_STATS_LEN * (size_t)n_ds * L);
+    stats_block.p = pinned_pool().get(sizeof(int64_t) * (URCCO_STATS_LEN + 1) * (size_t)n_ds * L);
     if (!stats_block.p) return fail(URCCO_OOM_HOST, "pinned statistics block");
     int64_t* h_stats = static_cast<int64_t*>(stats_block.p);
-    memset(h_stats, 0, sizeof(int64_t) * URCCO_STATS_LEN * (size_t)n_ds * L);
+    memset(h_stats, 0, sizeof(int64_t) * (URCCO_STATS_LEN + 1) * (size_t)n_ds * L);
+    int64_t* h_sampled = h_stats + (size_t)URCCO_STATS_LEN * (size_t)n_ds * L;  // [n_ds]: nnz' of the single-rank build
     for (int d = 0; d < n_ds; ++d) {
       urcco_indicators& o = out[d];
       o.n_rows = n_items_a;
@@ -1144,6 +1222,8 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
         // slice row_ptr[1..n] lands at out.row_ptr[item_lo + 1 ..]; re-based below once the slices' sizes are known
         if (n > 0) HIPC(hipMemcpyAsync(o.row_ptr + D.item_lo + 1, E.c_rp.p + 1, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, E.s->stream));
         HIPC(hipMemcpyAsync(h_stats + ((size_t)d * L + g) * URCCO_STATS_LEN, E.stats.p, sizeof(int64_t) * URCCO_STATS_LEN, hipMemcpyDeviceToHost, E.s->stream));
+        if (stats && !c->exchange() && g == 0)
+          HIPC(hipMemcpyAsync(h_sampled + d, E.s_rp.p + n_users, sizeof(int64_t), hipMemcpyDeviceToHost, E.s->stream));
         HIPC(hipEventRecord(E.ev_rp, E.s->stream));
       }
     }
@@ -1180,25 +1260,28 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
     if (stats)
       for (int d = 0; d < n_ds; ++d) {
         urcco_dataset_stats& st = stats[d];
-        st.nnz_raw = datasets[d].matrix.row_ptr[n_users];
+        st.nnz_raw = P->nnz_raw[(size_t)d];
         st.nnz_out = out[d].nnz;
         for (size_t g = 0; g < L; ++g) {
           const int64_t* h = h_stats + ((size_t)d * L + g) * URCCO_STATS_LEN;
           st.pairs += h[0];
           for (int b = 0; b < URCCO_N_BINS; ++b) st.rows_by_bin[b] += h[1 + (size_t)b];
         }
-        if (c->exchange()) {
-          st.nnz_sampled = c->h_sizes[(size_t)d];
-        } else {
-          DevState& D = c->devs[0];
-          HIPC(hipMemcpy(&st.nnz_sampled, D.ev[(size_t)d].s_rp.p + n_users, sizeof(int64_t), hipMemcpyDeviceToHost));
-        }
+        st.nnz_sampled = c->exchange() ? c->h_sizes[(size_t)d] : h_sampled[d];
       }
+    trace.mark("return");
     return URCCO_OK;
   });
-  if (status != URCCO_OK && out && n_ds > 0) urcco_free_indicators(out, n_ds);
-  trace.mark("return");
+  if (status != URCCO_OK && out && n_ds > 0) urcco_free_indicators(out, n_ds);  // out[0..n_ds) was zeroed above: only library blocks are released
   return status;
+}
+
+int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datasets, int32_t n_ds, int32_t seed, urcco_indicators* out,
+                                   urcco_dataset_stats* stats) {
+  if (out && n_ds > 0) memset(out, 0, sizeof(urcco_indicators) * (size_t)n_ds);  // before any fallible step: a failure frees nothing of the caller's
+  if (!out) return fail(URCCO_BAD_ARG, "out is NULL");
+  URC(urcco_context_stage(c, datasets, n_ds, seed));
+  return urcco_context_finish(c, out, stats);
 }
 
 // ---- process-wide default context + the Mahout-shaped one-shot entry points ---------------------------------
@@ -1219,29 +1302,58 @@ void urcco_free_indicators(urcco_indicators* ind, int32_t n) {
   }
 }
 
-int urcco_cross_occurrence_downsampled(const urcco_dataset* datasets, int32_t n_datasets, int32_t random_seed, const urcco_options* options,
-                                       urcco_indicators* out, urcco_dataset_stats* stats) {
-  int st = guarded([&]() -> int {
+// the process-wide context, (re)created when the options that shape it change: first device, number of GPUs, row-rate mode
+// AND the flags (a flag change on a warm context must not be dropped silently)
+static int default_context(const urcco_options* options, urcco_context** out) {
+  const int want_dev = options ? options->device : 0, want_n = options ? options->n_gpus : 0;
+  const int want_mode = options ? options->row_rate_mode : URCCO_ROW_RATE_MAHOUT_INT_DIV;
+  const int want_flags = options ? options->flags : 0;
+  if (g_default_ctx && (g_default_device != want_dev || g_default_n_gpus != want_n || g_default_mode != want_mode || g_default_flags != want_flags)) {
+    urcco_context_destroy(g_default_ctx);
+    g_default_ctx = nullptr;
+  }
+  if (!g_default_ctx) {
+    URC(urcco_context_create(options, nullptr, &g_default_ctx));
+    g_default_device = want_dev; g_default_n_gpus = want_n; g_default_mode = want_mode; g_default_flags = want_flags;
+  }
+  *out = g_default_ctx;
+  return URCCO_OK;
+}
+
+int urcco_cross_occurrence_stage(const urcco_dataset* datasets, int32_t n_datasets, int32_t random_seed, const urcco_options* options) {
+  return guarded([&]() -> int {
     err_buf()[0] = 0;
     std::lock_guard<std::mutex> g(g_default_mu);
-    const int want_dev = options ? options->device : 0, want_n = options ? options->n_gpus : 0;
-    const int want_mode = options ? options->row_rate_mode : URCCO_ROW_RATE_MAHOUT_INT_DIV;
-    if (g_default_ctx && (g_default_device != want_dev || g_default_n_gpus != want_n || g_default_mode != want_mode)) {
-      urcco_context_destroy(g_default_ctx);
-      g_default_ctx = nullptr;
-    }
-    if (!g_default_ctx) {
-      URC(urcco_context_create(options, nullptr, &g_default_ctx));
-      g_default_device = want_dev; g_default_n_gpus = want_n; g_default_mode = want_mode;
-    }
-    return urcco_context_cross_occurrence(g_default_ctx, datasets, n_datasets, random_seed, out, stats);
+    urcco_context* c = nullptr;
+    URC(default_context(options, &c));
+    return urcco_context_stage(c, datasets, n_datasets, random_seed);
   });
-  if (st != URCCO_OK && out && n_datasets > 0) urcco_free_indicators(out, n_datasets);
-  return st;
+}
+
+int urcco_cross_occurrence_finish(urcco_indicators* out, int32_t n_datasets, urcco_dataset_stats* stats) {
+  if (out && n_datasets > 0) memset(out, 0, sizeof(urcco_indicators) * (size_t)n_datasets);
+  return guarded([&]() -> int {
+    err_buf()[0] = 0;
+    std::lock_guard<std::mutex> g(g_default_mu);
+    if (!g_default_ctx || !g_default_ctx->pending) return fail(URCCO_BAD_ARG, "urcco_cross_occurrence_finish: nothing staged");
+    if (g_default_ctx->pending->n_ds != n_datasets) return fail(URCCO_BAD_ARG, "urcco_cross_occurrence_finish: %d datasets were staged, out holds %d", g_default_ctx->pending->n_ds, n_datasets);
+    return urcco_context_finish(g_default_ctx, out, stats);
+  });
+}
+
+int urcco_cross_occurrence_downsampled(const urcco_dataset* datasets, int32_t n_datasets, int32_t random_seed, const urcco_options* options,
+                                       urcco_indicators* out, urcco_dataset_stats* stats) {
+  // out[] is zeroed before any fallible step (context creation, argument checks): on failure only library-owned blocks are
+  // ever released, whatever the caller's array held on entry
+  if (out && n_datasets > 0) memset(out, 0, sizeof(urcco_indicators) * (size_t)n_datasets);
+  if (!out) return fail(URCCO_BAD_ARG, "out is NULL");
+  URC(urcco_cross_occurrence_stage(datasets, n_datasets, random_seed, options));
+  return urcco_cross_occurrence_finish(out, n_datasets, stats);
 }
 
 int urcco_cooccurrences_idss(const urcco_csr* datasets, int32_t n_datasets, int32_t random_seed, int32_t max_interesting_items_per_thing,
                              int32_t max_num_interactions, const urcco_options* options, urcco_indicators* out, urcco_dataset_stats* stats) {
+  if (out && n_datasets > 0) memset(out, 0, sizeof(urcco_indicators) * (size_t)n_datasets);
   return guarded([&]() -> int {
     err_buf()[0] = 0;
     if (!datasets || n_datasets <= 0) return fail(URCCO_BAD_ARG, "datasets is NULL or n_datasets <= 0");
