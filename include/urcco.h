@@ -377,6 +377,12 @@ int urcco_dev_dictionary_lookup(urcco_session* s, const urcco_key_table* table, 
  * on the host (synchronises).  first_pos = the array urcco_dev_dictionary_build filled. */
 int urcco_dev_dictionary_verify(urcco_session* s, const urcco_key_table* table, int64_t n, const uint64_t* keys, const int32_t* select,
                                 const uint64_t* check_keys, const int64_t* first_pos, int64_t* n_mismatch);
+/* The same check for ANOTHER stream looked up in the dictionary (Preparator.scala:173-179: the user keys of a secondary event
+ * type against the user dictionary of the primary): dict_check_keys = the check keys of the stream the dictionary was built
+ * from (first_pos indexes it).  A secondary-event user string whose 64-bit key collides with a primary user's would otherwise
+ * be merged into that user silently. */
+int urcco_dev_dictionary_verify_against(urcco_session* s, const urcco_key_table* table, int64_t n, const uint64_t* keys, const int32_t* select,
+                                        const uint64_t* check_keys, const uint64_t* dict_check_keys, const int64_t* first_pos, int64_t* n_mismatch);
 /* Frees the table (hipFree: waits for device work still using it). */
 void urcco_key_table_destroy(urcco_key_table* table);
 /* IndexedDatasetSpark's row assembly: (row id, column id) pairs (pairs with a negative id are skipped) -> binary CSR

@@ -396,10 +396,11 @@ def split_actions(by_event: Dict[str, List[Tuple[str, str]]], event_names: Seque
 # (Joda Interval, integer millisecond halves / thirds) is restated as written.
 # =====================================================================================================================
 def pop_calc_popular(events, event_names, start_ms: int, end_ms: int) -> Dict[str, float]:
-    """PopModel.calcPopular :113-122.  events = iterable of (event name, target item or None, time ms)."""
+    """PopModel.calcPopular :113-122.  events = iterable of (event name, target item or None, time ms).  An EMPTY event_names
+    means every event name (PopModel.eventsRDD :194: `if (eventNames.nonEmpty) Some(eventNames) else None`)."""
     out: Dict[str, float] = {}
     for name, item, t in events:
-        if name in event_names and item is not None and start_ms <= t < end_ms:
+        if (not event_names or name in event_names) and item is not None and start_ms <= t < end_ms:
             out[item] = out.get(item, 0.0) + 1.0
     return out
 
@@ -449,8 +450,9 @@ def get_ranks(rankings: Sequence[dict], events, model_event_names: Sequence[str]
     for r in rankings:
         rtype = r.get("type") or "popular"
         field = r.get("name") or name_by_type.get(rtype, "unknownRank")
-        names = r.get("eventNames") or list(model_event_names[:1])
-        ranks = pop_calc(rtype, events, names, int(r.get("duration_s", 3650 * 86400)), int(r.get("end_ms", now_ms)))
+        names = r["eventNames"] if r.get("eventNames") is not None else list(model_event_names[:1])  # Option.getOrElse: Some(Seq()) stays empty
+        end = r.get("end_ms")
+        ranks = pop_calc(rtype, events, names, int(r.get("duration_s", 3650 * 86400)), int(now_ms if end is None else end))
         for item, v in ranks.items():
             out.setdefault(item, {})[field] = v
     return out

@@ -121,7 +121,7 @@ def test_host_mirror_builds_the_same_model_as_the_oracle(sim_lib):
         ap = URAlgorithmParams.from_engine_json(engine)
         ap.seed = 1
         model = {}
-        for ev, ind in URAlgorithm(ap, library=sim_lib).train(pd):
+        for ev, ind in URAlgorithm(ap, library=sim_lib).train(pd).coocurrenceMatrices:
             for item, m in toStringMap(ind, ev).items():
                 model.setdefault(item, {}).update(m)
         ref, _ = _oracle_model(doc, by_event)
@@ -140,7 +140,7 @@ def test_model_documents_match_the_oracle_and_the_reference_document_shape(sim_l
     td = DataSource(DataSourceParams.from_engine_json(engine)).readTraining(lines)
     ap = URAlgorithmParams.from_engine_json(engine)
     ap.seed = 1
-    model = URModel(URAlgorithm(ap, library=sim_lib).train(Preparator().prepare(td)), [td.fields])
+    model = URAlgorithm(ap, library=sim_lib).train(Preparator().prepare(td))     # URModel(correlators, Seq(properties))
     docs = {d["id"]: d for d in model.documents()}
     ref, _ = _oracle_model(doc, by_event)
     props = item_properties(doc["sets"])

@@ -74,3 +74,62 @@ def test_pop_model_on_the_simulator(sim_session):
 @pytest.mark.gpu
 def test_pop_model_on_gpu(gpu_session):
     pop_model_case(gpu_session)
+
+
+def calc_all_with_ranks_case(sess, lib):
+    """URAlgorithm.calcAll(calcPopular = true) on the reference's rank data through the reference's own engine file
+    (examples/rank/rank-engine.json: parsed unchanged, `rankings` included): URModel(correlators, Seq(properties)) -> one
+    document per item carrying its indicator lists AND its ranking fields (URAlgorithm.scala:351-367, URModel.scala:57-75);
+    the popularRank values order the items as data/rank-test-query-expected.txt does.  recsModel = collabFiltering drops the
+    ranks (calcAll(calcPopular = false), :296)."""
+    from universal_recommender_amd.data_source import DataSource, DataSourceParams
+    from universal_recommender_amd.preparator import Preparator
+    from universal_recommender_amd.ur_algorithm import URAlgorithm, URAlgorithmParams, duration_seconds
+    d, events, now = _rank_fixture()
+    engine = {"datasource": {"params": {"appName": "default-rank", "eventNames": d["eventNames"]}},
+              "algorithms": [{"name": "ur", "params": {"appName": "default-rank", "indexName": "urindex", "typeName": "items", "recsModel": "all",
+                                                       "eventNames": d["eventNames"], "rankings": d["rankings"], "numGPUs": 1}}]}
+    lines = [f"{e[0]},{e[1]},{e[2]}" for e in d["events"]] + ["product-9,$set,color:green"]
+    td = DataSource(DataSourceParams.from_engine_json(engine)).readTraining(lines)
+    ap = URAlgorithmParams.from_engine_json(engine)
+    assert [r.type for r in ap.rankings] == ["popular", "userDefined", "random"] and ap.numGPUs == 1 and duration_seconds("3650 days") == 3650 * 86400
+    ap.seed = 3
+    algo = URAlgorithm(ap, library=lib, eventStore=events, sess=sess)
+    assert [r.name for r in algo.rankingsParams] == ["popularRank", "defaultRank", "uniqueRank"]
+    pd = Preparator().prepare(td)
+    model = algo.calcAll(pd, now_ms=now + 1)
+    docs = {x["id"]: x for x in model.documents()}
+    ranks = PO.pop_calc("popular", events, ["show", "like"], 3650 * 86400, now + 1)
+    assert {i: x["popularRank"] for i, x in docs.items() if "popularRank" in x} == ranks
+    order = d["popular_order_expected"]
+    by_rank = sorted(docs, key=lambda i: -docs[i].get("popularRank", 0.0))
+    assert [docs[i].get("popularRank", 0.0) for i in by_rank] == [ranks.get(i, 0.0) for i in order if i in docs]   # the golden's other items only exist through $set events
+    assert all("uniqueRank" in docs[i] for i in ranks) and not any("defaultRank" in x for x in docs.values())   # userDefined is empty
+    assert docs["product-9"]["color"] == ["green"] and "uniqueRank" in docs["product-9"]      # properties-only item, full outer join
+    corr = {n: m for n, m in model.coocurrenceMatrices}
+    assert set(corr) == {"show", "like"} and any("show" in x or "like" in x for x in docs.values())
+    # the default ranking (no `rankings` key): one all-time popularity ranking on the primary event, field popRank (:250-256)
+    engine["algorithms"][0]["params"].pop("rankings")
+    ap2 = URAlgorithmParams.from_engine_json(engine)
+    ap2.seed = 3
+    algo2 = URAlgorithm(ap2, library=lib, eventStore=events, sess=sess)
+    docs2 = {x["id"]: x for x in algo2.calcAll(pd, now_ms=now + 1).documents()}
+    assert {i: x["popRank"] for i, x in docs2.items() if "popRank" in x} == PO.pop_calc("popular", events, ["show"], 3650 * 86400, now + 1)
+    ap2.recsModel = "collabFiltering"
+    docs3 = {x["id"]: x for x in URAlgorithm(ap2, library=lib, eventStore=events, sess=sess).train(pd).documents()}
+    assert not any("popRank" in x for x in docs3.values()) and "product-9" not in docs3
+    # Some(Seq()) event names = every event name (PopModel.scala:194)
+    from universal_recommender_amd.pop_model import PopModel
+    pm = PopModel(events, {}, sess)
+    assert pm.calc("popular", [], 3650 * 86400, now + 1) == PO.pop_calc("popular", events, [], 3650 * 86400, now + 1) == \
+        PO.pop_calc("popular", events, ["show", "like"], 3650 * 86400, now + 1)
+
+
+def test_calc_all_with_ranks_on_the_simulator(sim_session, sim_lib):
+    calc_all_with_ranks_case(sim_session, sim_lib)
+
+
+@pytest.mark.gpu
+def test_calc_all_with_ranks_on_gpu(gpu_session):
+    from universal_recommender_amd import _lib
+    calc_all_with_ranks_case(gpu_session, _lib.load(_lib.DEFAULT_PATH))

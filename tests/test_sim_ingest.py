@@ -145,7 +145,7 @@ def test_events_to_model_without_leaving_the_device(sim_session, sim_lib):
                     model.setdefault(item, {}).update(m)
             return model
         on_device = algo.train_events_on_device(td, sim_session)
-        via_host = algo.train(Preparator().prepare(td))
+        via_host = algo.train(Preparator().prepare(td)).coocurrenceMatrices
         assert docs(on_device) == docs(via_host)
         for (_, a), (_, b) in zip(on_device, via_host):
             assert np.array_equal(a.row_ptr, b.row_ptr) and np.array_equal(a.col_idx, b.col_idx) and np.array_equal(a.values, b.values)
@@ -232,3 +232,15 @@ def test_native_string_hash_known_answers_and_collision_check(sim_session, sim_l
     uk_bad[np.asarray(users) == "u1"] = uk[users.index("u2")]
     with pytest.raises(ingest.HashCollision):
         ingest.prepare_device(sim_session, [("buy", t(uk_bad), t(ik), t(uc), t(ic))], 1)
+    # a SECONDARY event type whose user "v9" shares its 64-bit key with the primary's "u2" (different strings, different check
+    # keys): merged into u2 silently before; detected through the check keys of the primary's first occurrences now
+    users2 = [f"u{i % 5}" for i in range(20)] + ["v9"] * 3
+    items2 = [f"j{i % 4}" for i in range(23)]
+    uk2, ik2 = hash_keys(users2, 0, sim_lib), hash_keys(items2, 0, sim_lib)
+    uc2, ic2 = hash_keys(users2, CHECK_SEED, sim_lib), hash_keys(items2, CHECK_SEED, sim_lib)
+    good = ingest.prepare_device(sim_session, [("buy", t(uk), t(ik), t(uc), t(ic)), ("view", t(uk2), t(ik2), t(uc2), t(ic2))], 1)
+    assert good.events[1].matrix.n_cols == 4
+    uk2_bad = uk2.copy()
+    uk2_bad[np.asarray(users2) == "v9"] = uk[users.index("u2")]
+    with pytest.raises(ingest.HashCollision):
+        ingest.prepare_device(sim_session, [("buy", t(uk), t(ik), t(uc), t(ic)), ("view", t(uk2_bad), t(ik2), t(uc2), t(ic2))], 1)

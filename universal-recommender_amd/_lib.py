@@ -136,6 +136,7 @@ SYMBOLS = {
     "urcco_dev_dictionary_build": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int32, _p, C.POINTER(_p), C.POINTER(C.c_int64)]),
     "urcco_dev_dictionary_lookup": (C.c_int, [_p, _p, C.c_int64, _p, _p, _p]),
     "urcco_dev_dictionary_verify": (C.c_int, [_p, _p, C.c_int64, _p, _p, _p, _p, C.POINTER(C.c_int64)]),
+    "urcco_dev_dictionary_verify_against": (C.c_int, [_p, _p, C.c_int64, _p, _p, _p, _p, _p, C.POINTER(C.c_int64)]),
     "urcco_hash_strings": (C.c_int, [_p, _p, C.c_int64, C.c_uint64, _p]),
     "urcco_key_table_destroy": (None, [_p]),
     "urcco_dev_csr_from_pairs": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int64, _p, _p, C.POINTER(C.c_int64)]),

@@ -107,7 +107,7 @@ hipError_t launch_dictionary_build(hipStream_t st, int n_cu, KeyTable t, int64_t
 hipError_t launch_dictionary_lookup(hipStream_t st, int n_cu, KeyTable t, int64_t n, const unsigned long long* keys, const int32_t* select,
                                     int32_t* ids);
 hipError_t launch_dictionary_verify(hipStream_t st, int n_cu, KeyTable t, int64_t n, const unsigned long long* keys, const int32_t* select,
-                                    const unsigned long long* check, const int64_t* first_pos, unsigned long long* err);
+                                    const unsigned long long* check, const unsigned long long* ref_check, const int64_t* first_pos, unsigned long long* err);
 // cnt: int32[n_rows] scratch, raw_ptr: int64[n_rows + 1] scratch, tmp: int32[n] scratch
 hipError_t launch_csr_from_pairs(hipStream_t st, int n_cu, int64_t n, const int32_t* rows, const int32_t* cols, int64_t n_rows, int32_t* cnt,
                                  int64_t* raw_ptr, int32_t* tmp, int64_t* tile_sums, int64_t* out_row_ptr, int32_t* out_col_idx);

@@ -120,8 +120,8 @@ hipError_t launch_dictionary_build(hipStream_t st, int n_cu, KeyTable t, int64_t
 // collision check: the check key (a second, independent hash of the same string) of every position must equal the check key
 // of its id's first occurrence; err[0] counts the positions where it does not
 __global__ __launch_bounds__(256) void ig_verify_kernel(KeyTable t, int64_t n, const unsigned long long* __restrict__ keys, const int32_t* __restrict__ select,
-                                                        const unsigned long long* __restrict__ check, const int64_t* __restrict__ first_pos,
-                                                        unsigned long long* __restrict__ err) {
+                                                        const unsigned long long* __restrict__ check, const unsigned long long* __restrict__ ref_check,
+                                                        const int64_t* __restrict__ first_pos, unsigned long long* __restrict__ err) {
   unsigned bad = 0;
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n; p += (int64_t)gridDim.x * 256) {
     if (select && select[p] < 0) continue;
@@ -129,15 +129,15 @@ __global__ __launch_bounds__(256) void ig_verify_kernel(KeyTable t, int64_t n, c
     const unsigned long long slot = ig_find(t, key);
     if (t.keys[slot] != key) continue;
     const int32_t id = t.id[slot];
-    if (id >= 0 && check[p] != check[first_pos[id]]) ++bad;
+    if (id >= 0 && check[p] != ref_check[first_pos[id]]) ++bad;  // ref_check: check keys of the stream the dictionary was built from
   }
   if (bad) atomicAdd(err, (unsigned long long)bad);
 }
 hipError_t launch_dictionary_verify(hipStream_t st, int n_cu, KeyTable t, int64_t n, const unsigned long long* keys, const int32_t* select,
-                                    const unsigned long long* check, const int64_t* first_pos, unsigned long long* err) {
+                                    const unsigned long long* check, const unsigned long long* ref_check, const int64_t* first_pos, unsigned long long* err) {
   hipError_t e = hipMemsetAsync(err, 0, sizeof(unsigned long long), st);
   if (e != hipSuccess || n == 0) return e;
-  hipLaunchKernelGGL(ig_verify_kernel, dim3(ig_grid(n, n_cu)), dim3(256), 0, st, t, n, keys, select, check, first_pos, err);
+  hipLaunchKernelGGL(ig_verify_kernel, dim3(ig_grid(n, n_cu)), dim3(256), 0, st, t, n, keys, select, check, ref_check, first_pos, err);
   return hipGetLastError();
 }
 

@@ -408,18 +408,25 @@ int urcco_dev_dictionary_lookup(urcco_session* s, const urcco_key_table* table, 
   return URCCO_OK;
 }
 
-int urcco_dev_dictionary_verify(urcco_session* s, const urcco_key_table* table, int64_t n, const uint64_t* keys, const int32_t* select,
-                                const uint64_t* check_keys, const int64_t* first_pos, int64_t* n_mismatch) {
-  if (!s || !table || n < 0 || !n_mismatch || (n > 0 && (!keys || !check_keys || !first_pos))) return fail(URCCO_BAD_ARG, "urcco_dev_dictionary_verify: bad argument");
+int urcco_dev_dictionary_verify_against(urcco_session* s, const urcco_key_table* table, int64_t n, const uint64_t* keys, const int32_t* select,
+                                        const uint64_t* check_keys, const uint64_t* dict_check_keys, const int64_t* first_pos, int64_t* n_mismatch) {
+  if (!s || !table || n < 0 || !n_mismatch || (n > 0 && (!keys || !check_keys || !dict_check_keys || !first_pos)))
+    return fail(URCCO_BAD_ARG, "urcco_dev_dictionary_verify: bad argument");
   URC(s->reserve(urcco_session::need(1, 8)));
   unsigned long long* err = s->take<unsigned long long>(1);
   HIPC(urcco::launch_dictionary_verify(s->stream, s->n_cu, table->t, n, reinterpret_cast<const unsigned long long*>(keys), select,
-                                       reinterpret_cast<const unsigned long long*>(check_keys), first_pos, err));
+                                       reinterpret_cast<const unsigned long long*>(check_keys), reinterpret_cast<const unsigned long long*>(dict_check_keys),
+                                       first_pos, err));
   unsigned long long bad = 0;
   HIPC(hipMemcpyAsync(&bad, err, sizeof(bad), hipMemcpyDeviceToHost, s->stream));
   HIPC(hipStreamSynchronize(s->stream));
   *n_mismatch = (int64_t)bad;
   return URCCO_OK;
+}
+
+int urcco_dev_dictionary_verify(urcco_session* s, const urcco_key_table* table, int64_t n, const uint64_t* keys, const int32_t* select,
+                                const uint64_t* check_keys, const int64_t* first_pos, int64_t* n_mismatch) {
+  return urcco_dev_dictionary_verify_against(s, table, n, keys, select, check_keys, check_keys, first_pos, n_mismatch);
 }
 
 int urcco_dev_csr_from_pairs(urcco_session* s, int64_t n, const int32_t* rows, const int32_t* cols, int64_t n_rows, int64_t* out_row_ptr,

@@ -72,6 +72,15 @@ def dictionary_verify(sess: DeviceSession, d: DevDictionary, keys: torch.Tensor,
     return int(bad.value)
 
 
+def dictionary_verify_against(sess: DeviceSession, d: DevDictionary, keys: torch.Tensor, check_keys: torch.Tensor, dict_check_keys: torch.Tensor) -> int:
+    """dictionary_verify for another stream looked up in `d`: its check keys against the check keys of the ids' first occurrences
+    in the stream the dictionary was built from."""
+    bad = C.c_int64()
+    sess._check(sess.lib.urcco_dev_dictionary_verify_against(sess.handle, d.handle, keys.numel(), _ptr(keys), None, _ptr(check_keys), _ptr(dict_check_keys),
+                                                             _ptr(d.first_pos) if d.n_ids else _ptr(sess.empty(1, torch.int64)), C.byref(bad)))
+    return int(bad.value)
+
+
 def csr_from_pairs(sess: DeviceSession, rows: torch.Tensor, cols: torch.Tensor, n_rows: int, n_cols: int) -> DevCsr:
     n = rows.numel()
     out_rp = sess.empty(n_rows + 1, torch.int64)
@@ -114,6 +123,8 @@ def prepare_device(sess: DeviceSession, actions: Sequence[Tuple[str, torch.Tenso
             name, uk, ik = act[0], act[1], act[2]
             if uk.numel() != ik.numel():
                 raise ValueError(f"event type {name}: user and item key streams differ in length")
+            if act is not actions[0] and len(act) >= 5 and len(actions[0]) >= 5 and dictionary_verify_against(sess, users, uk, act[3], actions[0][3]):
+                raise HashCollision(f"event type {name}: a user id shares its 64-bit key with a different user id of the primary event type")
             rows = dictionary_lookup(sess, users, uk)                      # -1: user not in the dictionary -> event dropped
             items = dictionary_build(sess, ik, rows, 1)                     # column ids over the surviving events only
             try:

@@ -62,8 +62,8 @@ class PopModel:
         n_items = self.itemIDs.size
         if n_items == 0:
             return np.zeros((n_int, 0), np.int32)
-        wanted = set(event_names)
-        sel = np.fromiter((n in wanted for n in self.names), bool, count=len(self.names))
+        wanted = set(event_names)   # empty = every event name (PopModel.scala:194: `if (eventNames.nonEmpty) Some(eventNames) else None`)
+        sel = np.fromiter((not wanted or n in wanted for n in self.names), bool, count=len(self.names))
         ids = np.where(sel, self._ids, -1).astype(np.int32)
         dev = self.sess.device
         d_ids = torch.from_numpy(ids).to(dev) if ids.size else torch.zeros(1, dtype=torch.int32, device=dev)
@@ -76,7 +76,11 @@ class PopModel:
 
     def calc(self, modelName: str, eventNames: Sequence[str], duration: int = 0, end_ms: Optional[int] = None,
              now_ms: Optional[int] = None, seed: int = 0) -> Dict[str, float]:
-        """PopModel.calc :59-97.  duration in seconds; end_ms = parsed offsetDate (None = now_ms)."""
+        """PopModel.calc :59-97.  duration in seconds; end_ms = parsed offsetDate (None = now_ms, None = the wall clock: the
+        reference's `DateTime.now` :66-74)."""
+        if end_ms is None and now_ms is None:
+            import time
+            now_ms = int(time.time() * 1000)
         end = int(end_ms if end_ms is not None else now_ms)
         start = end - int(duration) * 1000
         inv = self.itemIDs.inverse
@@ -112,7 +116,7 @@ def getRanks(rankings: Sequence[dict], popModel: PopModel, modelEventNames: Sequ
     for r in rankings:
         rtype = r.get("type") or RankingType.Popular
         field = r.get("name") or nameByType.get(rtype, RankingFieldName.UnknownRank)
-        names = r.get("eventNames") or list(modelEventNames[:1])
+        names = r["eventNames"] if r.get("eventNames") is not None else list(modelEventNames[:1])   # Option.getOrElse: Some(Seq()) stays empty = all events
         ranks = popModel.calc(rtype, names, int(r.get("duration_s", 3650 * 86400)), r.get("end_ms"), now_ms)
         for item, v in ranks.items():
             out.setdefault(item, {})[field] = v

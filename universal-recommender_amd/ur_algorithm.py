@@ -1,8 +1,9 @@
 """Host-side mirror of the train side of URAlgorithm (reference src/main/scala/URAlgorithm.scala:142-171 params,
 :195-247 defaults, :292-369 train/calcAll) and of IndexedDatasetConversions.toStringMapRDD (package.scala:82-110).
 
-Only the CCO model build is in scope: calcAll returns the per-event indicator matrices (what the reference hands to
-URModel.save); PopModel ranks, Elasticsearch and the query side are out of scope."""
+calcAll builds what the reference hands to URModel.save: the per-event indicator matrices (the CCO build on the GPU) and --
+`calcPopular` -- the item properties joined with the PopModel ranks (getRanksRDD :537-560, device interval histogram behind
+pop_model.py).  Elasticsearch and the query side are out of scope."""
 from __future__ import annotations
 
 import time
@@ -19,6 +20,50 @@ class DefaultURAlgoParams:
     MaxEventsPerEventType = 500
     MaxCorrelatorsPerEventType = 50
     RecsModel = "all"
+    BackfillFieldName = "popRank"      # RankingFieldName.PopRank :64
+    BackfillType = "popular"           # RankingType.Popular :65
+    BackfillDuration = "3650 days"     # :66
+
+
+@dataclass
+class RankingParams:
+    """URAlgorithm.scala:110-117."""
+    name: Optional[str] = None
+    type: Optional[str] = None
+    eventNames: Optional[List[str]] = None
+    offsetDate: Optional[str] = None
+    endDate: Optional[str] = None
+    duration: Optional[str] = None
+
+
+_DURATION_UNITS = {"d": 86400, "day": 86400, "days": 86400, "h": 3600, "hour": 3600, "hours": 3600, "min": 60, "minute": 60, "minutes": 60,
+                   "s": 1, "sec": 1, "second": 1, "seconds": 1}
+
+
+def duration_seconds(text: str) -> int:
+    """scala.concurrent.duration.Duration("3650 days").toSeconds.toInt (URAlgorithm.scala:542-543) for the units engine.json
+    files use."""
+    parts = text.strip().split()
+    if len(parts) == 1:     # "90days"
+        num = parts[0].rstrip("abcdefghijklmnopqrstuvwxyz")
+        parts = [num, parts[0][len(num):]]
+    if len(parts) != 2 or parts[1].lower() not in _DURATION_UNITS:
+        raise ValueError(f"bad duration {text!r}")
+    return int(float(parts[0]) * _DURATION_UNITS[parts[1].lower()])
+
+
+def _iso_ms(text: Optional[str]) -> Optional[int]:
+    """ISODateTimeFormat.dateTimeParser (PopModel.scala:66-74); a bad date falls back to `now` there: None here."""
+    if not text:
+        return None
+    from datetime import datetime, timezone
+    try:
+        d = datetime.fromisoformat(text.replace("Z", "+00:00"))
+    except ValueError:
+        return None
+    if d.tzinfo is None:
+        d = d.replace(tzinfo=timezone.utc)
+    return int(d.timestamp() * 1000)
 
 
 @dataclass
@@ -42,6 +87,9 @@ class URAlgorithmParams:
     maxCorrelatorsPerEventType: Optional[int] = None
     indicators: Optional[List[IndicatorParams]] = None
     seed: Optional[int] = None
+    rankings: Optional[List[RankingParams]] = None      # :159
+    numGPUs: Optional[int] = None      # additive key: GPUs of the node the CCO build may use; absent = 1, 0 = every visible one
+    ccoBackend: Optional[str] = None   # additive key: "hip" (default) or "mahout" (the host falls back to the reference path: not available here)
 
     @staticmethod
     def from_engine_json(engine: dict, name: str = "ur") -> "URAlgorithmParams":
@@ -50,7 +98,11 @@ class URAlgorithmParams:
             raise ValueError(f"no algorithm named {name!r} in engine.json")
         p = algos[0]["params"]
         inds = p.get("indicators")
+        rk = p.get("rankings")
         return URAlgorithmParams(
+            rankings=None if rk is None else [RankingParams(r.get("name"), r.get("type"), r.get("eventNames"), r.get("offsetDate"), r.get("endDate"),
+                                                            r.get("duration")) for r in rk],
+            numGPUs=p.get("numGPUs"), ccoBackend=p.get("ccoBackend"),
             appName=p.get("appName", ""), indexName=p.get("indexName", ""), typeName=p.get("typeName", ""),
             recsModel=p.get("recsModel"), eventNames=p.get("eventNames"),
             maxEventsPerEventType=p.get("maxEventsPerEventType"), maxCorrelatorsPerEventType=p.get("maxCorrelatorsPerEventType"),
@@ -66,26 +118,75 @@ def _get_or_else(v, default):
 
 
 class URAlgorithm:
-    def __init__(self, ap: URAlgorithmParams, device: int = 0, library=None):
+    def __init__(self, ap: URAlgorithmParams, device: int = 0, library=None, eventStore=None, sess=None):
+        """eventStore: the timed event stream PopModel reads from PEventStore in the reference -- (event name, target item id or
+        None, time in ms) in stream order; None = no events (every ranking is empty).  sess: DeviceSession for the PopModel
+        histograms (created on `device` when needed)."""
         self.ap = ap
         self.device = device
         self.library = library
+        self.eventStore = eventStore
+        self.sess = sess
         self.recsModel = ap.recsModel or DefaultURAlgoParams.RecsModel
         if not ap.eventNames and not ap.indicators:                                            # :224-226
             raise ValueError("Must have either \"eventNames\" or \"indicators\" in algorithm parameters.")
         self.modelEventNames = [i.name for i in ap.indicators] if ap.indicators else list(ap.eventNames)  # :230-234
+        if ap.ccoBackend not in (None, "hip"):
+            raise ValueError(f"ccoBackend={ap.ccoBackend!r}: only the HIP backend exists in this package (\"mahout\" is the reference's own path)")
+        if ap.numGPUs is not None and ap.numGPUs < 0:
+            raise ValueError("numGPUs must be >= 0 (0 = every visible GPU)")
+        self.numGPUs = 1 if ap.numGPUs is None else int(ap.numGPUs)
 
-    def train(self, data: PreparedData) -> List[Tuple[str, IndexedDataset]]:
-        """URAlgorithm.train :292-307 (the model is returned instead of being written to Elasticsearch)."""
-        if self.recsModel in ("all", "collabFiltering"):
+    @property
+    def rankingsParams(self) -> List[RankingParams]:
+        """:250-256: the default is one all-time popularity ranking on the primary event; one entry per ranking type."""
+        rk = self.ap.rankings if self.ap.rankings is not None else [RankingParams(
+            DefaultURAlgoParams.BackfillFieldName, DefaultURAlgoParams.BackfillType, self.modelEventNames[:1], None, None, DefaultURAlgoParams.BackfillDuration)]
+        by_type: Dict[Optional[str], RankingParams] = {}
+        for r in rk:
+            by_type.setdefault(r.type, r)                                                       # groupBy(_.`type`).map(_._2.head)
+        return list(by_type.values())
+
+    def train(self, data: PreparedData):
+        """URAlgorithm.train :292-307 (the URModel is returned instead of being written to Elasticsearch)."""
+        if self.recsModel == "all":
             return self.calcAll(data)
+        if self.recsModel == "collabFiltering":
+            return self.calcAll(data, calcPopular=False)                                         # :296
         if self.recsModel == "backfill":
-            raise NotImplementedError("recsModel=backfill is the popularity-only retrain (PopModel): out of scope of the CCO path")
+            raise NotImplementedError("recsModel=backfill re-ranks an EXISTING Elasticsearch index (calcPop :371-391 reads it back): needs ES, out of scope")
         raise ValueError(f"Bad algorithm param recsModel=[{self.recsModel}] in engine definition params, possibly a bad json value. "
                          "Use one of the available parameter values (all, collabFiltering, backfill).")  # :299-303
 
-    def calcAll(self, data: PreparedData) -> List[Tuple[str, IndexedDataset]]:
-        """URAlgorithm.calcAll :310-349: picks the call form, hands the matrices to the CCO build, zips names back."""
+    def getRanks(self, fields: Dict[str, dict], now_ms: Optional[int] = None) -> Dict[str, Dict[str, float]]:
+        """URAlgorithm.getRanksRDD :537-560 over the event store handed to the constructor."""
+        from .pop_model import PopModel, getRanks
+        if not self.eventStore:
+            return {}
+        if self.sess is None:
+            import torch
+            from .device import DeviceSession
+            from . import _lib
+            lib = self.library if self.library is not None else _lib.lib()
+            self.sess = DeviceSession(torch.device("cuda", self.device) if torch.cuda.is_available() else torch.device("cpu"), lib)
+        now_ms = int(time.time() * 1000) if now_ms is None else now_ms
+        rankings = [{"name": r.name, "type": r.type, "eventNames": r.eventNames,
+                     "duration_s": duration_seconds(r.duration if r.duration is not None else DefaultURAlgoParams.BackfillDuration),
+                     "end_ms": _iso_ms(r.offsetDate)} for r in self.rankingsParams]
+        return getRanks(rankings, PopModel(self.eventStore, fields, self.sess), self.modelEventNames, now_ms)
+
+    def calcAll(self, data: PreparedData, calcPopular: bool = True, now_ms: Optional[int] = None):
+        """URAlgorithm.calcAll :310-369: picks the call form, hands the matrices to the CCO build, zips the names back (:349),
+        joins the item properties with the PopModel ranks (:351-358) and returns URModel(correlators, Seq(properties)) -- the
+        object the reference calls .save on (:364-367)."""
+        from .pop_model import propertiesWithRanks
+        from .ur_model import URModel
+        correlators = self.correlators(data)
+        properties = propertiesWithRanks(data.fields, self.getRanks(data.fields, now_ms)) if calcPopular else {}   # :351-361
+        return URModel(correlators, [properties])
+
+    def correlators(self, data: PreparedData) -> List[Tuple[str, IndexedDataset]]:
+        """The CCO half of calcAll (:321-349)."""
         ap = self.ap
         seed = ap.seed if ap.seed is not None else int(time.time() * 1000)                      # :240,:325 (default = wall clock)
         ids = [d for _, d in data.actions]
@@ -94,7 +195,7 @@ class URAlgorithm:
                 ids, randomSeed=seed,
                 maxInterestingItemsPerThing=_get_or_else(ap.maxCorrelatorsPerEventType, DefaultURAlgoParams.MaxCorrelatorsPerEventType),
                 maxNumInteractions=_get_or_else(ap.maxEventsPerEventType, DefaultURAlgoParams.MaxEventsPerEventType),
-                device=self.device, library=self.library)
+                device=self.device, library=self.library, numGPUs=self.numGPUs)
         else:
             if len(ap.indicators) < len(ids):
                 raise IndexError("indicators(i) is matched to the event matrices by position (URAlgorithm.scala:334-340)")
@@ -103,7 +204,7 @@ class URAlgorithm:
                 _get_or_else(ap.indicators[i].maxItemsPerUser, DefaultURAlgoParams.MaxEventsPerEventType),
                 _get_or_else(ap.indicators[i].maxCorrelatorsPerItem, DefaultURAlgoParams.MaxCorrelatorsPerEventType),
                 ap.indicators[i].minLLR) for i, iD in enumerate(ids)]
-            res = SimilarityAnalysis.crossOccurrenceDownsampled(datasets, seed, device=self.device, library=self.library)
+            res = SimilarityAnalysis.crossOccurrenceDownsampled(datasets, seed, device=self.device, library=self.library, numGPUs=self.numGPUs)
         return list(zip([n for n, _ in data.actions], res))                                    # :349
 
 
@@ -116,7 +217,7 @@ class URAlgorithm:
         from .preparator import Preparator
         from .similarity_analysis import _seed_to_int
         if self.recsModel not in ("all", "collabFiltering"):
-            return self.train(Preparator().prepare(trainingData))
+            return self.train(Preparator().prepare(trainingData)).coocurrenceMatrices
         ap = self.ap
         pd, dp = Preparator().prepare_on_device(trainingData, sess, keep_on_device=True)
         seed = ap.seed if ap.seed is not None else int(time.time() * 1000)
