@@ -15,21 +15,30 @@ from universal_recommender_amd import _lib, synth  # noqa: E402
 from universal_recommender_amd.device import DevCsr, DeviceSession  # noqa: E402
 
 sim = "--sim" in sys.argv
-argv = [a for a in sys.argv[1:] if a != "--sim"]
+hbm = "--hbm" in sys.argv     # one matrix far beyond the Infinity Cache: config 3's `view` generator with 8M users (what bench.py's csr_row_scan_hbm_resident runs)
+c4 = "--config4" in sys.argv  # the five matrices of BASELINE config 4, generated on the device
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 scale = float(argv[0]) if len(argv) > 0 else 1.0
 flags = [int(x) for x in argv[1].split(",")] if len(argv) > 1 else [0, 32, 64, 128, 224]
 reps = 2 if sim else 10
 dev = torch.device("cpu") if sim else torch.device("cuda", 0)
-cfg = synth.config3(scale)
-data = synth.generate(cfg)
-mats = [DevCsr(cfg.n_users, nc, torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), int(rp[-1])) for (_, nc, rp, ci) in data]
+if hbm or c4:
+    cfg = synth.config4(scale) if c4 else synth.config3(1.0)
+    if hbm:
+        cfg.n_users = int(8_000_000 * scale)
+        cfg.events = [cfg.events[1]]
+    mats = [DevCsr(cfg.n_users, nc, rp, ci, int(rp[-1].item())) for (_, nc, rp, ci) in synth.generate_device(cfg, dev)]
+else:
+    cfg = synth.config3(scale)
+    data = synth.generate(cfg)
+    mats = [DevCsr(cfg.n_users, nc, torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), int(rp[-1])) for (_, nc, rp, ci) in data]
 if sim:
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from hostsim import build_sim
     sess = DeviceSession(dev, _lib.load(build_sim.build()))
     sync = lambda: None
 else:
-    sess = DeviceSession(dev, _lib.load(_lib.DEFAULT_PATH))
+    sess = DeviceSession(dev, _lib.load(os.environ.get("URCCO_LIB", _lib.DEFAULT_PATH)))
     sync = torch.cuda.synchronize
 raws = [sess.column_counts(m.col_idx, m.nnz_bound, m.n_cols) for m in mats]
 for f in flags:

@@ -70,7 +70,7 @@ hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_i
 // scans: out[i] = sum_{t<i} in[t], out[n] = total.  tile_sums scratch: ceil(n / SCAN_TILE) + 1 int64.
 hipError_t launch_scan_i32(hipStream_t st, const int32_t* in, int64_t n, int64_t* out, int64_t* tile_sums);
 
-// CSR row scan.  Scratch: thresholds [n_cols] u64, tile_rows [tiles + 1] i64, flags [tiles * DS_TILE / 64] u64,
+// CSR row scan.  Scratch: thresholds [n_cols + n_cols / 8 + 2] u64 (the 8-byte thresholds, then their one-byte prefixes), tile_rows [tiles + 1] i64, flags [tiles * DS_TILE / 64] u64,
 // tile_count [tiles + 1] i64 (exclusive offsets after launch_downsample_scan), tiles = ceil(nnz / DS_TILE)
 hipError_t launch_downsample_flags(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
                                    int32_t n_cols, const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n,

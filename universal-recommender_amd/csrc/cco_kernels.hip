@@ -556,11 +556,11 @@ hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_i
 // ============================================================================================
 constexpr int DS_THREADS = 256;
 constexpr int DS_ITERS = DS_TILE / (DS_THREADS * 4);  // 4
-constexpr int DS_SLICE = DS_TILE + 2;                 // row_ptr entries staged per tile
 constexpr int DS_WORDS = DS_TILE / 64;
 static_assert(DS_WORDS == WAVE, "one wave scans the keep words of a tile");
 static_assert((DS_TILE & (DS_TILE - 1)) == 0, "tile index by shift");
 
+constexpr int THR8_SHIFT = 45;  // one-byte threshold prefix = bits 45..52 of the 53-bit threshold (see sample_threshold_kernel)
 constexpr unsigned long long RATE_ONE = 1ull << 53;  // threshold of a sample rate of 1.0 (every 53-bit hash passes)
 
 // first idx in [lo, hi] with rp[idx] > e   (rp[hi] > e guaranteed by the caller)
@@ -585,25 +585,42 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(int64_t n_rows, const in
 }
 
 // Each thread owns two runs of EIGHT consecutive entries (two 16-byte loads each): a run's keep bits are one byte of the
-// tile's keep words, written straight from the lane -- no cross-lane assembly -- and one entry -> row search serves eight
-// entries.  Index arithmetic inside the tile is 32-bit.  The eight threshold gathers of a run are issued before the row
-// walk; the hashes are evaluated four at a time (independent multiply chains).
+// tile's keep words, written straight from the lane -- no cross-lane assembly.
+//
+// entry -> row without a search and without a divergent walk (round 3; the round-2 kernel spent 40 scalar and 51 vector
+// instructions per entry slot -- a per-run binary search over the LDS row_ptr slice, then `while (entry >= row end)` per
+// entry, each `if` a handful of exec-mask instructions -- where the keep decision itself, the 64-bit hash, is 19): the
+// tile's NON-EMPTY rows mark their start position in a 4096-bit LDS mask and leave their slice index at s_row_at[start]
+// (one writer per position: empty rows own no entry).  One wave turns the mask into "last row starting before word w"
+// (a prefix maximum: row indices grow with the position).  A run then reads its byte of the mask, the eight s_row_at
+// words behind it (two 16-byte LDS reads) and selects, entry by entry, "the row that starts here, else the row so far":
+// three vector instructions per entry, no branch.  Rows longer than the interaction cap (perRowSampleRate != 1) are
+// rare: the tile notes whether it holds one and only then looks the row lengths up.  The row_ptr slice is read from
+// global memory (coalesced, twice: as a start and as the previous row's end), so a tile with any number of empty rows
+// needs no staging.
 // `debug` (profiling only, results meaningless): 32 = cheap hash, 64 = no threshold gather, 128 = no row lookup
 constexpr int DS_RUN = 8;
 constexpr int DS_RUNS = DS_TILE / (DS_THREADS * DS_RUN);  // 2
+template <bool DEBUG>
 __global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_rows, const int64_t* __restrict__ rp,
                                                                       const int32_t* __restrict__ ci, int64_t nnz,
                                                                       const int64_t* __restrict__ g,
-                                                                      const unsigned long long* __restrict__ thresholds, uint32_t seed,
+                                                                      const unsigned long long* __restrict__ thresholds,
+                                                                      const unsigned char* __restrict__ thr8, uint32_t seed,
                                                                       int32_t max_n, int row_rate_mode, int64_t row_base,
                                                                       unsigned long long* __restrict__ flags,
                                                                       int64_t* __restrict__ tile_count,
-                                                                      int32_t* __restrict__ post_counts, int vec_ok, int debug) {
-  __shared__ int s_rel[DS_SLICE];  // row_ptr slice of the tile, relative to the tile start (a row has < 2^31 entries)
+                                                                      int32_t* __restrict__ post_counts, int vec_ok, int debug_flags) {
+  const int debug = DEBUG ? debug_flags : 0;  // the ablation switches exist only in the profiling instantiation
+  __shared__ unsigned long long s_mask[DS_WORDS];  // bit p: a non-empty row starts at entry p of the tile
+  __shared__ int s_row_at[DS_TILE];                // [p] (only where the bit is set): slice index of that row
+  __shared__ int s_tbefore[DS_WORDS];              // slice index of the last row starting before word w (0: the row covering the tile start)
   __shared__ int s_cnt[DS_THREADS / WAVE];
+  __shared__ int s_long;                           // the tile holds a row with more than max_n entries
   const int64_t tile = blockIdx.x;
   const int64_t e0 = tile * DS_TILE;
   const int n_live = (int)((e0 + DS_TILE < nnz) ? DS_TILE : nnz - e0);  // entries of this tile
+  const int lane = threadIdx.x & (WAVE - 1);
   // all column loads of the thread are requested before anything else (independent of the row lookup)
   int cols[DS_RUNS][DS_RUN];
 #pragma unroll
@@ -619,6 +636,8 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_
       for (int q = 0; q < DS_RUN; ++q) cols[gq][q] = (el0 + q < n_live) ? ci[e + q] : 0;
     }
   }
+  if (threadIdx.x < DS_WORDS) s_mask[threadIdx.x] = 0ull;
+  if (threadIdx.x == 0) s_long = 0;
   // slice rp[r_s .. r_e]: r_s = the last row known to start at or before e0, r_e = the first row starting at or after e1
   const int64_t gp0 = g[tile];
   const int64_t g0 = gp0 >> 1, g1 = g[tile + 1] >> 1;
@@ -626,91 +645,92 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_
   const int64_t r_s = (gp0 & 1) ? g0 : g0 - 1;
   const int64_t r_e = g1 < n_rows ? g1 : n_rows;
   const int64_t n_slice = r_e - r_s + 1;
-  const bool in_lds = n_slice <= DS_SLICE;
-  if (in_lds)
-    for (int64_t t = threadIdx.x; t < n_slice; t += DS_THREADS) s_rel[t] = (int)(rp[r_s + t] - e0);
   __syncthreads();
-  const int lane = threadIdx.x & (WAVE - 1);
-  // slice-relative row of the first entry of each run = the last slice index whose start is <= the entry (empty rows in
-  // front of it are skipped by construction); the searches of a thread advance in lock step so that their LDS reads overlap
-  int rrel[DS_RUNS];
-#pragma unroll
-  for (int gq = 0; gq < DS_RUNS; ++gq) rrel[gq] = 0;
-  if (in_lds && !(debug & 128)) {
-    const int last = (int)n_slice - 1;  // s_rel[last] = rp[r_e] - e0 >= the tile length
-    int top = 1;
-    while (top < last) top <<= 1;
-    for (int sft = top >> 1; sft > 0; sft >>= 1) {
-#pragma unroll
-      for (int gq = 0; gq < DS_RUNS; ++gq) {
-        const int el0 = (gq * DS_THREADS + (int)threadIdx.x) * DS_RUN;
-        const int idx = rrel[gq] + sft;
-        if (idx < last && s_rel[idx] <= el0) rrel[gq] = idx;
+  if (!(debug & 128)) {
+    int any_long = 0;
+    for (int64_t t = threadIdx.x; t + 1 < n_slice; t += DS_THREADS) {  // rows r_s + t, t < n_slice - 1 (row r_e starts behind the tile)
+      const int64_t a = rp[r_s + t] - e0, b = rp[r_s + t + 1] - e0;
+      if (b > a) {  // non-empty: the one row that owns the entries from a on
+        if (a >= 0) {  // a < DS_TILE: only r_e may start at or behind the tile end
+          s_row_at[a] = (int)t;
+          atomicOr(&s_mask[a >> 6], 1ull << (a & 63));
+        }
+        any_long |= (b - a > (int64_t)max_n) ? 1 : 0;
       }
     }
+    if (any_long) s_long = 1;
   }
+  __syncthreads();
+  if (threadIdx.x < WAVE) {  // wave 0: slice index of the last row starting before each word (prefix maximum)
+    const unsigned long long m = s_mask[lane];
+    const int here = m ? s_row_at[lane * 64 + 63 - __clzll((long long)m)] : 0;
+    int inc = here;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const int o = __shfl_up(inc, d);
+      if (lane >= d) inc = o > inc ? o : inc;
+    }
+    const int ex = __shfl_up(inc, 1);
+    s_tbefore[lane] = lane == 0 ? 0 : ex;
+  }
+  __syncthreads();
+  const bool has_long = s_long != 0;
   const double dmax = (double)max_n;
   const uint32_t row0 = (uint32_t)(row_base + r_s);
   int kept = 0;
 #pragma unroll
   for (int gq = 0; gq < DS_RUNS; ++gq) {
-    const int el0 = (gq * DS_THREADS + (int)threadIdx.x) * DS_RUN;
+    const int run = gq * DS_THREADS + (int)threadIdx.x;
+    const int el0 = run * DS_RUN;
+    unsigned thr_col[DS_RUN];  // the eight one-byte threshold gathers of the run travel together, under its row lookup
+#pragma unroll
+    for (int q = 0; q < DS_RUN; ++q) thr_col[q] = (debug & 64) ? 255u : (unsigned)thr8[cols[gq][q]];
+    const int w = el0 >> 6, sh = el0 & 63;
+    const unsigned long long m = s_mask[w];
+    const unsigned starts = (unsigned)(m >> sh) & 0xffu;             // rows starting inside the run
+    const unsigned long long low = m & ((1ull << sh) - 1ull);        // ... and before it, in the same word
+    int t_cur = s_tbefore[w];
+    if (low) t_cur = s_row_at[w * 64 + 63 - __clzll((long long)low)];
+    const int4 ra = *reinterpret_cast<const int4*>(&s_row_at[el0]), rb = *reinterpret_cast<const int4*>(&s_row_at[el0 + 4]);
+    const int at[DS_RUN] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+    int r_of[DS_RUN];
+#pragma unroll
+    for (int q = 0; q < DS_RUN; ++q) {
+      t_cur = (starts >> q) & 1u ? at[q] : t_cur;
+      r_of[q] = t_cur;
+    }
+    // keep  <=>  hash <= perRow threshold  &&  hash <= perThing threshold: u01 = m * 2^-53 with integer m < 2^53, so
+    // u01 <= rate  <=>  m <= floor(rate * 2^53) (the scaling is exact); a rate of 1.0 (threshold 2^53) always passes
     unsigned keep_byte = 0;
-    if (el0 < n_live) {
-      unsigned long long thr_col[DS_RUN];  // the eight threshold gathers travel together
 #pragma unroll
-      for (int q = 0; q < DS_RUN; ++q) thr_col[q] = (debug & 64) ? RATE_ONE - 1 : thresholds[cols[gq][q]];
-      int r_rel, r_beg, r_end;  // slice-relative row of the current entry and its extent relative to e0
-      if (in_lds) {
-        r_rel = rrel[gq];
-        r_beg = s_rel[r_rel];
-        r_end = s_rel[r_rel + 1];
-      } else {
-        const int64_t r = upper_bound_i64(rp, r_s, r_e, e0 + el0) - 1;
-        r_rel = (int)(r - r_s);
-        r_beg = (int)(rp[r] - e0);
-        r_end = (int)(rp[r + 1] - e0);
-      }
-      int r_of[DS_RUN], n_of[DS_RUN];
-#pragma unroll
+    for (int q = 0; q < DS_RUN; ++q) {
+      const unsigned long long h = (debug & 32) ? ((unsigned long long)((unsigned)cols[gq][q] * 0x9E3779B1u) << 21) : hash53(seed, row0 + (uint32_t)r_of[q], (uint32_t)cols[gq][q]);
+      const unsigned h8 = (unsigned)(h >> THR8_SHIFT), b = thr_col[q];
+      bool keep = b == 255u || h8 < b;
+      if (b == 254u || (b < 254u && h8 == b)) keep = h <= thresholds[cols[gq][q]];  // 1 sampled interaction in 256: the full threshold
+      keep_byte |= (keep ? 1u : 0u) << q;
+    }
+    if (has_long) {  // block-uniform, rare: a user with more interactions than the cap sits in this tile
+#pragma unroll 1
       for (int q = 0; q < DS_RUN; ++q) {
-        if (el0 + q < n_live) {
-          while (el0 + q >= r_end && !(debug & 128)) {  // next non-empty row
-            ++r_rel;
-            r_beg = r_end;
-            r_end = in_lds ? s_rel[r_rel + 1] : (int)(rp[r_s + r_rel + 1] - e0);
-          }
-        }
-        r_of[q] = r_rel;
-        n_of[q] = r_end - r_beg;
-      }
-      // keep  <=>  hash <= perRow threshold  &&  hash <= perThing threshold: u01 = m * 2^-53 with integer m < 2^53, so
-      // u01 <= rate  <=>  m <= floor(rate * 2^53) (the scaling is exact); a rate of 1.0 (threshold 2^53) always passes
-#pragma unroll
-      for (int half = 0; half < DS_RUN; half += 4) {
-        unsigned long long h[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          h[q] = (debug & 32) ? ((unsigned long long)((unsigned)cols[gq][half + q] * 0x9E3779B1u) << 21)
-                              : hash53(seed, row0 + (uint32_t)r_of[half + q], (uint32_t)cols[gq][half + q]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int qq = half + q;
-          if (el0 + qq < n_live) {
-            bool keep = h[q] <= thr_col[qq];
-            if (n_of[qq] > max_n)  // rare: a user with more interactions than the cap (Int / Int = 0: only a hash of exactly 0 passes)
-              keep = keep && h[q] <= (row_rate_mode == 0 ? 0ull : (unsigned long long)((dmax / (double)n_of[qq]) * 9007199254740992.0));
-            if (keep) {
-              keep_byte |= 1u << qq;
-              if (post_counts) atomicAdd(&post_counts[cols[gq][qq]], 1);
-            }
-          }
+        const int64_t r = r_s + r_of[q];
+        const int64_t n_row = rp[r + 1] - rp[r];
+        if (n_row > (int64_t)max_n) {  // Int / Int = 0: only a hash of exactly 0 passes; fractional: min(max, n) / n
+          const unsigned long long thr_row = row_rate_mode == 0 ? 0ull : (unsigned long long)((dmax / (double)n_row) * 9007199254740992.0);
+          if (hash53(seed, row0 + (uint32_t)r_of[q], (uint32_t)cols[gq][q]) > thr_row) keep_byte &= ~(1u << q);
         }
       }
     }
+    const int live = n_live - el0;  // entries of the run inside the matrix (the last tile is ragged)
+    keep_byte &= live >= DS_RUN ? 0xffu : (live > 0 ? (1u << live) - 1u : 0u);
+    if (post_counts) {  // small matrices only: post-sampling column counts by L2 atomics
+#pragma unroll 1
+      for (int q = 0; q < DS_RUN; ++q)
+        if ((keep_byte >> q) & 1u) atomicAdd(&post_counts[cols[gq][q]], 1);
+    }
     kept += __popc(keep_byte);
     // byte b of keep word w covers entries 64 w + 8 b ..: this run's byte; runs behind the last entry are written as zero
-    reinterpret_cast<unsigned char*>(flags + tile * DS_WORDS)[gq * DS_THREADS + (int)threadIdx.x] = (unsigned char)keep_byte;
+    reinterpret_cast<unsigned char*>(flags + tile * DS_WORDS)[run] = (unsigned char)keep_byte;
   }
   for (int msk = 1; msk < WAVE; msk <<= 1) kept += __shfl_xor(kept, msk);
   if (lane == 0) s_cnt[threadIdx.x / WAVE] = kept;
@@ -782,14 +802,25 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_compact_kernel(int64_t 
   }
 }
 
-// perThingSampleRate = min(max, n) / n of sampleDownAndBinarize as the integer threshold floor(rate * 2^53)
+// perThingSampleRate = min(max, n) / n of sampleDownAndBinarize as the integer threshold floor(rate * 2^53), and its ONE-BYTE
+// prefix.  The scan gathers one threshold per interaction; an 8-byte table of a 2M-item catalogue is 16 MB -- four times an
+// XCD's L2 -- and the gather (its L2 misses, and the address processing of 64 scattered lines per wave instruction) was 70-80 %
+// of the flags kernel on the 10M x 2M configurations (profiles/r03_rowscan_ablation.log: 2.13 ms with, 0.42 ms without it).  The
+// byte table of the same catalogue is 2 MB; the top 8 bits of the 53-bit hash against the top 8 bits of the threshold decide all
+// but 1 in 256 sampled interactions, the rest compare in full:
+//   255   perThingSampleRate = 1.0: keep                     254   always compare in full (threshold prefix >= 254)
+//   b     hash >> 45 < b: keep   > b: drop   == b: compare in full
 __global__ __launch_bounds__(256) void sample_threshold_kernel(const int32_t* __restrict__ raw_counts, int32_t n_cols, int32_t max_n,
-                                                               unsigned long long* __restrict__ thresholds) {
+                                                               unsigned long long* __restrict__ thresholds, unsigned char* __restrict__ thr8) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= n_cols) return;
   const double n_thing = (double)raw_counts[j];
   const double dmax = (double)max_n;
-  thresholds[j] = n_thing <= dmax ? RATE_ONE : (unsigned long long)((dmax / n_thing) * 9007199254740992.0);
+  const bool one = n_thing <= dmax;
+  const unsigned long long thr = one ? RATE_ONE : (unsigned long long)((dmax / n_thing) * 9007199254740992.0);
+  thresholds[j] = thr;
+  const unsigned t8 = (unsigned)(thr >> THR8_SHIFT);
+  thr8[j] = (unsigned char)(one ? 255u : (t8 >= 254u ? 254u : t8));
 }
 
 hipError_t launch_downsample_flags(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
@@ -797,15 +828,20 @@ hipError_t launch_downsample_flags(hipStream_t st, int n_cu, int64_t n_rows, con
                                    int row_rate_mode, int64_t row_base, int64_t* tile_rows, unsigned long long* flags, int64_t* tile_count,
                                    int32_t* post_counts, int debug) {
   if (nnz == 0) return hipSuccess;
-  hipLaunchKernelGGL(sample_threshold_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, raw_counts, n_cols, max_n, thresholds);
+  unsigned char* thr8 = reinterpret_cast<unsigned char*>(thresholds + n_cols);  // the scratch holds n_cols u64 + n_cols bytes
+  hipLaunchKernelGGL(sample_threshold_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, raw_counts, n_cols, max_n, thresholds, thr8);
   const int64_t tiles = (nnz + DS_TILE - 1) / DS_TILE;
   int64_t rblocks = (n_rows + 1 + 255) / 256;
   const int64_t rcap = (int64_t)n_cu * 8;
   if (rblocks > rcap) rblocks = rcap;
   hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, n_rows, row_ptr, tiles, tile_rows);
   const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
-  hipLaunchKernelGGL(downsample_flags_kernel, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds,
-                     seed, max_n, row_rate_mode, row_base, flags, tile_count, post_counts, vec_ok, debug);
+  if (debug & (32 | 64 | 128))
+    hipLaunchKernelGGL(downsample_flags_kernel<true>, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds, thr8,
+                       seed, max_n, row_rate_mode, row_base, flags, tile_count, post_counts, vec_ok, debug);
+  else
+    hipLaunchKernelGGL(downsample_flags_kernel<false>, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds, thr8,
+                       seed, max_n, row_rate_mode, row_base, flags, tile_count, post_counts, vec_ok, 0);
   return hipGetLastError();
 }
 

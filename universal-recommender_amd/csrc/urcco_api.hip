@@ -142,9 +142,10 @@ int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_pt
   const int64_t ph_bytes = post_counts ? urcco::column_counts_scratch_bytes(nnz, n_cols) : 0;
   const int64_t ds_tiles = (nnz + urcco::DS_TILE - 1) / urcco::DS_TILE;
   const size_t n_words = (size_t)ds_tiles * (urcco::DS_TILE / 64);
-  URC(s->reserve(urcco_session::need((size_t)n_cols, 8) + urcco_session::need((size_t)ds_tiles + 1, 8) * 2 + urcco_session::need(n_words, 8) +
+  const size_t thr_words = (size_t)n_cols + (size_t)n_cols / 8 + 2;  // 8-byte thresholds + their one-byte prefixes
+  URC(s->reserve(urcco_session::need(thr_words, 8) + urcco_session::need((size_t)ds_tiles + 1, 8) * 2 + urcco_session::need(n_words, 8) +
                  (size_t)ph_bytes + 256));
-  unsigned long long* thresholds = s->take<unsigned long long>((size_t)n_cols);
+  unsigned long long* thresholds = s->take<unsigned long long>(thr_words);
   int64_t* tile_rows = s->take<int64_t>((size_t)ds_tiles + 1);
   int64_t* tile_count = s->take<int64_t>((size_t)ds_tiles + 1);
   unsigned long long* flags = s->take<unsigned long long>(n_words);
