@@ -187,6 +187,34 @@ def test_large_transpose_with_item_range(sim_session):
             assert np.array_equal(np.sort(ri[cp[j]:cp[j + 1]]), ri_ref[cp_ref[j]:cp_ref[j + 1]])
 
 
+def test_large_transpose_long_rows_and_empty_parts(sim_session):
+    """The two-level transposition's part table: rows longer than a part's quota (parts behind them are empty), a row beyond
+    the LDS staging capacity (that part scatters unstaged), runs of empty rows, a ragged last part; every column compared."""
+    rng = np.random.default_rng(14)
+    lengths = rng.poisson(19, 70000)
+    lengths[rng.random(70000) < 0.2] = 0
+    lengths[100] = 25_000          # > TR_CAP: unstaged scatter
+    lengths[101] = 17_000          # > TR_PART but staged
+    lengths[40_000:40_300] = 0
+    lengths[69_999] = 20_000       # the last part ends in a long row
+    m = _csr_from_lengths(rng, lengths, 50_000)
+    assert m.nnz >= (1 << 20)
+    dev = sim_session.device
+    d = to_dev(m, dev)
+    counts = torch.from_numpy(O.column_counts(m)).to(dev)
+    cp_ref, ri_ref = O.transpose(m)
+    for lo, hi in [(0, m.n_cols), (123, 45_678)]:
+        cp, ri = sim_session.transpose(d, counts, lo, hi)
+        sim_session.synchronize()
+        cp, ri = cp.cpu().numpy(), ri.cpu().numpy()
+        expect = np.diff(cp_ref).copy()
+        expect[:lo] = 0
+        expect[hi:] = 0
+        assert np.array_equal(np.diff(cp), expect)
+        for j in range(lo, hi):
+            assert np.array_equal(np.sort(ri[cp[j]:cp[j + 1]]), ri_ref[cp_ref[j]:cp_ref[j + 1]]), j
+
+
 def _csr_from_lengths(rng, lengths, n_cols):
     lengths = np.asarray(lengths, dtype=np.int64)
     rp = np.zeros(len(lengths) + 1, dtype=np.int64)

@@ -956,150 +956,180 @@ hipError_t launch_transpose(hipStream_t st, int n_cu, int64_t n_rows, const int6
 }
 
 // --------------------------------------------------------------------------------------------
-// K3b  CSR -> CSC as a counting sort by column (matrices large enough to repay the launches).
-// The cursor-atomic kernel above takes one RETURNING L2 atomic per entry (~25 G/s on this part, the whole of its
-// 0.24 ms on config 3).  Here the entries are grouped by column bucket (8192 columns, the partitioning of the
-// column-count histogram), counted per (histogram block, column) in LDS, prefixed across the blocks of a bucket, and
-// placed with LDS cursors -- every atomic is an LDS atomic, every pass streams, and a Zipf-head bucket is spread over as
-// many blocks as it has 32768-entry chunks (one block per BUCKET was measured at 0.55 ms: the head bucket serialised).
-//   count    per part of TR_ROWS user rows: entries per bucket        scan     bucket-major offsets
-//   scatter  (col & 8191, row) pairs grouped by bucket                blockmap buckets -> chunks of 32768 entries
-//   hist     per chunk: dense LDS counters -> partial[chunk][col]     prefix   per column, exclusive over its chunks
-//   place    per chunk: cursor[col] = col_ptr[col] - bucket start + prefix[chunk][col]; row ids to their slots
+// K3b  CSR -> CSC as a two-level counting sort by column (matrices large enough to repay the launches).
+// The cursor-atomic kernel above takes one RETURNING L2 atomic per entry (~25 G/s on this part).  Here:
+//   parts    row-aligned runs of ~TR_PART consecutive entries (part p starts at the first row at or behind entry p * TR_PART)
+//   count    per part: entries per column bucket (LDS atomics, lane-private copies)        scan   bucket-major offsets
+//   scatter  per part: (column in bucket, row) pairs grouped by bucket IN LDS, then written as whole runs -- with 245 buckets
+//            and 512-row parts the round-2 kernel scattered ~8-entry runs of 2- and 4-byte stores: 140 GB/s on config 4
+//   place    ONE block per bucket: the bucket's column cursors live in LDS (<= 8192 columns), its entries stream through once;
+//            the scattered 4-byte stores stay inside the bucket's CSC segment (a few hundred KB written by one CU: the L2 merges
+//            them) -- no per-chunk histograms, no prefix pass (round 2: blockmap + hist + prefix + place, 2 x 48 MB of partials)
+// The bucket width adapts to the catalogue so that there are ~256+ buckets (one per CU and more) whenever n_cols allows.
 // Only columns in [col_lo, col_hi) are kept (multi-GPU item range).  Order inside a column is arbitrary, as above.
 // --------------------------------------------------------------------------------------------
-constexpr int TR_ROWS = 512;  // user rows per part
+constexpr int TR_PART = 16384;
+constexpr int TR_CAP = TR_PART + 2048;  // staged entries per part; a part whose last row overshoots this scatters unstaged
+constexpr int TR_THREADS = 1024;
+constexpr int TR_COPIES = 8;
 
-__global__ __launch_bounds__(256) void tr_count_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, int g_log2,
-                                                       int n_buckets, int64_t n_parts, int32_t col_lo, int32_t col_hi,
-                                                       int32_t* __restrict__ part_counts) {
-  __shared__ int s_cnt[PH_MAX_BUCKETS];
-  for (int b = threadIdx.x; b < n_buckets; b += 256) s_cnt[b] = 0;
-  __syncthreads();
-  const int G = 1 << g_log2;
-  const int gl = threadIdx.x & (G - 1);
-  const int64_t r0 = (int64_t)blockIdx.x * TR_ROWS;
-  const int64_t r1 = r0 + TR_ROWS < n_rows ? r0 + TR_ROWS : n_rows;
-  for (int64_t r = r0 + (threadIdx.x >> g_log2); r < r1; r += 256 >> g_log2) {
-    const int64_t s = rp[r], e = rp[r + 1];
-    for (int64_t p = s + gl; p < e; p += G) {
-      const int j = ci[p];
-      if (j >= col_lo && j < col_hi) atomicAdd(&s_cnt[j >> PH_BITS], 1);
-    }
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < n_buckets; b += 256) part_counts[(int64_t)b * n_parts + blockIdx.x] = s_cnt[b];
+static int tr_bucket_bits(int32_t n_cols) {
+  int bits = 6;
+  while (bits < PH_BITS && (((int64_t)n_cols + ((int64_t)1 << bits) - 1) >> bits) > 512) ++bits;
+  return bits;
 }
 
-__global__ __launch_bounds__(256) void tr_scatter_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, int g_log2,
-                                                         int n_buckets, int64_t n_parts, int32_t col_lo, int32_t col_hi,
-                                                         const int64_t* __restrict__ offsets, unsigned short* __restrict__ bk_col,
-                                                         int32_t* __restrict__ bk_row) {
-  __shared__ long long s_base[PH_MAX_BUCKETS];
-  __shared__ int s_cur[PH_MAX_BUCKETS];
-  for (int b = threadIdx.x; b < n_buckets; b += 256) {
-    s_base[b] = offsets[(int64_t)b * n_parts + blockIdx.x];
-    s_cur[b] = 0;
+// R[p] = first row r with rp[r] >= p * TR_PART (p < n_parts), R[n_parts] = n_rows: part p = rows [R[p], R[p + 1])
+__global__ __launch_bounds__(256) void tr_parts_kernel(int64_t n_rows, const int64_t* __restrict__ rp, int64_t n_parts, int64_t* __restrict__ R) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p > n_parts) return;
+  if (p == n_parts) { R[p] = n_rows; return; }
+  const int64_t target = p * TR_PART;
+  int64_t lo = 0, hi = n_rows;  // first r in [0, n_rows] with rp[r] >= target
+  while (lo < hi) {
+    const int64_t mid = lo + ((hi - lo) >> 1);
+    if (rp[mid] >= target) hi = mid; else lo = mid + 1;
+  }
+  R[p] = lo;
+}
+
+__global__ __launch_bounds__(TR_THREADS) void tr_count_kernel(const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, const int64_t* __restrict__ R,
+                                                              int bits, int n_buckets, int64_t n_parts, int32_t col_lo, int32_t col_hi,
+                                                              int32_t* __restrict__ part_counts) {
+  __shared__ int s_cnt[TR_COPIES * PH_MAX_BUCKETS];
+  for (int b = threadIdx.x; b < TR_COPIES * n_buckets; b += TR_THREADS) s_cnt[b] = 0;
+  __syncthreads();
+  int* mine = s_cnt + (threadIdx.x & (TR_COPIES - 1)) * n_buckets;
+  const int64_t e0 = rp[R[blockIdx.x]], e1 = rp[R[blockIdx.x + 1]];
+  for (int64_t e = e0 + threadIdx.x; e < e1; e += TR_THREADS) {
+    const int j = ci[e];
+    if (j >= col_lo && j < col_hi) atomicAdd(&mine[j >> bits], 1);
   }
   __syncthreads();
+  for (int b = threadIdx.x; b < n_buckets; b += TR_THREADS) {
+    int tot = 0;
+#pragma unroll
+    for (int c = 0; c < TR_COPIES; ++c) tot += s_cnt[c * n_buckets + b];
+    part_counts[(int64_t)b * n_parts + blockIdx.x] = tot;
+  }
+}
+
+__global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, const int64_t* __restrict__ R,
+                                                                int g_log2, int bits, int n_buckets, int64_t n_parts, int32_t col_lo, int32_t col_hi,
+                                                                const int64_t* __restrict__ offsets, unsigned short* __restrict__ bk_col,
+                                                                int32_t* __restrict__ bk_row) {
+  __shared__ long long s_base[PH_MAX_BUCKETS];
+  __shared__ int s_loc[PH_MAX_BUCKETS + 1];  // where the bucket's run starts inside the staging arrays
+  __shared__ int s_cur[PH_MAX_BUCKETS];
+  __shared__ unsigned short s_col[TR_CAP];
+  __shared__ int s_row[TR_CAP];
+  __shared__ long long s_wave[TR_THREADS / WAVE];
+  long long carry = 0;
+  for (int base = 0; base < n_buckets; base += TR_THREADS) {  // block-uniform: exclusive prefix of this part's slice lengths
+    const int b = base + threadIdx.x;
+    long long len = 0;
+    if (b < n_buckets) {
+      const int64_t idx = (int64_t)b * n_parts + blockIdx.x;
+      const long long o = offsets[idx];
+      s_base[b] = o;
+      len = offsets[idx + 1] - o;
+      s_cur[b] = 0;
+    }
+    long long tot;
+    const long long ex = block_exclusive_scan<TR_THREADS>(len, s_wave, &tot);
+    if (b < n_buckets) s_loc[b] = (int)(carry + ex < (long long)TR_CAP ? carry + ex : (long long)TR_CAP);  // only read when the part is staged
+    carry += tot;
+  }
+  if (threadIdx.x == 0) s_loc[n_buckets] = (int)(carry < (long long)TR_CAP ? carry : (long long)TR_CAP);
+  __syncthreads();
+  const bool staged = carry <= TR_CAP;  // block-uniform: the part's kept entries fit the staging arrays
+  const unsigned cmask = (1u << bits) - 1u;
   const int G = 1 << g_log2;
   const int gl = threadIdx.x & (G - 1);
-  const int64_t r0 = (int64_t)blockIdx.x * TR_ROWS;
-  const int64_t r1 = r0 + TR_ROWS < n_rows ? r0 + TR_ROWS : n_rows;
-  for (int64_t r = r0 + (threadIdx.x >> g_log2); r < r1; r += 256 >> g_log2) {
+  const int64_t r0 = R[blockIdx.x], r1 = R[blockIdx.x + 1];
+  for (int64_t r = r0 + (threadIdx.x >> g_log2); r < r1; r += TR_THREADS >> g_log2) {
     const int64_t s = rp[r], e = rp[r + 1];
     for (int64_t p = s + gl; p < e; p += G) {
       const int j = ci[p];
       if (j < col_lo || j >= col_hi) continue;
-      const int b = j >> PH_BITS;
-      const int64_t pos = s_base[b] + atomicAdd(&s_cur[b], 1);
-      bk_col[pos] = (unsigned short)(j & (PH_BUCKET - 1));
-      bk_row[pos] = (int32_t)r;
+      const int b = j >> bits;
+      const int k = atomicAdd(&s_cur[b], 1);
+      if (staged) {
+        s_col[s_loc[b] + k] = (unsigned short)((unsigned)j & cmask);
+        s_row[s_loc[b] + k] = (int32_t)r;
+      } else {
+        bk_col[s_base[b] + k] = (unsigned short)((unsigned)j & cmask);
+        bk_row[s_base[b] + k] = (int32_t)r;
+      }
+    }
+  }
+  if (!staged) return;
+  __syncthreads();
+  // one wave per bucket run, lanes on consecutive entries
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+  for (int b = wave; b < n_buckets; b += TR_THREADS / WAVE) {
+    const int l0 = s_loc[b], len = s_loc[b + 1] - l0;
+    const long long dst = s_base[b];
+    for (int t = lane; t < len; t += WAVE) {
+      bk_col[dst + t] = s_col[l0 + t];
+      bk_row[dst + t] = s_row[l0 + t];
     }
   }
 }
 
-// prefix[chunk][c] = entries of column c in the earlier chunks of the same bucket
-__global__ __launch_bounds__(256) void tr_prefix_kernel(const unsigned* __restrict__ partial, const int32_t* __restrict__ blk_prefix, int32_t n_cols,
-                                                        unsigned* __restrict__ prefix) {
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (j >= n_cols) return;
-  const int b = (int)(j >> PH_BITS);
-  const int c = (int)(j & (PH_BUCKET - 1));
-  unsigned run = 0;
-  for (int blk = blk_prefix[b]; blk < blk_prefix[b + 1]; ++blk) {
-    prefix[(int64_t)blk * PH_BUCKET + c] = run;
-    run += partial[(int64_t)blk * PH_BUCKET + c];
-  }
-}
-
-// 1024 threads per chunk of 32768 entries: a matrix of a few million entries yields only ~150 chunks, and with 256 threads each
-// block walked its chunk in 128 dependent rounds of (LDS atomic -> scattered store) on less than one wave per SIMD.
-constexpr int TRP_THREADS = 1024;
-__global__ __launch_bounds__(TRP_THREADS) void tr_place_kernel(const unsigned short* __restrict__ bk_col, const int32_t* __restrict__ bk_row,
-                                                       const int64_t* __restrict__ offsets, int n_buckets, int64_t n_parts,
-                                                       const int32_t* __restrict__ blk_prefix, const unsigned* __restrict__ prefix,
-                                                       const int64_t* __restrict__ col_ptr, int32_t n_cols, int32_t* __restrict__ out_rows) {
+__global__ __launch_bounds__(TR_THREADS) void tr_place_kernel(const unsigned short* __restrict__ bk_col, const int32_t* __restrict__ bk_row,
+                                                              const int64_t* __restrict__ offsets, int bits, int64_t n_parts,
+                                                              const int64_t* __restrict__ col_ptr, int32_t n_cols, int32_t* __restrict__ out_rows) {
   __shared__ unsigned s_cur[PH_BUCKET];
-  const int blk = blockIdx.x;
-  if (blk >= blk_prefix[n_buckets]) return;  // block-uniform
-  int lo = 0, hi = n_buckets;  // last b with blk_prefix[b] <= blk
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (blk_prefix[mid] <= blk) lo = mid; else hi = mid;
-  }
-  const int b = lo;
-  const int64_t col0 = (int64_t)b << PH_BITS;
+  const int b = blockIdx.x;
+  const int width = 1 << bits;
+  const int64_t col0 = (int64_t)b << bits;
   const int64_t base = col_ptr[col0];  // where the bucket's CSC segment starts (a bucket holds < 2^32 entries)
-  for (int c = threadIdx.x; c < PH_BUCKET; c += TRP_THREADS)
-    s_cur[c] = (col0 + c < n_cols ? (unsigned)(col_ptr[col0 + c] - base) : 0u) + prefix[(int64_t)blk * PH_BUCKET + c];
+  for (int c = threadIdx.x; c < width; c += TR_THREADS) s_cur[c] = col0 + c < n_cols ? (unsigned)(col_ptr[col0 + c] - base) : 0u;
   __syncthreads();
   const int64_t bs = offsets[(int64_t)b * n_parts], be = offsets[(int64_t)(b + 1) * n_parts];
-  const int64_t e0 = bs + (int64_t)(blk - blk_prefix[b]) * PH_CHUNK;
-  const int64_t e1 = e0 + PH_CHUNK < be ? e0 + PH_CHUNK : be;
-  for (int64_t e = e0 + threadIdx.x; e < e1; e += TRP_THREADS) {
+  for (int64_t e = bs + threadIdx.x; e < be; e += TR_THREADS) {
     const unsigned p = atomicAdd(&s_cur[bk_col[e]], 1u);
     out_rows[base + p] = bk_row[e];
   }
 }
 
+static void tr_geometry(int64_t nnz, int32_t n_cols, int* bits, int64_t* n_buckets, int64_t* n_parts) {
+  *bits = tr_bucket_bits(n_cols);
+  *n_buckets = ((int64_t)n_cols + ((int64_t)1 << *bits) - 1) >> *bits;
+  *n_parts = (nnz + TR_PART - 1) / TR_PART;
+}
+
 int64_t transpose_scratch_bytes(int64_t n_rows, int64_t nnz, int32_t n_cols) {
-  const int64_t n_buckets = ((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS;
+  int bits;
+  int64_t n_buckets, n_parts;
+  tr_geometry(nnz, n_cols, &bits, &n_buckets, &n_parts);
   if (nnz < PH_MIN_NNZ || n_buckets > PH_MAX_BUCKETS || n_buckets < 1) return 0;
-  const int64_t n_parts = (n_rows + TR_ROWS - 1) / TR_ROWS;
   const int64_t m = n_buckets * n_parts;
-  const int64_t max_blocks = n_buckets + (nnz + PH_CHUNK - 1) / PH_CHUNK;
   auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
-  return al(m * 4) + al((m + 1) * 8) + al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8) + al(nnz * 2 + 16) + al(nnz * 4 + 16) + al((n_buckets + 1) * 4) +
-         2 * al(max_blocks * PH_BUCKET * 4);
+  return al((n_parts + 1) * 8) + al(m * 4) + al((m + 1) * 8) + al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8) + al(nnz * 2 + 16) + al(nnz * 4 + 16);
 }
 
 hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int g_log2,
                                         int32_t n_cols, const int64_t* col_ptr, int32_t* out_row_idx, int32_t col_lo, int32_t col_hi, char* scratch) {
-  const int n_buckets = (int)(((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS);
-  const int64_t n_parts = (n_rows + TR_ROWS - 1) / TR_ROWS;
-  const int64_t m = (int64_t)n_buckets * n_parts;
-  const int64_t max_blocks = n_buckets + (nnz + PH_CHUNK - 1) / PH_CHUNK;
+  int bits;
+  int64_t n_buckets, n_parts;
+  tr_geometry(nnz, n_cols, &bits, &n_buckets, &n_parts);
+  const int64_t m = n_buckets * n_parts;
   auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  int64_t* R = reinterpret_cast<int64_t*>(scratch); scratch += al((n_parts + 1) * 8);
   int32_t* part_counts = reinterpret_cast<int32_t*>(scratch); scratch += al(m * 4);
   int64_t* offsets = reinterpret_cast<int64_t*>(scratch); scratch += al((m + 1) * 8);
   int64_t* tile_sums = reinterpret_cast<int64_t*>(scratch); scratch += al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8);
   unsigned short* bk_col = reinterpret_cast<unsigned short*>(scratch); scratch += al(nnz * 2 + 16);
-  int32_t* bk_row = reinterpret_cast<int32_t*>(scratch); scratch += al(nnz * 4 + 16);
-  int32_t* blk_prefix = reinterpret_cast<int32_t*>(scratch); scratch += al(((int64_t)n_buckets + 1) * 4);
-  unsigned* partial = reinterpret_cast<unsigned*>(scratch); scratch += al(max_blocks * PH_BUCKET * 4);
-  unsigned* prefix = reinterpret_cast<unsigned*>(scratch);
-  hipLaunchKernelGGL(tr_count_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, n_rows, row_ptr, col_idx, g_log2, n_buckets, n_parts, col_lo, col_hi,
-                     part_counts);
+  int32_t* bk_row = reinterpret_cast<int32_t*>(scratch);
+  hipLaunchKernelGGL(tr_parts_kernel, dim3((unsigned)((n_parts + 256) / 256)), dim3(256), 0, st, n_rows, row_ptr, n_parts, R);
+  hipLaunchKernelGGL(tr_count_kernel, dim3((unsigned)n_parts), dim3(TR_THREADS), 0, st, row_ptr, col_idx, R, bits, (int)n_buckets, n_parts, col_lo, col_hi, part_counts);
   hipError_t e = launch_scan_i32(st, part_counts, m, offsets, tile_sums);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(tr_scatter_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, n_rows, row_ptr, col_idx, g_log2, n_buckets, n_parts, col_lo, col_hi,
+  hipLaunchKernelGGL(tr_scatter_kernel, dim3((unsigned)n_parts), dim3(TR_THREADS), 0, st, row_ptr, col_idx, R, g_log2, bits, (int)n_buckets, n_parts, col_lo, col_hi,
                      offsets, bk_col, bk_row);
-  hipLaunchKernelGGL(ph_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, offsets, n_buckets, n_parts, blk_prefix);
-  hipLaunchKernelGGL(ph_hist_kernel, dim3((unsigned)max_blocks), dim3(PHH_THREADS), 0, st, bk_col, offsets, n_buckets, n_parts, blk_prefix, partial);
-  hipLaunchKernelGGL(tr_prefix_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, partial, blk_prefix, n_cols, prefix);
-  hipLaunchKernelGGL(tr_place_kernel, dim3((unsigned)max_blocks), dim3(TRP_THREADS), 0, st, bk_col, bk_row, offsets, n_buckets, n_parts, blk_prefix, prefix,
-                     col_ptr, n_cols, out_row_idx);
+  hipLaunchKernelGGL(tr_place_kernel, dim3((unsigned)n_buckets), dim3(TR_THREADS), 0, st, bk_col, bk_row, offsets, bits, n_parts, col_ptr, n_cols, out_row_idx);
   return hipGetLastError();
 }
 
