@@ -13,14 +13,20 @@ import torch  # noqa: E402
 from universal_recommender_amd import _lib, synth  # noqa: E402
 from universal_recommender_amd.device import DatasetParams, DevCsr, DeviceSession, cross_occurrence_device  # noqa: E402
 
-scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
-flags = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 4, 6, 7]
+c4 = "--config4" in sys.argv      # BASELINE config 4 (HBM-resident), generated on the device
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+scale = float(argv[0]) if len(argv) > 0 else 1.0
+flags = [int(x) for x in argv[1].split(",")] if len(argv) > 1 else [0, 4, 6, 7]
 dev = torch.device("cuda", 0)
-cfg = synth.config3(scale)
-data = synth.generate(cfg)
-mats = [DevCsr(cfg.n_users, nc, torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), int(rp[-1])) for (_, nc, rp, ci) in data]
+if c4:
+    cfg = synth.config4(scale)
+    mats = [DevCsr(cfg.n_users, nc, rp, ci, int(rp[-1].item())) for (_, nc, rp, ci) in synth.generate_device(cfg, dev)]
+else:
+    cfg = synth.config3(scale)
+    data = synth.generate(cfg)
+    mats = [DevCsr(cfg.n_users, nc, torch.from_numpy(rp).to(dev), torch.from_numpy(ci).to(dev), int(rp[-1])) for (_, nc, rp, ci) in data]
 params = [DatasetParams(500, 50, None) for _ in mats]
-sess = DeviceSession(dev, _lib.load(_lib.DEFAULT_PATH))
+sess = DeviceSession(dev, _lib.load(os.environ.get("URCCO_LIB", _lib.DEFAULT_PATH)))
 for f in flags:
     sess.set_debug(f)
     for _ in range(2):
@@ -35,5 +41,5 @@ for f in flags:
     wall = (time.perf_counter() - t0) / steps * 1e3
     tm = sess.get_timings()
     sess.set_timing(False)
-    print(f"debug={f} wall {wall:.3f} ms/step | " + " ".join(f"{k}={v[0] / steps:.3f}" for k, v in tm.items() if v[1]))
+    print(f"debug={f} wall {wall:.3f} ms/step | " + " ".join(f"{k.replace('cco_rows_', '')}={v[0] / steps:.3f}" for k, v in tm.items() if v[1] and k.startswith("cco_rows")))
 sess.set_debug(0)

@@ -81,6 +81,13 @@ __device__ __forceinline__ double x_log_x_hi(long long x, long long n_users, con
   const long long d = n_users - x;
   return (d >= 0 && d < (long long)XLX_TABLE) ? xlx_hi[d] : x_log_x_tab(x, xlx_tab);
 }
+// columnEntropy = entropy(cB, N - cB) = (xLogX(N) - xLogX(cB)) - xLogX(N - cB) from the two tables: the same three values in the
+// same order as entropy2(cB, N - cB), so bit-identical to the per-item array it replaces -- without the 8-byte gather per candidate
+// (a 2M-item catalogue's entropy array is 16 MB: four times an XCD's L2).
+__device__ __forceinline__ double column_entropy_tab(long long cb, double xlx_n, long long n_users, const double* __restrict__ xlx_tab,
+                                                     const double* __restrict__ xlx_hi) {
+  return (xlx_n - x_log_x_tab(cb, xlx_tab)) - x_log_x_hi(n_users - cb, n_users, xlx_hi, xlx_tab);
+}
 __device__ __forceinline__ double llr_from_entropies_tab(double row_entropy, double column_entropy, double xlx_n, long long k11, long long k12,
                                                          long long k21, long long k22, const double* __restrict__ xlx_tab,
                                                          long long n_users, const double* __restrict__ xlx_hi) {

@@ -31,7 +31,8 @@ struct CcoArgs {
   const int32_t* cnt_a;
   const int32_t* cnt_b;
   const double* ent_a;       // rowEntropy per item of A
-  const double* ent_b;       // columnEntropy per item of B
+  const unsigned short* cnt_b16;  // 16-bit copy of cnt_b (a quarter of the bytes behind the one gather per candidate); valid while *cnt16_bad == 0
+  const int32_t* cnt16_bad;  // [1] number of counts beyond 16 bits (then cnt_b is gathered)
   const double* xlx_n;       // [1] xLogX(N)
   const double* xlx_tab;     // [XLX_TABLE_HOST] xLogX of small integers
   const double* xlx_hi;      // [XLX_TABLE_HOST] xLogX(n_users - d): the k22 term without a logarithm
@@ -127,6 +128,8 @@ hipError_t launch_pop_counts(hipStream_t st, int n_cu, int64_t n, const int32_t*
 hipError_t launch_xlx_table(hipStream_t st, double* tab);
 hipError_t launch_xlx_hi_table(hipStream_t st, double* tab, long long n_users);
 hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, double* xlx_n);
+// out16[i] = counts[i] (low 16 bits); bad[0] = number of counts that do not fit
+hipError_t launch_narrow_counts(hipStream_t st, int n_cu, const int32_t* counts, int32_t n, unsigned short* out16, int32_t* bad);
 
 // pstart[cap], plen[cap] (scratch), wp[cap + 1]; cap >= nnz(A'); tile_sums scratch as for scans over cap elements
 hipError_t launch_expand_prepare(hipStream_t st, int n_cu, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx,

@@ -1185,6 +1185,25 @@ hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n,
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void narrow_counts_kernel(const int32_t* __restrict__ counts, int32_t n, unsigned short* __restrict__ out16,
+                                                            int32_t* __restrict__ bad) {
+  int over = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int c = counts[i];
+    out16[i] = (unsigned short)c;
+    over += (c < 0 || c > 0xffff) ? 1 : 0;
+  }
+  if (over) atomicAdd(bad, over);
+}
+hipError_t launch_narrow_counts(hipStream_t st, int n_cu, const int32_t* counts, int32_t n, unsigned short* out16, int32_t* bad) {
+  hipError_t e = hipMemsetAsync(bad, 0, sizeof(int32_t), st);
+  if (e != hipSuccess || n <= 0) return e;
+  int64_t blocks = ((int64_t)n + 255) / 256;
+  if (blocks > (int64_t)n_cu * 8) blocks = (int64_t)n_cu * 8;
+  hipLaunchKernelGGL(narrow_counts_kernel, dim3((unsigned)blocks), dim3(256), 0, st, counts, n, out16, bad);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void xlx_table_kernel(double* __restrict__ tab) {
   const int x = blockIdx.x * 256 + threadIdx.x;
   if (x < XLX_TABLE) tab[x] = x_log_x((long long)x);
@@ -1684,6 +1703,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   const int cb = a.count_bits;
   const unsigned cmask = (1u << cb) - 1u;
   const double xlx_n = *a.xlx_n;
+  const bool use16 = *a.cnt16_bad == 0;
 
   // T == 64: teams are independent waves (wave-level sync only).  T > 64: one team per block, loop is block-uniform.
   int li = blockIdx.x * TEAMS + team;
@@ -1820,17 +1840,14 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
         const unsigned t0 = base + (unsigned)tl;
         unsigned vv[U];
         int cbj[U];
-        double eb[U];
 #pragma unroll
         for (int x = 0; x < U; ++x) {
           const unsigned t = t0 + (unsigned)x * T;
           vv[x] = t < D ? tab[t] : 0u;
           cbj[x] = 0;
-          eb[x] = 0.0;
           if (vv[x] != 0u) {
             const int j = (int)(vv[x] >> cb) - 1;
-            cbj[x] = a.cnt_b[j];
-            eb[x] = a.ent_b[j];
+            cbj[x] = use16 ? (int)a.cnt_b16[j] : a.cnt_b[j];  // the ONE scattered gather per candidate
           }
         }
 #pragma unroll
@@ -1842,8 +1859,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             unsigned long long key = 0ull;
             if (!(a.exclude_self && j == i)) {
               const double llr = (a.debug & 2) ? (double)k11
-                                               : llr_from_entropies_tab(row_entropy, eb[x], xlx_n, k11, ca - k11, (long long)cbj[x] - k11,
-                                                                        a.n_users - ca - (long long)cbj[x] + k11, a.xlx_tab, a.n_users, a.xlx_hi);
+                                               : llr_from_entropies_tab(row_entropy, column_entropy_tab((long long)cbj[x], xlx_n, a.n_users, a.xlx_tab, a.xlx_hi), xlx_n, k11,
+                                                                        ca - k11, (long long)cbj[x] - k11, a.n_users - ca - (long long)cbj[x] + k11, a.xlx_tab, a.n_users,
+                                                                        a.xlx_hi);
               if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
             }
             kk[t] = key;
@@ -2130,6 +2148,7 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
   const int cb = a.count_bits;
   const unsigned cmask = (1u << cb) - 1u;
   const double xlx_n = *a.xlx_n;
+  const bool use16 = *a.cnt16_bad == 0;
   const unsigned long long lt = (1ull << lane) - 1ull;
 
   int li = blockIdx.x * TEAMS + team;
@@ -2211,10 +2230,10 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
       const int j = (int)(vv >> cb) - 1;
       const long long k11 = (long long)(vv & cmask);
       if (!(a.exclude_self && j == i)) {
-        const long long cbj = a.cnt_b[j];
+        const long long cbj = use16 ? (long long)a.cnt_b16[j] : (long long)a.cnt_b[j];
         const double llr = (a.debug & 2) ? (double)k11
-                                         : llr_from_entropies_tab(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11,
-                                                                  a.xlx_tab, a.n_users, a.xlx_hi);
+                                         : llr_from_entropies_tab(row_entropy, column_entropy_tab(cbj, xlx_n, a.n_users, a.xlx_tab, a.xlx_hi), xlx_n, k11, ca - k11,
+                                                                  cbj - k11, a.n_users - ca - cbj + k11, a.xlx_tab, a.n_users, a.xlx_hi);
         if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
           mk = (unsigned long long)__double_as_longlong(llr);
           mc = j;
@@ -2303,7 +2322,8 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
         const long long k11 = atomicExch(&cnt[j], 0);  // exactly one lane claims (and clears) each column
         if (k11 > 0 && !(a.exclude_self && j == i)) {
           const long long cbj = a.cnt_b[j];
-          const double llr = llr_from_entropies_tab(row_entropy, a.ent_b[j], xlx_n, k11, ca - k11, cbj - k11, a.n_users - ca - cbj + k11, a.xlx_tab, a.n_users, a.xlx_hi);
+          const double llr = llr_from_entropies_tab(row_entropy, column_entropy_tab(cbj, xlx_n, a.n_users, a.xlx_tab, a.xlx_hi), xlx_n, k11, ca - k11, cbj - k11,
+                                                    a.n_users - ca - cbj + k11, a.xlx_tab, a.n_users, a.xlx_hi);
           if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
             const int pos = atomicAdd(&s_ncand, 1);
             ckey[pos] = (unsigned long long)__double_as_longlong(llr);

@@ -276,14 +276,13 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
     s->xlx_hi_n = n_users;
   }
   const int64_t n_tiles = ((int64_t)n + urcco::BIN_TILE - 1) / urcco::BIN_TILE;
-  const bool same = (counts_a == counts_b) && (n_items_a == n_cols_b);
   const int64_t cap = nnz_a_bound;
   const int64_t p_tiles = (cap + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
   URC(s->reserve(urcco_session::need((size_t)cap, 8) + urcco_session::need((size_t)cap, 4) + urcco_session::need((size_t)cap + 1, 8) +
                  urcco_session::need((size_t)p_tiles + 2, 8) +
                  urcco_session::need((size_t)n, 8) + urcco_session::need((size_t)(n_tiles + 1) * urcco::BIN_COLS_HOST, 8) +
                  urcco_session::need(urcco::NBINS + 1, 4) + urcco_session::need((size_t)n, 4) + urcco_session::need((size_t)n_items_a, 8) +
-                 urcco_session::need((size_t)n_cols_b, 8) + urcco_session::need(1, 8) + urcco_session::need(URCCO_STATS_LEN, 8) +
+                 urcco_session::need((size_t)n_cols_b, 2) + urcco_session::need(1, 4) + urcco_session::need(1, 8) + urcco_session::need(URCCO_STATS_LEN, 8) +
                  urcco_session::need((size_t)n_users + 1, 4)));
   int64_t* pstart = s->take<int64_t>((size_t)cap);
   int32_t* plen = s->take<int32_t>((size_t)cap);
@@ -294,7 +293,8 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   int32_t* bin_off = s->take<int32_t>(urcco::NBINS + 1);
   int32_t* bin_rows = s->take<int32_t>((size_t)n);
   double* ent_a = s->take<double>((size_t)n_items_a);
-  double* ent_b = same ? ent_a : s->take<double>((size_t)n_cols_b);
+  unsigned short* cnt_b16 = s->take<unsigned short>((size_t)n_cols_b);
+  int32_t* cnt16_bad = s->take<int32_t>(1);
   double* xlx_n = s->take<double>(1);
   int64_t* stats = stats_dev ? stats_dev : s->take<int64_t>(URCCO_STATS_LEN);
   unsigned* b_rp32 = s->take<unsigned>((size_t)n_users + 1);
@@ -309,13 +309,13 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   s->end();
   s->begin(URCCO_STAGE_ENTROPY);
   HIPC(urcco::launch_item_entropy(s->stream, counts_a, n_items_a, n_users, ent_a, xlx_n));
-  if (!same) HIPC(urcco::launch_item_entropy(s->stream, counts_b, n_cols_b, n_users, ent_b, nullptr));
+  HIPC(urcco::launch_narrow_counts(s->stream, s->n_cu, counts_b, n_cols_b, cnt_b16, cnt16_bad));
   s->end();
 
   urcco::CcoArgs a;
   a.bin_rows = bin_rows; a.bin_off = bin_off;
   a.a_col_ptr = a_col_ptr; a.pstart = pstart; a.wp = wp; a.b_col_idx = b_col_idx;
-  a.cnt_a = counts_a; a.cnt_b = counts_b; a.ent_a = ent_a; a.ent_b = ent_b; a.xlx_n = xlx_n; a.xlx_tab = s->xlx_tab; a.xlx_hi = s->xlx_hi; a.debug = s->debug;
+  a.cnt_a = counts_a; a.cnt_b = counts_b; a.ent_a = ent_a; a.cnt_b16 = cnt_b16; a.cnt16_bad = cnt16_bad; a.xlx_n = xlx_n; a.xlx_tab = s->xlx_tab; a.xlx_hi = s->xlx_hi; a.debug = s->debug;
   a.n_users = n_users; a.n_cols_b = n_cols_b; a.item_lo = item_lo; a.exclude_self = exclude_self ? 1 : 0; a.k = k;
   a.has_min_llr = has_min_llr ? 1 : 0; a.min_llr = min_llr; a.count_bits = count_bits;
   a.col_bytes = n_cols_b <= (1 << 8) ? 1 : (n_cols_b <= (1 << 16) ? 2 : (n_cols_b <= (1 << 24) ? 3 : 4));
