@@ -351,3 +351,24 @@ def test_global_class_ties_at_the_cut(sim_session):
     for k in (7, 50, 150):
         _, _, st = compare_with_oracle(sim_session, [a, b], [P(1000000, k), P(1000000, k)], 3, exact_ids=True)
         assert st[1][0][7] > 0          # global class used
+
+
+def test_multipass_class_adversarial_low_bits_and_k_limits(sim_session):
+    """The multi-pass class (bin 6) partitions a row's columns by their LOW bits.  Here every column the heavy rows touch is a
+    multiple of 8, so the first partitions are empty or overflowing and the row has to start over with twice the passes several
+    times (P = 2, 4, 8 leave everything in pass 0; P = 16 splits it).  k = 256 is the largest the class keeps running lists for;
+    k = 257 takes the dense global-accumulator kernel instead: both must equal the oracle, ids exact."""
+    rng = np.random.default_rng(21)
+    n_users, n_b = 700, 200_000
+    a = rand_csr(rng, n_users, 3, 2, zipf_s=2.0)                    # three items, item 0 owned by most users
+    cols = np.sort(rng.choice(n_b // 8, size=15_000, replace=False)).astype(np.int64) * 8
+    b_rows = []
+    for u in range(n_users):
+        pick = np.sort(rng.choice(cols.size, size=120, replace=False))
+        b_rows.append(cols[pick])
+    rp = np.zeros(n_users + 1, np.int64)
+    np.cumsum([len(r) for r in b_rows], out=rp[1:])
+    b = O.Csr(n_users, n_b, rp, np.concatenate(b_rows).astype(np.int32))
+    for k in (50, 256, 257):
+        _, _, st = compare_with_oracle(sim_session, [a, b], [P(1000000, k), P(1000000, k)], 9)
+        assert st[1][0][7] > 0, st[1][0]                            # bin 6 used for A'B

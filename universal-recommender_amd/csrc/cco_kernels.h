@@ -8,7 +8,9 @@ namespace urcco {
 
 constexpr int NBINS = 7;  // accumulator classes: 0 micro (one wave, <= 64 pairs), 1 wave-LDS (64 thr, 1024 words),
                           // 2 small-block-LDS (256 thr, 4096 words), 3 block-LDS (256 thr, 8192 words),
-                          // 4 half-CU-LDS (512 thr, 16384 words), 5 CU-LDS (1024 thr, 32768 words), 6 global dense counters
+                          // 4 half-CU-LDS (512 thr, 16384 words), 5 CU-LDS (1024 thr, 32768 words),
+                          // 6 multi-pass CU-LDS (rows no single table holds; dense global counters when k > MP_KMAX_HOST)
+constexpr int MP_KMAX_HOST = 256;  // largest k the multi-pass class serves (== MP_KMAX in cco_kernels.hip)
 
 // Geometry the host side needs for scratch sizing.
 constexpr int SCAN_TILE = 2048;          // elements per scan tile (256 threads x 8)
@@ -53,11 +55,12 @@ struct CcoArgs {
   int32_t* out_idx;
   double* out_llr;
   unsigned long long* err;   // stats[1 + 4 * NBINS]: LDS table overflows (must stay 0)
+  unsigned long long* cand;  // stats[2 + 4 * NBINS]: distinct (row, column) candidates scored (LLR evaluations)
   // global-accumulator scratch (bin 3)
   int32_t* g_counts;         // [GLOBAL_BIN_BLOCKS][n_cols_b] zero on entry, zero on exit
   unsigned long long* g_cand_key;  // [GLOBAL_BIN_BLOCKS][n_cols_b]
   int32_t* g_cand_col;       // [GLOBAL_BIN_BLOCKS][n_cols_b]
-  int32_t g_blocks;          // resident blocks of the global-accumulator kernel (<= GLOBAL_BIN_BLOCKS; fewer for very wide B)
+  int32_t g_blocks;          // > 0: bin 6 runs on the dense global-accumulator kernel with this many resident blocks; 0: multi-pass LDS class
 };
 
 hipError_t launch_column_counts(hipStream_t st, int n_cu, const int32_t* col_idx, int64_t nnz, int32_t n_cols, int32_t* counts);

@@ -1327,6 +1327,7 @@ hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t it
 // hundreds of thousands of increments on four addresses).
 // ============================================================================================
 constexpr int E0 = 1024, E1S = 4096, E1 = 8192, E2S = 16384, E2 = 32768;  // LDS table words: wave / small block / block / half CU / CU
+constexpr int MP_KMAX = 256;  // largest k the multi-pass class keeps its running lists for (MP_KMAX_HOST in cco_kernels.h)
 
 #ifndef URCCO_WB1
 #define URCCO_WB1 512
@@ -1640,7 +1641,15 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 #ifndef URCCO_G_CU
 #define URCCO_G_CU 1
 #endif
-template <int T, int E, int U>
+// MP ("multi-pass", bin 6): rows no single LDS table can hold -- a hot item of a skewed catalogue pairs with tens of thousands
+// of distinct columns -- or whose counts overflow the packed field.  Such a row is accumulated in P = 2^s passes over its
+// cooccurrence pairs: pass q keeps the columns with (col mod P) == q, keyed by col div P (so the key narrows by s bits and the
+// count field widens by as many), cuts them to their own top k, and merges those into the row's running top k (ranked over
+// <= 2k elements).  The exact top k of the row is the top k of the passes' top k's: ties are cut by the full column.  P starts
+// from the row's work (1.25 x the expected distinct columns per pass must fit) and doubles whenever a pass still overflows --
+// at the latest when ceil(n_cols / P) columns are GUARANTEED to fit, so every row ends.  Round 2 served these rows from dense
+// counters in global memory (n_cols x 16 B of scratch per resident block, L2 atomics): 35.9 ms for 16K rows of config 5.
+template <int T, int E, int U, bool MP = false>
 __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T == 256 && E == 4096 ? 7 : 1))) void cco_rows_kernel(CcoArgs a, int bin) {
   constexpr int BLOCK = T < 256 ? 256 : T;
   constexpr int TEAMS = BLOCK / T;
@@ -1681,6 +1690,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   // +0..4 %, so only T == 256 tracks the shared bytes.
   constexpr bool SKIP_SHARED = T == 256;
   __shared__ unsigned long long s_kbits[2 * NW];  // per wave: AND / OR over its valid keys
+  __shared__ unsigned s_mpflag;                    // MP: a pass overflowed its table
+  __shared__ unsigned long long s_runk[MP ? 2 * MP_KMAX : 1];  // MP: the row's running top k (two buffers: a merge reads one, writes the other)
+  __shared__ unsigned s_runc[MP ? 2 * MP_KMAX : 1];
 
   const int team = TEAMS == 1 ? 0 : uni((int)threadIdx.x / T);  // a team is one wave (T == 64) or the whole block
   const int tl = threadIdx.x % T;
@@ -1699,9 +1711,10 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   const int list_start = a.bin_off[bin];
   const int list_n = a.bin_off[bin + 1] - list_start;
   const int total_teams = gridDim.x * TEAMS;
-  const bool ident = (long long)a.n_cols_b * 3 + (long long)a.k * 3 + 2 <= E;  // the table spans every column of B: slots addressed by column
-  const int cb = a.count_bits;
-  const unsigned cmask = (1u << cb) - 1u;
+  bool ident = (long long)a.n_cols_b * 3 + (long long)a.k * 3 + 2 <= E;  // the table spans every column of B: slots addressed by column
+  int cb = a.count_bits;                                                   // (MP: both follow the row's pass count)
+  unsigned cmask = (1u << cb) - 1u;
+  unsigned long long cand_acc = 0ull;  // distinct (row, column) candidates scored by this team (statistics)
   const double xlx_n = *a.xlx_n;
   const bool use16 = *a.cnt16_bad == 0;
 
@@ -1734,13 +1747,42 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
       cs_nx = uni(a.a_col_ptr[i_nx]);
       ce_nx = uni(a.a_col_ptr[i_nx + 1]);
     }
+    // MP: number of passes 2^mp_s, current pass mp_q, entries of the running top k and which of its two buffers is current
+    int mp_s = 0;
+    unsigned mp_q = 0u, n_run = 0u, run_cur = 0u;
+    bool nx_fetched = false;
+    if (MP) {
+      const long long w_row = (long long)(uni(a.wp[ce]) - uni(a.wp[cs]));
+      const long long ca_row = a.cnt_a[i];
+      const long long dd = w_row < (long long)a.n_cols_b ? w_row : (long long)a.n_cols_b;
+      const long long cap = ((long long)E - 3ll * a.k - 2ll) / 3ll;  // distinct columns a pass may hold (packed counts + keys + survivors)
+      for (;; ++mp_s) {
+        const long long cols_pp = ((long long)a.n_cols_b + (1ll << mp_s) - 1) >> mp_s;  // columns a pass can see
+        int kb = 1;
+        while ((1ll << kb) <= cols_pp) ++kb;
+        const bool count_ok = kb <= 1 || ca_row <= (1ll << (32 - kb)) - 1;
+        const long long exp_d = ((dd >> mp_s) + (dd >> (mp_s + 2)) + 1) < cols_pp ? ((dd >> mp_s) + (dd >> (mp_s + 2)) + 1) : cols_pp;
+        if (count_ok && exp_d <= cap) break;
+      }
+    }
+  mp_again:  // MP: the next pass, or the row again with twice the passes (team-uniform jumps)
+    if (MP) {
+      const long long cols_pp = ((long long)a.n_cols_b + (1ll << mp_s) - 1) >> mp_s;
+      int kb = 1;
+      while ((1ll << kb) <= cols_pp) ++kb;
+      cb = 32 - kb;
+      cmask = cb >= 32 ? 0xffffffffu : (1u << cb) - 1u;
+      ident = cols_pp * 3 + 3ll * a.k + 2ll <= (long long)E;
+      if (tl == 0) s_mpflag = 0u;
+    }
+    const unsigned mp_mask = MP ? (1u << mp_s) - 1u : 0u;
 #pragma unroll
     for (int q = 0; q < SPT; ++q) tab[tl + q * T] = 0u;
     team_sync<T>();
     // ---- 2. expand + accumulate
     for (int64_t c0 = cs; c0 < ce; c0 += T) {  // team-uniform
       const int64_t c1 = c0 + T < ce ? c0 + T : ce;
-      const bool pre = c0 == cs;  // the first chunk's operands were prefetched
+      const bool pre = !MP && c0 == cs;  // the first chunk's operands were prefetched
       const int64_t w0 = pre ? pf_w0 : uni(a.wp[c0]);
       const unsigned total = (unsigned)((pre ? pf_w1 : uni(a.wp[c1])) - w0);
       const int64_t p = c0 + tl;
@@ -1789,6 +1831,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
               if (on[q]) {
                 if (a.debug & 1) {  // ablation: gather only
                   if (jj[q] == 0xffffffffu) tab[0] = 1u;
+                } else if (MP) {
+                  if ((jj[q] & mp_mask) == mp_q && !tab_insert(tab, (jj[q] >> mp_s) + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) s_mpflag = 1u;
                 } else if (!tab_insert(tab, jj[q] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) {
                   atomicAdd(a.err, 1ull);
                 }
@@ -1829,6 +1873,18 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
         if (v[q] != 0u) tab[wpos++] = v[q];
     }
     team_sync<T>();
+    if (MP) {
+      // the pass must leave room for its keys and its survivors behind the packed counts; a pass that does not (or whose table
+      // filled up) is abandoned and the row starts over with twice the passes
+      if (s_mpflag != 0u || 3ll * D + 3ll * a.k + 2ll > (long long)E) {  // team-uniform
+        team_sync<T>();
+        ++mp_s;
+        mp_q = 0u;
+        n_run = 0u;
+        goto mp_again;
+      }
+    }
+    cand_acc += D;
     unsigned long long* kk = reinterpret_cast<unsigned long long*>(tab + ((D + 1u) & ~1u));
     // ---- 4. score candidates tl, tl + T, ... (dense); keys go to LDS behind the packed counts
     unsigned n_valid = 0;
@@ -1846,15 +1902,15 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
           vv[x] = t < D ? tab[t] : 0u;
           cbj[x] = 0;
           if (vv[x] != 0u) {
-            const int j = (int)(vv[x] >> cb) - 1;
-            cbj[x] = use16 ? (int)a.cnt_b16[j] : a.cnt_b[j];  // the ONE scattered gather per candidate
+            const int j = MP ? (int)((((vv[x] >> cb) - 1u) << mp_s) | mp_q) : (int)(vv[x] >> cb) - 1;
+            cbj[x] = (a.debug & 512) ? 100 : (use16 ? (int)a.cnt_b16[j] : a.cnt_b[j]);  // the ONE scattered gather per candidate (ablation 512: none)
           }
         }
 #pragma unroll
         for (int x = 0; x < U; ++x) {
           const unsigned t = t0 + (unsigned)x * T;
           if (t < D) {
-            const int j = (int)(vv[x] >> cb) - 1;
+            const int j = MP ? (int)((((vv[x] >> cb) - 1u) << mp_s) | mp_q) : (int)(vv[x] >> cb) - 1;
             const long long k11 = (long long)(vv[x] & cmask);
             unsigned long long key = 0ull;
             if (!(a.exclude_self && j == i)) {
@@ -1876,7 +1932,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
         }
       }
     }
-    if (has_next) {  // the next row's first-chunk operands travel while this row is ranked
+    if (has_next && !nx_fetched) {  // the next row's first-chunk operands travel while this row is ranked
+      nx_fetched = true;
       const int64_t c1 = cs_nx + T < ce_nx ? cs_nx + T : ce_nx;
       pf_w0 = a.wp[cs_nx];
       pf_w1 = a.wp[c1];
@@ -2051,7 +2108,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
       team_sync<T>();
       unsigned long long* selk = kk + D;                                  // [k]
       unsigned* selc = reinterpret_cast<unsigned*>(selk + a.k);          // [k]
-      if (a.unordered) {
+      if (a.unordered && !MP) {
         // URCCO_FLAG_UNORDERED_ROWS: the top-k SET of the row, in whatever order the lanes claim output slots -- what
         // Mahout's computeSimilarities returns (a sparse vector has no score order; the reference sorts later, in
         // toStringMapRDD, package.scala:102).  No ranking pass.
@@ -2081,11 +2138,35 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
         if (key > thr_key || (key == thr_key && ~col >= thr_ncol)) {
           const unsigned pos = atomicAdd(nsel, 1u);
           selk[pos] = key;
-          selc[pos] = col;
+          selc[pos] = MP ? ((col << mp_s) | mp_q) : col;  // MP: the pass cut by the column inside the pass, the merge cuts by the full column
         }
       }
       team_sync<T>();
       const unsigned n = (a.debug & 16) ? 0u : uni(*nsel);  // ablation 16: no ranking / output
+      if (MP) {
+        // merge the pass's <= k survivors into the running top k: every element of both lists is ranked over both (by counting),
+        // the best k land in the other running buffer at their rank -- which is the output order
+        const unsigned long long* rk = s_runk + run_cur * MP_KMAX;
+        const unsigned* rc = s_runc + run_cur * MP_KMAX;
+        unsigned long long* wk = s_runk + (run_cur ^ 1u) * MP_KMAX;
+        unsigned* wc = s_runc + (run_cur ^ 1u) * MP_KMAX;
+        const unsigned total = n_run + n;
+        for (unsigned base = 0; base < total; base += T) {  // scalar loop control
+          const unsigned x = base + (unsigned)tl;
+          if (x >= total) continue;
+          const unsigned long long mk = x < n_run ? rk[x] : selk[x - n_run];
+          const int mc = (int)(x < n_run ? rc[x] : selc[x - n_run]);
+          const unsigned rank = rank_by_counting(rk, n_run, mk, mc, [&](unsigned u) { return (int)rc[u]; }) +
+                                rank_by_counting(selk, n, mk, mc, [&](unsigned u) { return (int)selc[u]; });
+          if (rank < (unsigned)a.k) {
+            wk[rank] = mk;
+            wc[rank] = (unsigned)mc;
+          }
+        }
+        n_run = total < (unsigned)a.k ? total : (unsigned)a.k;
+        run_cur ^= 1u;
+        team_sync<T>();
+      } else {
       // Rank by counting.  Up to SEL_M survivors are put in order in LDS first (the arrays of the select's ambiguous set
       // are free again) and leave as contiguous stores: one element per lane scattered straight to its rank made every
       // store a partial-line write (measured 4x write amplification on the one-wave class).
@@ -2114,9 +2195,22 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
         }
       }
       if (tl == 0) a.out_count[i - a.item_lo] = (int)n;
+      }
+    }
+    if (MP) {
+      team_sync<T>();
+      if (++mp_q < (1u << mp_s)) goto mp_again;  // team-uniform
+      const unsigned long long* rk = s_runk + run_cur * MP_KMAX;
+      const unsigned* rc = s_runc + run_cur * MP_KMAX;
+      for (unsigned t = (unsigned)tl; t < n_run; t += T) {
+        a.out_idx[obase + t] = (int)rc[t];
+        a.out_llr[obase + t] = __longlong_as_double((long long)rk[t]);
+      }
+      if (tl == 0) a.out_count[i - a.item_lo] = (int)n_run;
     }
     team_sync<T>();  // the table is re-zeroed by the next row
   }
+  if (tl == 0 && cand_acc != 0ull) atomicAdd(a.cand, cand_acc);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -2150,6 +2244,7 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
   const double xlx_n = *a.xlx_n;
   const bool use16 = *a.cnt16_bad == 0;
   const unsigned long long lt = (1ull << lane) - 1ull;
+  unsigned long long cand_acc = 0ull;  // candidates scored by this wave (statistics)
 
   int li = blockIdx.x * TEAMS + team;
   int i_nx = 0;
@@ -2222,6 +2317,7 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
       if (v != 0u) cand[D + lanes_below(m)] = v;
       D += (unsigned)__popcll(m);
     }
+    cand_acc += D;
     wave_sync();
     unsigned long long mk = 0ull;
     int mc = 0x7fffffff;
@@ -2230,7 +2326,7 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
       const int j = (int)(vv >> cb) - 1;
       const long long k11 = (long long)(vv & cmask);
       if (!(a.exclude_self && j == i)) {
-        const long long cbj = use16 ? (long long)a.cnt_b16[j] : (long long)a.cnt_b[j];
+        const long long cbj = (a.debug & 512) ? 100ll : (use16 ? (long long)a.cnt_b16[j] : (long long)a.cnt_b[j]);
         const double llr = (a.debug & 2) ? (double)k11
                                          : llr_from_entropies_tab(row_entropy, column_entropy_tab(cbj, xlx_n, a.n_users, a.xlx_tab, a.xlx_hi), xlx_n, k11, ca - k11,
                                                                   cbj - k11, a.n_users - ca - cbj + k11, a.xlx_tab, a.n_users, a.xlx_hi);
@@ -2273,6 +2369,7 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
     }
     wave_sync();
   }
+  if (lane == 0 && cand_acc != 0ull) atomicAdd(a.cand, cand_acc);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -2469,7 +2566,7 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
 // resident blocks per CU of each LDS-accumulator kernel (registers / LDS decide), so that the persistent grids fill
 // the chip exactly once
 static int blocks_per_cu(int bin) {
-  static int cache[6] = {0, 0, 0, 0, 0, 0};
+  static int cache[7] = {0, 0, 0, 0, 0, 0, 0};
   if (cache[bin] == 0) {
     int n = 0;
     hipError_t e = hipErrorUnknown;
@@ -2479,6 +2576,7 @@ static int blocks_per_cu(int bin) {
     if (bin == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1, URCCO_U_B>, 256, 0);
     if (bin == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<512, E2S, URCCO_U_H>, 512, 0);
     if (bin == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2, URCCO_U_C>, 1024, 0);
+    if (bin == 6) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2, URCCO_U_C, true>, 1024, 0);
     cache[bin] = (e == hipSuccess && n > 0) ? n : 1;
   }
   return cache[bin];
@@ -2492,7 +2590,7 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
   // of the other event types' streams in -- a grid that exactly fills the chip locks them out until it ends (measured:
   // single-block kernels of another stream waited 0.2 ms).  3.5-3.7 -> 3.2-3.3 ms per build of config 3; 3x, 4x and 8x
   // measured no better than 1x (profiles/r02_grid_factor_sweep.log).
-  static int factor[6] = {0, 0, 0, 0, 0, 0};
+  static int factor[7] = {0, 0, 0, 0, 0, 0, 2};
   if (factor[0] == 0) {
     const int dflt[6] = {2, 2, 2, 2, 2, 2};
     for (int b = 0; b < 6; ++b) factor[b] = dflt[b];
@@ -2511,7 +2609,10 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
     case 3: hipLaunchKernelGGL((cco_rows_kernel<256, E1, URCCO_U_B>), grid(3), dim3(256), 0, st, args, 3); break;
     case 4: hipLaunchKernelGGL((cco_rows_kernel<512, E2S, URCCO_U_H>), grid(4), dim3(512), 0, st, args, 4); break;
     case 5: hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C>), grid(5), dim3(1024), 0, st, args, 5); break;
-    default: hipLaunchKernelGGL(cco_rows_global_kernel, dim3((unsigned)(args.g_blocks > 0 ? args.g_blocks : 1)), dim3(GB_THREADS), 0, st, args); break;
+    default:
+      if (args.g_blocks > 0) hipLaunchKernelGGL(cco_rows_global_kernel, dim3((unsigned)args.g_blocks), dim3(GB_THREADS), 0, st, args);
+      else hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C, true>), grid(6), dim3(1024), 0, st, args, 6);
+      break;
   }
   return hipGetLastError();
 }

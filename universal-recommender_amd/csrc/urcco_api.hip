@@ -265,7 +265,10 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   while (((int64_t)1 << key_bits) <= (int64_t)n_cols_b) ++key_bits;  // values 1..n_cols_b
   const int count_bits = 32 - key_bits;
   if (count_bits < 1) return fail(URCCO_BAD_ARG, "n_cols_b %d too large for the packed accumulator", n_cols_b);
-  URC(s->ensure_global_bin(n_cols_b));
+  // bin 6 = the multi-pass LDS class; only a k beyond its running lists (or beyond any LDS table) falls back to the dense
+  // global-accumulator kernel and pays for its n_cols x 16 B of scratch per resident block
+  const bool dense_bin6 = k > urcco::MP_KMAX_HOST || 3ll * k + 5 > 32768ll;
+  if (dense_bin6) URC(s->ensure_global_bin(n_cols_b));
   if (!s->xlx_tab) {
     HIPC(hipMalloc((void**)&s->xlx_tab, sizeof(double) * urcco::XLX_TABLE_HOST));
     HIPC(urcco::launch_xlx_table(s->stream, s->xlx_tab));
@@ -323,7 +326,8 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   a.g_log2 = 4;  // 16 lanes stream one user's B' row: 64 B segments, matches the ~10-40 item rows the cut leaves
   a.out_count = out_count; a.out_idx = out_idx; a.out_llr = out_llr;
   a.err = reinterpret_cast<unsigned long long*>(stats + 1 + 4 * urcco::NBINS);
-  a.g_counts = s->g_counts; a.g_cand_key = s->g_cand_key; a.g_cand_col = s->g_cand_col; a.g_blocks = s->g_blocks;
+  a.cand = reinterpret_cast<unsigned long long*>(stats + 2 + 4 * urcco::NBINS);
+  a.g_counts = s->g_counts; a.g_cand_key = s->g_cand_key; a.g_cand_col = s->g_cand_col; a.g_blocks = dense_bin6 ? s->g_blocks : 0;
   // Heaviest classes first (global, whole-CU, half-CU, ...): they have few, long rows and end raggedly; the fine-grained
   // one-wave and micro classes run last and finish sharply -- and, with a stream per event type, fill the heavy classes'
   // tails of the other event types instead of leaving a tail of their own.  debug 65536 restores the ascending order.
