@@ -372,3 +372,41 @@ def test_multipass_class_adversarial_low_bits_and_k_limits(sim_session):
     for k in (50, 256, 257):
         _, _, st = compare_with_oracle(sim_session, [a, b], [P(1000000, k), P(1000000, k)], 9)
         assert st[1][0][7] > 0, st[1][0]                            # bin 6 used for A'B
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_row_scan_one_pass_edges(sim_session, mode):
+    """The ONE-PASS row scan (matrices of >= 2^20 interactions: persistent blocks, tile totals through decoupled look-back, LDS
+    cache of threshold prefixes): runs of empty rows across tile boundaries, rows beyond the interaction cap (both row-rate
+    modes), a row spanning several tiles, trailing empty rows, and an interaction count that is an exact multiple of the tile --
+    row_ptr and col_idx bit for bit against the oracle, and against the two-pass kernels (debug 2048)."""
+    rng = np.random.default_rng(31 + mode)
+    for exact in (False, True):
+        lengths = rng.poisson(17, 80_000)
+        lengths[rng.random(80_000) < 0.15] = 0
+        lengths[5_000:5_700] = 0                     # 700 empty rows in a row
+        lengths[123] = 9_000                         # spans three tiles, > max_n
+        lengths[40_000] = 300                        # > max_n inside a tile
+        lengths[79_990:] = 0                         # trailing empty rows
+        total = int(lengths.sum())
+        assert total >= (1 << 20)
+        if exact:
+            lengths[77_777] += (-total) % 4096       # nnz becomes a multiple of the tile size
+        m = _csr_from_lengths(rng, lengths, 30_000)
+        assert (m.nnz % 4096 == 0) == exact
+        dev = sim_session.device
+        raw_ref = O.column_counts(m)
+        raw = torch.from_numpy(raw_ref).to(dev)
+        ref = O.downsample(m, raw_ref, 4242, 200, mode)
+        out, post = sim_session.downsample(to_dev(m, dev), m.nnz, raw, 4242, 200, mode)
+        sim_session.synchronize()
+        assert np.array_equal(out.row_ptr.cpu().numpy(), ref.row_ptr)
+        assert np.array_equal(out.col_idx.cpu().numpy()[:ref.nnz], ref.col_idx)
+        assert np.array_equal(post.cpu().numpy()[:m.n_cols], O.column_counts(ref))
+        sim_session.set_debug(2048)                  # the two-pass kernels on the same input
+        try:
+            out2, _ = sim_session.downsample(to_dev(m, dev), m.nnz, raw, 4242, 200, mode)
+            sim_session.synchronize()
+        finally:
+            sim_session.set_debug(0)
+        assert np.array_equal(out2.row_ptr.cpu().numpy(), ref.row_ptr) and np.array_equal(out2.col_idx.cpu().numpy()[:ref.nnz], ref.col_idx)
