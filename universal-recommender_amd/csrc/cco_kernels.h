@@ -81,12 +81,6 @@ hipError_t launch_downsample_flags(hipStream_t st, int n_cu, int64_t n_rows, con
                                    int row_rate_mode, int64_t row_base, int64_t* tile_rows, unsigned long long* flags, int64_t* tile_count,
                                    int32_t* post_counts, int debug);
 hipError_t launch_downsample_scan(hipStream_t st, int64_t nnz, int64_t* tile_count);
-// One-pass form (matrices of >= OP_MIN_NNZ interactions; the caller falls back to the two-pass kernels below it): same scratch for
-// thresholds and tile_rows, status = [tiles + 1] u64 (look-back words + the tile counter).
-constexpr int64_t OP_MIN_NNZ = 1 << 20;
-hipError_t launch_downsample_onepass(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
-                                     const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n, int row_rate_mode,
-                                     int64_t row_base, int64_t* tile_rows, unsigned long long* status, int64_t* out_row_ptr, int32_t* out_col_idx, int debug);
 hipError_t launch_downsample_compact(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz,
                                      const int64_t* tile_rows, const unsigned long long* flags, const int64_t* tile_off, int64_t* out_row_ptr,
                                      int32_t* out_col_idx);

@@ -43,38 +43,6 @@ __device__ __forceinline__ long long shfl_up_i64(long long v, unsigned d) {
   return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
-// Inclusive prefix sum over the 64 lanes of a wave, entirely in the VALU: four DPP row shifts inside the rows of 16 lanes,
-// then the two row broadcasts that carry the row totals upwards.  (A __shfl_up ladder is six dependent ds_bpermute round
-// trips through the LDS pipe, each with its own lane-bound bookkeeping; a row of the SpGEMM ran ~5 such ladders.)  Every lane
-// of the wave must be active.  One DPP per source line: the test simulator keys wave operations by line.
-__device__ __forceinline__ unsigned wave_inclusive_sum(unsigned v) {
-  int x = (int)v;
-  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
-  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
-  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
-  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
-  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
-  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
-  return (unsigned)x;
-}
-// A value every lane of the wave agrees on, moved to a scalar register.  The compiler cannot tell that threadIdx.x / T, or
-// anything loaded through it (the row id, its CSC bounds, the chunk's work bounds, counts read back from LDS), is uniform, and
-// keeps all arithmetic, addressing and loop control that derives from it in the vector unit -- where every instruction costs a
-// wave four issue cycles and the SpGEMM classes are bound by exactly that.
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ int64_t uni(int64_t v) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-  const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
-  return ((int64_t)hi << 32) | (int64_t)lo;
-}
-// value of lane l (wave-uniform l): one v_readlane, no LDS
-__device__ __forceinline__ unsigned wave_read_lane(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
-// number of set bits of m below this lane
-__device__ __forceinline__ unsigned lanes_below(unsigned long long m) {
-  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-}
-
 // ============================================================================================
 // K1  column counts (numNonZeroElementsPerColumn)
 // Zipf-headed data puts millions of increments on a handful of addresses and a device-scope atomic on one
@@ -940,251 +908,6 @@ hipError_t launch_downsample_compact(hipStream_t st, int64_t n_rows, const int64
 }
 
 // ============================================================================================
-// K2'  sampleDownAndBinarize in ONE pass (matrices of >= OP_MIN_NNZ interactions).  The two-pass scan above reads the
-// column indices twice (flags, then compaction) and pays one scattered global byte gather per interaction for the threshold
-// prefix -- address processing of 64 scattered lines per wave instruction, ~1 lane per clock per CU, more than the hash.
-//   * persistent blocks claim tiles in order from a counter; a tile's kept total is published in a status word and the tile's
-//     output offset comes from a decoupled look-back over its predecessors' words (aggregate / inclusive-prefix flags): the
-//     entries are read once, the keep bits never leave the CU, the kept columns are staged in LDS and leave as one run;
-//   * the threshold prefixes of the columns a block meets live in a direct-mapped LDS cache ((column << 8) | prefix, 8192
-//     entries, persistent across the block's tiles): under a Zipf catalogue most interactions hit it, only misses gather;
-//   * the new row_ptr of the rows that start inside the tile comes from the per-run kept prefixes kept in LDS.
-// Same decisions, same output as the two-pass scan (which small matrices and the tests' odd shapes still take).
-// ============================================================================================
-constexpr int OP_THREADS = DS_TILE / DS_RUN;  // 512: one run of eight entries per thread
-constexpr int OP_CACHE = 8192;
-constexpr unsigned long long OP_AGG = 1ull << 62, OP_PRE = 2ull << 62, OP_VAL = (1ull << 62) - 1ull;
-static_assert(OP_THREADS == 512, "one-pass geometry");
-
-template <bool DEBUG>
-__global__ __launch_bounds__(OP_THREADS, 2) void downsample_onepass_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
-                                                                          int64_t nnz, const int64_t* __restrict__ g,
-                                                                          const unsigned long long* __restrict__ thresholds,
-                                                                          const unsigned char* __restrict__ thr8, int32_t n_cols, uint32_t seed, int32_t max_n,
-                                                                          int row_rate_mode, int64_t row_base, unsigned long long* __restrict__ status,
-                                                                          unsigned* __restrict__ tile_counter, int64_t* __restrict__ out_rp,
-                                                                          int32_t* __restrict__ out_ci, int vec_ok, int debug_flags) {
-  const int debug = DEBUG ? debug_flags : 0;
-  __shared__ unsigned long long s_mask[DS_WORDS];
-  __shared__ int s_row_at[DS_TILE];  // entry -> row lookup; afterwards the tile's kept columns in output order
-  __shared__ int s_tbefore[DS_WORDS];
-  __shared__ unsigned s_cache[OP_CACHE];
-  __shared__ unsigned short s_runpre[OP_THREADS];  // kept entries of the tile before each run
-  __shared__ unsigned char s_keepb[OP_THREADS];
-  __shared__ int s_wsum[OP_THREADS / WAVE];
-  __shared__ int s_long;
-  __shared__ unsigned s_tile;
-  __shared__ long long s_prefix;
-  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-  const int64_t n_tiles = (nnz + DS_TILE - 1) / DS_TILE;
-  const bool use_cache = n_cols < 0xffffff;  // the cache word holds the column in 24 bits
-  for (int c = threadIdx.x; c < OP_CACHE; c += OP_THREADS) s_cache[c] = 0xffffffffu;
-  const double dmax = (double)max_n;
-  for (;;) {
-    if (threadIdx.x == 0) {
-      s_tile = atomicAdd(tile_counter, 1u);
-      s_long = 0;
-    }
-    if (threadIdx.x < DS_WORDS) s_mask[threadIdx.x] = 0ull;
-    __syncthreads();
-    const int64_t tile = s_tile;
-    if (tile >= n_tiles) break;  // block-uniform
-    const int64_t e0 = tile * DS_TILE;
-    const int n_live = (int)((e0 + DS_TILE < nnz) ? DS_TILE : nnz - e0);
-    const int el0 = (int)threadIdx.x * DS_RUN;
-    int cols[DS_RUN];
-    if (vec_ok && el0 + DS_RUN <= n_live) {
-      const int4 x = *reinterpret_cast<const int4*>(ci + e0 + el0), y = *reinterpret_cast<const int4*>(ci + e0 + el0 + 4);
-      cols[0] = x.x; cols[1] = x.y; cols[2] = x.z; cols[3] = x.w; cols[4] = y.x; cols[5] = y.y; cols[6] = y.z; cols[7] = y.w;
-    } else {
-#pragma unroll
-      for (int q = 0; q < DS_RUN; ++q) cols[q] = (el0 + q < n_live) ? ci[e0 + el0 + q] : 0;
-    }
-    const int64_t gp0 = g[tile];
-    const int64_t g0 = gp0 >> 1, g1 = g[tile + 1] >> 1;
-    const int64_t r_s = (gp0 & 1) ? g0 : g0 - 1;
-    const int64_t r_e = g1 < n_rows ? g1 : n_rows;
-    const int64_t n_slice = r_e - r_s + 1;
-    if (!(debug & 128)) {
-      int any_long = 0;
-      for (int64_t t = threadIdx.x; t + 1 < n_slice; t += OP_THREADS) {
-        const int64_t a = rp[r_s + t] - e0, b = rp[r_s + t + 1] - e0;
-        if (b > a) {
-          if (a >= 0) {
-            s_row_at[a] = (int)t;
-            atomicOr(&s_mask[a >> 6], 1ull << (a & 63));
-          }
-          any_long |= (b - a > (int64_t)max_n) ? 1 : 0;
-        }
-      }
-      if (any_long) s_long = 1;
-    }
-    // threshold prefixes: the LDS cache first, the byte table for the misses
-    unsigned thr_b[DS_RUN];
-    if (debug & 64) {
-#pragma unroll
-      for (int q = 0; q < DS_RUN; ++q) thr_b[q] = 255u;
-    } else if (use_cache) {
-      unsigned ce[DS_RUN];
-#pragma unroll
-      for (int q = 0; q < DS_RUN; ++q) ce[q] = s_cache[(unsigned)cols[q] & (OP_CACHE - 1)];
-#pragma unroll
-      for (int q = 0; q < DS_RUN; ++q) {
-        if ((ce[q] >> 8) == (unsigned)cols[q]) {
-          thr_b[q] = ce[q] & 0xffu;
-        } else {
-          thr_b[q] = (unsigned)thr8[cols[q]];
-          s_cache[(unsigned)cols[q] & (OP_CACHE - 1)] = ((unsigned)cols[q] << 8) | thr_b[q];  // racing fills write valid words
-        }
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < DS_RUN; ++q) thr_b[q] = (unsigned)thr8[cols[q]];
-    }
-    __syncthreads();
-    if (threadIdx.x < WAVE) {  // wave 0: slice index of the last row starting before each word (prefix maximum)
-      const unsigned long long m = s_mask[lane];
-      const int here = m ? s_row_at[lane * 64 + 63 - __clzll((long long)m)] : 0;
-      int inc = here;
-#pragma unroll
-      for (int d = 1; d < WAVE; d <<= 1) {
-        const int o = __shfl_up(inc, d);
-        if (lane >= d) inc = o > inc ? o : inc;
-      }
-      const int ex = __shfl_up(inc, 1);
-      s_tbefore[lane] = lane == 0 ? 0 : ex;
-    }
-    __syncthreads();
-    const bool has_long = s_long != 0;
-    const uint32_t row0 = (uint32_t)(row_base + r_s);
-    unsigned keep_byte = 0;
-    {
-      const int w = el0 >> 6, sh = el0 & 63;
-      const unsigned long long m = s_mask[w];
-      const unsigned starts = (unsigned)(m >> sh) & 0xffu;
-      const unsigned long long low = m & ((1ull << sh) - 1ull);
-      int t_cur = s_tbefore[w];
-      if (low) t_cur = s_row_at[w * 64 + 63 - __clzll((long long)low)];
-      const int4 ra = *reinterpret_cast<const int4*>(&s_row_at[el0]), rb = *reinterpret_cast<const int4*>(&s_row_at[el0 + 4]);
-      const int at[DS_RUN] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-      int r_of[DS_RUN];
-#pragma unroll
-      for (int q = 0; q < DS_RUN; ++q) {
-        t_cur = (starts >> q) & 1u ? at[q] : t_cur;
-        r_of[q] = t_cur;
-      }
-#pragma unroll
-      for (int q = 0; q < DS_RUN; ++q) {
-        const unsigned long long h = (debug & 32) ? ((unsigned long long)((unsigned)cols[q] * 0x9E3779B1u) << 21) : hash53(seed, row0 + (uint32_t)r_of[q], (uint32_t)cols[q]);
-        const unsigned h8 = (unsigned)(h >> THR8_SHIFT), b = thr_b[q];
-        bool keep = b == 255u || h8 < b;
-        if (b == 254u || (b < 254u && h8 == b)) keep = h <= thresholds[cols[q]];
-        keep_byte |= (keep ? 1u : 0u) << q;
-      }
-      if (has_long) {  // block-uniform, rare
-#pragma unroll 1
-        for (int q = 0; q < DS_RUN; ++q) {
-          const int64_t r = r_s + r_of[q];
-          const int64_t n_row = rp[r + 1] - rp[r];
-          if (n_row > (int64_t)max_n) {
-            const unsigned long long thr_row = row_rate_mode == 0 ? 0ull : (unsigned long long)((dmax / (double)n_row) * 9007199254740992.0);
-            if (hash53(seed, row0 + (uint32_t)r_of[q], (uint32_t)cols[q]) > thr_row) keep_byte &= ~(1u << q);
-          }
-        }
-      }
-      const int live = n_live - el0;
-      keep_byte &= live >= DS_RUN ? 0xffu : (live > 0 ? (1u << live) - 1u : 0u);
-    }
-    // kept entries before this run inside the tile, and the tile's total
-    const unsigned c = (unsigned)__popc(keep_byte);
-    const unsigned inc = wave_inclusive_sum(c);
-    if (lane == WAVE - 1) s_wsum[wave] = (int)inc;
-    __syncthreads();  // also: every read of s_row_at as a lookup table is done
-    unsigned before = 0, total = 0;
-#pragma unroll
-    for (int w2 = 0; w2 < OP_THREADS / WAVE; ++w2) {
-      const unsigned sw = (unsigned)s_wsum[w2];
-      if (w2 < wave) before += sw;
-      total += sw;
-    }
-    const unsigned pre = before + inc - c;
-    s_runpre[threadIdx.x] = (unsigned short)pre;
-    s_keepb[threadIdx.x] = (unsigned char)keep_byte;
-    {
-      unsigned pos = pre;
-#pragma unroll
-      for (int q = 0; q < DS_RUN; ++q)
-        if ((keep_byte >> q) & 1u) s_row_at[pos++] = cols[q];
-    }
-    if (threadIdx.x < WAVE) {  // wave 0: publish the tile's total, look back for its offset
-      unsigned long long excl = 0ull;
-      if (tile == 0) {
-        if (lane == 0) __hip_atomic_store(&status[0], OP_PRE | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else {
-        if (lane == 0) __hip_atomic_store(&status[tile], OP_AGG | (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int64_t base = tile - 1;; base -= WAVE) {  // wave-uniform loop: lane l reads the word of tile base - l
-          const int64_t idx = base - lane;
-          unsigned long long st = OP_PRE;  // before tile 0: an inclusive prefix of zero
-          if (idx >= 0) {
-            do {
-              st = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } while ((st >> 62) == 0ull);
-          }
-          const unsigned long long has_pre = __ballot((st >> 62) == 2ull);
-          const int first = has_pre ? __ffsll((unsigned long long)has_pre) - 1 : WAVE;  // nearest predecessor that knows its inclusive prefix
-          unsigned long long v = lane <= first ? (st & OP_VAL) : 0ull;
-#pragma unroll
-          for (int msk = 1; msk < WAVE; msk <<= 1) v += shfl_xor_u64(v, msk);
-          excl += v;
-          if (has_pre) break;
-        }
-        if (lane == 0) __hip_atomic_store(&status[tile], OP_PRE | (excl + (unsigned long long)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (lane == 0) s_prefix = (long long)excl;
-    }
-    __syncthreads();
-    const int64_t off = s_prefix;
-    for (unsigned t = threadIdx.x; t < total; t += OP_THREADS) out_ci[off + t] = s_row_at[t];
-    // new row_ptr of the rows that start inside this tile (empty ones included; the last tile also takes the end marker)
-    for (int64_t t = threadIdx.x; t + 1 < n_slice; t += OP_THREADS) {
-      const int64_t a = rp[r_s + t] - e0;
-      if (a >= 0) {
-        const int run = a >= DS_TILE ? OP_THREADS - 1 : (int)(a >> 3), bit = (int)(a & 7);
-        out_rp[r_s + t] = off + (a >= DS_TILE ? (int64_t)total : (int64_t)s_runpre[run] + __popc((unsigned)s_keepb[run] & ((1u << bit) - 1u)));
-      }
-    }
-    if (tile == n_tiles - 1 && threadIdx.x == 0) out_rp[n_rows] = off + (int64_t)total;
-    __syncthreads();  // the next tile rewrites the tables
-  }
-}
-
-hipError_t launch_downsample_onepass(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
-                                     const int32_t* raw_counts, unsigned long long* thresholds, uint32_t seed, int32_t max_n, int row_rate_mode,
-                                     int64_t row_base, int64_t* tile_rows, unsigned long long* status, int64_t* out_row_ptr, int32_t* out_col_idx, int debug) {
-  if (nnz == 0) return hipSuccess;
-  unsigned char* thr8 = reinterpret_cast<unsigned char*>(thresholds + n_cols);
-  hipLaunchKernelGGL(sample_threshold_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, raw_counts, n_cols, max_n, thresholds, thr8);
-  const int64_t tiles = (nnz + DS_TILE - 1) / DS_TILE;
-  int64_t rblocks = (n_rows + 1 + 255) / 256;
-  const int64_t rcap = (int64_t)n_cu * 8;
-  if (rblocks > rcap) rblocks = rcap;
-  hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, n_rows, row_ptr, tiles, tile_rows);
-  hipError_t e = hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)(tiles + 1), st);  // status[tiles] = the tile counter
-  if (e != hipSuccess) return e;
-  unsigned* counter = reinterpret_cast<unsigned*>(status + tiles);
-  const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
-  int64_t blocks = (int64_t)n_cu * 3;  // persistent: ~50 KB of LDS per block
-  if (blocks > tiles) blocks = tiles;
-  if (debug & (32 | 64 | 128))
-    hipLaunchKernelGGL(downsample_onepass_kernel<true>, dim3((unsigned)blocks), dim3(OP_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds, thr8, n_cols,
-                       seed, max_n, row_rate_mode, row_base, status, counter, out_row_ptr, out_col_idx, vec_ok, debug);
-  else
-    hipLaunchKernelGGL(downsample_onepass_kernel<false>, dim3((unsigned)blocks), dim3(OP_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds, thr8, n_cols,
-                       seed, max_n, row_rate_mode, row_base, status, counter, out_row_ptr, out_col_idx, vec_ok, 0);
-  return hipGetLastError();
-}
-
-// ============================================================================================
 // K3  CSR -> CSC (the A.t of A.t %*% B).  2^g lanes walk one user row; destination slots come from
 // per-column cursors (returning L2 atomics; after the interaction cut a column sees <= ~max of them).
 // Order inside a column is whatever the atomics produce: only integer sums are formed from it.
@@ -1832,6 +1555,38 @@ __device__ __forceinline__ void wave_sync() {
 template <int T>
 __device__ __forceinline__ void team_sync() {
   if (T == WAVE) wave_sync(); else __syncthreads();
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave, entirely in the VALU: four DPP row shifts inside the rows of 16 lanes,
+// then the two row broadcasts that carry the row totals upwards.  (A __shfl_up ladder is six dependent ds_bpermute round
+// trips through the LDS pipe, each with its own lane-bound bookkeeping; a row of the SpGEMM ran ~5 such ladders.)  Every lane
+// of the wave must be active.  One DPP per source line: the test simulator keys wave operations by line.
+__device__ __forceinline__ unsigned wave_inclusive_sum(unsigned v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return (unsigned)x;
+}
+// A value every lane of the wave agrees on, moved to a scalar register.  The compiler cannot tell that threadIdx.x / T, or
+// anything loaded through it (the row id, its CSC bounds, the chunk's work bounds, counts read back from LDS), is uniform, and
+// keeps all arithmetic, addressing and loop control that derives from it in the vector unit -- where every instruction costs a
+// wave four issue cycles and the SpGEMM classes are bound by exactly that.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned uni(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int64_t uni(int64_t v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((int64_t)hi << 32) | (int64_t)lo;
+}
+// value of lane l (wave-uniform l): one v_readlane, no LDS
+__device__ __forceinline__ unsigned wave_read_lane(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+// number of set bits of m below this lane
+__device__ __forceinline__ unsigned lanes_below(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
 // exclusive scan of one unsigned per thread across a team of T threads; *total = team sum.  Every thread must call.

@@ -149,20 +149,6 @@ int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_pt
   int64_t* tile_rows = s->take<int64_t>((size_t)ds_tiles + 1);
   int64_t* tile_count = s->take<int64_t>((size_t)ds_tiles + 1);
   unsigned long long* flags = s->take<unsigned long long>(n_words);
-  // one pass for large matrices (their post-sampling counts come from the partitioned histogram anyway); debug 2048 forces the
-  // two-pass kernels (profiling / A-B)
-  if (nnz >= urcco::OP_MIN_NNZ && (ph_bytes > 0 || !post_counts) && !(s->debug & 2048)) {
-    s->begin(URCCO_STAGE_DOWNSAMPLE_FLAGS);
-    HIPC(urcco::launch_downsample_onepass(s->stream, s->n_cu, n_rows, row_ptr, col_idx, nnz, n_cols, raw_counts, thresholds, (uint32_t)seed, max_elements_per_row,
-                                          row_rate_mode, row_base, tile_rows, flags, out_row_ptr, out_col_idx, s->debug));
-    s->end();
-    if (ph_bytes > 0) {
-      s->begin(URCCO_STAGE_COLUMN_COUNTS);
-      HIPC(urcco::launch_column_counts_partitioned(s->stream, out_col_idx, nnz, out_row_ptr + n_rows, n_cols, post_counts, s->take<char>((size_t)ph_bytes)));
-      s->end();
-    }
-    return URCCO_OK;
-  }
   s->begin(URCCO_STAGE_DOWNSAMPLE_FLAGS);
   HIPC(urcco::launch_downsample_flags(s->stream, s->n_cu, n_rows, row_ptr, col_idx, nnz, n_cols, raw_counts, thresholds, (uint32_t)seed,
                                       max_elements_per_row, row_rate_mode, row_base, tile_rows, flags, tile_count,
