@@ -215,6 +215,33 @@ def test_large_transpose_long_rows_and_empty_parts(sim_session):
             assert np.array_equal(np.sort(ri[cp[j]:cp[j + 1]]), ri_ref[cp_ref[j]:cp_ref[j + 1]]), j
 
 
+def test_large_transpose_skewed_ids_heavy_bucket(sim_session):
+    """Ids that follow popularity (what first-appearance ids do): nearly every interaction falls into the first column bucket,
+    which is then placed by several blocks sharing cursors in global memory instead of one block with LDS cursors."""
+    rng = np.random.default_rng(15)
+    n_rows, n_cols = 300_000, 30_000
+    hot = np.sort(rng.integers(0, 60, size=(n_rows, 6)), axis=1)
+    rows = []
+    for r in range(n_rows):
+        c = np.unique(hot[r])
+        if r % 50 == 0:
+            c = np.unique(np.concatenate([c, rng.integers(60, n_cols, 3)]))
+        rows.append(c)
+    rp = np.zeros(n_rows + 1, np.int64)
+    np.cumsum([len(c) for c in rows], out=rp[1:])
+    m = O.Csr(n_rows, n_cols, rp, np.concatenate(rows).astype(np.int32))
+    assert m.nnz >= (1 << 20)
+    dev = sim_session.device
+    counts = torch.from_numpy(O.column_counts(m)).to(dev)
+    cp_ref, ri_ref = O.transpose(m)
+    cp, ri = sim_session.transpose(to_dev(m, dev), counts, 0, n_cols)
+    sim_session.synchronize()
+    cp, ri = cp.cpu().numpy(), ri.cpu().numpy()
+    assert np.array_equal(cp, cp_ref)
+    for j in list(range(0, 70)) + rng.integers(60, n_cols, 300).tolist():
+        assert np.array_equal(np.sort(ri[cp[j]:cp[j + 1]]), ri_ref[cp_ref[j]:cp_ref[j + 1]]), j
+
+
 def _csr_from_lengths(rng, lengths, n_cols):
     lengths = np.asarray(lengths, dtype=np.int64)
     rp = np.zeros(len(lengths) + 1, dtype=np.int64)

@@ -1077,20 +1077,73 @@ __global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(const int64_t* _
   }
 }
 
+// blk_prefix[b] = first placement block of bucket b: a bucket gets one block per TR_CHUNK entries (at least one)
+constexpr int64_t TR_CHUNK = 1 << 18;
+__global__ __launch_bounds__(SCAN_THREADS) void tr_blockmap_kernel(const int64_t* __restrict__ offsets, int n_buckets, int64_t n_parts,
+                                                                  int32_t* __restrict__ blk_prefix) {
+  __shared__ long long s_wave[SCAN_THREADS / WAVE];
+  long long carry = 0;
+  for (int base = 0; base < n_buckets; base += SCAN_THREADS) {  // block-uniform
+    const int b = base + threadIdx.x;
+    long long v = 0;
+    if (b < n_buckets) {
+      const long long size = offsets[(int64_t)(b + 1) * n_parts] - offsets[(int64_t)b * n_parts];
+      v = size > 0 ? (size + TR_CHUNK - 1) / TR_CHUNK : 1;
+    }
+    long long tot;
+    const long long ex = block_exclusive_scan(v, s_wave, &tot);
+    if (b < n_buckets) blk_prefix[b] = (int32_t)(carry + ex);
+    carry += tot;
+  }
+  if (threadIdx.x == 0) blk_prefix[n_buckets] = (int32_t)carry;
+}
+
+// A bucket of up to TR_CHUNK entries is placed by ONE block with its column cursors in LDS.  A heavier bucket -- a catalogue whose
+// ids follow popularity (ids by first appearance do) concentrates the interactions in the first buckets -- is split over several
+// blocks that share cursors in global memory (returning L2 atomics, the price of the cursor-atomic kernel, paid by those buckets only).
 __global__ __launch_bounds__(TR_THREADS) void tr_place_kernel(const unsigned short* __restrict__ bk_col, const int32_t* __restrict__ bk_row,
-                                                              const int64_t* __restrict__ offsets, int bits, int64_t n_parts,
-                                                              const int64_t* __restrict__ col_ptr, int32_t n_cols, int32_t* __restrict__ out_rows) {
+                                                              const int64_t* __restrict__ offsets, int bits, int n_buckets, int64_t n_parts,
+                                                              const int32_t* __restrict__ blk_prefix, const int64_t* __restrict__ col_ptr, int32_t n_cols,
+                                                              int32_t* __restrict__ g_cursor /* [n_cols] zero */, int32_t* __restrict__ out_rows) {
   __shared__ unsigned s_cur[PH_BUCKET];
-  const int b = blockIdx.x;
+  const int blk = blockIdx.x;
+  if (blk >= blk_prefix[n_buckets]) return;  // block-uniform
+  int lo = 0, hi = n_buckets;  // last b with blk_prefix[b] <= blk
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (blk_prefix[mid] <= blk) lo = mid; else hi = mid;
+  }
+  const int b = lo;
+  const int n_blk = blk_prefix[b + 1] - blk_prefix[b];
   const int width = 1 << bits;
   const int64_t col0 = (int64_t)b << bits;
+  const int64_t bs = offsets[(int64_t)b * n_parts], be_all = offsets[(int64_t)(b + 1) * n_parts];
+  if (n_blk > 1) {  // block-uniform: a chunk of a heavy bucket
+    const int64_t c0 = bs + (int64_t)(blk - blk_prefix[b]) * TR_CHUNK;
+    const int64_t c1 = c0 + TR_CHUNK < be_all ? c0 + TR_CHUNK : be_all;
+    for (int64_t e = c0 + threadIdx.x; e < c1; e += TR_THREADS) {
+      const int64_t j = col0 + bk_col[e];
+      out_rows[col_ptr[j] + atomicAdd(&g_cursor[j], 1)] = bk_row[e];
+    }
+    return;
+  }
   const int64_t base = col_ptr[col0];  // where the bucket's CSC segment starts (a bucket holds < 2^32 entries)
   for (int c = threadIdx.x; c < width; c += TR_THREADS) s_cur[c] = col0 + c < n_cols ? (unsigned)(col_ptr[col0 + c] - base) : 0u;
   __syncthreads();
-  const int64_t bs = offsets[(int64_t)b * n_parts], be = offsets[(int64_t)(b + 1) * n_parts];
-  for (int64_t e = bs + threadIdx.x; e < be; e += TR_THREADS) {
-    const unsigned p = atomicAdd(&s_cur[bk_col[e]], 1u);
-    out_rows[base + p] = bk_row[e];
+  const int64_t be = be_all;
+  // four entries per thread and round: their loads are requested together (a round is a chain load -> LDS atomic -> store)
+  for (int64_t e = bs + threadIdx.x; e < be; e += TR_THREADS * 4) {
+    unsigned c[4];
+    int r[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t x = e + (int64_t)q * TR_THREADS;
+      c[q] = x < be ? (unsigned)bk_col[x] : 0u;
+      r[q] = x < be ? bk_row[x] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (e + (int64_t)q * TR_THREADS < be) out_rows[base + atomicAdd(&s_cur[c[q]], 1u)] = r[q];
   }
 }
 
@@ -1107,11 +1160,13 @@ int64_t transpose_scratch_bytes(int64_t n_rows, int64_t nnz, int32_t n_cols) {
   if (nnz < PH_MIN_NNZ || n_buckets > PH_MAX_BUCKETS || n_buckets < 1) return 0;
   const int64_t m = n_buckets * n_parts;
   auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
-  return al((n_parts + 1) * 8) + al(m * 4) + al((m + 1) * 8) + al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8) + al(nnz * 2 + 16) + al(nnz * 4 + 16);
+  return al((n_parts + 1) * 8) + al(m * 4) + al((m + 1) * 8) + al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8) + al(nnz * 2 + 16) + al(nnz * 4 + 16) +
+         al((n_buckets + 1) * 4);
 }
 
 hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int g_log2,
-                                        int32_t n_cols, const int64_t* col_ptr, int32_t* out_row_idx, int32_t col_lo, int32_t col_hi, char* scratch) {
+                                        int32_t n_cols, const int64_t* col_ptr, int32_t* cursor, int32_t* out_row_idx, int32_t col_lo, int32_t col_hi,
+                                        char* scratch) {
   int bits;
   int64_t n_buckets, n_parts;
   tr_geometry(nnz, n_cols, &bits, &n_buckets, &n_parts);
@@ -1122,14 +1177,18 @@ hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const in
   int64_t* offsets = reinterpret_cast<int64_t*>(scratch); scratch += al((m + 1) * 8);
   int64_t* tile_sums = reinterpret_cast<int64_t*>(scratch); scratch += al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8);
   unsigned short* bk_col = reinterpret_cast<unsigned short*>(scratch); scratch += al(nnz * 2 + 16);
-  int32_t* bk_row = reinterpret_cast<int32_t*>(scratch);
+  int32_t* bk_row = reinterpret_cast<int32_t*>(scratch); scratch += al(nnz * 4 + 16);
+  int32_t* blk_prefix = reinterpret_cast<int32_t*>(scratch);
   hipLaunchKernelGGL(tr_parts_kernel, dim3((unsigned)((n_parts + 256) / 256)), dim3(256), 0, st, n_rows, row_ptr, n_parts, R);
   hipLaunchKernelGGL(tr_count_kernel, dim3((unsigned)n_parts), dim3(TR_THREADS), 0, st, row_ptr, col_idx, R, bits, (int)n_buckets, n_parts, col_lo, col_hi, part_counts);
   hipError_t e = launch_scan_i32(st, part_counts, m, offsets, tile_sums);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tr_scatter_kernel, dim3((unsigned)n_parts), dim3(TR_THREADS), 0, st, row_ptr, col_idx, R, g_log2, bits, (int)n_buckets, n_parts, col_lo, col_hi,
                      offsets, bk_col, bk_row);
-  hipLaunchKernelGGL(tr_place_kernel, dim3((unsigned)n_buckets), dim3(TR_THREADS), 0, st, bk_col, bk_row, offsets, bits, n_parts, col_ptr, n_cols, out_row_idx);
+  hipLaunchKernelGGL(tr_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, offsets, (int)n_buckets, n_parts, blk_prefix);
+  const int64_t max_blocks = n_buckets + nnz / TR_CHUNK;
+  hipLaunchKernelGGL(tr_place_kernel, dim3((unsigned)max_blocks), dim3(TR_THREADS), 0, st, bk_col, bk_row, offsets, bits, (int)n_buckets, n_parts, blk_prefix, col_ptr,
+                     n_cols, cursor, out_row_idx);
   return hipGetLastError();
 }
 
