@@ -45,6 +45,7 @@ struct alignas(8) int2 { int x, y; };
 struct alignas(8) uint2 { unsigned x, y; };
 static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorNoDevice = 100, hipErrorInvalidDevice = 101, hipErrorInvalidHandle = 400,

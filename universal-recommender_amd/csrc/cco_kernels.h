@@ -139,6 +139,11 @@ hipError_t launch_narrow_counts(hipStream_t st, int n_cu, const int32_t* counts,
 hipError_t launch_expand_prepare(hipStream_t st, int n_cu, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx,
                                  const int64_t* b_row_ptr, unsigned* b_rp32_scratch /* nullable: n_rows_b + 1 words */, int64_t n_rows_b, int64_t cap,
                                  int64_t* pstart, int32_t* plen, int64_t* wp, int64_t* tile_sums);
+// the same for up to EXPAND_MULTI_MAX event types with ONE gather per CSC entry: T = scratch of n_rows_b * n * 8 bytes
+constexpr int EXPAND_MULTI_MAX = 8;
+hipError_t launch_expand_prepare_multi(hipStream_t st, int n_cu, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx, int n,
+                                       const int64_t* const* b_row_ptr, int64_t n_rows_b, int64_t cap, int64_t* const* pstart, int32_t* const* plen, void* T);
+hipError_t launch_expand_scan(hipStream_t st, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* plen, int64_t cap, int64_t* wp, int64_t* tile_sums);
 hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr, const int64_t* wp, int64_t* work);
 
 // binning: tile_counts scratch [(ceil(n/BIN_TILE)+1) * BIN_COLS_HOST] int64;

@@ -1357,6 +1357,94 @@ hipError_t launch_expand_prepare(hipStream_t st, int n_cu, const int64_t* a_col_
   return launch_scan(st, LoadI32{plen}, cap, wp, tile_sums, a_col_ptr + n_items_a);
 }
 
+// --------------------------------------------------------------------------------------------
+// Expand preparation for SEVERAL event types at once.  expand_prepare gathers two row_ptr words of B per CSC entry of A' -- one
+// scattered 64-byte line per entry and event type, the whole cost of the kernel (0.93 ms per event type on config 4: 40M entries,
+// a 40 MB table, fabric-bound).  The secondaries' (start, length) pairs are first interleaved per user -- T[u][d] = {start32, len32},
+// 32 bytes per user for four secondaries: ONE sector -- so that a CSC entry's single gather serves every event type.
+// --------------------------------------------------------------------------------------------
+struct ExpandMultiArgs {
+  const int64_t* b_rp[EXPAND_MULTI_MAX];
+  int64_t* pstart[EXPAND_MULTI_MAX];
+  int32_t* plen[EXPAND_MULTI_MAX];
+  int n;
+};
+__global__ __launch_bounds__(256) void expand_pack_kernel(ExpandMultiArgs a, int64_t n_rows_b, uint2* __restrict__ T) {
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < n_rows_b; u += (int64_t)gridDim.x * 256)
+    for (int d = 0; d < a.n; ++d) {
+      const int64_t s = a.b_rp[d][u], e = a.b_rp[d][u + 1];
+      T[u * a.n + d] = make_uint2((unsigned)s, (unsigned)(e - s));
+    }
+}
+template <int N>
+__global__ __launch_bounds__(256) void expand_prepare_multi_kernel(const int64_t* __restrict__ a_cp, int32_t n_items_a, const int32_t* __restrict__ a_ri,
+                                                                   const uint2* __restrict__ T, int64_t cap, ExpandMultiArgs a) {
+  const int64_t nnz = a_cp[n_items_a];
+  int64_t lim = (nnz / SCAN_TILE + 1) * SCAN_TILE;  // the scans skip tiles that start at or beyond nnz
+  if (lim > cap) lim = cap;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t p0 = (int64_t)blockIdx.x * 256 + threadIdx.x; p0 < lim; p0 += stride * 2) {  // two entries per thread and round: both gathers in flight
+    int u[2];
+    uint2 v[2][N];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int64_t p = p0 + q * stride;
+      u[q] = p < nnz ? a_ri[p] : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int d = 0; d < N; ++d) v[q][d] = u[q] >= 0 ? T[(int64_t)u[q] * N + d] : make_uint2(0u, 0u);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int64_t p = p0 + q * stride;
+      if (p < lim) {
+#pragma unroll
+        for (int d = 0; d < N; ++d) {
+          a.pstart[d][p] = (int64_t)v[q][d].x;
+          a.plen[d][p] = (int32_t)v[q][d].y;
+        }
+      }
+    }
+  }
+}
+// pstart[d][cap], plen[d][cap] for n <= EXPAND_MULTI_MAX event types (every B must hold fewer than 2^32 entries); T: n_rows_b * n uint2
+hipError_t launch_expand_prepare_multi(hipStream_t st, int n_cu, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx, int n,
+                                       const int64_t* const* b_row_ptr, int64_t n_rows_b, int64_t cap, int64_t* const* pstart, int32_t* const* plen, void* T) {
+  if (n < 1 || n > EXPAND_MULTI_MAX) return hipErrorInvalidValue;
+  if (cap <= 0) return hipSuccess;
+  ExpandMultiArgs a;
+  a.n = n;
+  for (int d = 0; d < EXPAND_MULTI_MAX; ++d) {
+    a.b_rp[d] = d < n ? b_row_ptr[d] : nullptr;
+    a.pstart[d] = d < n ? pstart[d] : nullptr;
+    a.plen[d] = d < n ? plen[d] : nullptr;
+  }
+  int64_t nb = (n_rows_b + 255) / 256;
+  if (nb > (int64_t)n_cu * 8) nb = (int64_t)n_cu * 8;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(expand_pack_kernel, dim3((unsigned)nb), dim3(256), 0, st, a, n_rows_b, static_cast<uint2*>(T));
+  int64_t blocks = (cap + 511) / 512;
+  const int64_t lim = (int64_t)n_cu * 16;
+  if (blocks > lim) blocks = lim;
+  const uint2* Tc = static_cast<const uint2*>(T);
+  switch (n) {
+    case 1: hipLaunchKernelGGL(expand_prepare_multi_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, Tc, cap, a); break;
+    case 2: hipLaunchKernelGGL(expand_prepare_multi_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, Tc, cap, a); break;
+    case 3: hipLaunchKernelGGL(expand_prepare_multi_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, Tc, cap, a); break;
+    case 4: hipLaunchKernelGGL(expand_prepare_multi_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, Tc, cap, a); break;
+    case 5: hipLaunchKernelGGL(expand_prepare_multi_kernel<5>, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, Tc, cap, a); break;
+    case 6: hipLaunchKernelGGL(expand_prepare_multi_kernel<6>, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, Tc, cap, a); break;
+    case 7: hipLaunchKernelGGL(expand_prepare_multi_kernel<7>, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, Tc, cap, a); break;
+    default: hipLaunchKernelGGL(expand_prepare_multi_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, Tc, cap, a); break;
+  }
+  return hipGetLastError();
+}
+// wp = exclusive prefix of plen over cap entries (the second half of launch_expand_prepare, for lengths produced by the multi form)
+hipError_t launch_expand_scan(hipStream_t st, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* plen, int64_t cap, int64_t* wp, int64_t* tile_sums) {
+  return launch_scan(st, LoadI32{plen}, cap, wp, tile_sums, a_col_ptr + n_items_a);
+}
+
 __global__ __launch_bounds__(256) void row_work_kernel(int32_t item_lo, int32_t item_hi, const int64_t* __restrict__ a_cp,
                                                        const int64_t* __restrict__ wp, int64_t* __restrict__ work) {
   const int64_t n = (int64_t)item_hi - item_lo;

@@ -246,6 +246,19 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
                        const int32_t* a_row_idx, int64_t nnz_a_bound, const int64_t* b_row_ptr, const int32_t* b_col_idx, int32_t n_cols_b,
                        const int32_t* counts_a, const int32_t* counts_b, int64_t n_users, int32_t exclude_self, int32_t k,
                        int32_t has_min_llr, double min_llr, int32_t* out_count, int32_t* out_idx, double* out_llr, int64_t* stats_dev) {
+  return urcco_detail::cco_rows_impl(s, item_lo, item_hi, n_items_a, a_col_ptr, a_row_idx, nnz_a_bound, b_row_ptr, b_col_idx, n_cols_b, counts_a, counts_b, n_users,
+                                     exclude_self, k, has_min_llr, min_llr, out_count, out_idx, out_llr, stats_dev, nullptr, nullptr);
+}
+
+}  // extern "C"
+
+namespace urcco_detail {
+
+// One secondary's share of a fused expand preparation (see urcco_expand_multi) may be handed in as pre_pstart / pre_plen.
+int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a, const int64_t* a_col_ptr, const int32_t* a_row_idx, int64_t nnz_a_bound,
+                  const int64_t* b_row_ptr, const int32_t* b_col_idx, int32_t n_cols_b, const int32_t* counts_a, const int32_t* counts_b, int64_t n_users,
+                  int32_t exclude_self, int32_t k, int32_t has_min_llr, double min_llr, int32_t* out_count, int32_t* out_idx, double* out_llr, int64_t* stats_dev,
+                  const int64_t* pre_pstart, const int32_t* pre_plen) {
   if (!s || item_lo < 0 || item_hi < item_lo || item_hi > n_items_a || n_cols_b < 0 || n_users < 0 || nnz_a_bound < 0 || !a_col_ptr || !b_row_ptr)
     return fail(URCCO_BAD_ARG, "urcco_dev_cco_rows: bad argument");
   if (k <= 0) return fail(URCCO_BAD_ARG, "maxInterestingElements must be positive, got %d", k);
@@ -287,8 +300,9 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
                  urcco_session::need(urcco::NBINS + 1, 4) + urcco_session::need((size_t)n, 4) + urcco_session::need((size_t)n_items_a, 8) +
                  urcco_session::need((size_t)n_cols_b, 2) + urcco_session::need(1, 4) + urcco_session::need(1, 8) + urcco_session::need(URCCO_STATS_LEN, 8) +
                  urcco_session::need((size_t)n_users + 1, 4)));
-  int64_t* pstart = s->take<int64_t>((size_t)cap);
-  int32_t* plen = s->take<int32_t>((size_t)cap);
+  int64_t* own_pstart = s->take<int64_t>((size_t)cap);
+  int32_t* own_plen = s->take<int32_t>((size_t)cap);
+  const int64_t* pstart = pre_pstart ? pre_pstart : own_pstart;
   int64_t* wp = s->take<int64_t>((size_t)cap + 1);
   int64_t* p_tile_sums = s->take<int64_t>((size_t)p_tiles + 2);
   int64_t* work = s->take<int64_t>((size_t)n);
@@ -303,7 +317,10 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   unsigned* b_rp32 = s->take<unsigned>((size_t)n_users + 1);
 
   s->begin(URCCO_STAGE_ROW_WORK);
-  HIPC(urcco::launch_expand_prepare(s->stream, s->n_cu, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, b_rp32, n_users, cap, pstart, plen, wp, p_tile_sums));
+  if (pre_pstart && pre_plen)
+    HIPC(urcco::launch_expand_scan(s->stream, a_col_ptr, n_items_a, pre_plen, cap, wp, p_tile_sums));
+  else
+    HIPC(urcco::launch_expand_prepare(s->stream, s->n_cu, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, b_rp32, n_users, cap, own_pstart, own_plen, wp, p_tile_sums));
   HIPC(urcco::launch_row_work(s->stream, s->n_cu, item_lo, item_hi, a_col_ptr, wp, work));
   s->end();
   s->begin(URCCO_STAGE_BINNING);
@@ -340,6 +357,23 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
   if (s->timing) HIPC(urcco::launch_bin_out_stats(s->stream, bin_rows, bin_off, item_lo, out_count, stats));
   return URCCO_OK;
 }
+
+// Expand preparation of n secondaries in one pass over the CSC of A' (cco_kernels.hip, expand_prepare_multi): pstart[d] / plen[d] hold
+// cap entries each.  The interleaved (start, length) table lives in the session's arena for the duration of the launch.
+int expand_multi(urcco_session* s, int n, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx, int64_t cap, const int64_t* const* b_row_ptr,
+                 int64_t n_users, int64_t* const* pstart, int32_t* const* plen) {
+  if (!s || n < 1 || n > urcco::EXPAND_MULTI_MAX || !a_col_ptr || cap < 0) return fail(URCCO_BAD_ARG, "expand_multi: bad argument");
+  URC(s->reserve(urcco_session::need((size_t)n_users * (size_t)n, 8) + 256));
+  void* T = s->take<unsigned long long>((size_t)n_users * (size_t)n);
+  s->begin(URCCO_STAGE_ROW_WORK);
+  HIPC(urcco::launch_expand_prepare_multi(s->stream, s->n_cu, a_col_ptr, n_items_a, a_row_idx, n, b_row_ptr, n_users, cap, pstart, plen, T));
+  s->end();
+  return URCCO_OK;
+}
+
+}  // namespace urcco_detail
+
+extern "C" {
 
 int urcco_dev_compact_indicators(urcco_session* s, int32_t n_rows, int32_t k, const int32_t* count, const int32_t* idx, const double* llr,
                                  int64_t* out_row_ptr, int32_t* out_col_idx, double* out_llr) {

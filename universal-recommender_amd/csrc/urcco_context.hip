@@ -180,6 +180,8 @@ struct EvState {
   DBuf<double> c_llr;
   DBuf<int64_t> stats;
   DBuf<unsigned long long> verr;
+  DBuf<int64_t> pre_pstart;     // this event type's share of the fused expand preparation (single-rank builds with >= 2 secondaries)
+  DBuf<int32_t> pre_plen;
   hipEvent_t ev_sampled = nullptr, ev_done = nullptr, ev_rp = nullptr;
   hipEvent_t ev_cons[A_SETS] = {};  // ev_cons[q]: the A'B_d of the last build that used the primary's buffer set q has finished
   bool cons_valid[A_SETS] = {};
@@ -190,7 +192,7 @@ struct EvState {
   void release() {
     in_rp.release(); in_ci.release(); raw.release(); post.release(); s_rp.release(); s_ci.release(); deg.release(); f_deg.release();
     f_rp.release(); f_ci.release(); sizes.release(); scan_tmp.release(); o_count.release(); o_idx.release(); o_llr.release(); c_rp.release();
-    c_idx.release(); c_llr.release(); stats.release(); verr.release();
+    c_idx.release(); c_llr.release(); stats.release(); verr.release(); pre_pstart.release(); pre_plen.release();
     if (ev_sampled) (void)hipEventDestroy(ev_sampled);
     if (ev_done) (void)hipEventDestroy(ev_done);
     if (ev_rp) (void)hipEventDestroy(ev_rp);
@@ -218,7 +220,7 @@ struct DevState {
   int par = 0;
   DBuf<int64_t> work;
   DBuf<int32_t> bounds;
-  hipEvent_t a_ready = nullptr, in_ready = nullptr;
+  hipEvent_t a_ready = nullptr, in_ready = nullptr, b_expanded = nullptr;
   Rccl::Comm comm = nullptr;
   int32_t item_lo = 0, item_hi = 0;
 };
@@ -448,6 +450,7 @@ int ensure_events(urcco_context* c, DevState& D, int n_ds) {
   }
   if (!D.a_ready) HIPC(hipEventCreateWithFlags(&D.a_ready, hipEventDisableTiming));
   if (!D.in_ready) HIPC(hipEventCreateWithFlags(&D.in_ready, hipEventDisableTiming));
+  if (!D.b_expanded) HIPC(hipEventCreateWithFlags(&D.b_expanded, hipEventDisableTiming));
   return URCCO_OK;
 }
 
@@ -470,7 +473,7 @@ int stage_downsample(urcco_context* c, DevState& D, int d, const Shard& sh, cons
 }
 
 // A'B_d for the GPU's item range + strided -> CSR, on event d's stream
-int stage_rows(DevState& D, EvState& E, EvState& A, int d, const DsParams& pa, const DsParams& p, int64_t n_users, int64_t a_nnz_bound) {
+int stage_rows(DevState& D, EvState& E, EvState& A, int d, const DsParams& pa, const DsParams& p, int64_t n_users, int64_t a_nnz_bound, bool pre_expanded = false) {
   const int32_t n = D.item_hi - D.item_lo;
   const size_t strided = (size_t)(n > 0 ? n : 1) * (size_t)p.k;
   URC(E.o_count.ensure((size_t)n + 1));
@@ -480,9 +483,9 @@ int stage_rows(DevState& D, EvState& E, EvState& A, int d, const DsParams& pa, c
   URC(E.c_idx.ensure(strided));
   URC(E.c_llr.ensure(strided));
   URC(E.stats.ensure(URCCO_STATS_LEN));
-  URC(urcco_dev_cco_rows(E.s, D.item_lo, D.item_hi, (int32_t)pa.n_cols, D.a_cp[D.par].p, D.a_ri[D.par].p, a_nnz_bound, E.b_rp, E.b_ci, (int32_t)p.n_cols,
-                         post_of(D, 0).p, post_of(D, d).p,
-                         n_users, d == 0 ? 1 : 0, p.k, p.has_min_llr, p.min_llr, E.o_count.p, E.o_idx.p, E.o_llr.p, E.stats.p));
+  URC(cco_rows_impl(E.s, D.item_lo, D.item_hi, (int32_t)pa.n_cols, D.a_cp[D.par].p, D.a_ri[D.par].p, a_nnz_bound, E.b_rp, E.b_ci, (int32_t)p.n_cols,
+                    post_of(D, 0).p, post_of(D, d).p, n_users, d == 0 ? 1 : 0, p.k, p.has_min_llr, p.min_llr, E.o_count.p, E.o_idx.p, E.o_llr.p, E.stats.p,
+                    pre_expanded ? E.pre_pstart.p : nullptr, pre_expanded ? E.pre_plen.p : nullptr));
   URC(urcco_dev_compact_indicators(E.s, n, p.k, E.o_count.p, E.o_idx.p, E.o_llr.p, E.c_rp.p, E.c_idx.p, E.c_llr.p));
   HIPC(hipEventRecord(E.ev_done, E.s->stream));
   HIPC(hipEventRecord(E.ev_cons[D.par], E.s->stream));
@@ -524,15 +527,16 @@ struct InputGate {
 // one rank, nothing to exchange: every event type on its own stream; B_d is sampled while A is sampled and transposed,
 // every A'B_d runs behind an event on A's CSC; the heaviest event type is enqueued first
 // ---------------------------------------------------------------------------------------------------------
-int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, const std::vector<DsParams>& ps, int64_t n_users, int32_t seed,
+int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, const std::vector<DsParams>& ps_, int64_t n_users, int32_t seed,
                  InputGate* gate) {
   const int n_ds = (int)sh.size();
   URC(set_dev(D));
   EvState& A = D.ev[0];
   D.item_lo = 0;
-  D.item_hi = (int32_t)ps[0].n_cols;
-  URC(D.a_cp[D.par].ensure((size_t)ps[0].n_cols + 2));
+  D.item_hi = (int32_t)ps_[0].n_cols;
+  URC(D.a_cp[D.par].ensure((size_t)ps_[0].n_cols + 2));
   URC(D.a_ri[D.par].ensure((size_t)sh[0].nnz + 4));
+  std::atomic<bool> a_ok{false};  // the primary's chain up to its CSC was enqueued successfully
   // A build is ~150 launches of mostly short kernels: enqueued by ONE host thread the first ~0.5 ms of every build are
   // launch-bound (measured: the primary's stream idles 0.4 ms between its transposition and its SpGEMM while the host is
   // still enqueueing the other event types).  With a stream per event type each secondary gets its own enqueueing thread:
@@ -541,21 +545,82 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
   const bool threaded = n_ds > 1 && !c->single_stream();
   std::promise<void> a_recorded;
   std::shared_future<void> a_recorded_f = a_recorded.get_future().share();
-  auto secondary = [&](int d, bool wait_host) -> int {
+  // With two or more secondaries their expand preparation is FUSED: one pass over the CSC of A' gathers an interleaved
+  // (start, length) record per user and writes every secondary's pstart / plen (one scattered sector per CSC entry instead of one
+  // line per entry AND event type).  It runs on the first secondary's stream once every secondary has been sampled and A'
+  // transposed; the primary's own A'A does not wait for it.  (debug 4096: every event type prepares its own, as in round 2.)
+  bool fuse = n_ds >= 3 && n_ds - 1 <= urcco::EXPAND_MULTI_MAX && !(c->debug & 4096);
+  for (int d = 1; d < n_ds; ++d) fuse = fuse && sh[(size_t)d].nnz < ((int64_t)1 << 32);
+  std::vector<std::promise<int>> sampled((size_t)n_ds);
+  std::vector<std::shared_future<int>> sampled_f((size_t)n_ds);
+  for (int d = 0; d < n_ds; ++d) sampled_f[(size_t)d] = sampled[(size_t)d].get_future().share();
+  std::promise<int> expanded;
+  std::shared_future<int> expanded_f = expanded.get_future().share();
+  const int64_t a_cap = sh[0].nnz;
+  auto fused_expand = [&]() -> int {  // on the first secondary's stream; every secondary's ev_sampled and a_ready have been recorded
+    EvState& L = D.ev[1];
+    if (L.s != A.s) HIPC(hipStreamWaitEvent(L.s->stream, D.a_ready, 0));
+    std::vector<const int64_t*> rp((size_t)n_ds - 1);
+    std::vector<int64_t*> ps((size_t)n_ds - 1);
+    std::vector<int32_t*> pl((size_t)n_ds - 1);
+    for (int d = 1; d < n_ds; ++d) {
+      EvState& E = D.ev[(size_t)d];
+      if (E.s != L.s) HIPC(hipStreamWaitEvent(L.s->stream, E.ev_sampled, 0));
+      URC(E.pre_pstart.ensure((size_t)a_cap + 1));
+      URC(E.pre_plen.ensure((size_t)a_cap + 1));
+      rp[(size_t)d - 1] = E.s_rp.p;
+      ps[(size_t)d - 1] = E.pre_pstart.p;
+      pl[(size_t)d - 1] = E.pre_plen.p;
+    }
+    URC(expand_multi(L.s, n_ds - 1, D.a_cp[D.par].p, (int32_t)ps_[0].n_cols, D.a_ri[D.par].p, a_cap, rp.data(), n_users, ps.data(), pl.data()));
+    HIPC(hipEventRecord(D.b_expanded, L.s->stream));
+    return URCCO_OK;
+  };
+  auto sample_secondary = [&](int d) -> int {
     URC(set_dev(D));
     EvState& E = D.ev[(size_t)d];
     if (gate) URC(gate->wait(D, d));
-    URC(stage_raw_counts(D, E, sh[(size_t)d], ps[(size_t)d]));
-    URC(stage_downsample(c, D, d, sh[(size_t)d], ps[(size_t)d], seed));
-    if (wait_host) a_recorded_f.wait();
+    URC(stage_raw_counts(D, E, sh[(size_t)d], ps_[(size_t)d]));
+    URC(stage_downsample(c, D, d, sh[(size_t)d], ps_[(size_t)d], seed));
+    HIPC(hipEventRecord(E.ev_sampled, E.s->stream));
+    return URCCO_OK;
+  };
+  auto rows_secondary = [&](int d) -> int {
+    EvState& E = D.ev[(size_t)d];
     if (E.s != A.s) HIPC(hipStreamWaitEvent(E.s->stream, D.a_ready, 0));
+    if (fuse && E.s != D.ev[1].s) HIPC(hipStreamWaitEvent(E.s->stream, D.b_expanded, 0));
     E.b_rp = E.s_rp.p;
     E.b_ci = E.s_ci.p;
     E.b_rows = sh[(size_t)d].n_rows;
     E.b_nnz_bound = sh[(size_t)d].nnz;
-    URC(stage_rows(D, E, A, d, ps[0], ps[(size_t)d], n_users, sh[0].nnz));
+    URC(stage_rows(D, E, A, d, ps_[0], ps_[(size_t)d], n_users, sh[0].nnz, fuse));
     if (gate && gate->trace) gate->trace->mark("chain enqueued", d);
     return URCCO_OK;
+  };
+  // one enqueueing thread per secondary (see above); host-side hand-offs make sure an event has been RECORDED before a stream is
+  // told to wait for it, and every promise is fulfilled on every path so that nobody waits forever
+  struct Fulfil {  // a promise that is kept even if the code in between throws
+    std::promise<int>* p;
+    bool done = false;
+    void set(int v) { if (p && !done) { done = true; p->set_value(v); } }
+    ~Fulfil() { set(URCCO_INTERNAL); }
+  };
+  auto secondary_thread = [&](int d) -> int {
+    Fulfil my_sample{fuse ? &sampled[(size_t)d] : nullptr};
+    Fulfil my_expand{fuse && d == 1 ? &expanded : nullptr};
+    int st = sample_secondary(d);
+    my_sample.set(st);
+    if (st == URCCO_OK) a_recorded_f.wait();
+    if (fuse && d == 1) {
+      for (int d2 = 2; d2 < n_ds && st == URCCO_OK; ++d2) st = sampled_f[(size_t)d2].get();
+      if (st == URCCO_OK) st = a_ok ? fused_expand() : URCCO_INTERNAL;
+      my_expand.set(st);
+    } else if (fuse && st == URCCO_OK) {
+      st = expanded_f.get();
+    }
+    if (st != URCCO_OK) return st;
+    if (!a_ok) return URCCO_INTERNAL;
+    return rows_secondary(d);
   };
   std::vector<std::thread> workers;
   std::vector<int> status((size_t)n_ds, URCCO_OK);
@@ -563,31 +628,35 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
   if (threaded)
     for (int d = 1; d < n_ds; ++d)
       workers.emplace_back([&, d] {
-        status[(size_t)d] = guarded([&] { return secondary(d, true); });
+        status[(size_t)d] = guarded([&] { return secondary_thread(d); });
         if (status[(size_t)d] != URCCO_OK) message[(size_t)d] = err_buf();  // the message lives in the worker's thread-local buffer
       });
   int st = [&]() -> int {
     if (gate) URC(gate->wait(D, 0));
-    URC(stage_raw_counts(D, A, sh[0], ps[0]));
-    URC(stage_downsample(c, D, 0, sh[0], ps[0], seed));
-    URC(urcco_dev_transpose(A.s, sh[0].n_rows, A.s_rp.p, A.s_ci.p, sh[0].nnz, (int32_t)ps[0].n_cols, post_of(D, 0).p, 0, (int32_t)ps[0].n_cols,
+    URC(stage_raw_counts(D, A, sh[0], ps_[0]));
+    URC(stage_downsample(c, D, 0, sh[0], ps_[0], seed));
+    URC(urcco_dev_transpose(A.s, sh[0].n_rows, A.s_rp.p, A.s_ci.p, sh[0].nnz, (int32_t)ps_[0].n_cols, post_of(D, 0).p, 0, (int32_t)ps_[0].n_cols,
                             D.a_cp[D.par].p, D.a_ri[D.par].p));
     HIPC(hipEventRecord(D.a_ready, A.s->stream));
     return URCCO_OK;
   }();
+  a_ok = st == URCCO_OK;
   a_recorded.set_value();  // also on failure: the workers must not wait forever
   if (st == URCCO_OK) {
     A.b_rp = A.s_rp.p;
     A.b_ci = A.s_ci.p;
     A.b_rows = sh[0].n_rows;
     A.b_nnz_bound = sh[0].nnz;
-    st = stage_rows(D, A, A, 0, ps[0], ps[0], n_users, sh[0].nnz);
+    st = stage_rows(D, A, A, 0, ps_[0], ps_[0], n_users, sh[0].nnz);
     if (gate && gate->trace) gate->trace->mark("chain enqueued", 0);
   }
   for (std::thread& t : workers) t.join();
   if (st != URCCO_OK) return st;
-  if (!threaded)
-    for (int d = 1; d < n_ds; ++d) URC(secondary(d, false));
+  if (!threaded) {
+    for (int d = 1; d < n_ds; ++d) URC(sample_secondary(d));
+    if (fuse) URC(fused_expand());
+    for (int d = 1; d < n_ds; ++d) URC(rows_secondary(d));
+  }
   for (int d = 1; d < n_ds; ++d)
     if (status[(size_t)d] != URCCO_OK) return fail(status[(size_t)d], "%s", message[(size_t)d].c_str());
   return URCCO_OK;
@@ -862,6 +931,7 @@ void urcco_context_destroy(urcco_context* c) {
     D.work.release(); D.bounds.release();
     if (D.a_ready) (void)hipEventDestroy(D.a_ready);
     if (D.in_ready) (void)hipEventDestroy(D.in_ready);
+    if (D.b_expanded) (void)hipEventDestroy(D.b_expanded);
     for (urcco_session* s : D.sessions) urcco_session_destroy(s);
   }
   c->rings.clear();
