@@ -19,6 +19,7 @@ constexpr int GLOBAL_BIN_BLOCKS = 128;    // persistent blocks of the global-acc
 constexpr int BIN_TILE = 1024;           // items per binning tile
 constexpr int XLX_TABLE_HOST = 4096;     // entries of the small-integer xLogX table (== XLX_TABLE in cco_device.h)
 constexpr int BIN_COLS_HOST = 3 * NBINS + 1;  // int64 per binning tile
+constexpr int CAND_SLOTS = 64;           // words the row kernels spread their candidate counts over (see CcoArgs::cand)
 constexpr int STATS_LEN = 32;            // [0] pairs, then NBINS each of rows / pairs / users / out entries per bin, [1 + 4 NBINS] table overflows
 
 struct CcoArgs {
@@ -55,7 +56,7 @@ struct CcoArgs {
   int32_t* out_idx;
   double* out_llr;
   unsigned long long* err;   // stats[1 + 4 * NBINS]: LDS table overflows (must stay 0)
-  unsigned long long* cand;  // stats[2 + 4 * NBINS]: distinct (row, column) candidates scored (LLR evaluations)
+  unsigned long long* cand;  // nullable [CAND_SLOTS], zero on entry: distinct (row, column) candidates scored, spread over the slots (statistics)
   // global-accumulator scratch (bin 3)
   int32_t* g_counts;         // [GLOBAL_BIN_BLOCKS][n_cols_b] zero on entry, zero on exit
   unsigned long long* g_cand_key;  // [GLOBAL_BIN_BLOCKS][n_cols_b]
@@ -153,7 +154,7 @@ hipError_t launch_binning(hipStream_t st, int32_t item_lo, int32_t n, const int6
 
 hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, int bin);
 hipError_t launch_bin_out_stats(hipStream_t st, const int32_t* bin_rows, const int32_t* bin_off, int32_t item_lo, const int32_t* out_count,
-                                int64_t* stats);
+                                const unsigned long long* cand, int64_t* stats);
 
 hipError_t launch_compact_indicators(hipStream_t st, int32_t n_rows, int32_t k, const int32_t* count, const int32_t* idx,
                                      const double* llr, const int64_t* row_ptr, int32_t* out_idx, double* out_llr);

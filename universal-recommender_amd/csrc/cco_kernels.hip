@@ -2357,7 +2357,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
     }
     team_sync<T>();  // the table is re-zeroed by the next row
   }
-  if (tl == 0 && cand_acc != 0ull) atomicAdd(a.cand, cand_acc);
+  // statistics (only while stage timing is on): spread over CAND_SLOTS words -- every team of the grid adding to ONE address was
+  // 16K serialised L2 atomics, +0.4 ms per launch
+  if (a.cand && tl == 0 && cand_acc != 0ull) atomicAdd(&a.cand[(blockIdx.x * TEAMS + team) & (CAND_SLOTS - 1)], cand_acc);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -2516,7 +2518,7 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
     }
     wave_sync();
   }
-  if (lane == 0 && cand_acc != 0ull) atomicAdd(a.cand, cand_acc);
+  if (a.cand && lane == 0 && cand_acc != 0ull) atomicAdd(&a.cand[(blockIdx.x * TEAMS + team) & (CAND_SLOTS - 1)], cand_acc);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -2766,9 +2768,15 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
 
 // stats[1 + 3 * NBINS + bin] = indicator entries emitted by the rows of each bin (profiling aid, deterministic block reduce)
 __global__ __launch_bounds__(256) void bin_out_stats_kernel(const int32_t* __restrict__ bin_rows, const int32_t* __restrict__ bin_off,
-                                                            int32_t item_lo, const int32_t* __restrict__ out_count, int64_t* __restrict__ stats) {
+                                                            int32_t item_lo, const int32_t* __restrict__ out_count, const unsigned long long* __restrict__ cand,
+                                                            int64_t* __restrict__ stats) {
   __shared__ long long s_wave[SCAN_THREADS / WAVE];
   const int bin = blockIdx.x;
+  if (bin == 0 && blockIdx.y == 0 && threadIdx.x == 0 && cand) {  // distinct (row, column) candidates scored: the slots the row kernels added to
+    long long c = 0;
+    for (int q = 0; q < CAND_SLOTS; ++q) c += (long long)cand[q];
+    stats[2 + 4 * NBINS] = c;
+  }
   long long v = 0;
   for (int t = bin_off[bin] + blockIdx.y * 256 + threadIdx.x; t < bin_off[bin + 1]; t += 256 * gridDim.y) v += out_count[bin_rows[t] - item_lo];
   long long tot;
@@ -2776,8 +2784,8 @@ __global__ __launch_bounds__(256) void bin_out_stats_kernel(const int32_t* __res
   if (threadIdx.x == 0 && tot) atomicAdd((unsigned long long*)&stats[1 + 3 * NBINS + bin], (unsigned long long)tot);
 }
 hipError_t launch_bin_out_stats(hipStream_t st, const int32_t* bin_rows, const int32_t* bin_off, int32_t item_lo, const int32_t* out_count,
-                                int64_t* stats) {
-  hipLaunchKernelGGL(bin_out_stats_kernel, dim3(NBINS, 128), dim3(256), 0, st, bin_rows, bin_off, item_lo, out_count, stats);
+                                const unsigned long long* cand, int64_t* stats) {
+  hipLaunchKernelGGL(bin_out_stats_kernel, dim3(NBINS, 128), dim3(256), 0, st, bin_rows, bin_off, item_lo, out_count, cand, stats);
   return hipGetLastError();
 }
 

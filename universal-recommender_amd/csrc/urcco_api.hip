@@ -298,7 +298,7 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
                  urcco_session::need((size_t)p_tiles + 2, 8) +
                  urcco_session::need((size_t)n, 8) + urcco_session::need((size_t)(n_tiles + 1) * urcco::BIN_COLS_HOST, 8) +
                  urcco_session::need(urcco::NBINS + 1, 4) + urcco_session::need((size_t)n, 4) + urcco_session::need((size_t)n_items_a, 8) +
-                 urcco_session::need((size_t)n_cols_b, 2) + urcco_session::need(1, 4) + urcco_session::need(1, 8) + urcco_session::need(URCCO_STATS_LEN, 8) +
+                 urcco_session::need((size_t)n_cols_b, 2) + urcco_session::need(1, 4) + urcco_session::need(urcco::CAND_SLOTS, 8) + urcco_session::need(1, 8) + urcco_session::need(URCCO_STATS_LEN, 8) +
                  urcco_session::need((size_t)n_users + 1, 4)));
   int64_t* own_pstart = s->take<int64_t>((size_t)cap);
   int32_t* own_plen = s->take<int32_t>((size_t)cap);
@@ -312,6 +312,7 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
   double* ent_a = s->take<double>((size_t)n_items_a);
   unsigned short* cnt_b16 = s->take<unsigned short>((size_t)n_cols_b);
   int32_t* cnt16_bad = s->take<int32_t>(1);
+  unsigned long long* cand = s->take<unsigned long long>(urcco::CAND_SLOTS);
   double* xlx_n = s->take<double>(1);
   int64_t* stats = stats_dev ? stats_dev : s->take<int64_t>(URCCO_STATS_LEN);
   unsigned* b_rp32 = s->take<unsigned>((size_t)n_users + 1);
@@ -343,7 +344,8 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
   a.g_log2 = 4;  // 16 lanes stream one user's B' row: 64 B segments, matches the ~10-40 item rows the cut leaves
   a.out_count = out_count; a.out_idx = out_idx; a.out_llr = out_llr;
   a.err = reinterpret_cast<unsigned long long*>(stats + 1 + 4 * urcco::NBINS);
-  a.cand = reinterpret_cast<unsigned long long*>(stats + 2 + 4 * urcco::NBINS);
+  a.cand = s->timing ? cand : nullptr;
+  if (s->timing) HIPC(hipMemsetAsync(cand, 0, sizeof(unsigned long long) * urcco::CAND_SLOTS, s->stream));
   a.g_counts = s->g_counts; a.g_cand_key = s->g_cand_key; a.g_cand_col = s->g_cand_col; a.g_blocks = dense_bin6 ? s->g_blocks : 0;
   // Heaviest classes first (global, whole-CU, half-CU, ...): they have few, long rows and end raggedly; the fine-grained
   // one-wave and micro classes run last and finish sharply -- and, with a stream per event type, fill the heavy classes'
@@ -354,7 +356,7 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
     HIPC(urcco::launch_cco_rows_bin(s->stream, s->n_cu, a, bin));
     s->end();
   }
-  if (s->timing) HIPC(urcco::launch_bin_out_stats(s->stream, bin_rows, bin_off, item_lo, out_count, stats));
+  if (s->timing) HIPC(urcco::launch_bin_out_stats(s->stream, bin_rows, bin_off, item_lo, out_count, cand, stats));
   return URCCO_OK;
 }
 
