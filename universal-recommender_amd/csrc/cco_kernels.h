@@ -10,10 +10,6 @@ constexpr int NBINS = 7;  // accumulator classes: 0 micro (one wave, <= 64 pairs
                           // 2 small-block-LDS (256 thr, 4096 words), 3 block-LDS (256 thr, 8192 words),
                           // 4 half-CU-LDS (512 thr, 16384 words), 5 CU-LDS (1024 thr, 32768 words),
                           // 6 multi-pass CU-LDS (rows no single table holds; dense global counters when k > MP_KMAX_HOST)
-// Row lists are built per INTERNAL class: the micro class is three lists (rows of <= 16, <= 32, <= 64 users and pairs: four, two
-// and one row per wave), then the six classes above.  Statistics and stage timings stay per accumulator class (NBINS).
-constexpr int NB_INT = NBINS + 2;
-inline int ext_bin(int internal) { return internal < 3 ? 0 : internal - 2; }
 constexpr int MP_KMAX_HOST = 256;  // largest k the multi-pass class serves (== MP_KMAX in cco_kernels.hip)
 
 // Geometry the host side needs for scratch sizing.
@@ -22,14 +18,14 @@ constexpr int DS_TILE = 4096;            // entries per down-sample tile (256 th
 constexpr int GLOBAL_BIN_BLOCKS = 128;    // persistent blocks of the global-accumulator kernel (upper bound)
 constexpr int BIN_TILE = 1024;           // items per binning tile
 constexpr int XLX_TABLE_HOST = 4096;     // entries of the small-integer xLogX table (== XLX_TABLE in cco_device.h)
-constexpr int BIN_COLS_HOST = 3 * (NBINS + 2) + 1;  // int64 per binning tile (3 per internal class + the pair total)
+constexpr int BIN_COLS_HOST = 3 * NBINS + 1;  // int64 per binning tile
 constexpr int CAND_SLOTS = 64;           // words the row kernels spread their candidate counts over (see CcoArgs::cand)
 constexpr int STATS_LEN = 32;            // [0] pairs, then NBINS each of rows / pairs / users / out entries per bin, [1 + 4 NBINS] table overflows
 
 struct CcoArgs {
   // row lists per bin
   const int32_t* bin_rows;   // item ids grouped by bin
-  const int32_t* bin_off;    // [NB_INT+1] offsets into bin_rows (internal classes)
+  const int32_t* bin_off;    // [NBINS+1] offsets into bin_rows
   // matrices
   const int64_t* a_col_ptr;  // CSC of A': users of item i are entries [a_col_ptr[i], a_col_ptr[i+1])
   const int64_t* pstart;     // per CSC entry: start of that user's B' row in b_col_idx
@@ -152,11 +148,11 @@ hipError_t launch_expand_scan(hipStream_t st, const int64_t* a_col_ptr, int32_t 
 hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr, const int64_t* wp, int64_t* work);
 
 // binning: tile_counts scratch [(ceil(n/BIN_TILE)+1) * BIN_COLS_HOST] int64;
-// bin_off[NB_INT+1] int32 (internal classes), bin_rows[n] int32, stats[STATS_LEN] int64.
+// bin_off[NBINS+1] int32, bin_rows[n] int32, stats[STATS_LEN] int64.
 hipError_t launch_binning(hipStream_t st, int32_t item_lo, int32_t n, const int64_t* work, const int32_t* cnt_a, int32_t n_cols_b,
                           int32_t count_bits, int32_t k, int64_t* tile_counts, int32_t* bin_off, int32_t* bin_rows, int64_t* stats);
 
-hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, int internal_bin);
+hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, int bin);
 hipError_t launch_bin_out_stats(hipStream_t st, const int32_t* bin_rows, const int32_t* bin_off, int32_t item_lo, const int32_t* out_count,
                                 const unsigned long long* cand, int64_t* stats);
 

@@ -1482,28 +1482,26 @@ constexpr int MP_KMAX = 256;  // largest k the multi-pass class keeps its runnin
 #ifndef URCCO_WB2
 #define URCCO_WB2 8192
 #endif
-// internal class of a row (see NB_INT in cco_kernels.h): 0 / 1 / 2 micro (<= 16 / 32 / 64 users and pairs), 3 .. 7 the five LDS
-// accumulator classes, 8 multi-pass
 __device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_cols_b, int32_t count_bits, int32_t k) {
   if (ca <= 0 || w <= 0) return -1;  // no users or no pairs: empty indicator row
-  if (count_bits < 31 && ca > ((1ll << count_bits) - 1)) return NB_INT - 1;
-  if (w <= 64 && ca <= 64) return (w <= 16 && ca <= 16) ? 0 : ((w <= 32 && ca <= 32) ? 1 : 2);  // micro: one pair per lane
-  int cap_bin = NB_INT - 1;
+  if (count_bits < 31 && ca > ((1ll << count_bits) - 1)) return NBINS - 1;
+  if (w <= 64 && ca <= 64) return 0;  // micro: one pair per lane
+  int cap_bin = NBINS - 1;
   // a table of E words must hold D packed counts + D 64-bit keys + the k selected (key, col): 3 D + 3 k + 1 <= E,
   // with D <= min(w, n_cols_b)
   const long long dmax = (w < (long long)n_cols_b ? w : (long long)n_cols_b) * 3 + (long long)k * 3 + 2;
-  if (dmax <= E0) cap_bin = 3;
-  else if (dmax <= E1S) cap_bin = 4;
-  else if (dmax <= E1) cap_bin = 5;
-  else if (dmax <= E2S) cap_bin = 6;
-  else if (dmax <= E2) cap_bin = 7;
-  const int work_bin = w <= URCCO_WB1 ? 3 : (w <= URCCO_WB2 ? 4 : 6);  // long rows want more lanes even when a small table would hold them
+  if (dmax <= E0) cap_bin = 1;
+  else if (dmax <= E1S) cap_bin = 2;
+  else if (dmax <= E1) cap_bin = 3;
+  else if (dmax <= E2S) cap_bin = 4;
+  else if (dmax <= E2) cap_bin = 5;
+  const int work_bin = w <= URCCO_WB1 ? 1 : (w <= URCCO_WB2 ? 2 : 4);  // long rows want more lanes even when a small table would hold them
   return cap_bin > work_bin ? cap_bin : work_bin;
 }
 
 constexpr int BIN_THREADS = 256;
 constexpr int BIN_ITEMS = BIN_TILE / BIN_THREADS;  // 4
-constexpr int BIN_COLS = 3 * NB_INT + 1;           // per tile: rows / pairs / users per internal class, total pairs
+constexpr int BIN_COLS = 3 * NBINS + 1;            // per tile: rows per bin, pairs per bin, users per bin, total pairs
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo, int32_t n, const int64_t* __restrict__ work,
                                                                 const int32_t* __restrict__ cnt_a, int32_t n_cols_b, int32_t count_bits, int32_t k,
@@ -1511,10 +1509,10 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo,
   __shared__ long long s_acc[BIN_COLS];
   if (threadIdx.x < BIN_COLS) s_acc[threadIdx.x] = 0;
   __syncthreads();
-  int c[NB_INT];
-  long long pw[NB_INT], pu[NB_INT];
+  int c[NBINS];
+  long long pw[NBINS], pu[NBINS];
 #pragma unroll
-  for (int k = 0; k < NB_INT; ++k) { c[k] = 0; pw[k] = 0; pu[k] = 0; }
+  for (int k = 0; k < NBINS; ++k) { c[k] = 0; pw[k] = 0; pu[k] = 0; }
   long long pairs = 0;
 #pragma unroll
   for (int q = 0; q < BIN_ITEMS; ++q) {
@@ -1525,7 +1523,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo,
       pairs += w;
       const int b = choose_bin(w, ca, n_cols_b, count_bits, k);
 #pragma unroll
-      for (int k = 0; k < NB_INT; ++k) {
+      for (int k = 0; k < NBINS; ++k) {
         c[k] += (b == k);
         pw[k] += (b == k) ? w : 0;
         pu[k] += (b == k) ? ca : 0;
@@ -1533,13 +1531,13 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo,
     }
   }
 #pragma unroll
-  for (int k = 0; k < NB_INT; ++k)
+  for (int k = 0; k < NBINS; ++k)
     if (c[k]) {
       atomicAdd((unsigned long long*)&s_acc[k], (unsigned long long)c[k]);
-      atomicAdd((unsigned long long*)&s_acc[NB_INT + k], (unsigned long long)pw[k]);
-      atomicAdd((unsigned long long*)&s_acc[2 * NB_INT + k], (unsigned long long)pu[k]);
+      atomicAdd((unsigned long long*)&s_acc[NBINS + k], (unsigned long long)pw[k]);
+      atomicAdd((unsigned long long*)&s_acc[2 * NBINS + k], (unsigned long long)pu[k]);
     }
-  if (pairs) atomicAdd((unsigned long long*)&s_acc[3 * NB_INT], (unsigned long long)pairs);
+  if (pairs) atomicAdd((unsigned long long*)&s_acc[3 * NBINS], (unsigned long long)pairs);
   __syncthreads();
   if (threadIdx.x < BIN_COLS) tile_counts[(int64_t)blockIdx.x * BIN_COLS + threadIdx.x] = s_acc[threadIdx.x];
 }
@@ -1570,18 +1568,17 @@ __global__ __launch_bounds__(BS_THREADS) void bin_scan_kernel(int64_t* __restric
   __syncthreads();
   if (threadIdx.x == 0) {
     int32_t off = 0;
-    for (int k = 0; k < NB_INT; ++k) {
+    for (int k = 0; k < NBINS; ++k) {
       bin_off[k] = off;
       off += (int32_t)s_tot[k];
-      if (stats) {  // per accumulator class: the three micro lists are one class (stats[] was zeroed by the caller)
-        const int x = k < 3 ? 0 : k - 2;
-        stats[1 + x] += s_tot[k];                             // rows
-        stats[1 + NBINS + x] += s_tot[NB_INT + k];            // pairs
-        stats[1 + 2 * NBINS + x] += s_tot[2 * NB_INT + k];    // users (sum of cA over the bin's rows)
+      if (stats) {
+        stats[1 + k] = s_tot[k];                          // rows
+        stats[1 + NBINS + k] = s_tot[NBINS + k];          // pairs
+        stats[1 + 2 * NBINS + k] = s_tot[2 * NBINS + k];  // users (sum of cA over the bin's rows)
       }
     }
-    bin_off[NB_INT] = off;
-    if (stats) stats[0] = s_tot[3 * NB_INT];
+    bin_off[NBINS] = off;
+    if (stats) stats[0] = s_tot[3 * NBINS];
   }
 }
 
@@ -1596,7 +1593,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int32_t item_l
     const int64_t t = (int64_t)blockIdx.x * BIN_TILE + (int64_t)threadIdx.x * BIN_ITEMS + q;
     b[q] = t < n ? choose_bin(work[t], cnt_a[item_lo + t], n_cols_b, count_bits, k) : -1;
   }
-  for (int k = 0; k < NB_INT; ++k) {  // block-uniform: one block scan per bin
+  for (int k = 0; k < NBINS; ++k) {  // block-uniform: one block scan per bin
     int c = 0;
 #pragma unroll
     for (int q = 0; q < BIN_ITEMS; ++q) c += (b[q] == k);
@@ -1611,7 +1608,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int32_t item_l
 hipError_t launch_binning(hipStream_t st, int32_t item_lo, int32_t n, const int64_t* work, const int32_t* cnt_a, int32_t n_cols_b,
                           int32_t count_bits, int32_t k, int64_t* tile_counts, int32_t* bin_off, int32_t* bin_rows, int64_t* stats) {
   if (n <= 0) {
-    hipError_t e = hipMemsetAsync(bin_off, 0, sizeof(int32_t) * (NB_INT + 1), st);
+    hipError_t e = hipMemsetAsync(bin_off, 0, sizeof(int32_t) * (NBINS + 1), st);
     if (e == hipSuccess && stats) e = hipMemsetAsync(stats, 0, sizeof(int64_t) * STATS_LEN, st);
     return e;
   }
@@ -2053,7 +2050,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
           cbj[x] = 0;
           if (vv[x] != 0u) {
             const int j = MP ? (int)((((vv[x] >> cb) - 1u) << mp_s) | mp_q) : (int)(vv[x] >> cb) - 1;
-            cbj[x] = (a.debug & 512) ? (int)(vv[x] & cmask) + 100 : (use16 ? (int)a.cnt_b16[j] : a.cnt_b[j]);  // the ONE scattered gather per candidate (ablation 512: none)
+            cbj[x] = (a.debug & 512) ? 100 : (use16 ? (int)a.cnt_b16[j] : a.cnt_b[j]);  // the ONE scattered gather per candidate (ablation 512: none)
           }
         }
 #pragma unroll
@@ -2366,51 +2363,39 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
 }
 
 // --------------------------------------------------------------------------------------------
-// Micro rows: <= 64 users and <= 64 cooccurrence pairs -- two thirds of all item rows under a Zipf catalogue.  One pair per
-// lane, a small accumulator, compaction by ballots, at most one candidate per lane ranked by counting: no scans, no chunk
-// loop, no selection passes, few registers (8 waves/SIMD).
-// Round 3: SEG lanes per row, 64 / SEG rows per wave.  A row of this class is a chain of dependent gathers (row id -> CSC bounds
-// -> prefix -> B' columns -> counts) that eight waves per SIMD do not hide (45 % of the wave cycles parked), and most of these
-// rows fill a fraction of a wave: rows of <= 16 users and pairs run four to a wave (SEG = 16), <= 32 two to a wave -- a
-// quarter / half of the wave instructions per row and four / two rows' gathers in flight per wave.  Segments are DPP-row sized,
-// cross-lane work is ballots cut to the segment's bits.
-// Wave LDS layout (words): [0,256) accumulators (4 SEG slots per row), [256,320) packed candidates (slot = lane),
-// [320,448) their 64-bit keys (slot = lane).
+// Micro rows (bin 0): <= 64 users and <= 64 cooccurrence pairs -- more than half of all item rows under a Zipf
+// catalogue.  One wave per row, one pair per lane, a 256-word accumulator, compaction by ballots, at most one
+// candidate per lane ranked by counting: no scans, no chunk loop, no selection passes, few registers (8 waves/SIMD).
+// Team LDS layout (words): [0,256) accumulator, [256,320) packed candidates, [320,448) their 64-bit keys.
 // --------------------------------------------------------------------------------------------
 constexpr int MICRO_WORDS = 448;
 
-template <int SEG>
-__global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a, int bin) {
+__global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
   constexpr int TEAMS = 256 / WAVE;
-  constexpr int R = WAVE / SEG;        // rows per wave
-  constexpr int TW = 4 * SEG;          // accumulator slots per row (load factor <= 1/4)
-  constexpr int LOG2TW = SEG == 16 ? 6 : (SEG == 32 ? 7 : 8);
-  static_assert((1 << LOG2TW) == TW, "accumulator size");
   __shared__ unsigned s_tab[TEAMS * MICRO_WORDS];
   __shared__ long long s_ustart[TEAMS * WAVE];
-  __shared__ unsigned s_uoff[TEAMS * R * (SEG + 1)];
+  __shared__ unsigned s_uoff[TEAMS * (WAVE + 1)];
+  // (moving the row id, bounds and counts to scalar registers as in cco_rows_kernel was measured 12 % SLOWER here: the kernel
+  // argument block alone keeps ~60 SGPRs live and the extra scalars spill to VGPR lanes)
   const int team = threadIdx.x / WAVE;
   const int lane = threadIdx.x & (WAVE - 1);
-  const int sgm = lane / SEG, sl = lane % SEG;  // segment (row slot) of the wave, lane inside it
   unsigned* tab = s_tab + team * MICRO_WORDS;
-  unsigned* acc = tab + sgm * TW;
   unsigned* cand = tab + 256;
   unsigned long long* kkm = reinterpret_cast<unsigned long long*>(tab + 320);
-  long long* ustart = s_ustart + team * WAVE + sgm * SEG;
-  unsigned* uoff = s_uoff + (team * R + sgm) * (SEG + 1);
-  const int list_start = a.bin_off[bin];
-  const int list_n = a.bin_off[bin + 1] - list_start;
-  const int stride = gridDim.x * TEAMS * R;
-  const bool ident = a.n_cols_b <= TW;
+  long long* ustart = s_ustart + team * WAVE;
+  unsigned* uoff = s_uoff + team * (WAVE + 1);
+  const int list_start = a.bin_off[0];
+  const int list_n = a.bin_off[1] - list_start;
+  const int total_teams = gridDim.x * TEAMS;
+  const bool ident = a.n_cols_b <= 256;
   const int cb = a.count_bits;
   const unsigned cmask = (1u << cb) - 1u;
   const double xlx_n = *a.xlx_n;
   const bool use16 = *a.cnt16_bad == 0;
-  const unsigned long long seg_bits = SEG == 64 ? ~0ull : ((1ull << SEG) - 1ull);
-  const unsigned long long below = (1ull << sl) - 1ull;  // the segment's lanes below this one
-  unsigned long long cand_acc = 0ull;  // candidates scored by this wave's segments (statistics)
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  unsigned long long cand_acc = 0ull;  // candidates scored by this wave (statistics)
 
-  int li = (blockIdx.x * TEAMS + team) * R + sgm;  // this segment's position in the class's row list
+  int li = blockIdx.x * TEAMS + team;
   int i_nx = 0;
   int64_t cs_nx = 0, ce_nx = 0;
   if (li < list_n) {
@@ -2425,75 +2410,72 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a, int b
   if (li < list_n) {
     pf_w0 = a.wp[cs_nx];
     pf_w1 = a.wp[ce_nx];
-    if (cs_nx + sl < ce_nx) {
-      pf_wp = a.wp[cs_nx + sl];
-      pf_start = a.pstart[cs_nx + sl];
+    if (cs_nx + lane < ce_nx) {
+      pf_wp = a.wp[cs_nx + lane];
+      pf_start = a.pstart[cs_nx + lane];
     }
     pf_ca = a.cnt_a[i_nx];
     pf_ent = a.ent_a[i_nx];
   }
-  // segment 0 holds the smallest list position of the wave: the wave loops while it has a row (wave-uniform); segments past the
-  // end of the list idle through the remaining rounds
-  for (int li0 = (blockIdx.x * TEAMS + team) * R; li0 < list_n; li0 += stride, li += stride) {
-    const bool act = li < list_n;
+  for (; li < list_n; li += total_teams) {  // each wave runs its own row loop: wave-level sync only
     const int i = i_nx;
     const int64_t cs = cs_nx, ce = ce_nx;
-    const bool has_next = li + stride < list_n;
+    const bool has_next = li + total_teams < list_n;
     if (has_next) {  // the next row's id and CSC bounds travel while this row is processed
-      i_nx = a.bin_rows[list_start + li + stride];
+      i_nx = a.bin_rows[list_start + li + total_teams];
       cs_nx = a.a_col_ptr[i_nx];
       ce_nx = a.a_col_ptr[i_nx + 1];
     }
     const int64_t w0 = pf_w0;
-    const unsigned total = act ? (unsigned)(pf_w1 - w0) : 0u;  // <= SEG by the binning rule
-    const bool owns_user = act && cs + sl < ce;
+    const unsigned total = (unsigned)(pf_w1 - w0);  // <= 64 by the binning rule
+    const bool owns_user = cs + lane < ce;
     const long long ca = pf_ca;
     const double row_entropy = pf_ent;
 #pragma unroll
     for (int q = 0; q < 4; ++q) tab[lane + q * WAVE] = 0u;
-    ustart[sl] = owns_user ? pf_start : 0;
-    uoff[sl] = owns_user ? (unsigned)(pf_wp - w0) : total;
-    if (sl == 0) uoff[SEG] = total;
+    ustart[lane] = owns_user ? pf_start : 0;
+    uoff[lane] = owns_user ? (unsigned)(pf_wp - w0) : total;
+    if (lane == 0) uoff[WAVE] = total;
     wave_sync();
-    if ((unsigned)sl < total) {
-      int lo = 1, hi = SEG;  // first idx in [1, SEG] with uoff[idx] > sl
+    if ((unsigned)lane < total) {
+      int lo = 1, hi = WAVE;  // first idx in [1, 64] with uoff[idx] > lane
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (uoff[mid] > (unsigned)sl) hi = mid; else lo = mid + 1;
+        if (uoff[mid] > (unsigned)lane) hi = mid; else lo = mid + 1;
       }
       const int o = lo - 1;
-      const unsigned jj = (unsigned)a.b_col_idx[ustart[o] + ((unsigned)sl - uoff[o])];
-      if (!(a.debug & 1) && !tab_insert(acc, jj + 1u, cb, (unsigned)(TW - 1), 32 - LOG2TW, ident)) atomicAdd(a.err, 1ull);
+      const unsigned jj = (unsigned)a.b_col_idx[ustart[o] + ((unsigned)lane - uoff[o])];
+      if (!(a.debug & 1) && !tab_insert(tab, jj + 1u, cb, 255u, 24, ident)) atomicAdd(a.err, 1ull);
     }
     wave_sync();
     if (has_next) {  // next row's operands (its CSC bounds arrived during the insert phase)
       pf_w0 = a.wp[cs_nx];
       pf_w1 = a.wp[ce_nx];
-      if (cs_nx + sl < ce_nx) {
-        pf_wp = a.wp[cs_nx + sl];
-        pf_start = a.pstart[cs_nx + sl];
+      if (cs_nx + lane < ce_nx) {
+        pf_wp = a.wp[cs_nx + lane];
+        pf_start = a.pstart[cs_nx + lane];
       }
       pf_ca = a.cnt_a[i_nx];
       pf_ent = a.ent_a[i_nx];
     }
-    unsigned D = 0;  // distinct columns of this segment's row
+    unsigned D = 0;
 #pragma unroll
-    for (int q = 0; q < TW / SEG; ++q) {
-      const unsigned v = acc[sl + q * SEG];
-      const unsigned long long m = (__ballot(v != 0u) >> (sgm * SEG)) & seg_bits;  // the segment's share of the ballot
-      if (v != 0u) cand[sgm * SEG + D + (unsigned)__popcll(m & below)] = v;
+    for (int q = 0; q < 4; ++q) {
+      const unsigned v = tab[lane + q * WAVE];
+      const unsigned long long m = __ballot(v != 0u);
+      if (v != 0u) cand[D + lanes_below(m)] = v;
       D += (unsigned)__popcll(m);
     }
-    if (sl == 0) cand_acc += D;
+    cand_acc += D;
     wave_sync();
     unsigned long long mk = 0ull;
     int mc = 0x7fffffff;
-    if ((unsigned)sl < D) {
+    if ((unsigned)lane < D) {
       const unsigned vv = cand[lane];
       const int j = (int)(vv >> cb) - 1;
       const long long k11 = (long long)(vv & cmask);
       if (!(a.exclude_self && j == i)) {
-        const long long cbj = (a.debug & 512) ? k11 + 100ll : (use16 ? (long long)a.cnt_b16[j] : (long long)a.cnt_b[j]);
+        const long long cbj = (a.debug & 512) ? 100ll : (use16 ? (long long)a.cnt_b16[j] : (long long)a.cnt_b[j]);
         const double llr = (a.debug & 2) ? (double)k11
                                          : llr_from_entropies_tab(row_entropy, column_entropy_tab(cbj, xlx_n, a.n_users, a.xlx_tab, a.xlx_hi), xlx_n, k11, ca - k11,
                                                                   cbj - k11, a.n_users - ca - cbj + k11, a.xlx_tab, a.n_users, a.xlx_hi);
@@ -2502,57 +2484,41 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a, int b
           mc = j;
         }
       }
+      kkm[lane] = mk;
     }
-    kkm[lane] = mk;  // every lane: a zero key ranks behind everything and is never emitted
     wave_sync();
-    const unsigned long long valid = (__ballot(mk != 0ull) >> (sgm * SEG)) & seg_bits;
-    const int n_valid = __popcll(valid);
-    const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
-    if (!(a.debug & 4)) {
-      const bool direct = a.unordered && n_valid <= a.k;  // every candidate is emitted: no ranking needed (uniform within the segment)
-      if (direct) {
-        if (mk != 0ull) {
-          const int pos = __popcll(valid & below);
-          a.out_idx[obase + pos] = mc;
-          a.out_llr[obase + pos] = __longlong_as_double((long long)mk);
-        }
-        if (act && sl == 0) a.out_count[i - a.item_lo] = n_valid;
+    const unsigned long long valid_mask = __ballot(mk != 0ull);
+    const int n_valid = __popcll(valid_mask);
+    if (a.unordered && n_valid <= a.k && !(a.debug & 4)) {  // every candidate is emitted: no ranking needed (wave-uniform)
+      const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
+      if (mk != 0ull) {
+        const int pos = __popcll(valid_mask & lt);
+        a.out_idx[obase + pos] = mc;
+        a.out_llr[obase + pos] = __longlong_as_double((long long)mk);
       }
-      // rank by counting over the segment's SEG key slots (zero keys behind the candidates never count); a fixed trip count keeps
-      // the loop in scalar control for every segment at once
-      unsigned rank = 0;
-      if (!a.unordered || __ballot(!direct && mk != 0ull) != 0ull) {  // wave-uniform
-        unsigned r0 = 0, r1 = 0;
-#pragma unroll 4
-        for (int u = 0; u < SEG; u += 2) {
-          const unsigned long long k0 = kkm[sgm * SEG + u], k1 = kkm[sgm * SEG + u + 1];
-          const int c0 = (int)(cand[sgm * SEG + u] >> cb) - 1, c1 = (int)(cand[sgm * SEG + u + 1] >> cb) - 1;
-          r0 += best_before(k0, c0, mk, mc) ? 1u : 0u;
-          r1 += best_before(k1, c1, mk, mc) ? 1u : 0u;
-        }
-        rank = r0 + r1;
-      }
-      // the row is put in order in LDS (its accumulator words are free again) and leaves as contiguous stores
+      if (lane == 0) a.out_count[i - a.item_lo] = n_valid;
+    } else if (!(a.debug & 4)) {
+      const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
+      const unsigned rank = mk == 0ull ? 0u : rank_by_counting(kkm, D, mk, mc, [&](unsigned u) { return (int)(cand[u] >> cb) - 1; });  // broadcast LDS reads
+      // the row is put in order in LDS (the accumulator words are free again) and leaves as contiguous stores
       wave_sync();
-      unsigned* srt_col = acc;                                                      // [SEG]
-      unsigned long long* srt_key = reinterpret_cast<unsigned long long*>(acc + SEG);  // [SEG]
+      unsigned* srt_col = tab;                                                    // [64]
+      unsigned long long* srt_key = reinterpret_cast<unsigned long long*>(tab + 64);  // [64]
       const unsigned n_out = (unsigned)(n_valid < a.k ? n_valid : a.k);
-      if (!direct && mk != 0ull && rank < n_out) {
+      if (mk != 0ull && rank < n_out) {
         srt_col[rank] = (unsigned)mc;
         srt_key[rank] = mk;
       }
       wave_sync();
-      if (!direct) {
-        if ((unsigned)sl < n_out) {
-          a.out_idx[obase + sl] = (int)srt_col[sl];
-          a.out_llr[obase + sl] = __longlong_as_double((long long)srt_key[sl]);
-        }
-        if (act && sl == 0) a.out_count[i - a.item_lo] = (int)n_out;
+      if ((unsigned)lane < n_out) {
+        a.out_idx[obase + lane] = (int)srt_col[lane];
+        a.out_llr[obase + lane] = __longlong_as_double((long long)srt_key[lane]);
       }
+      if (lane == 0) a.out_count[i - a.item_lo] = (int)n_out;
     }
     wave_sync();
   }
-  if (a.cand && sl == 0 && cand_acc != 0ull) atomicAdd(&a.cand[((blockIdx.x * TEAMS + team) * R + sgm) & (CAND_SLOTS - 1)], cand_acc);
+  if (a.cand && lane == 0 && cand_acc != 0ull) atomicAdd(&a.cand[(blockIdx.x * TEAMS + team) & (CAND_SLOTS - 1)], cand_acc);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -2574,7 +2540,7 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
   __shared__ int s_nsel;
   __shared__ unsigned long long s_selk[GSEL_K];
   __shared__ unsigned s_selc[GSEL_K];
-  const int bin = NB_INT - 1;
+  const int bin = NBINS - 1;
   const int list_start = a.bin_off[bin];
   const int list_n = a.bin_off[bin + 1] - list_start;
   int32_t* cnt = a.g_counts + (int64_t)blockIdx.x * a.n_cols_b;
@@ -2748,22 +2714,18 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
 
 // resident blocks per CU of each LDS-accumulator kernel (registers / LDS decide), so that the persistent grids fill
 // the chip exactly once
-// resident blocks per CU of each row kernel (registers / LDS decide), so that the persistent grids fill the chip exactly once;
-// indexed by the INTERNAL class
 static int blocks_per_cu(int bin) {
-  static int cache[NB_INT] = {0};
+  static int cache[7] = {0, 0, 0, 0, 0, 0, 0};
   if (cache[bin] == 0) {
     int n = 0;
     hipError_t e = hipErrorUnknown;
-    if (bin == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_micro_kernel<16>, 256, 0);
-    if (bin == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_micro_kernel<32>, 256, 0);
-    if (bin == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_micro_kernel<64>, 256, 0);
-    if (bin == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<64, E0, URCCO_U_WAVE>, 256, 0);
-    if (bin == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1S, URCCO_U_BS>, 256, 0);
-    if (bin == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1, URCCO_U_B>, 256, 0);
-    if (bin == 6) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<512, E2S, URCCO_U_H>, 512, 0);
-    if (bin == 7) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2, URCCO_U_C>, 1024, 0);
-    if (bin == 8) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2, URCCO_U_C, true>, 1024, 0);
+    if (bin == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_micro_kernel, 256, 0);
+    if (bin == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<64, E0, URCCO_U_WAVE>, 256, 0);
+    if (bin == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1S, URCCO_U_BS>, 256, 0);
+    if (bin == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1, URCCO_U_B>, 256, 0);
+    if (bin == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<512, E2S, URCCO_U_H>, 512, 0);
+    if (bin == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2, URCCO_U_C>, 1024, 0);
+    if (bin == 6) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2, URCCO_U_C, true>, 1024, 0);
     cache[bin] = (e == hipSuccess && n > 0) ? n : 1;
   }
   return cache[bin];
@@ -2772,9 +2734,9 @@ static int blocks_per_cu(int bin) {
 hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, int bin) {
   // Persistent grids sized to the chip; each kernel reads its own row list length from bin_off on the device,
   // so no host synchronisation sits between binning and the SpGEMM.
-  // Twice as many blocks as fit the chip (tunable per accumulator class through URCCO_GRID_FACTORS="f0,f1,..,f5" for
-  // measurements): the second half starts as blocks of the first retire, which evens out the classes' ragged ends and lets short
-  // kernels of the other event types' streams in -- a grid that exactly fills the chip locks them out until it ends (measured:
+  // Twice as many blocks as fit the chip (tunable per class through URCCO_GRID_FACTORS="f0,f1,..,f5" for measurements):
+  // the second half starts as blocks of the first retire, which evens out the classes' ragged ends and lets short kernels
+  // of the other event types' streams in -- a grid that exactly fills the chip locks them out until it ends (measured:
   // single-block kernels of another stream waited 0.2 ms).  3.5-3.7 -> 3.2-3.3 ms per build of config 3; 3x, 4x and 8x
   // measured no better than 1x (profiles/r02_grid_factor_sweep.log).
   static int factor[7] = {0, 0, 0, 0, 0, 0, 2};
@@ -2788,19 +2750,17 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
           if (v[b] >= 1 && v[b] <= 64) factor[b] = v[b];
     }
   }
-  auto grid = [&](int b) { return dim3((unsigned)(n_cu * blocks_per_cu(b)) * (unsigned)factor[ext_bin(b)]); };
+  auto grid = [&](int b) { return dim3((unsigned)(n_cu * blocks_per_cu(b)) * (unsigned)factor[b]); };
   switch (bin) {
-    case 0: hipLaunchKernelGGL(cco_rows_micro_kernel<16>, grid(0), dim3(256), 0, st, args, 0); break;
-    case 1: hipLaunchKernelGGL(cco_rows_micro_kernel<32>, grid(1), dim3(256), 0, st, args, 1); break;
-    case 2: hipLaunchKernelGGL(cco_rows_micro_kernel<64>, grid(2), dim3(256), 0, st, args, 2); break;
-    case 3: hipLaunchKernelGGL((cco_rows_kernel<64, E0, URCCO_U_WAVE>), grid(3), dim3(256), 0, st, args, 3); break;
-    case 4: hipLaunchKernelGGL((cco_rows_kernel<256, E1S, URCCO_U_BS>), grid(4), dim3(256), 0, st, args, 4); break;
-    case 5: hipLaunchKernelGGL((cco_rows_kernel<256, E1, URCCO_U_B>), grid(5), dim3(256), 0, st, args, 5); break;
-    case 6: hipLaunchKernelGGL((cco_rows_kernel<512, E2S, URCCO_U_H>), grid(6), dim3(512), 0, st, args, 6); break;
-    case 7: hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C>), grid(7), dim3(1024), 0, st, args, 7); break;
+    case 0: hipLaunchKernelGGL(cco_rows_micro_kernel, grid(0), dim3(256), 0, st, args); break;
+    case 1: hipLaunchKernelGGL((cco_rows_kernel<64, E0, URCCO_U_WAVE>), grid(1), dim3(256), 0, st, args, 1); break;
+    case 2: hipLaunchKernelGGL((cco_rows_kernel<256, E1S, URCCO_U_BS>), grid(2), dim3(256), 0, st, args, 2); break;
+    case 3: hipLaunchKernelGGL((cco_rows_kernel<256, E1, URCCO_U_B>), grid(3), dim3(256), 0, st, args, 3); break;
+    case 4: hipLaunchKernelGGL((cco_rows_kernel<512, E2S, URCCO_U_H>), grid(4), dim3(512), 0, st, args, 4); break;
+    case 5: hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C>), grid(5), dim3(1024), 0, st, args, 5); break;
     default:
       if (args.g_blocks > 0) hipLaunchKernelGGL(cco_rows_global_kernel, dim3((unsigned)args.g_blocks), dim3(GB_THREADS), 0, st, args);
-      else hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C, true>), grid(8), dim3(1024), 0, st, args, 8);
+      else hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C, true>), grid(6), dim3(1024), 0, st, args, 6);
       break;
   }
   return hipGetLastError();
@@ -2821,11 +2781,11 @@ __global__ __launch_bounds__(256) void bin_out_stats_kernel(const int32_t* __res
   for (int t = bin_off[bin] + blockIdx.y * 256 + threadIdx.x; t < bin_off[bin + 1]; t += 256 * gridDim.y) v += out_count[bin_rows[t] - item_lo];
   long long tot;
   block_exclusive_scan(v, s_wave, &tot);
-  if (threadIdx.x == 0 && tot) atomicAdd((unsigned long long*)&stats[1 + 3 * NBINS + (bin < 3 ? 0 : bin - 2)], (unsigned long long)tot);
+  if (threadIdx.x == 0 && tot) atomicAdd((unsigned long long*)&stats[1 + 3 * NBINS + bin], (unsigned long long)tot);
 }
 hipError_t launch_bin_out_stats(hipStream_t st, const int32_t* bin_rows, const int32_t* bin_off, int32_t item_lo, const int32_t* out_count,
                                 const unsigned long long* cand, int64_t* stats) {
-  hipLaunchKernelGGL(bin_out_stats_kernel, dim3(NB_INT, 128), dim3(256), 0, st, bin_rows, bin_off, item_lo, out_count, cand, stats);
+  hipLaunchKernelGGL(bin_out_stats_kernel, dim3(NBINS, 128), dim3(256), 0, st, bin_rows, bin_off, item_lo, out_count, cand, stats);
   return hipGetLastError();
 }
 

@@ -297,7 +297,7 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
   URC(s->reserve(urcco_session::need((size_t)cap, 8) + urcco_session::need((size_t)cap, 4) + urcco_session::need((size_t)cap + 1, 8) +
                  urcco_session::need((size_t)p_tiles + 2, 8) +
                  urcco_session::need((size_t)n, 8) + urcco_session::need((size_t)(n_tiles + 1) * urcco::BIN_COLS_HOST, 8) +
-                 urcco_session::need(urcco::NB_INT + 1, 4) + urcco_session::need((size_t)n, 4) + urcco_session::need((size_t)n_items_a, 8) +
+                 urcco_session::need(urcco::NBINS + 1, 4) + urcco_session::need((size_t)n, 4) + urcco_session::need((size_t)n_items_a, 8) +
                  urcco_session::need((size_t)n_cols_b, 2) + urcco_session::need(1, 4) + urcco_session::need(urcco::CAND_SLOTS, 8) + urcco_session::need(1, 8) + urcco_session::need(URCCO_STATS_LEN, 8) +
                  urcco_session::need((size_t)n_users + 1, 4)));
   int64_t* own_pstart = s->take<int64_t>((size_t)cap);
@@ -307,7 +307,7 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
   int64_t* p_tile_sums = s->take<int64_t>((size_t)p_tiles + 2);
   int64_t* work = s->take<int64_t>((size_t)n);
   int64_t* tile_counts = s->take<int64_t>((size_t)(n_tiles + 1) * urcco::BIN_COLS_HOST);
-  int32_t* bin_off = s->take<int32_t>(urcco::NB_INT + 1);
+  int32_t* bin_off = s->take<int32_t>(urcco::NBINS + 1);
   int32_t* bin_rows = s->take<int32_t>((size_t)n);
   double* ent_a = s->take<double>((size_t)n_items_a);
   unsigned short* cnt_b16 = s->take<unsigned short>((size_t)n_cols_b);
@@ -350,9 +350,9 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
   // Heaviest classes first (global, whole-CU, half-CU, ...): they have few, long rows and end raggedly; the fine-grained
   // one-wave and micro classes run last and finish sharply -- and, with a stream per event type, fill the heavy classes'
   // tails of the other event types instead of leaving a tail of their own.  debug 65536 restores the ascending order.
-  for (int step = 0; step < urcco::NB_INT; ++step) {  // internal classes: the micro class is three row lists (16 / 32 / 64 lanes per row)
-    const int bin = (s->debug & 65536) ? step : urcco::NB_INT - 1 - step;
-    s->begin(URCCO_STAGE_CCO_BIN0 + urcco::ext_bin(bin));
+  for (int step = 0; step < urcco::NBINS; ++step) {
+    const int bin = (s->debug & 65536) ? step : urcco::NBINS - 1 - step;
+    s->begin(URCCO_STAGE_CCO_BIN0 + bin);
     HIPC(urcco::launch_cco_rows_bin(s->stream, s->n_cu, a, bin));
     s->end();
   }
