@@ -584,7 +584,10 @@ def main():
     job = Job(library, workload, args, world, rank, devs, args.single_process)
     m = measure(job, args, full=True)
     if args.timed_only:
-        print(json.dumps(m))
+        print(json.dumps(m), flush=True)
+        job.close()        # a clean teardown: profilers wrapping this process wait for every queue to drain
+        if world > 1 and not args.single_process:
+            dist.destroy_process_group()
         return
     if rank != 0:
         job.close()
