@@ -49,11 +49,11 @@ PCIE_PEAK_GBS = 63.0   # same guide: PCIe gen5 x16, per direction
 LDS_ATOMIC_PEAK_GOPS = 16 * 256 * 2.4
 
 BIN_STAGES = ["cco_rows_micro", "cco_rows_wave", "cco_rows_block_small", "cco_rows_block", "cco_rows_cu_half", "cco_rows_cu", "cco_rows_global"]
-STAGE_TO_KERNEL = {"cco_rows_micro": "cco_rows_micro_kernel", "cco_rows_wave": "cco_rows_kernel<64, 1024, 1, false>",
-                   "cco_rows_block_small": "cco_rows_kernel<256, 4096, 1, false>", "cco_rows_block": "cco_rows_kernel<256, 8192, 1, false>",
+STAGE_TO_KERNEL = {"cco_rows_micro": "cco_rows_micro_kernel", "cco_rows_wave": "cco_rows_kernel<64, 1024, 2, false>",
+                   "cco_rows_block_small": "cco_rows_kernel<256, 4096, 2, false>", "cco_rows_block": "cco_rows_kernel<256, 8192, 2, false>",
                    "cco_rows_cu_half": "cco_rows_kernel<512, 16384, 1, false>", "cco_rows_cu": "cco_rows_kernel<1024, 32768, 1, false>",
                    "cco_rows_global": "cco_rows_kernel<1024, 32768, 1, true>",
-                   "downsample_flags": "downsample_flags_kernel", "compact_indicators": "compact_indicators_kernel"}
+                   "downsample_flags": "downsample_flags_kernel<false>", "compact_indicators": "compact_indicators_kernel"}
 NAMES = {"config3": "config3: synthetic 1M users x 200K items, Zipf-1.0, purchase/view/category-pref",
          "config4": "config4: synthetic 10M users x 2M items, Zipf-1.0, 5 event types (purchase/view/add-to-cart/search/category-pref)",
          "config5": "config5: synthetic 10M x 2M skewed (top 0.1 % of the items = 40 % of the interactions, 1 % heavy users x50), 5 event types, indicators form"}

@@ -1760,15 +1760,16 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
   return base + inc - v;
 }
 
-// candidates scored together per lane (their column-info gathers travel together), per class
+// candidates scored together per lane (their count gathers travel together), per class.  Round 3, config 4 (the count table no
+// longer fits an L2): two per lane -5 % on the one-wave and both 256-thread classes, +11 % on the half-CU class, +-0 on the CU class
 #ifndef URCCO_U_WAVE
-#define URCCO_U_WAVE 1
+#define URCCO_U_WAVE 2
 #endif
 #ifndef URCCO_U_BS
-#define URCCO_U_BS 1
+#define URCCO_U_BS 2
 #endif
 #ifndef URCCO_U_B
-#define URCCO_U_B 1
+#define URCCO_U_B 2
 #endif
 #ifndef URCCO_U_H
 #define URCCO_U_H 1
