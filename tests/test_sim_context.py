@@ -225,3 +225,87 @@ def unordered_rows_case(lib, device):
 
 def test_unordered_rows_flag(sim_lib):
     unordered_rows_case(sim_lib, torch.device("cpu"))
+
+
+def fused_expand_case(lib, device):
+    """The fused expand preparation of the secondaries (one interleaved (start, length) gather per CSC entry of A' for every
+    secondary at once) against the per-event form (debug 4096) and the one-session driver, bit for bit: 2, 5 and 8 secondaries
+    (the most one fused pass takes), 9 (falls back to the per-event form), an EMPTY secondary, stream-per-event and
+    single-stream mode, twice per shape (the buffers are reused)."""
+    from universal_recommender_amd import _lib
+    from universal_recommender_amd.device import Context, DeviceSession, cross_occurrence_context, cross_occurrence_device
+    rng = np.random.default_rng(47)
+    n_users = 1500
+    empty = O.Csr(n_users, 9, np.zeros(n_users + 1, np.int64), np.zeros(0, np.int32))
+    sess = DeviceSession(device, lib)
+    try:
+        for n_sec in (2, 5, 8, 9):
+            mats = [rand_csr(rng, n_users, 300, 5, zipf_s=1.1)] + [rand_csr(rng, n_users, 40 + 37 * d, 3 + d, empty_frac=0.1 * (d % 3)) for d in range(n_sec)]
+            if n_sec == 5:
+                mats[3] = empty
+            ps = [P(30, 10)] + [P(25 + d, 6 + d, 0.1 if d == 1 else None) for d in range(n_sec)]
+            ref = [r.to_host() for r in cross_occurrence_device(sess, [to_dev(m, device) for m in mats], to_params(ps), 5)]
+            sess.synchronize()
+            for flags in (0, _lib.FLAG_SINGLE_STREAM):
+                for debug in (0, 4096):
+                    ctx = Context(device, lib, flags=flags)
+                    try:
+                        ctx.set_debug(debug)
+                        for _ in range(2):
+                            out = cross_occurrence_context(ctx, [to_dev(m, device) for m in mats], to_params(ps), 5)
+                            assert len(out) == len(ref)
+                            for a, b in zip(out, ref):
+                                for x, y in zip(a.to_host(), b):
+                                    assert np.array_equal(x, y)
+                    finally:
+                        ctx.close()
+    finally:
+        sess.close()
+
+
+def test_fused_expand_of_the_secondaries(sim_lib):
+    fused_expand_case(sim_lib, torch.device("cpu"))
+
+
+def test_stage_finish_protocol(sim_lib):
+    """urcco_context_stage / _finish: finish without stage, a second stage before finish and a mismatching finish count are
+    BAD_ARG; a staged build that nobody finishes is abandoned cleanly by urcco_shutdown / context destruction; out[] of a
+    failing call is zeroed (the caller's garbage is never freed)."""
+    import ctypes as C
+    from universal_recommender_amd import _lib
+    lib = sim_lib
+    rng = np.random.default_rng(53)
+    mats = [rand_csr(rng, 400, 60, 5), rand_csr(rng, 400, 30, 4), rand_csr(rng, 400, 12, 2)]
+    n = len(mats)
+    arr = (_lib.Dataset * n)()
+    for d, m in enumerate(mats):
+        arr[d].matrix.n_rows, arr[d].matrix.n_cols = m.n_rows, m.n_cols
+        arr[d].matrix.row_ptr, arr[d].matrix.col_idx = m.row_ptr.ctypes.data, m.col_idx.ctypes.data
+        arr[d].max_elements_per_row, arr[d].max_interesting_elements = 500, 50
+    opts = _lib.Options(device=0, row_rate_mode=0, n_gpus=1)
+    out = (_lib.Indicators * n)()
+    lib.urcco_shutdown()
+    assert lib.urcco_cross_occurrence_finish(out, n, None) == _lib.BAD_ARG          # nothing staged
+    assert lib.urcco_cross_occurrence_stage(arr, n, 3, C.byref(opts)) == _lib.OK
+    assert lib.urcco_cross_occurrence_stage(arr, n, 3, C.byref(opts)) == _lib.BAD_ARG   # the previous one is not finished
+    assert lib.urcco_cross_occurrence_finish(out, n - 1, None) == _lib.BAD_ARG
+    assert lib.urcco_cross_occurrence_finish(out, n, None) == _lib.OK
+    ref = O.cross_occurrence_downsampled(mats, [P()] * n, 3)
+    for d, r in enumerate(ref):
+        o = out[d]
+        nnz = int(o.nnz)
+        check_indicators((np.ctypeslib.as_array(o.row_ptr, shape=(o.n_rows + 1,)).copy(), np.ctypeslib.as_array(o.col_idx, shape=(max(nnz, 1),))[:nnz].copy(),
+                          np.ctypeslib.as_array(o.llr, shape=(max(nnz, 1),))[:nnz].copy()), r)
+    lib.urcco_free_indicators(out, n)
+    assert lib.urcco_cross_occurrence_stage(arr, n, 3, C.byref(opts)) == _lib.OK
+    assert lib.urcco_shutdown() == 0                                                  # abandons the staged build
+    assert lib.urcco_cross_occurrence_finish(out, n, None) == _lib.BAD_ARG
+    # a failing one-shot call leaves out[] zeroed even if the caller handed in garbage pointers
+    junk = (_lib.Indicators * n)()
+    for d in range(n):
+        junk[d].nnz = 7
+        junk[d].row_ptr = C.cast(C.c_void_p(0xdead0000), C.POINTER(C.c_int64))
+    bad_opts = _lib.Options(device=99, row_rate_mode=0, n_gpus=1)
+    assert lib.urcco_cross_occurrence_downsampled(arr, n, 3, C.byref(bad_opts), junk, None) == _lib.BAD_ARG
+    assert all(not junk[d].row_ptr and junk[d].nnz == 0 for d in range(n))
+    lib.urcco_shutdown()
