@@ -206,6 +206,15 @@ def test_unordered_rows_flag_on_gpu(gpu_session):
     ctx_cases.unordered_rows_case(_lib.load(_lib.DEFAULT_PATH), gpu_session.device)
 
 
+def test_fused_expand_of_the_secondaries_on_gpu(gpu_session):
+    """The fused expand preparation (one gather per CSC entry for every secondary) == the per-event form == the one-session
+    driver, 2 / 5 / 8 / 9 secondaries, an empty one, both stream modes (real streams and events: the hand-off between the
+    secondaries' streams is what this exercises on hardware)."""
+    from universal_recommender_amd import _lib
+    import test_sim_context as ctx_cases
+    ctx_cases.fused_expand_case(_lib.load(_lib.DEFAULT_PATH), gpu_session.device)
+
+
 def test_back_to_back_builds_on_gpu(gpu_session):
     """Builds enqueued without a wait in between: the primary's shared products alternate between two buffer sets."""
     from universal_recommender_amd import _lib
