@@ -168,8 +168,11 @@ int64_t orc_cco_rows(int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr,
                      int32_t* out_idx, double* out_llr, int n_threads) {
   int64_t pairs_total = 0;
 #ifdef _OPENMP
-  if (n_threads > 0) omp_set_num_threads(n_threads);
-#pragma omp parallel reduction(+ : pairs_total)
+  /* a num_threads clause, NOT omp_set_num_threads: the setter is process-wide and sticky -- a one-thread call (the small parity
+   * tests) used to leave every later orc_downsample / orc_transpose, and orc_max_threads itself, single-threaded for the rest of
+   * the process: the 10M-row tests then ran 6-9x longer when they came after the small ones */
+  const int nt = n_threads > 0 ? n_threads : omp_get_max_threads();
+#pragma omp parallel num_threads(nt) reduction(+ : pairs_total)
 #endif
   {
     int32_t* acc = (int32_t*)calloc((size_t)(n_cols_b > 0 ? n_cols_b : 1), sizeof(int32_t));
