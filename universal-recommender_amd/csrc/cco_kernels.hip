@@ -200,18 +200,55 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(Load ld, int6
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
 }
 
-// single block: in-place exclusive scan of tile_sums[0..n_tiles), tile_sums[n_tiles] = total
-__global__ __launch_bounds__(SCAN_THREADS) void scan_tiles_kernel(int64_t* __restrict__ tile_sums, int64_t n_tiles) {
-  __shared__ long long s_wave[SCAN_THREADS / WAVE];
+// single block: in-place exclusive scan of tile_sums[0..n_tiles), tile_sums[n_tiles] = total.  1024 threads x 8 consecutive values per
+// round (a 97M-element scan has 47K tile sums: with 256 values per round this one block ran 185 rounds of two barriers each,
+// 35 us -- 0.7 ms per build of config 4 over its twenty scans); tiles at or beyond *n_live hold zeros and are not visited.
+constexpr int ST_THREADS = 1024;
+constexpr int ST_ITEMS = 8;
+__global__ __launch_bounds__(ST_THREADS) void scan_tiles_kernel(int64_t* __restrict__ tile_sums, int64_t n_tiles, const int64_t* __restrict__ n_live) {
+  __shared__ long long s_wave[ST_THREADS / WAVE];
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+  int64_t live_tiles = n_tiles;
+  if (n_live) {
+    const int64_t lt = *n_live / SCAN_TILE + 1;  // tiles that can hold a non-zero sum
+    if (lt < live_tiles) live_tiles = lt;
+  }
   long long carry = 0;
-  for (int64_t base = 0; base < n_tiles; base += SCAN_THREADS) {  // block-uniform trip count
-    const int64_t i = base + threadIdx.x;
-    const long long v = i < n_tiles ? tile_sums[i] : 0;
-    long long tot;
-    const long long ex = block_exclusive_scan(v, s_wave, &tot);
-    if (i < n_tiles) tile_sums[i] = carry + ex;
+  for (int64_t base = 0; base < live_tiles; base += ST_THREADS * ST_ITEMS) {  // block-uniform trip count
+    const int64_t first = base + (int64_t)threadIdx.x * ST_ITEMS;
+    long long x[ST_ITEMS];
+    long long sum = 0;
+#pragma unroll
+    for (int q = 0; q < ST_ITEMS; ++q) {
+      x[q] = first + q < live_tiles ? tile_sums[first + q] : 0;
+      sum += x[q];
+    }
+    long long inc = sum;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+      const long long o = shfl_up_i64(inc, d);
+      if (lane >= d) inc += o;
+    }
+    if (lane == WAVE - 1) s_wave[wave] = inc;
+    __syncthreads();
+    long long before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < ST_THREADS / WAVE; ++w) {
+      const long long sw = s_wave[w];
+      if (w < wave) before += sw;
+      tot += sw;
+    }
+    __syncthreads();
+    long long run = carry + before + inc - sum;
+#pragma unroll
+    for (int q = 0; q < ST_ITEMS; ++q) {
+      if (first + q < live_tiles) tile_sums[first + q] = run;
+      run += x[q];
+    }
     carry += tot;
   }
+  // the prefix of a tile beyond the live ones is the total (the downsweep never reads them, but keep the table well-defined)
+  for (int64_t t = live_tiles + threadIdx.x; t < n_tiles; t += ST_THREADS) tile_sums[t] = carry;
   if (threadIdx.x == 0) tile_sums[n_tiles] = carry;
 }
 
@@ -316,7 +353,7 @@ static hipError_t launch_scan(hipStream_t st, Load ld, int64_t n, int64_t* out, 
   }
   const int64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
   hipLaunchKernelGGL((scan_reduce_kernel<Load>), dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, st, ld, n, tile_sums, n_live);
-  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, tile_sums, n_tiles);
+  hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(ST_THREADS), 0, st, tile_sums, n_tiles, n_live);
   hipLaunchKernelGGL((scan_downsweep_kernel<Load>), dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, st, ld, n, tile_sums, n_tiles, out, n_live);
   return hipGetLastError();
 }
@@ -601,8 +638,11 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(int64_t n_rows, const in
 // `debug` (profiling only, results meaningless): 32 = cheap hash, 64 = no threshold gather, 128 = no row lookup
 constexpr int DS_RUN = 8;
 constexpr int DS_RUNS = DS_TILE / (DS_THREADS * DS_RUN);  // 2
+#ifndef URCCO_DS_WAVES
+#define URCCO_DS_WAVES 1  // minimum waves per SIMD the flags kernel is compiled for (A/B knob: 8 caps it at 64 VGPRs)
+#endif
 template <bool DEBUG>
-__global__ __launch_bounds__(DS_THREADS) void downsample_flags_kernel(int64_t n_rows, const int64_t* __restrict__ rp,
+__global__ __launch_bounds__(DS_THREADS, URCCO_DS_WAVES) void downsample_flags_kernel(int64_t n_rows, const int64_t* __restrict__ rp,
                                                                       const int32_t* __restrict__ ci, int64_t nnz,
                                                                       const int64_t* __restrict__ g,
                                                                       const unsigned long long* __restrict__ thresholds,
