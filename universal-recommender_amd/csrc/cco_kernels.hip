@@ -381,7 +381,10 @@ hipError_t launch_scan_i64(hipStream_t st, const int64_t* in, int64_t n, int64_t
 constexpr int PH_BITS = 13;
 constexpr int PH_BUCKET = 1 << PH_BITS;
 constexpr int PH_PART = 16384;
-constexpr int PH_CHUNK = 32768;
+#ifndef URCCO_PH_CHUNK
+#define URCCO_PH_CHUNK 32768
+#endif
+constexpr int PH_CHUNK = URCCO_PH_CHUNK;  // interactions per histogram block: a block writes one 32 KB partial histogram per bucket chunk
 constexpr int PH_MAX_BUCKETS = 1024;
 
 // Eight private copies of the bucket counters, chosen by lane: with a few dozen buckets (25 for a 200K-column matrix) the 64
