@@ -1826,6 +1826,12 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 #ifndef URCCO_G_WAVE
 #define URCCO_G_WAVE 1
 #endif
+#ifndef URCCO_SEL_AMB_WAVE
+#define URCCO_SEL_AMB_WAVE 64
+#endif
+#ifndef URCCO_SEL_AMB_BLOCK
+#define URCCO_SEL_AMB_BLOCK 128
+#endif
 #ifndef URCCO_G_BLOCK
 #define URCCO_G_BLOCK 1
 #endif
@@ -1859,7 +1865,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   // two words it has just read.
   constexpr int NH = T == WAVE ? 1 : 3;
   constexpr int SEL_CAP = T == WAVE ? 0 : (T == 256 ? 512 : 2048);  // explicit survivor list (16-bit indices); a wave sweeps its <= 341 candidates directly
-  constexpr int SEL_M = T == WAVE ? 64 : 128;                        // ambiguous set ranked directly
+  constexpr int SEL_M = T == WAVE ? 64 : 128;                        // capacity of the ambiguous-set / staged-output arrays
+  constexpr int SEL_AMB = T == WAVE ? URCCO_SEL_AMB_WAVE : URCCO_SEL_AMB_BLOCK;  // the cut bin is ranked directly once it holds this many or fewer
+  static_assert(SEL_AMB <= SEL_M, "ambiguous set capacity");
   constexpr bool SHARE = T == WAVE || (T == 256 && E == 4096);
   constexpr int SH_INS = T * 8 + (T + 1) * 4;                                                     // ustart | uoff
   constexpr int SH_LST = ((NH * 128 * 4 > SEL_M * 12 ? NH * 128 * 4 : SEL_M * 12) + 7) / 8 * 8;  // histograms or amb_key | amb_col, then the list
@@ -2257,7 +2265,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             if (NH == 1) team_sync<T>();  // the histogram just cleared is the next pass's target
             ++q;
           }
-          if (prev_cnt <= (unsigned)SEL_M) {
+          if (prev_cnt <= (unsigned)SEL_AMB) {
             // finish: copy out the members of the cut bin (they match the prefix through digit p) ...
             const unsigned n_scan2 = have_list ? list_n : D;
             for (unsigned base = 0; base < n_scan2; base += T) {
