@@ -22,11 +22,36 @@ def sim_lib():
     return _lib.load(build_sim.build())
 
 
+def guarded_tensor(lib, n, dtype):
+    """HIPSIM_GUARD runs: a CPU tensor whose storage ends at a PROT_NONE page of the simulator (tests/hostsim/hipsim.cpp), so a
+    kernel that runs past a caller-owned input or output faults."""
+    import ctypes as C
+    import weakref
+    import numpy as np
+    import torch
+    item = torch.empty(0, dtype=dtype).element_size()
+    lib.hipsim_guard_malloc.restype = C.c_void_p
+    lib.hipsim_guard_malloc.argtypes = [C.c_size_t]
+    lib.hipsim_guard_release.argtypes = [C.c_void_p]
+    nbytes = max(int(n), 1) * item
+    body = (nbytes + 15) & ~15 if os.environ.get("HIPSIM_GUARD") != "2" else (nbytes + 3) & ~3
+    ptr = lib.hipsim_guard_malloc(nbytes)
+    buf = (C.c_uint8 * nbytes).from_address(ptr + (body - nbytes))  # the requested bytes END where the allocation ends
+    arr = np.frombuffer(buf, dtype=np.uint8)
+    t = torch.from_numpy(arr).view(dtype)[: int(n)]
+    weakref.finalize(arr, lib.hipsim_guard_release, ptr)
+    return t
+
+
 @pytest.fixture(scope="session")
 def sim_session(sim_lib):
     import torch
     from universal_recommender_amd.device import DeviceSession
     s = DeviceSession(torch.device("cpu"), sim_lib)
+    if os.environ.get("HIPSIM_GUARD"):
+        import helpers
+        s.empty = lambda n, dtype: guarded_tensor(sim_lib, n, dtype)
+        helpers.GUARD_LIB = sim_lib
     yield s
     s.close()
 

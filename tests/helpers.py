@@ -30,8 +30,22 @@ def rand_csr(rng, n_rows, n_cols, avg, zipf_s=1.0, empty_frac=0.0):
     return O.Csr(n_rows, n_cols, rp, (key - u * n_cols).astype(np.int32))
 
 
+GUARD_LIB = None  # set by conftest.sim_session under HIPSIM_GUARD: inputs of simulator runs end at guard pages
+
+
+def guarded(t: torch.Tensor) -> torch.Tensor:
+    if GUARD_LIB is None or t.device.type != "cpu":
+        return t
+    from conftest import guarded_tensor
+    g = guarded_tensor(GUARD_LIB, t.numel(), t.dtype)
+    g.copy_(t.reshape(-1))
+    return g
+
+
 def to_dev(m: O.Csr, device) -> D.DevCsr:
     ci = m.col_idx if m.nnz else np.zeros(1, np.int32)
+    if GUARD_LIB is not None and torch.device(device).type == "cpu":
+        return D.DevCsr(m.n_rows, m.n_cols, guarded(torch.from_numpy(m.row_ptr.copy())), guarded(torch.from_numpy(ci[: max(m.nnz, 1)].copy())), m.nnz)
     return D.DevCsr(m.n_rows, m.n_cols, torch.from_numpy(m.row_ptr.copy()).to(device), torch.from_numpy(ci.copy()).to(device), m.nnz)
 
 

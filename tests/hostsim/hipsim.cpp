@@ -7,6 +7,9 @@
 #include <cstring>
 #include <vector>
 #include <dlfcn.h>
+#include <sys/mman.h>
+#include <mutex>
+#include <unordered_map>
 
 #if !defined(__x86_64__)
 #error "hostsim context switch is written for x86-64"
@@ -41,6 +44,56 @@ namespace hipsim {
 thread_local Idx tIdx, bIdx, bDim, gDim;
 thread_local int cur_device = 0;
 thread_local int last_error = 0;
+
+// ---- guard-page allocations (HIPSIM_GUARD=1) ------------------------------------------------------------
+bool guard_on() {
+  static const bool on = [] { const char* e = getenv("HIPSIM_GUARD"); return e && *e && *e != '0'; }();
+  return on;
+}
+namespace {
+std::mutex g_guard_mu;
+std::unordered_map<void*, std::pair<void*, size_t>> g_guard;  // user pointer -> (mapping, length)
+}  // namespace
+namespace {
+size_t guard_align() {  // HIPSIM_GUARD=2: buffers end to 4 bytes at the guard page (their starts are then 4-aligned only: scalar paths)
+  static const size_t a = [] { const char* e = getenv("HIPSIM_GUARD"); return (e && *e == '2') ? (size_t)4 : (size_t)16; }();
+  return a;
+}
+}  // namespace
+void* guard_alloc(size_t n) {
+  const size_t body = (n + guard_align() - 1) & ~(guard_align() - 1);
+  const size_t pages = (body + GUARD_PAGE - 1) & ~(GUARD_PAGE - 1);
+  char* m = static_cast<char*>(mmap(nullptr, pages + GUARD_PAGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+  if (m == MAP_FAILED) return nullptr;
+  mprotect(m + pages, GUARD_PAGE, PROT_NONE);
+  char* p = m + pages - body;
+  memset(m, 0xA5, pages - body);  // whatever precedes the buffer is not zero either
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  g_guard[p] = {m, pages + GUARD_PAGE};
+  return p;
+}
+bool guard_free(void* p) {
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  auto it = g_guard.find(p);
+  if (it == g_guard.end()) return false;
+  munmap(it->second.first, it->second.second);
+  g_guard.erase(it);
+  return true;
+}
+void arena_unguard(void* base, size_t cap) {
+  if (!base || !cap) return;
+  char* b = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(base) + GUARD_PAGE - 1) & ~(uintptr_t)(GUARD_PAGE - 1));
+  char* e = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(base) + cap) & ~(uintptr_t)(GUARD_PAGE - 1));
+  if (e > b) mprotect(b, (size_t)(e - b), PROT_READ | PROT_WRITE);
+}
+char* arena_place(char* base, size_t off, size_t bytes, size_t* new_off) {
+  const size_t body = (bytes + guard_align() - 1) & ~(guard_align() - 1);
+  const uintptr_t lo = reinterpret_cast<uintptr_t>(base) + off;
+  const uintptr_t end = (lo + body + GUARD_PAGE - 1) & ~(uintptr_t)(GUARD_PAGE - 1);
+  mprotect(reinterpret_cast<void*>(end), GUARD_PAGE, PROT_NONE);
+  *new_off = (size_t)(end + GUARD_PAGE - reinterpret_cast<uintptr_t>(base));
+  return reinterpret_cast<char*>(end - body);
+}
 
 namespace {
 
@@ -206,3 +259,7 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 }
 
 }  // namespace hipsim
+
+// test-side allocations (tests/conftest.py wraps them as tensors for kernel inputs and outputs)
+extern "C" void* hipsim_guard_malloc(size_t n) { return hipsim::guard_alloc(n ? n : 1); }
+extern "C" void hipsim_guard_release(void* p) { if (p) (void)hipsim::guard_free(p); }

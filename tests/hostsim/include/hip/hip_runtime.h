@@ -71,7 +71,16 @@ void sync_threads();
 enum WaveOp { OP_BALLOT = 1, OP_SHFL = 2 };
 uint64_t wave_op(int op, uint64_t payload, int arg, const void* site);
 int lane_id();
+// HIPSIM_GUARD=1 (tests/test_sim_guard.py): every hipMalloc ends (to 16 bytes) at a PROT_NONE page, and the session arena places every
+// sub-buffer the same way, so that a kernel reading or writing past the end of a buffer faults here the way it can on the GPU.
+bool guard_on();
+void* guard_alloc(size_t n);
+bool guard_free(void* p);                       // false: not a guarded allocation
+void arena_unguard(void* base, size_t cap);     // make the whole arena read/write again (its layout is about to change)
+char* arena_place(char* base, size_t off, size_t bytes, size_t* new_off);  // address of a sub-buffer ending at a guard page
+constexpr size_t GUARD_PAGE = 4096;
 }  // namespace hipsim
+#define HIPSIM_HOST_BUILD 1
 
 #define threadIdx (hipsim::tIdx)
 #define blockIdx (hipsim::bIdx)
@@ -232,12 +241,12 @@ static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned base) {
 static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess(sim)" : "hipError(sim)"; }
 static inline hipError_t hipGetLastError() { const int e = hipsim::last_error; hipsim::last_error = hipSuccess; return e; }
 static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = hipsim::guard_on() ? hipsim::guard_alloc(n ? n : 1) : malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
-static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipFree(void* p) { if (!p || !hipsim::guard_free(p)) free(p); return hipSuccess; }
 enum { hipHostMallocDefault = 0, hipHostMallocPortable = 1 };
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
-static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostFree(void* p) { return hipFree(p); }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { if (n) memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }

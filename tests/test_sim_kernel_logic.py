@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import compare_with_oracle, rand_csr, to_dev
+from helpers import compare_with_oracle, guarded, rand_csr, to_dev
 from oracle import c_oracle as O
 
 
@@ -84,7 +84,7 @@ def test_downsample_row_base_matches_sharded_rows(sim_session):
     rng = np.random.default_rng(7)
     m = rand_csr(rng, 1000, 60, 30, zipf_s=1.3)
     dev = sim_session.device
-    raw = sim_session.column_counts(torch.from_numpy(m.col_idx.copy()).to(dev), m.nnz, m.n_cols)
+    raw = sim_session.column_counts(guarded(torch.from_numpy(m.col_idx.copy()).to(dev)), m.nnz, m.n_cols)
     full, _ = sim_session.downsample(to_dev(m, dev), m.nnz, raw, 77, 25)
     lo, hi = 333, 901
     shard = O.Csr(hi - lo, m.n_cols, m.row_ptr[lo:hi + 1] - m.row_ptr[lo], m.col_idx[m.row_ptr[lo]:m.row_ptr[hi]])
@@ -108,7 +108,7 @@ def test_unaligned_col_idx_takes_scalar_path(sim_session):
     assert view.data_ptr() % 16 != 0
     cnt = sim_session.column_counts(view, m.nnz, m.n_cols)
     from universal_recommender_amd.device import DevCsr
-    out, post = sim_session.downsample(DevCsr(m.n_rows, m.n_cols, torch.from_numpy(m.row_ptr.copy()).to(dev), view, m.nnz), m.nnz, cnt, 5, 7)
+    out, post = sim_session.downsample(DevCsr(m.n_rows, m.n_cols, guarded(torch.from_numpy(m.row_ptr.copy()).to(dev)), view, m.nnz), m.nnz, cnt, 5, 7)
     sim_session.synchronize()
     assert np.array_equal(cnt.cpu().numpy(), O.column_counts(m))
     ref = O.downsample(m, O.column_counts(m), 5, 7)
@@ -119,7 +119,7 @@ def test_unaligned_col_idx_takes_scalar_path(sim_session):
 
 def test_partition_balances_work(sim_session):
     rng = np.random.default_rng(9)
-    work = torch.from_numpy(rng.zipf(1.5, 5000).astype(np.int64)).to(sim_session.device)
+    work = guarded(torch.from_numpy(rng.zipf(1.5, 5000).astype(np.int64)).to(sim_session.device))
     bounds = sim_session.partition(work, 8)
     assert bounds[0] == 0 and bounds[-1] == 5000 and all(a <= b for a, b in zip(bounds, bounds[1:]))
     pref = np.concatenate([[0], np.cumsum(work.cpu().numpy())])
@@ -172,7 +172,7 @@ def test_large_transpose_with_item_range(sim_session):
     assert m.nnz >= (1 << 20)
     dev = sim_session.device
     d = to_dev(m, dev)
-    counts = torch.from_numpy(O.column_counts(m)).to(dev)
+    counts = guarded(torch.from_numpy(O.column_counts(m)).to(dev))
     cp_ref, ri_ref = O.transpose(m)
     for lo, hi in [(0, m.n_cols), (9000, 17123)]:
         cp, ri = sim_session.transpose(d, counts, lo, hi)
@@ -201,7 +201,7 @@ def test_large_transpose_long_rows_and_empty_parts(sim_session):
     assert m.nnz >= (1 << 20)
     dev = sim_session.device
     d = to_dev(m, dev)
-    counts = torch.from_numpy(O.column_counts(m)).to(dev)
+    counts = guarded(torch.from_numpy(O.column_counts(m)).to(dev))
     cp_ref, ri_ref = O.transpose(m)
     for lo, hi in [(0, m.n_cols), (123, 45_678)]:
         cp, ri = sim_session.transpose(d, counts, lo, hi)
@@ -232,7 +232,7 @@ def test_large_transpose_skewed_ids_heavy_bucket(sim_session):
     m = O.Csr(n_rows, n_cols, rp, np.concatenate(rows).astype(np.int32))
     assert m.nnz >= (1 << 20)
     dev = sim_session.device
-    counts = torch.from_numpy(O.column_counts(m)).to(dev)
+    counts = guarded(torch.from_numpy(O.column_counts(m)).to(dev))
     cp_ref, ri_ref = O.transpose(m)
     cp, ri = sim_session.transpose(to_dev(m, dev), counts, 0, n_cols)
     sim_session.synchronize()
@@ -265,7 +265,7 @@ def test_row_scan_tile_edges(sim_session, mode):
     m = _csr_from_lengths(rng, lengths, n_cols)
     dev = sim_session.device
     raw_ref = O.column_counts(m)
-    raw = torch.from_numpy(raw_ref).to(dev)
+    raw = guarded(torch.from_numpy(raw_ref).to(dev))
     for max_n in (3, 500):
         out, post = sim_session.downsample(to_dev(m, dev), m.nnz, raw, 99, max_n, mode)
         sim_session.synchronize()
@@ -352,7 +352,7 @@ def test_row_scan_threshold_table_forms(sim_session):
              (rand_csr(rng, 30000, 400000, 40, zipf_s=0.9), 5)]         # (c) 400K columns: bitmap does not fit
     for m, max_n in cases:
         raw_ref = O.column_counts(m)
-        raw = torch.from_numpy(raw_ref).to(dev)
+        raw = guarded(torch.from_numpy(raw_ref).to(dev))
         for mode in (0, 1):
             out, post = sim_session.downsample(to_dev(m, dev), m.nnz, raw, 1234, max_n, mode)
             sim_session.synchronize()
@@ -423,7 +423,7 @@ def test_row_scan_large_matrix_edges(sim_session, mode):
         assert (m.nnz % 4096 == 0) == exact
         dev = sim_session.device
         raw_ref = O.column_counts(m)
-        raw = torch.from_numpy(raw_ref).to(dev)
+        raw = guarded(torch.from_numpy(raw_ref).to(dev))
         ref = O.downsample(m, raw_ref, 4242, 200, mode)
         out, post = sim_session.downsample(to_dev(m, dev), m.nnz, raw, 4242, 200, mode)
         sim_session.synchronize()

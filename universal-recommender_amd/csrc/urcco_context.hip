@@ -97,7 +97,10 @@ struct DBuf {  // device buffer that only grows (hipFree synchronises the device
     if (p) HIPC(hipFree(p));
     p = nullptr;
     cap = 0;
-    const size_t want = n + n / 16 + 64;
+    size_t want = n + n / 16 + 64;
+#ifdef HIPSIM_HOST_BUILD  // test-only host simulator: no slack, so that an overrun meets the guard page
+    if (hipsim::guard_on()) want = n ? n : 1;
+#endif
     HIPC(hipMalloc((void**)&p, want * sizeof(T)));
     cap = want;
     return URCCO_OK;

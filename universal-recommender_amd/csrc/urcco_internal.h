@@ -145,6 +145,12 @@ struct urcco_session {
 
   int reserve(size_t bytes) {
     arena_off = 0;
+#ifdef HIPSIM_HOST_BUILD  // test-only host simulator (tests/hostsim): sub-buffers end at guard pages under HIPSIM_GUARD=1
+    if (hipsim::guard_on()) {
+      hipsim::arena_unguard(arena, arena_cap);
+      bytes += 64 * hipsim::GUARD_PAGE;  // callers that reserve raw byte counts (one block carved by the launcher) do not go through need()
+    }
+#endif
     if (bytes <= arena_cap) return URCCO_OK;
     if (arena) {
       HIPC(hipStreamSynchronize(stream));
@@ -159,12 +165,24 @@ struct urcco_session {
   }
   template <typename T>
   T* take(size_t n) {
+#ifdef HIPSIM_HOST_BUILD
+    if (hipsim::guard_on()) {
+      T* q = reinterpret_cast<T*>(hipsim::arena_place(arena, arena_off, (n ? n : 1) * sizeof(T), &arena_off));
+      if (arena_off > arena_cap) { fprintf(stderr, "hipsim guard: arena overflow (%zu > %zu)\n", arena_off, arena_cap); abort(); }
+      return q;
+    }
+#endif
     const size_t bytes = align_up((n ? n : 1) * sizeof(T), 256);
     char* p = arena + arena_off;
     arena_off += bytes;
     return reinterpret_cast<T*>(p);
   }
-  static size_t need(size_t n, size_t elem) { return align_up((n ? n : 1) * elem, 256); }
+  static size_t need(size_t n, size_t elem) {
+#ifdef HIPSIM_HOST_BUILD
+    if (hipsim::guard_on()) return align_up((n ? n : 1) * elem, hipsim::GUARD_PAGE) + 2 * hipsim::GUARD_PAGE;
+#endif
+    return align_up((n ? n : 1) * elem, 256);
+  }
 
   // Dense per-block counters of the global-accumulator class: g_blocks x n_cols_b x 16 B.  The block count shrinks with
   // the width of B so that the scratch stays within 1 GiB per session (4 GiB from 1M columns on: 128 blocks at 2M, 26 at 10M, never fewer
