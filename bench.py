@@ -336,6 +336,8 @@ class Job:
             self.ctx = Context(devs[0], library, n_local, flags)      # ncclCommInitAll inside the library when n_local > 1
         else:
             self.ctx = sharded.make_context(devs[0], library, flags=flags)
+        if args.gathered_primary:
+            self.ctx.set_debug(8192)
 
     def host_copy(self):
         """(name, n_cols, row_ptr, col_idx) numpy, whole matrices (single-GPU jobs)."""
@@ -540,7 +542,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the host-level, row-scan, LLR-rate and config-3 legs")
     ap.add_argument("--single-stream", action="store_true", help="run the event types back to back on one HIP stream")
     ap.add_argument("--force-exchange", action="store_true",
-                    help="debug: run the N > 1 code path (RCCL collectives, range-restricted transpose) in a one-rank communicator")
+                    help="debug: run the N > 1 code path (RCCL collectives, CSC fragments of the primary) in a one-rank communicator")
+    ap.add_argument("--gathered-primary", action="store_true",
+                    help="A/B (N > 1 path): the primary's CSC from a pass of every rank over the whole gathered A' (rounds 1-2) instead of fragments")
     ap.add_argument("--timed-only", action="store_true", help="stop after the timed region (timeline captures)")
     ap.add_argument("--seed", type=int, default=20260925)
     args = ap.parse_args()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define URCCO_VERSION 300 /* 0.3.0 */
+#define URCCO_VERSION 301 /* 0.3.1 */
 
 typedef enum urcco_status {
   URCCO_OK = 0,
@@ -166,6 +166,10 @@ typedef struct urcco_collectives {
   /* recv + byte_offsets[r] receives byte_counts[r] bytes = rank r's send buffer; send holds byte_counts[rank] bytes */
   int (*all_gather_v)(void* user, int32_t rank, const void* send, void* recv, const int64_t* byte_offsets,
                       const int64_t* byte_counts, void* stream);
+  /* send + send_offsets[q] holds send_counts[q] bytes for rank q; recv + recv_offsets[p] receives recv_counts[p] bytes
+   * from rank p (the CSC fragments of the primary).  Since 301. */
+  int (*all_to_all_v)(void* user, int32_t rank, const void* send, const int64_t* send_offsets, const int64_t* send_counts,
+                      void* recv, const int64_t* recv_offsets, const int64_t* recv_counts, void* stream);
 } urcco_collectives;
 
 typedef struct urcco_comm_config {
@@ -311,6 +315,18 @@ int urcco_dev_row_work_csr(urcco_session* s, int64_t n_rows, const int64_t* a_ro
  * (host memory).  Synchronises. */
 int urcco_dev_partition(urcco_session* s, int32_t n_items, const int64_t* work, int32_t n_parts,
                         int32_t* bounds_host);
+
+/* Multi-GPU: the CSC of the item range [item_lo, item_hi) of the primary from the fragments of `world` user shards.  Rank p
+ * transposed its own shard (urcco_dev_transpose over all columns: shard-local user ids) and sent the slice of that CSC
+ * that belongs to the range: lens[p * (item_hi - item_lo) + j] = length of column item_lo + j in shard p (uint16 when
+ * wire16, else int32), entries = the W slices one behind the other in rank order (n_entries in all).
+ * sizes[3 * p] = rows of shard p (the record of the exchange: rows, nnz, rows longer than 65535); counts[n_items] = the
+ * all-reduced column counts.  out_col_ptr[n_items + 1] (columns outside the range are empty), out_row_idx = global
+ * user ids, ascending inside a column when the fragments were.  Replaces the pass every rank used to make over the
+ * whole gathered A' to pick its columns out (Spark: the shuffle inside `A.t %*% B`, URAlgorithm.scala:323-346). */
+int urcco_dev_merge_fragments(urcco_session* s, int32_t world, int32_t item_lo, int32_t item_hi, int32_t n_items,
+                              const void* lens, int32_t wire16, const int32_t* entries, int64_t n_entries,
+                              const int64_t* sizes, const int32_t* counts, int64_t* out_col_ptr, int32_t* out_row_idx);
 
 /* Rows [item_lo, item_hi) of A'B, LLR scored, cut to the top k (computeSimilarities fused onto the SpGEMM).
  *   a_col_ptr/a_row_idx   CSC of down-sampled A (nnz_a_bound >= its nnz: sizes scratch, no host sync needed)

@@ -103,6 +103,13 @@ def _ge(user):
             tot = np.sum(views, axis=0, dtype=views[0].dtype)
             for v in views:
                 v[:] = tot
+        elif kind == "aa":
+            pieces = {(r, q): bytes((C.c_char * o[3][q]).from_address(o[1] + o[2][q])) if o[3][q] > 0 else b"" for r, o in ops.items() for q in range(3)}
+            for r, o in ops.items():
+                for p in range(3):
+                    assert len(pieces[(p, r)]) == o[6][p]
+                    if o[6][p] > 0:
+                        C.memmove(o[4] + o[5][p], pieces[(p, r)], o[6][p])
         else:
             pieces = {r: bytes((C.c_char * o[4][r]).from_address(o[1])) if o[4][r] > 0 else b"" for r, o in ops.items()}
             for r, o in ops.items():
@@ -123,7 +130,13 @@ def _ag(user, rank, send, recv, offs, cnts, stream):
     return 0
 
 
-cbs = (_lib.GROUP_FN(_gs), _lib.GROUP_FN(_ge), _lib.ALL_REDUCE_FN(_ar), _lib.ALL_GATHER_V_FN(_ag))
+def _aa(user, rank, send, soff, scnt, recv, roff, rcnt, stream):
+    w = range(3)
+    pend.setdefault(rank, []).append(("aa", send, [soff[r] for r in w], [scnt[r] for r in w], recv, [roff[r] for r in w], [rcnt[r] for r in w]))
+    return 0
+
+
+cbs = (_lib.GROUP_FN(_gs), _lib.GROUP_FN(_ge), _lib.ALL_REDUCE_FN(_ar), _lib.ALL_GATHER_V_FN(_ag), _lib.ALL_TO_ALL_V_FN(_aa))
 coll = _lib.Collectives(None, *cbs)
 comm = _lib.CommConfig(world_size=3, first_rank=0)
 comm.collectives = C.pointer(coll)

@@ -34,6 +34,11 @@ def test_logic_case_on_gpu(case, gpu_session):
     case(gpu_session)
 
 
+@pytest.mark.parametrize("wire", ["u16", "i32"])
+def test_merge_of_csc_fragments_on_gpu(gpu_session, wire):
+    logic.test_merge_of_csc_fragments(gpu_session, wire)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_row_scan_tile_edges_on_gpu(gpu_session, mode):
     logic.test_row_scan_tile_edges(gpu_session, mode)

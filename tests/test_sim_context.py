@@ -137,8 +137,8 @@ def test_context_reuse_and_stream_modes(sim_lib):
     context_reuse_case(sim_lib, torch.device("cpu"))
 
 
-@pytest.mark.parametrize("n_gpus", [2, 3])
-def test_one_process_drives_several_gpus(sim_lib, n_gpus, monkeypatch):
+@pytest.mark.parametrize("n_gpus,primary", [(2, "fragments"), (3, "fragments"), (2, "gathered")])
+def test_one_process_drives_several_gpus(sim_lib, n_gpus, primary, monkeypatch):
     """n_gpus ranks in ONE process (what the JVM host does; here simulated devices, collectives looped back in-process
     through the urcco_collectives callbacks): the device-resident build on user-range shards and the host-level build
     (the library shards the users itself, balances the item ranges by work, concatenates the slices) both equal the
@@ -154,6 +154,8 @@ def test_one_process_drives_several_gpus(sim_lib, n_gpus, monkeypatch):
     ref = O.cross_occurrence_downsampled(mats, params, 2024)
     coll = sharded.TorchCollectives(n_gpus, list(range(n_gpus)))
     ctx = Context(torch.device("cpu"), sim_lib, n_gpus=n_gpus, collectives=coll)
+    if primary == "gathered":
+        ctx.set_debug(8192)       # A/B path: the primary's CSC from a pass over the whole gathered A' instead of fragments
     try:
         assert ctx.n_local == n_gpus
         cuts = [n_users * g // n_gpus for g in range(n_gpus + 1)]
@@ -195,6 +197,63 @@ def test_one_process_drives_several_gpus(sim_lib, n_gpus, monkeypatch):
             assert stats[d].pairs == r.pairs and stats[d].nnz_out == nnz and stats[d].nnz_raw == mats[d].nnz
         sim_lib.urcco_free_indicators(out, n)
         assert coll.error is None
+        # what travelled: the primary's CSC as an all-to-all of fragments (16-bit column lengths, then entries), row lengths as 16 bits
+        a2a = [e for e in coll.log if e[0] == "aa"]
+        if primary == "fragments":
+            assert len(a2a) == 2 * 2 * n_gpus                            # two builds x (lengths, entries) x ranks
+            assert sum(a2a[0][2]) == 2 * mats[0].n_cols                  # rank 0 sends every column's length once, as uint16
+            sampled = O.downsample(mats[0], O.column_counts(mats[0]), 2024, params[0].max_elements_per_row)
+            assert sum(sum(e[2]) for e in a2a[n_gpus:2 * n_gpus]) == 4 * sampled.nnz   # the entries of A' cross the wire exactly once
+        else:
+            assert not a2a
+        assert any(e[0] == "ag" and e[2] == 2 * 100 for e in coll.log)     # rank 0's 100 row lengths of one event type, as uint16
+    finally:
+        ctx.close()
+
+
+def test_exchange_falls_back_to_32_bit_lengths(sim_lib, monkeypatch):
+    """Column lengths of a shard's CSC and row lengths of a shard travel as uint16 unless one does not fit: a primary column held
+    by 70 000 users of one shard switches that build's fragments to int32 lengths, a secondary user with 66 000 items switches that
+    event type's row lengths to int32 (decided from the records every rank publishes, so all ranks agree) -- and the result is
+    still the oracle's."""
+    from universal_recommender_amd import sharded
+    from universal_recommender_amd.device import Context
+    n_gpus = 2
+    monkeypatch.setenv("HIPSIM_DEVICE_COUNT", str(n_gpus))
+    rng = np.random.default_rng(8)
+    n_users, n_a, n_b = 80_000, 300, 66_500
+    extra = rng.integers(1, n_a, (n_users, 2))
+    rows = [np.unique(np.concatenate([[0] if u < 70_000 else [], extra[u]])).astype(np.int32) for u in range(n_users)]
+    rp = np.zeros(n_users + 1, np.int64)
+    np.cumsum([len(r) for r in rows], out=rp[1:])
+    a = O.Csr(n_users, n_a, rp, np.concatenate(rows).astype(np.int32))
+    brows = [np.unique(rng.integers(0, n_b, 2)).astype(np.int32) for _ in range(n_users)]
+    brows[75_000] = np.arange(66_000, dtype=np.int32)                    # one very long row in the second shard
+    rp = np.zeros(n_users + 1, np.int64)
+    np.cumsum([len(r) for r in brows], out=rp[1:])
+    b = O.Csr(n_users, n_b, rp, np.concatenate(brows).astype(np.int32))
+    mats, params = [a, b], [P(100_000, 5), P(100_000, 5)]
+    ref = O.cross_occurrence_downsampled(mats, params, 11)
+    coll = sharded.TorchCollectives(n_gpus, list(range(n_gpus)))
+    ctx = Context(torch.device("cpu"), sim_lib, n_gpus=n_gpus, collectives=coll)
+    try:
+        cuts = [0, 72_000, n_users]
+        shards = [[to_dev(O.Csr(hi - lo, m.n_cols, m.row_ptr[lo:hi + 1] - m.row_ptr[lo], m.col_idx[m.row_ptr[lo]:m.row_ptr[hi]]), "cpu")
+                   for lo, hi in zip(cuts, cuts[1:])] for m in mats]
+        ctx.build(shards, to_params(params), 11, n_users, cuts[:-1])
+        res = ctx.results()
+        for d, r in enumerate(ref):
+            parts = [ind.to_host() for ind in res[d]]
+            ln = np.concatenate([np.diff(p[0]) for p in parts])
+            full_rp = np.zeros(ln.size + 1, np.int64)
+            np.cumsum(ln, out=full_rp[1:])
+            check_indicators((full_rp, np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])), r, exact_ids=True)
+        assert coll.error is None
+        a2a = [e for e in coll.log if e[0] == "aa"]
+        assert sum(a2a[0][2]) == 4 * n_a                                   # int32 column lengths
+        ag = [e for e in coll.log if e[0] == "ag"]
+        assert any(e[1] == 0 and e[2] == 2 * 72_000 for e in ag)           # the primary's row lengths as uint16 ...
+        assert any(e[1] == 0 and e[2] == 4 * 72_000 for e in ag)           # ... the secondary's as int32
     finally:
         ctx.close()
 

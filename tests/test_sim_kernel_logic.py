@@ -242,6 +242,48 @@ def test_large_transpose_skewed_ids_heavy_bucket(sim_session):
         assert np.array_equal(np.sort(ri[cp[j]:cp[j + 1]]), ri_ref[cp_ref[j]:cp_ref[j + 1]]), j
 
 
+@pytest.mark.parametrize("wire", ["u16", "i32"])
+def test_merge_of_csc_fragments(sim_session, wire):
+    """urcco_dev_merge_fragments (multi-GPU: every rank transposes its own user shard, a rank's item range arrives as W fragments):
+    fragments made with the library's own transposition of uneven shards (one of them empty), merged for every range of a
+    3-way split, against the CSC of the whole matrix (global user ids)."""
+    sess = sim_session
+    dev = sess.device
+    rng = np.random.default_rng(21)
+    n_users, n_items = 5000, 700
+    m = rand_csr(rng, n_users, n_items, 11, zipf_s=1.1)
+    cuts = [0, 1700, 1700, 4100, n_users]                    # W = 4, shard 1 is empty
+    W = len(cuts) - 1
+    counts = O.column_counts(m)
+    csc_cp = np.zeros(n_items + 1, np.int64)
+    np.cumsum(counts, out=csc_cp[1:])
+    order = np.argsort(m.col_idx, kind="stable")
+    csc_ri = np.repeat(np.arange(n_users), np.diff(m.row_ptr))[order]
+    frags = []
+    for lo, hi in zip(cuts, cuts[1:]):
+        sh = O.Csr(hi - lo, n_items, m.row_ptr[lo:hi + 1] - m.row_ptr[lo], m.col_idx[m.row_ptr[lo]:m.row_ptr[hi]])
+        l_cnt = O.column_counts(sh)
+        cp, ri = sess.transpose(to_dev(sh, dev), guarded(torch.from_numpy(l_cnt).to(dev)))
+        frags.append((l_cnt, cp.cpu().numpy(), ri.cpu().numpy()))
+    sizes = np.zeros(3 * W, np.int64)
+    sizes[0::3] = np.diff(cuts)
+    bounds = [0, 90, 90 + 333, n_items]
+    for lo, hi in zip(bounds, bounds[1:]):
+        lens = np.concatenate([f[0][lo:hi] for f in frags])
+        ents = np.concatenate([f[2][f[1][lo]:f[1][hi]] for f in frags]).astype(np.int32)
+        lens_t = torch.from_numpy(lens.astype(np.uint16) if wire == "u16" else lens.astype(np.int32))
+        cp, ri = sess.merge_fragments(W, lo, hi, n_items, guarded(lens_t.to(dev)), guarded(torch.from_numpy(np.concatenate([ents, np.zeros(1, np.int32)])).to(dev)),
+                                      int(ents.size), guarded(torch.from_numpy(sizes).to(dev)), guarded(torch.from_numpy(counts).to(dev)))
+        cp, ri = cp.cpu().numpy(), ri.cpu().numpy()
+        ref_cp = np.zeros(n_items + 1, np.int64)
+        np.cumsum(np.where((np.arange(n_items) >= lo) & (np.arange(n_items) < hi), counts, 0), out=ref_cp[1:])
+        assert np.array_equal(cp, ref_cp)
+        got = ri[: ref_cp[-1]].copy()
+        for j in range(lo, hi):                                # the library's transposition does not order a column; a fragment's run stays together
+            got[ref_cp[j]:ref_cp[j + 1]].sort()
+        assert np.array_equal(got, csc_ri[csc_cp[lo]:csc_cp[hi]])
+
+
 def _csr_from_lengths(rng, lengths, n_cols):
     lengths = np.asarray(lengths, dtype=np.int64)
     rp = np.zeros(len(lengths) + 1, dtype=np.int64)

@@ -13,6 +13,7 @@ for s in "$@"; do
     bench)      timeout 1200 python bench.py > $O/bench.log 2>&1; tail -c 12000 $O/bench.log ;;
     bench_lite) timeout 900 python bench.py --workload $W --steps ${STEPS:-10} --warmup 3 --no-cpu-baseline --no-extras > $O/bench_lite_$W.log 2>&1; tail -c 5000 $O/bench_lite_$W.log ;;
     bench_fx)   timeout 900 python bench.py --workload $W --steps 10 --warmup 3 --force-exchange --no-cpu-baseline --no-extras > $O/bench_fx.log 2>&1; tail -c 1500 $O/bench_fx.log ;;
+    bench_fxg)  timeout 900 python bench.py --workload $W --steps 10 --warmup 3 --force-exchange --gathered-primary --no-cpu-baseline --no-extras > $O/bench_fxg.log 2>&1; tail -c 1500 $O/bench_fxg.log ;;
     bench_c3)   timeout 900 python bench.py --workload config3 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_c3.log 2>&1; tail -c 5000 $O/bench_c3.log ;;
     bench_c5)   timeout 900 python bench.py --workload config5 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_c5.log 2>&1; tail -c 5000 $O/bench_c5.log ;;
     prof)       (cd /tmp && timeout -k 10 ${PROF_TIMEOUT:-150} rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_$W -o ks -- python $GRAFT_REPO_ROOT/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-extras --single-stream --timed-only > $GRAFT_REPO_ROOT/$O/prof_$W.log 2>&1); rm -f $O/prof_$W/*kernel_trace.csv; ls $O/prof_$W; head -30 $O/prof_$W/*kernel_stats.csv ;;

@@ -51,9 +51,13 @@ ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int6
 ALL_GATHER_V_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p)
 
 
+ALL_TO_ALL_V_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64),
+                              C.POINTER(C.c_int64), C.c_void_p)
+
+
 class Collectives(C.Structure):
     _fields_ = [("user", C.c_void_p), ("group_start", GROUP_FN), ("group_end", GROUP_FN), ("all_reduce_sum", ALL_REDUCE_FN),
-                ("all_gather_v", ALL_GATHER_V_FN)]
+                ("all_gather_v", ALL_GATHER_V_FN), ("all_to_all_v", ALL_TO_ALL_V_FN)]
 
 
 class CommConfig(C.Structure):
@@ -127,6 +131,7 @@ SYMBOLS = {
     "urcco_dev_row_work_csr": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int64, _p, C.c_int32, _p]),
     "urcco_dev_row_work": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, C.c_int64, _p, _p]),
     "urcco_dev_partition": (C.c_int, [_p, C.c_int32, _p, C.c_int32, C.POINTER(C.c_int32)]),
+    "urcco_dev_merge_fragments": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p, C.c_int32, _p, C.c_int64, _p, _p, _p, _p]),
     "urcco_dev_cco_rows": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, C.c_int64, _p, _p, C.c_int32, _p, _p, C.c_int64, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_double, _p, _p, _p, _p]),
     "urcco_dev_compact_indicators": (C.c_int, [_p, C.c_int32, C.c_int32, _p, _p, _p, _p, _p, _p]),

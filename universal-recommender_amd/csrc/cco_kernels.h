@@ -118,8 +118,14 @@ hipError_t launch_dictionary_verify(hipStream_t st, int n_cu, KeyTable t, int64_
 hipError_t launch_csr_from_pairs(hipStream_t st, int n_cu, int64_t n, const int32_t* rows, const int32_t* cols, int64_t n_rows, int32_t* cnt,
                                  int64_t* raw_ptr, int32_t* tmp, int64_t* tile_sums, int64_t* out_row_ptr, int32_t* out_col_idx);
 
-// len[n_rows] = row lengths; sizes (nullable) = {n_rows, nnz}
-hipError_t launch_row_lengths(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, int32_t* len, int64_t* sizes);
+// len[n_rows] = row lengths, len16 (nullable) = the same as uint16; sizes (nullable) = {n_rows, nnz, rows longer than 65535}
+constexpr int EXCH_SIZES = 3;
+hipError_t launch_row_lengths(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, int32_t* len, unsigned short* len16, int64_t* sizes);
+hipError_t launch_scan_u16(hipStream_t st, const unsigned short* in, int64_t n, int64_t* out, int64_t* tile_sums);
+// CSC fragments of the primary (multi-GPU): the record a rank publishes ((2 * world + 3) int64) and the merge of received fragments
+hipError_t launch_frag_record(hipStream_t st, int32_t world, const int32_t* bounds, const int64_t* l_cp, const int32_t* bad, int64_t* rec);
+hipError_t launch_frag_place(hipStream_t st, int n_cu, int32_t world, int32_t lo, int32_t n_range, const void* lens, int wire16, const int64_t* src_off,
+                             const int32_t* ents, const int64_t* a_cp, const int64_t* sizes, int32_t* a_ri);
 
 // boundary checks of a caller-supplied CSR (rp0 = value of row_ptr[0] of the slice); err[0] += violations
 hipError_t launch_validate_csr(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,

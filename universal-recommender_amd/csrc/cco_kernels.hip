@@ -2894,24 +2894,117 @@ hipError_t launch_partition(hipStream_t st, int32_t n_items, const int64_t* work
 }
 
 // ============================================================================================
-// Multi-GPU exchange helpers: row lengths of a CSR shard as int32 (what travels in the all-gather-v next to the column
-// indices; the receiver rebuilds row_ptr with one scan over the concatenated lengths), and the (rows, nnz) record a rank
-// publishes about its down-sampled shard.
+// Multi-GPU exchange helpers.
+//  * Row lengths of a CSR shard -- what travels in the all-gather-v next to the column indices; the receiver rebuilds row_ptr
+//    with one scan over the concatenated lengths.  Written twice, as int32 and as uint16: the record a rank publishes about its
+//    down-sampled shard is {rows, nnz, rows whose length does not fit 16 bits}, and the host sends the 16-bit copy when that
+//    last figure is zero on every rank.
+//  * CSC fragments of the primary: every rank transposes ITS user shard (all columns, shard-local user ids); the slice of
+//    that CSC belonging to the item range of rank q is contiguous, so it is sent as it lies (entries + 16-bit column lengths)
+//    and rank q merges the W fragments it receives into the CSC of its range -- no rank ever walks the whole of A' to pick
+//    its columns out.
 // ============================================================================================
 __global__ __launch_bounds__(256) void row_lengths_kernel(int64_t n_rows, const int64_t* __restrict__ rp, int32_t* __restrict__ len,
-                                                          int64_t* __restrict__ sizes) {
-  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * 256) len[r] = (int32_t)(rp[r + 1] - rp[r]);
+                                                          unsigned short* __restrict__ len16, int64_t* __restrict__ sizes) {
+  int over = 0;
+  for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < n_rows; r += (int64_t)gridDim.x * 256) {
+    const int64_t l = rp[r + 1] - rp[r];
+    len[r] = (int32_t)l;
+    if (len16) {
+      len16[r] = (unsigned short)l;
+      over += l > 0xffff ? 1 : 0;
+    }
+  }
+  if (sizes && over) atomicAdd(reinterpret_cast<unsigned long long*>(sizes + 2), (unsigned long long)over);
   if (sizes && blockIdx.x == 0 && threadIdx.x == 0) {
     sizes[0] = n_rows;
     sizes[1] = rp[n_rows];
   }
 }
-hipError_t launch_row_lengths(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, int32_t* len, int64_t* sizes) {
+hipError_t launch_row_lengths(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, int32_t* len, unsigned short* len16, int64_t* sizes) {
   int64_t blocks = (n_rows + 255) / 256;
   const int64_t cap = (int64_t)n_cu * 8;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(row_lengths_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, row_ptr, len, sizes);
+  if (sizes) {
+    hipError_t e = hipMemsetAsync(sizes, 0, sizeof(int64_t) * EXCH_SIZES, st);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(row_lengths_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, row_ptr, len, len16, sizes);
+  return hipGetLastError();
+}
+
+struct LoadU16 {
+  const unsigned short* p;
+  __device__ __forceinline__ long long operator()(int64_t i) const { return p[i]; }
+  __device__ __forceinline__ void load8(int64_t i, long long* x) const {
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+      const uint4 a = *reinterpret_cast<const uint4*>(p + i);
+      x[0] = a.x & 0xffffu; x[1] = a.x >> 16; x[2] = a.y & 0xffffu; x[3] = a.y >> 16;
+      x[4] = a.z & 0xffffu; x[5] = a.z >> 16; x[6] = a.w & 0xffffu; x[7] = a.w >> 16;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) x[q] = p[i + q];
+    }
+  }
+};
+hipError_t launch_scan_u16(hipStream_t st, const unsigned short* in, int64_t n, int64_t* out, int64_t* tile_sums) {
+  return launch_scan(st, LoadU16{in}, n, out, tile_sums);
+}
+
+// rec[0 .. W] = entry offsets of the local CSC at the range bounds, rec[W + 1 .. 2W + 1] = the bounds,
+// rec[2W + 2] = local column lengths that do not fit 16 bits
+__global__ void frag_record_kernel(int32_t world, const int32_t* __restrict__ bounds, const int64_t* __restrict__ l_cp, const int32_t* __restrict__ bad,
+                                   int64_t* __restrict__ rec) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > world) return;
+  const int32_t b = bounds[p];
+  rec[p] = l_cp[b];
+  rec[world + 1 + p] = b;
+  if (p == 0) rec[2 * world + 2] = bad ? *bad : 0;
+}
+hipError_t launch_frag_record(hipStream_t st, int32_t world, const int32_t* bounds, const int64_t* l_cp, const int32_t* bad, int64_t* rec) {
+  hipLaunchKernelGGL(frag_record_kernel, dim3((unsigned)((world + 64) / 64)), dim3(64), 0, st, world, bounds, l_cp, bad, rec);
+  return hipGetLastError();
+}
+
+// Merge of the fragments received for the item range [lo, lo + n_range): lens[p * n_range + j] = length of column lo + j in the
+// shard of rank p, src_off = exclusive scan of lens in that (rank-major) order = where that run starts in `ents` (the fragments
+// lie one behind the other in rank order); a_cp = CSC pointers of the range (scan of the all-reduced column counts).  The
+// shard-local user ids become global ones: + the rows of the ranks before p (sizes[EXCH_SIZES * q] = rows of rank q).  Runs are
+// placed in rank order, so a column ascends in the user id if the fragments did.  16 lanes per column.
+constexpr int FRAG_LANES = 16;
+template <typename L>
+__global__ __launch_bounds__(256) void frag_place_kernel(int32_t world, int32_t lo, int32_t n_range, const L* __restrict__ lens,
+                                                         const int64_t* __restrict__ src_off, const int32_t* __restrict__ ents,
+                                                         const int64_t* __restrict__ a_cp, const int64_t* __restrict__ sizes,
+                                                         int32_t* __restrict__ a_ri) {
+  const int gl = threadIdx.x & (FRAG_LANES - 1);
+  const int64_t groups = (int64_t)gridDim.x * (256 / FRAG_LANES);
+  for (int64_t j = (int64_t)blockIdx.x * (256 / FRAG_LANES) + threadIdx.x / FRAG_LANES; j < n_range; j += groups) {
+    int64_t dst = a_cp[lo + j];
+    int64_t base = 0;
+    for (int p = 0; p < world; ++p) {
+      const int64_t at = (int64_t)p * n_range + j;
+      const int64_t n = (int64_t)lens[at];
+      const int64_t src = src_off[at];
+      for (int64_t t = gl; t < n; t += FRAG_LANES) a_ri[dst + t] = (int32_t)(ents[src + t] + base);
+      dst += n;
+      base += sizes[(int64_t)EXCH_SIZES * p];
+    }
+  }
+}
+hipError_t launch_frag_place(hipStream_t st, int n_cu, int32_t world, int32_t lo, int32_t n_range, const void* lens, int wire16, const int64_t* src_off,
+                             const int32_t* ents, const int64_t* a_cp, const int64_t* sizes, int32_t* a_ri) {
+  if (n_range <= 0) return hipSuccess;
+  int64_t blocks = ((int64_t)n_range + (256 / FRAG_LANES) - 1) / (256 / FRAG_LANES);
+  if (blocks > (int64_t)n_cu * 16) blocks = (int64_t)n_cu * 16;
+  if (wire16)
+    hipLaunchKernelGGL((frag_place_kernel<unsigned short>), dim3((unsigned)blocks), dim3(256), 0, st, world, lo, n_range,
+                       static_cast<const unsigned short*>(lens), src_off, ents, a_cp, sizes, a_ri);
+  else
+    hipLaunchKernelGGL((frag_place_kernel<int32_t>), dim3((unsigned)blocks), dim3(256), 0, st, world, lo, n_range, static_cast<const int32_t*>(lens),
+                       src_off, ents, a_cp, sizes, a_ri);
   return hipGetLastError();
 }
 

@@ -230,15 +230,34 @@ int urcco_dev_row_work(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
 
 int urcco_dev_partition(urcco_session* s, int32_t n_items, const int64_t* work, int32_t n_parts, int32_t* bounds_host) {
   if (!s || n_items < 0 || n_parts <= 0 || n_parts > 4096 || !bounds_host || (n_items > 0 && !work)) return fail(URCCO_BAD_ARG, "urcco_dev_partition: bad argument");
-  const int64_t n_tiles = ((int64_t)n_items + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
-  URC(s->reserve(urcco_session::need((size_t)n_items + 1, 8) + urcco_session::need((size_t)n_tiles + 2, 8) + urcco_session::need((size_t)n_parts + 1, 4)));
-  int64_t* prefix = s->take<int64_t>((size_t)n_items + 1);
-  int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
-  int32_t* bounds = s->take<int32_t>((size_t)n_parts + 1);
-  HIPC(urcco::launch_scan_i64(s->stream, work, n_items, prefix, tile_sums));
-  HIPC(urcco::launch_partition(s->stream, n_items, prefix, n_parts, bounds));
+  int32_t* bounds = nullptr;
+  URC(urcco_detail::partition_dev(s, n_items, work, n_parts, nullptr, &bounds));
   HIPC(hipMemcpyAsync(bounds_host, bounds, sizeof(int32_t) * (size_t)(n_parts + 1), hipMemcpyDeviceToHost, s->stream));
   HIPC(hipStreamSynchronize(s->stream));
+  return URCCO_OK;
+}
+
+int urcco_dev_merge_fragments(urcco_session* s, int32_t world, int32_t item_lo, int32_t item_hi, int32_t n_items, const void* lens, int32_t wire16,
+                              const int32_t* entries, int64_t n_entries, const int64_t* sizes, const int32_t* counts, int64_t* out_col_ptr,
+                              int32_t* out_row_idx) {
+  if (!s || world <= 0 || item_lo < 0 || item_hi < item_lo || item_hi > n_items || n_entries < 0 || !sizes || !out_col_ptr || (n_items > 0 && !counts) ||
+      (item_hi > item_lo && !lens) || (n_entries > 0 && (!entries || !out_row_idx)))
+    return fail(URCCO_BAD_ARG, "urcco_dev_merge_fragments: bad argument");
+  const int32_t n_range = item_hi - item_lo;
+  const int64_t n_runs = (int64_t)world * n_range;
+  const int64_t t_items = ((int64_t)n_items + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE, t_runs = (n_runs + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
+  URC(s->reserve(urcco_session::need((size_t)n_runs + 1, 8) + urcco_session::need((size_t)(t_items > t_runs ? t_items : t_runs) + 2, 8)));
+  int64_t* src_off = s->take<int64_t>((size_t)n_runs + 1);
+  int64_t* tile_sums = s->take<int64_t>((size_t)(t_items > t_runs ? t_items : t_runs) + 2);
+  s->begin(URCCO_STAGE_TRANSPOSE);
+  HIPC(urcco::launch_scan_i32_range(s->stream, counts, n_items, item_lo, item_hi, out_col_ptr, tile_sums));
+  if (wire16) {
+    HIPC(urcco::launch_scan_u16(s->stream, static_cast<const unsigned short*>(lens), n_runs, src_off, tile_sums));
+  } else {
+    HIPC(urcco::launch_scan_i32(s->stream, static_cast<const int32_t*>(lens), n_runs, src_off, tile_sums));
+  }
+  HIPC(urcco::launch_frag_place(s->stream, s->n_cu, world, item_lo, n_range, lens, wire16, src_off, entries, out_col_ptr, sizes, out_row_idx));
+  s->end();
   return URCCO_OK;
 }
 
@@ -253,6 +272,19 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
 }  // extern "C"
 
 namespace urcco_detail {
+
+// bounds stay on the device: `bounds_dev` if given, else arena scratch returned through *bounds_out (valid until the session's next reserve)
+int partition_dev(urcco_session* s, int32_t n_items, const int64_t* work, int32_t n_parts, int32_t* bounds_dev, int32_t** bounds_out) {
+  const int64_t n_tiles = ((int64_t)n_items + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE;
+  URC(s->reserve(urcco_session::need((size_t)n_items + 1, 8) + urcco_session::need((size_t)n_tiles + 2, 8) + urcco_session::need((size_t)n_parts + 1, 4)));
+  int64_t* prefix = s->take<int64_t>((size_t)n_items + 1);
+  int64_t* tile_sums = s->take<int64_t>((size_t)n_tiles + 2);
+  int32_t* bounds = bounds_dev ? bounds_dev : s->take<int32_t>((size_t)n_parts + 1);
+  HIPC(urcco::launch_scan_i64(s->stream, work, n_items, prefix, tile_sums));
+  HIPC(urcco::launch_partition(s->stream, n_items, prefix, n_parts, bounds));
+  if (bounds_out) *bounds_out = bounds;
+  return URCCO_OK;
+}
 
 // One secondary's share of a fused expand preparation (see urcco_expand_multi) may be handed in as pre_pstart / pre_plen.
 int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a, const int64_t* a_col_ptr, const int32_t* a_row_idx, int64_t nnz_a_bound,

@@ -172,9 +172,10 @@ struct EvState {
   DBuf<int64_t> s_rp;           // down-sampled shard
   DBuf<int32_t> s_ci;
   DBuf<int32_t> deg, f_deg;     // exchange: row lengths of the shard / of the whole matrix
+  DBuf<unsigned short> deg16, f_deg16;  // ... as they travel when every row of every shard fits 16 bits
   DBuf<int64_t> f_rp;           // whole down-sampled matrix (multi-rank builds)
   DBuf<int32_t> f_ci;
-  DBuf<int64_t> sizes;          // [2 * world] (rows, nnz') of every rank's shard; own record at [2 * rank]
+  DBuf<int64_t> sizes;          // [EXCH_SIZES * world] (rows, nnz', rows longer than 65535) of every rank's shard; own record at [EXCH_SIZES * rank]
   DBuf<int64_t> scan_tmp;
   DBuf<int32_t> o_count, o_idx; // strided top-k
   DBuf<double> o_llr;
@@ -194,6 +195,7 @@ struct EvState {
   int64_t b_rows = 0, b_nnz_bound = 0;
   void release() {
     in_rp.release(); in_ci.release(); raw.release(); post.release(); s_rp.release(); s_ci.release(); deg.release(); f_deg.release();
+    deg16.release(); f_deg16.release();
     f_rp.release(); f_ci.release(); sizes.release(); scan_tmp.release(); o_count.release(); o_idx.release(); o_llr.release(); c_rp.release();
     c_idx.release(); c_llr.release(); stats.release(); verr.release(); pre_pstart.release(); pre_plen.release();
     if (ev_sampled) (void)hipEventDestroy(ev_sampled);
@@ -223,9 +225,17 @@ struct DevState {
   int par = 0;
   DBuf<int64_t> work;
   DBuf<int32_t> bounds;
+  // CSC fragments of the primary (several ranks): the shard's own column counts and CSC, their 16-bit lengths, the record
+  // every rank publishes ((2 W + 3) int64: entry offsets at the range bounds, the bounds, lengths that do not fit 16 bits),
+  // and what arrives for this GPU's item range
+  DBuf<int32_t> l_cnt, l_ri, len_bad, f_ent;
+  DBuf<int64_t> l_cp, rec;
+  DBuf<unsigned short> len16;
+  DBuf<char> f_len;
   hipEvent_t a_ready = nullptr, in_ready = nullptr, b_expanded = nullptr;
   Rccl::Comm comm = nullptr;
   int32_t item_lo = 0, item_hi = 0;
+  int64_t a_ents = 0;  // entries of the primary's CSC over [item_lo, item_hi) (known exactly when it was merged from fragments)
 };
 
 struct Shard {  // one device-resident user-range shard handed to the pipelines
@@ -415,6 +425,19 @@ struct urcco_context {
     for (int p = 0; p < world; ++p) {
       if (cnt[D.rank] > 0) RCCLC(rccl, rccl->Send(send, (size_t)cnt[D.rank], Rccl::kInt8, p, D.comm, st));
       if (cnt[p] > 0) RCCLC(rccl, rccl->Recv((char*)recv + off[p], (size_t)cnt[p], Rccl::kInt8, p, D.comm, st));
+    }
+    RCCLC(rccl, rccl->GroupEnd());
+    return URCCO_OK;
+  }
+  int all_to_all_v(DevState& D, const void* send, const int64_t* soff, const int64_t* scnt, void* recv, const int64_t* roff, const int64_t* rcnt, hipStream_t st) {
+    if (have_cb) {
+      if (!cb.all_to_all_v) return fail(URCCO_BAD_ARG, "collectives.all_to_all_v is required (urcco.h, since 301)");
+      return cb.all_to_all_v(cb.user, D.rank, send, soff, scnt, recv, roff, rcnt, (void*)st) == 0 ? URCCO_OK : fail(URCCO_RCCL_ERROR, "collectives.all_to_all_v failed");
+    }
+    RCCLC(rccl, rccl->GroupStart());
+    for (int p = 0; p < world; ++p) {
+      if (scnt[p] > 0) RCCLC(rccl, rccl->Send((const char*)send + soff[p], (size_t)scnt[p], Rccl::kInt8, p, D.comm, st));
+      if (rcnt[p] > 0) RCCLC(rccl, rccl->Recv((char*)recv + roff[p], (size_t)rcnt[p], Rccl::kInt8, p, D.comm, st));
     }
     RCCLC(rccl, rccl->GroupEnd());
     return URCCO_OK;
@@ -668,6 +691,11 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
 // ---------------------------------------------------------------------------------------------------------
 // several ranks (or the forced exchange path): SURVEY.md 8e.  `L` = this process's GPUs; every phase walks them.
 // ---------------------------------------------------------------------------------------------------------
+constexpr int XS = urcco::EXCH_SIZES;
+// the primary's CSC of a rank's item range comes from fragments (default) or, for A/B runs (debug bit 8192), from the pass every
+// rank makes over the whole gathered A'
+bool fragments(const urcco_context* c) { return !(c->debug & 8192); }
+
 int input_phase(urcco_context* c, int d, const std::vector<std::vector<Shard>>& sh, const std::vector<DsParams>& ps, int32_t seed) {
   const DsParams& p = ps[(size_t)d];
   URC(c->workers->run([&](size_t g) -> int {
@@ -684,7 +712,12 @@ int input_phase(urcco_context* c, int d, const std::vector<std::vector<Shard>>& 
   URC(c->workers->run([&](size_t g) -> int {
     DevState& D = c->devs[g];
     URC(set_dev(D));
-    return stage_downsample(c, D, d, sh[(size_t)d][g], p, seed);
+    URC(stage_downsample(c, D, d, sh[(size_t)d][g], p, seed));
+    if (d == 0 && fragments(c)) {  // the shard's own column counts = the column lengths of its CSC, before the all-reduce adds the others'
+      URC(D.l_cnt.ensure((size_t)p.n_cols + 1));
+      if (p.n_cols > 0) HIPC(hipMemcpyAsync(D.l_cnt.p, post_of(D, 0).p, sizeof(int32_t) * (size_t)p.n_cols, hipMemcpyDeviceToDevice, D.ev[0].s->stream));
+    }
+    return URCCO_OK;
   }));
   URC(c->group_start());
   for (DevState& D : c->devs) {
@@ -692,70 +725,138 @@ int input_phase(urcco_context* c, int d, const std::vector<std::vector<Shard>>& 
     URC(c->all_reduce(D, post_of(D, d).p, p.n_cols, 0, D.ev[(size_t)d].s->stream));
   }
   URC(c->group_end());
-  // row lengths (what travels) + the (rows, nnz') record of the shard, gathered over the ranks
+  // row lengths (what travels) + the (rows, nnz', long rows) record of the shard, gathered over the ranks
   for (DevState& D : c->devs) {
     URC(set_dev(D));
     EvState& E = D.ev[(size_t)d];
     const Shard& s = sh[(size_t)d][(size_t)(&D - c->devs.data())];
     URC(E.deg.ensure((size_t)s.n_rows + 1));
-    URC(E.sizes.ensure((size_t)2 * (size_t)c->world));
-    HIPC(urcco::launch_row_lengths(E.s->stream, D.n_cu, s.n_rows, E.s_rp.p, E.deg.p, E.sizes.p + 2 * D.rank));
+    URC(E.deg16.ensure((size_t)s.n_rows + 8));
+    URC(E.sizes.ensure((size_t)XS * (size_t)c->world));
+    HIPC(urcco::launch_row_lengths(E.s->stream, D.n_cu, s.n_rows, E.s_rp.p, E.deg.p, E.deg16.p, E.sizes.p + XS * D.rank));
   }
-  std::vector<int64_t> off((size_t)c->world), cnt((size_t)c->world, 16);
-  for (int r = 0; r < c->world; ++r) off[(size_t)r] = 16 * (int64_t)r;
+  std::vector<int64_t> off((size_t)c->world), cnt((size_t)c->world, 8 * XS);
+  for (int r = 0; r < c->world; ++r) off[(size_t)r] = 8 * XS * (int64_t)r;
   URC(c->group_start());
   for (DevState& D : c->devs) {
     URC(set_dev(D));
     EvState& E = D.ev[(size_t)d];
-    URC(c->all_gather_v(D, E.sizes.p + 2 * D.rank, E.sizes.p, off.data(), cnt.data(), E.s->stream));
+    URC(c->all_gather_v(D, E.sizes.p + XS * D.rank, E.sizes.p, off.data(), cnt.data(), E.s->stream));
   }
   URC(c->group_end());
   return URCCO_OK;
 }
 
-// reads event d's shard sizes on the host (waits for that event's stream only), exchanges the down-sampled shards and
-// rebuilds the whole matrix on every GPU
-int exchange_phase(urcco_context* c, int d, const std::vector<DsParams>& ps, int64_t n_users, std::vector<int64_t>& sizes /*out [2 * world]*/) {
+// What the host learns about the primary's fragments in the one blocking read of a multi-rank build
+struct FragPlan {
+  bool on = false, wire16 = true;
+  std::vector<int32_t> bounds;         // [W + 1]
+  std::vector<int64_t> cpb;            // [W][W + 1]: entry offsets of rank p's CSC at the bounds
+};
+
+// reads event d's shard sizes on the host (waits for that event's stream only; for the primary with fragments the same read
+// brings every rank's fragment record), exchanges the down-sampled shards and rebuilds the whole matrix on every GPU
+int exchange_phase(urcco_context* c, int d, const std::vector<DsParams>& ps, int64_t n_users, std::vector<int64_t>& sizes /*out [XS * world]*/, FragPlan* fp = nullptr) {
   const int W = c->world;
-  sizes.assign((size_t)2 * (size_t)W, 0);
+  const int R = 2 * W + 3;
+  sizes.assign((size_t)XS * (size_t)W, 0);
+  std::vector<int64_t> recs;
   {
     DevState& D = c->devs[0];
     URC(set_dev(D));
     EvState& E = D.ev[(size_t)d];
-    HIPC(hipMemcpyAsync(sizes.data(), E.sizes.p, sizeof(int64_t) * 2 * (size_t)W, hipMemcpyDeviceToHost, E.s->stream));
+    HIPC(hipMemcpyAsync(sizes.data(), E.sizes.p, sizeof(int64_t) * (size_t)XS * (size_t)W, hipMemcpyDeviceToHost, E.s->stream));
+    if (fp && fp->on) {
+      recs.assign((size_t)R * (size_t)W, 0);
+      HIPC(hipMemcpyAsync(recs.data(), D.rec.p, sizeof(int64_t) * (size_t)R * (size_t)W, hipMemcpyDeviceToHost, E.s->stream));
+    }
     HIPC(hipStreamSynchronize(E.s->stream));
   }
   std::vector<int64_t> off_r((size_t)W), cnt_r((size_t)W), off_c((size_t)W), cnt_c((size_t)W);
   int64_t rows = 0, nnz = 0;
+  bool deg16 = true;
+  for (int r = 0; r < W; ++r) deg16 = deg16 && sizes[(size_t)XS * r + 2] == 0;
+  const int64_t deg_bytes = deg16 ? 2 : 4;
   for (int r = 0; r < W; ++r) {
-    off_r[(size_t)r] = rows * 4;
-    cnt_r[(size_t)r] = sizes[(size_t)2 * r] * 4;
+    off_r[(size_t)r] = rows * deg_bytes;
+    cnt_r[(size_t)r] = sizes[(size_t)XS * r] * deg_bytes;
     off_c[(size_t)r] = nnz * 4;
-    cnt_c[(size_t)r] = sizes[(size_t)2 * r + 1] * 4;
-    rows += sizes[(size_t)2 * r];
-    nnz += sizes[(size_t)2 * r + 1];
+    cnt_c[(size_t)r] = sizes[(size_t)XS * r + 1] * 4;
+    rows += sizes[(size_t)XS * r];
+    nnz += sizes[(size_t)XS * r + 1];
   }
   if (rows != n_users) return fail(URCCO_BAD_ARG, "event type %d: the user shards hold %lld rows, n_users_total is %lld", d, (long long)rows, (long long)n_users);
+  if (fp && fp->on) {
+    fp->bounds.assign((size_t)W + 1, 0);
+    fp->cpb.assign((size_t)W * (size_t)(W + 1), 0);
+    fp->wire16 = true;
+    for (int p = 0; p < W; ++p) {
+      const int64_t* rec = recs.data() + (size_t)R * (size_t)p;
+      for (int q = 0; q <= W; ++q) {
+        fp->cpb[(size_t)p * (size_t)(W + 1) + (size_t)q] = rec[q];
+        if (p == 0) fp->bounds[(size_t)q] = (int32_t)rec[W + 1 + q];
+        else if (fp->bounds[(size_t)q] != (int32_t)rec[W + 1 + q]) return fail(URCCO_INTERNAL, "ranks 0 and %d disagree on the item range bounds", p);
+      }
+      if (rec[0] != 0 || rec[W] != sizes[(size_t)XS * p + 1]) return fail(URCCO_INTERNAL, "rank %d: the fragment record does not cover its shard", p);
+      fp->wire16 = fp->wire16 && rec[2 * W + 2] == 0;
+    }
+    c->h_bounds = fp->bounds;
+  }
   for (DevState& D : c->devs) {
     URC(set_dev(D));
     EvState& E = D.ev[(size_t)d];
     URC(E.f_deg.ensure((size_t)rows + 1));
+    URC(E.f_deg16.ensure((size_t)rows + 8));
     URC(E.f_rp.ensure((size_t)rows + 2));
     URC(E.f_ci.ensure((size_t)nnz + 4));
     URC(E.scan_tmp.ensure((size_t)(rows / urcco::SCAN_TILE + 4)));
+    if (fp && fp->on) {
+      D.item_lo = fp->bounds[(size_t)D.rank];
+      D.item_hi = fp->bounds[(size_t)D.rank + 1];
+      int64_t ents = 0;
+      for (int p = 0; p < W; ++p) ents += fp->cpb[(size_t)p * (size_t)(W + 1) + (size_t)D.rank + 1] - fp->cpb[(size_t)p * (size_t)(W + 1) + (size_t)D.rank];
+      URC(D.f_len.ensure((size_t)W * (size_t)(D.item_hi - D.item_lo) * 4 + 64));
+      URC(D.f_ent.ensure((size_t)ents + 4));
+    }
   }
   URC(c->group_start());
   for (DevState& D : c->devs) {
     URC(set_dev(D));
     EvState& E = D.ev[(size_t)d];
-    URC(c->all_gather_v(D, E.deg.p, E.f_deg.p, off_r.data(), cnt_r.data(), E.s->stream));
+    if (deg16) URC(c->all_gather_v(D, E.deg16.p, E.f_deg16.p, off_r.data(), cnt_r.data(), E.s->stream));
+    else URC(c->all_gather_v(D, E.deg.p, E.f_deg.p, off_r.data(), cnt_r.data(), E.s->stream));
     URC(c->all_gather_v(D, E.s_ci.p, E.f_ci.p, off_c.data(), cnt_c.data(), E.s->stream));
+    if (fp && fp->on) {
+      // to rank q: the column lengths and the entries of q's item range, as they lie in this shard's CSC; from rank p: the same
+      // for this GPU's range, one fragment behind the other in rank order
+      const int64_t lb = fp->wire16 ? 2 : 4;
+      const int64_t n_range = D.item_hi - D.item_lo;
+      std::vector<int64_t> so((size_t)W), sc((size_t)W), ro((size_t)W), rc((size_t)W), eso((size_t)W), esc((size_t)W), ero((size_t)W), erc((size_t)W);
+      int64_t e_at = 0;
+      const int64_t* mine = fp->cpb.data() + (size_t)D.rank * (size_t)(W + 1);
+      for (int q = 0; q < W; ++q) {
+        so[(size_t)q] = (int64_t)fp->bounds[(size_t)q] * lb;
+        sc[(size_t)q] = (int64_t)(fp->bounds[(size_t)q + 1] - fp->bounds[(size_t)q]) * lb;
+        ro[(size_t)q] = (int64_t)q * n_range * lb;
+        rc[(size_t)q] = n_range * lb;
+        eso[(size_t)q] = mine[q] * 4;
+        esc[(size_t)q] = (mine[q + 1] - mine[q]) * 4;
+        const int64_t* theirs = fp->cpb.data() + (size_t)q * (size_t)(W + 1);
+        ero[(size_t)q] = e_at * 4;
+        erc[(size_t)q] = (theirs[D.rank + 1] - theirs[D.rank]) * 4;
+        e_at += theirs[D.rank + 1] - theirs[D.rank];
+      }
+      const void* lens = fp->wire16 ? (const void*)D.len16.p : (const void*)D.l_cnt.p;
+      URC(c->all_to_all_v(D, lens, so.data(), sc.data(), D.f_len.p, ro.data(), rc.data(), E.s->stream));
+      URC(c->all_to_all_v(D, D.l_ri.p, eso.data(), esc.data(), D.f_ent.p, ero.data(), erc.data(), E.s->stream));
+    }
   }
   URC(c->group_end());
   for (DevState& D : c->devs) {
     URC(set_dev(D));
     EvState& E = D.ev[(size_t)d];
-    HIPC(urcco::launch_scan_i32(E.s->stream, E.f_deg.p, rows, E.f_rp.p, E.scan_tmp.p));
+    if (deg16) HIPC(urcco::launch_scan_u16(E.s->stream, E.f_deg16.p, rows, E.f_rp.p, E.scan_tmp.p));
+    else HIPC(urcco::launch_scan_i32(E.s->stream, E.f_deg.p, rows, E.f_rp.p, E.scan_tmp.p));
     E.b_rp = E.f_rp.p;
     E.b_ci = E.f_ci.p;
     E.b_rows = rows;
@@ -767,10 +868,14 @@ int exchange_phase(urcco_context* c, int d, const std::vector<DsParams>& ps, int
 int build_sharded(urcco_context* c, const std::vector<std::vector<Shard>>& sh, const std::vector<DsParams>& ps, int64_t n_users, int32_t seed) {
   const int n_ds = (int)ps.size();
   const int W = c->world;
+  const int R = 2 * W + 3;
   const int32_t n_items_a = (int32_t)ps[0].n_cols;
+  FragPlan fp;
+  fp.on = fragments(c);
   // ---- primary: input phase, then the balance key.  The key is the A'A row work added up from the user shards (the
   // work of A'B_d sums the same users' B_d row lengths and follows it closely), so the ranges are fixed before any
-  // whole-matrix work and the one blocking host read comes right after the primary's short chain.
+  // whole-matrix work and the one blocking host read comes right after the primary's short chain.  With fragments every
+  // rank also transposes its own shard here (1 / W of the entries each), under the all-reduce of the key.
   URC(input_phase(c, 0, sh, ps, seed));
   URC(c->workers->run([&](size_t g) -> int {
     DevState& D = c->devs[g];
@@ -786,30 +891,70 @@ int build_sharded(urcco_context* c, const std::vector<std::vector<Shard>>& sh, c
     URC(c->all_reduce(D, D.work.p, n_items_a, 1, D.ev[0].s->stream));
   }
   URC(c->group_end());
-  c->h_bounds.assign((size_t)W + 1, 0);
-  for (DevState& D : c->devs) {  // identical bounds on every rank: the same scan + split of the same summed key
-    URC(set_dev(D));
-    std::vector<int32_t> b((size_t)W + 1);
-    URC(urcco_dev_partition(D.ev[0].s, n_items_a, D.work.p, W, b.data()));  // synchronises the primary's stream
-    c->h_bounds = b;
-    D.item_lo = b[(size_t)D.rank];
-    D.item_hi = b[(size_t)D.rank + 1];
-  }
   std::vector<int64_t> sizes;
-  URC(exchange_phase(c, 0, ps, n_users, sizes));
+  if (fp.on) {
+    URC(c->workers->run([&](size_t g) -> int {
+      DevState& D = c->devs[g];
+      URC(set_dev(D));
+      EvState& A = D.ev[0];
+      const Shard& s = sh[0][g];
+      URC(D.l_cp.ensure((size_t)n_items_a + 2));
+      URC(D.l_ri.ensure((size_t)s.nnz + 4));
+      URC(D.len16.ensure((size_t)n_items_a + 8));
+      URC(D.len_bad.ensure(1));
+      URC(D.bounds.ensure((size_t)W + 1));
+      URC(D.rec.ensure((size_t)R * (size_t)W));
+      URC(urcco_dev_transpose(A.s, s.n_rows, A.s_rp.p, A.s_ci.p, s.nnz, n_items_a, D.l_cnt.p, 0, n_items_a, D.l_cp.p, D.l_ri.p));
+      HIPC(urcco::launch_narrow_counts(A.s->stream, D.n_cu, D.l_cnt.p, n_items_a, D.len16.p, D.len_bad.p));
+      // identical bounds on every rank: the same scan + split of the same summed key; they stay on the device
+      URC(urcco_detail::partition_dev(A.s, n_items_a, D.work.p, W, D.bounds.p, nullptr));
+      HIPC(urcco::launch_frag_record(A.s->stream, W, D.bounds.p, D.l_cp.p, D.len_bad.p, D.rec.p + (size_t)R * (size_t)D.rank));
+      return URCCO_OK;
+    }));
+    std::vector<int64_t> off((size_t)W), cnt((size_t)W, 8 * (int64_t)R);
+    for (int r = 0; r < W; ++r) off[(size_t)r] = 8 * (int64_t)R * r;
+    URC(c->group_start());
+    for (DevState& D : c->devs) {
+      URC(set_dev(D));
+      URC(c->all_gather_v(D, D.rec.p + (size_t)R * (size_t)D.rank, D.rec.p, off.data(), cnt.data(), D.ev[0].s->stream));
+    }
+    URC(c->group_end());
+    URC(exchange_phase(c, 0, ps, n_users, sizes, &fp));  // the build's one blocking read for the primary: shard sizes + fragment records
+  } else {
+    c->h_bounds.assign((size_t)W + 1, 0);
+    for (DevState& D : c->devs) {
+      URC(set_dev(D));
+      std::vector<int32_t> b((size_t)W + 1);
+      URC(urcco_dev_partition(D.ev[0].s, n_items_a, D.work.p, W, b.data()));  // synchronises the primary's stream
+      c->h_bounds = b;
+      D.item_lo = b[(size_t)D.rank];
+      D.item_hi = b[(size_t)D.rank + 1];
+    }
+    URC(exchange_phase(c, 0, ps, n_users, sizes));
+  }
   c->h_sizes.assign((size_t)n_ds, 0);
   int64_t a_nnz = 0;
-  for (int r = 0; r < W; ++r) a_nnz += sizes[(size_t)2 * r + 1];
+  for (int r = 0; r < W; ++r) a_nnz += sizes[(size_t)XS * r + 1];
   c->h_sizes[0] = a_nnz;
   URC(c->workers->run([&](size_t g) -> int {
     DevState& D = c->devs[g];
     URC(set_dev(D));
     EvState& A = D.ev[0];
     URC(D.a_cp[D.par].ensure((size_t)n_items_a + 2));
-    URC(D.a_ri[D.par].ensure((size_t)a_nnz + 4));
-    URC(urcco_dev_transpose(A.s, n_users, A.f_rp.p, A.f_ci.p, a_nnz, n_items_a, post_of(D, 0).p, D.item_lo, D.item_hi, D.a_cp[D.par].p, D.a_ri[D.par].p));
+    if (fp.on) {
+      int64_t ents = 0;
+      for (int p = 0; p < W; ++p) ents += fp.cpb[(size_t)p * (size_t)(W + 1) + (size_t)D.rank + 1] - fp.cpb[(size_t)p * (size_t)(W + 1) + (size_t)D.rank];
+      D.a_ents = ents;
+      URC(D.a_ri[D.par].ensure((size_t)ents + 4));
+      URC(urcco_dev_merge_fragments(A.s, W, D.item_lo, D.item_hi, n_items_a, D.f_len.p, fp.wire16 ? 1 : 0, D.f_ent.p, ents, A.sizes.p, post_of(D, 0).p,
+                                    D.a_cp[D.par].p, D.a_ri[D.par].p));
+    } else {
+      D.a_ents = a_nnz;
+      URC(D.a_ri[D.par].ensure((size_t)a_nnz + 4));
+      URC(urcco_dev_transpose(A.s, n_users, A.f_rp.p, A.f_ci.p, a_nnz, n_items_a, post_of(D, 0).p, D.item_lo, D.item_hi, D.a_cp[D.par].p, D.a_ri[D.par].p));
+    }
     HIPC(hipEventRecord(D.a_ready, A.s->stream));
-    return stage_rows(D, A, A, 0, ps[0], ps[0], n_users, a_nnz);
+    return stage_rows(D, A, A, 0, ps[0], ps[0], n_users, D.a_ents);
   }));
   // ---- secondaries: every input phase is enqueued on its own stream (they run under A'A); then per event type the shard
   // sizes are read (the host waits for that stream's sampling only), the exchange is issued and A'B_d runs behind it
@@ -817,14 +962,14 @@ int build_sharded(urcco_context* c, const std::vector<std::vector<Shard>>& sh, c
   for (int d = 1; d < n_ds; ++d) {
     URC(exchange_phase(c, d, ps, n_users, sizes));
     int64_t b_nnz = 0;
-    for (int r = 0; r < W; ++r) b_nnz += sizes[(size_t)2 * r + 1];
+    for (int r = 0; r < W; ++r) b_nnz += sizes[(size_t)XS * r + 1];
     c->h_sizes[(size_t)d] = b_nnz;
     URC(c->workers->run([&](size_t g) -> int {
       DevState& D = c->devs[g];
       URC(set_dev(D));
       EvState& E = D.ev[(size_t)d];
       if (E.s != D.ev[0].s) HIPC(hipStreamWaitEvent(E.s->stream, D.a_ready, 0));
-      return stage_rows(D, E, D.ev[0], d, ps[0], ps[(size_t)d], n_users, a_nnz);
+      return stage_rows(D, E, D.ev[0], d, ps[0], ps[(size_t)d], n_users, D.a_ents);
     }));
   }
   return URCCO_OK;
@@ -932,6 +1077,7 @@ void urcco_context_destroy(urcco_context* c) {
     for (EvState& E : D.ev) E.release();
     for (int q = 0; q < A_SETS; ++q) { D.a_cp[q].release(); D.a_ri[q].release(); D.a_post[q].release(); }
     D.work.release(); D.bounds.release();
+    D.l_cnt.release(); D.l_ri.release(); D.len_bad.release(); D.f_ent.release(); D.l_cp.release(); D.rec.release(); D.len16.release(); D.f_len.release();
     if (D.a_ready) (void)hipEventDestroy(D.a_ready);
     if (D.in_ready) (void)hipEventDestroy(D.in_ready);
     if (D.b_expanded) (void)hipEventDestroy(D.b_expanded);

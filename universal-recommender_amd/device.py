@@ -138,6 +138,17 @@ class DeviceSession:
                                                 col_lo, col_hi, _ptr(col_ptr), _ptr(row_idx)))
         return col_ptr, row_idx
 
+    def merge_fragments(self, world: int, item_lo: int, item_hi: int, n_items: int, lens: torch.Tensor, entries: torch.Tensor, n_entries: int,
+                        sizes: torch.Tensor, counts: torch.Tensor):
+        """CSC of the item range [item_lo, item_hi) from the fragments of `world` user shards (urcco_dev_merge_fragments):
+        lens = uint16 or int32 column lengths, rank-major; entries = shard-local user ids, the fragments in rank order."""
+        assert lens.dtype in (torch.uint16, torch.int16, torch.int32)
+        col_ptr = self.empty(n_items + 1, torch.int64)
+        row_idx = self.empty(max(n_entries, 1), torch.int32)
+        self._check(self.lib.urcco_dev_merge_fragments(self.handle, world, item_lo, item_hi, n_items, _ptr(lens), int(lens.dtype != torch.int32), _ptr(entries),
+                                                      n_entries, _ptr(sizes), _ptr(counts), _ptr(col_ptr), _ptr(row_idx)))
+        return col_ptr, row_idx
+
     def row_work_csr(self, a: DevCsr, b_row_ptr: torch.Tensor) -> torch.Tensor:
         """Per-item work contributed by this user shard (sum over ranks = row_work)."""
         work = self.empty(max(a.n_cols, 1), torch.int64)

@@ -10,9 +10,11 @@ that a single JVM process reaches every GPU the same way.  This module only wire
     `TorchCollectives`, an implementation of the urcco_collectives callbacks on host memory through torch.distributed.
 
 Collectives per model build: per event type 2 all-reduces (int32 column counts before / after sampling), 1 tiny
-all-gather of (rows, nnz') records and an all-gather-v of row lengths + column indices (no padding); plus 1 all-reduce of
-the int64 row-work key.  The host blocks once per event type on that event's own stream (shard sizes; for the primary
-also the range bounds).  Mahout does the same job with Spark broadcasts of the count vectors and a shuffle inside
+all-gather of (rows, nnz', long rows) records and an all-gather-v of row lengths (16-bit when they fit) + column indices
+(no padding); for the primary also 1 all-reduce of the int64 row-work key, 1 tiny all-gather of fragment records and an
+all-to-all-v of CSC fragments (every rank transposes its own user shard and sends each rank the columns of that rank's item
+range: 16-bit column lengths + entries).  The host blocks once per event type on that event's own stream (shard sizes; for
+the primary the same read brings the range bounds and the fragment sizes).  Mahout does the same job with Spark broadcasts of the count vectors and a shuffle inside
 `A.t %*% B` (reference call sites URAlgorithm.scala:323-346).
 """
 from __future__ import annotations
@@ -48,11 +50,13 @@ class TorchCollectives:
         self.pending = {}
         self.depth = 0
         self.error: Optional[BaseException] = None
+        self.log: List[tuple] = []   # (kind, rank, bytes sent) of every collective executed (tests read the wire widths off it)
         self._gs = _lib.GROUP_FN(self._group_start)
         self._ge = _lib.GROUP_FN(self._group_end)
         self._ar = _lib.ALL_REDUCE_FN(self._all_reduce)
         self._ag = _lib.ALL_GATHER_V_FN(self._all_gather_v)
-        self.struct = _lib.Collectives(None, self._gs, self._ge, self._ar, self._ag)
+        self._aa = _lib.ALL_TO_ALL_V_FN(self._all_to_all_v)
+        self.struct = _lib.Collectives(None, self._gs, self._ge, self._ar, self._ag, self._aa)
 
     def _group_start(self, user):
         self.depth += 1
@@ -68,6 +72,11 @@ class TorchCollectives:
         self.pending.setdefault(rank, []).append(("ag", send, recv, off, cnt))
         return 0
 
+    def _all_to_all_v(self, user, rank, send, soff, scnt, recv, roff, rcnt, stream):
+        w = range(self.world)
+        self.pending.setdefault(rank, []).append(("aa", send, [soff[r] for r in w], [scnt[r] for r in w], recv, [roff[r] for r in w], [rcnt[r] for r in w]))
+        return 0
+
     def _group_end(self, user):
         self.depth -= 1
         if self.depth > 0:
@@ -78,10 +87,13 @@ class TorchCollectives:
             for j in range(n_ops.pop() if n_ops else 0):
                 ops = {r: self.pending[r][j] for r in self.local}
                 kind = ops[self.local[0]][0]
+                assert all(op[0] == kind for op in ops.values()), "local ranks issued different collectives"
                 if kind == "ar":
                     self._run_all_reduce(ops)
-                else:
+                elif kind == "ag":
                     self._run_all_gather_v(ops)
+                else:
+                    self._run_all_to_all_v(ops)
             self.pending = {}
             return 0
         except BaseException as e:  # surfaces as URCCO_RCCL_ERROR; the test reads .error
@@ -93,6 +105,7 @@ class TorchCollectives:
         views = []
         for r in self.local:
             _, buf, count, dtype = ops[r]
+            self.log.append(("ar", r, count * (4 if dtype == 0 else 8)))
             ct = C.c_int32 if dtype == 0 else C.c_int64
             views.append(np.ctypeslib.as_array((ct * count).from_address(buf)))
         total = np.sum(views, axis=0, dtype=views[0].dtype)
@@ -106,6 +119,7 @@ class TorchCollectives:
         pieces = {}
         for r in self.local:
             _, send, recv, off, cnt = ops[r]
+            self.log.append(("ag", r, cnt[r]))
             pieces[r] = bytes((C.c_char * cnt[r]).from_address(send)) if cnt[r] > 0 else b""
         if self.multi_process:
             gathered = [None] * dist.get_world_size(self.group)
@@ -118,6 +132,26 @@ class TorchCollectives:
                 assert len(pieces[p]) == cnt[p], f"rank {p} sent {len(pieces[p])} bytes, {cnt[p]} expected"
                 if cnt[p] > 0:
                     C.memmove(recv + off[p], pieces[p], cnt[p])
+
+
+    def _run_all_to_all_v(self, ops):
+        pieces = {}  # (source, destination) -> bytes
+        for r in self.local:
+            _, send, soff, scnt, recv, roff, rcnt = ops[r]
+            self.log.append(("aa", r, tuple(scnt)))
+            for q in range(self.world):
+                pieces[(r, q)] = bytes((C.c_char * scnt[q]).from_address(send + soff[q])) if scnt[q] > 0 else b""
+        if self.multi_process:
+            gathered = [None] * dist.get_world_size(self.group)
+            dist.all_gather_object(gathered, pieces, group=self.group)
+            for g in gathered:
+                pieces.update(g)
+        for r in self.local:
+            _, send, soff, scnt, recv, roff, rcnt = ops[r]
+            for p in range(self.world):
+                assert len(pieces[(p, r)]) == rcnt[p], f"rank {p} sent {len(pieces[(p, r)])} bytes to rank {r}, {rcnt[p]} expected"
+                if rcnt[p] > 0:
+                    C.memmove(recv + roff[p], pieces[(p, r)], rcnt[p])
 
 
 def make_context(device, library=None, group=None, flags: int = 0, row_rate_mode: int = _lib.ROW_RATE_MAHOUT_INT_DIV) -> Context:
