@@ -4,6 +4,7 @@ samples.  The 10M x 2M configurations keep their 2M-wide item spaces (21-bit pac
 column buckets); the users are scaled so that a test stays within minutes of host time for the oracle."""
 import numpy as np
 import pytest
+import torch
 
 from helpers import compare_with_oracle_large
 from oracle import c_oracle as O
@@ -165,3 +166,43 @@ def test_host_level_c_abi_config3_size(gpu_session):
             assert stats[d].pairs == r.pairs and stats[d].nnz_out == nnz and stats[d].nnz_raw == mats[d].nnz
         lib.urcco_free_indicators(out, n)
     assert lib.urcco_shutdown() == 0
+
+
+def test_ingest_path_model_equals_oracle_on_its_own_ids_at_config3_size(gpu_session):
+    """Events -> device Preparator -> CCO build at the FULL config-3 size, checked on the ids the device Preparator assigned:
+    first-appearance ids permute the (seed, row, col) key of the down-sampling RNG, so this model is NOT the one of the
+    generator's ids (90 665 276 vs 90 668 283 pairs) -- the matrices the Preparator built are copied to the host, the oracle
+    runs on exactly those, and every down-sampled entry and every indicator row must agree; the Preparator's matrices
+    themselves must be the generator's up to the two id permutations (same shapes, same entry count per event type, row-length
+    and column-count multisets equal)."""
+    from universal_recommender_amd import ingest, synth
+    from universal_recommender_amd.device import DevCsr
+    cfg = synth.config3(1.0)
+    data = synth.generate(cfg)
+    rng = np.random.default_rng(1)
+    dev = gpu_session.device
+    actions = []
+    for (name, n_cols, rp, ci) in data:                                  # the stream bench.py's ingest_to_model leg builds
+        rows = np.repeat(np.arange(cfg.n_users, dtype=np.int64), np.diff(rp))
+        cols = ci.astype(np.int64)
+        dup = rng.integers(0, rows.size, rows.size // 10)
+        rows, cols = np.concatenate([rows, rows[dup]]), np.concatenate([cols, cols[dup]])
+        order = rng.permutation(rows.size)
+        uk = rows[order] * np.int64(0x9E3779B97F4A7C15 - (1 << 64)) + 11
+        ik = cols[order] * np.int64(0xC2B2AE3D27D4EB4F - (1 << 64)) + 5
+        actions.append((name, torch.from_numpy(uk).to(dev), torch.from_numpy(ik).to(dev)))
+    dp = ingest.prepare_device(gpu_session, actions, 1)
+    gpu_session.synchronize()
+    dev_mats, mats = [], []
+    for ev, (name, n_cols, rp, ci) in zip(dp.events, data):
+        m = ev.matrix
+        h = O.Csr(m.n_rows, m.n_cols, m.row_ptr.cpu().numpy(), m.col_idx[: m.nnz_bound].cpu().numpy())
+        assert h.nnz == int(rp[-1]) and h.n_rows <= cfg.n_users and h.n_cols <= n_cols
+        if name == data[0][0]:                                           # every user has a primary event: the dictionary holds them all
+            assert h.n_rows == cfg.n_users
+            assert np.array_equal(np.sort(np.diff(h.row_ptr)), np.sort(np.diff(rp)))
+        assert np.array_equal(np.sort(np.bincount(h.col_idx, minlength=h.n_cols)), np.sort(np.bincount(ci, minlength=n_cols))[-h.n_cols:])
+        dev_mats.append(DevCsr(m.n_rows, m.n_cols, m.row_ptr, m.col_idx, h.nnz))
+        mats.append(h)
+    _, res = compare_with_oracle_large(gpu_session, mats, [P(), P(), P()], 20260925, dev_mats=dev_mats)
+    assert sum(int(st[0]) for st, _ in res) > 80_000_000
