@@ -153,6 +153,27 @@ def test_partitioned_column_counts_large_matrix(sim_session):
     assert np.array_equal(cnt2.cpu().numpy(), O.column_counts(m))
 
 
+def test_partitioned_column_counts_big_chunks_and_hot_columns(sim_session, monkeypatch):
+    """The histogram blocks of matrices beyond URCCO_PH_CHUNK_BIG_NNZ take 61440 ids each and publish 16-bit partial counters: a column
+    that fills most of a chunk (count > 32767 inside one block) must survive the packing, with both chunk sizes."""
+    rng = np.random.default_rng(14)
+    n_users = 75000
+    base = rand_csr(rng, n_users, 20_000, 15, zipf_s=1.0)          # its columns move to [16384, 36384): buckets 0 and 1 hold one hot column each
+    rows = [np.concatenate([[17, 8200], base.col_idx[base.row_ptr[u]:base.row_ptr[u + 1]] + 16384]) for u in range(n_users)]
+    rp = np.zeros(n_users + 1, np.int64)
+    np.cumsum([len(r) for r in rows], out=rp[1:])
+    m = O.Csr(n_users, 36_384, rp, np.concatenate(rows).astype(np.int32))
+    assert m.nnz >= (1 << 20)
+    ref = O.column_counts(m)
+    assert ref[17] == n_users and ref[8200] == n_users
+    d = to_dev(m, sim_session.device)
+    for big in ("1000000", "2000000000"):
+        monkeypatch.setenv("URCCO_PH_CHUNK_BIG_NNZ", big)
+        cnt = sim_session.column_counts(d.col_idx, m.nnz, m.n_cols)
+        sim_session.synchronize()
+        assert np.array_equal(cnt.cpu().numpy(), ref), big
+
+
 def test_large_matrix_full_pipeline(sim_session):
     """>= 2^20 interactions in the primary matrix: partitioned column counts AND the bucketed CSR->CSC feed the SpGEMM;
     the whole build (and an item-range slice, as a multi-GPU rank would run it) still equals the oracle."""

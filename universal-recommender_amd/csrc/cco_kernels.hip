@@ -381,10 +381,18 @@ hipError_t launch_scan_i64(hipStream_t st, const int64_t* in, int64_t n, int64_t
 constexpr int PH_BITS = 13;
 constexpr int PH_BUCKET = 1 << PH_BITS;
 constexpr int PH_PART = 16384;
-#ifndef URCCO_PH_CHUNK
-#define URCCO_PH_CHUNK 32768
-#endif
-constexpr int PH_CHUNK = URCCO_PH_CHUNK;  // interactions per histogram block: a block writes one 32 KB partial histogram per bucket chunk
+// Interactions per histogram block.  A block writes one partial histogram of its bucket (PH_BUCKET 16-bit counters: a chunk holds
+// fewer than 65536 ids) which the reduce pass reads back, so the partials cost 2 * 16 KB / chunk bytes per interaction: 1.0 B at
+// 32768, 0.53 B at 61440.  The larger chunk only where it still leaves a few thousand blocks (measured with 32-bit partials: 131072
+// was -6 % on config 4's column counts and +9 % on config 3's, whose largest matrix then had 305 blocks for 512 slots).
+// URCCO_PH_CHUNK_BIG_NNZ (environment, read per call): the entry count from which the larger chunk is used (tests lower it).
+constexpr int PH_CHUNK_SMALL = 32768, PH_CHUNK_BIG = 61440;
+static inline int ph_chunk(int64_t nnz) {
+  const char* e = getenv("URCCO_PH_CHUNK_BIG_NNZ");
+  const long long big = e && *e ? atoll(e) : 120000000ll;
+  return nnz >= big ? PH_CHUNK_BIG : PH_CHUNK_SMALL;
+}
+static_assert(PH_CHUNK_BIG < 65536 && PH_CHUNK_BIG % 8 == 0 && PH_CHUNK_SMALL % 8 == 0, "16-bit partial counters; 16-byte loads");
 constexpr int PH_MAX_BUCKETS = 1024;
 
 // Eight private copies of the bucket counters, chosen by lane: with a few dozen buckets (25 for a 200K-column matrix) the 64
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(PHS_THREADS) void ph_scatter_kernel(const int32_t* 
 
 // single block: blk_prefix[b] = first histogram block of bucket b, blk_prefix[n_buckets] = number of blocks
 __global__ __launch_bounds__(SCAN_THREADS) void ph_blockmap_kernel(const int64_t* __restrict__ offsets, int n_buckets, int64_t n_parts,
-                                                                  int32_t* __restrict__ blk_prefix) {
+                                                                  int32_t* __restrict__ blk_prefix, int PH_CHUNK) {
   __shared__ long long s_wave[SCAN_THREADS / WAVE];
   long long carry = 0;
   for (int base = 0; base < n_buckets; base += SCAN_THREADS) {  // block-uniform
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void ph_blockmap_kernel(const int64_t
 constexpr int PHH_THREADS = 1024;  // a few-million-entry matrix has only ~150 chunks: four times the waves per chunk
 __global__ __launch_bounds__(PHH_THREADS) void ph_hist_kernel(const unsigned short* __restrict__ bucketed, const int64_t* __restrict__ offsets,
                                                       int n_buckets, int64_t n_parts, const int32_t* __restrict__ blk_prefix,
-                                                      unsigned* __restrict__ partial) {
+                                                      unsigned short* __restrict__ partial, int PH_CHUNK) {
   __shared__ unsigned s_cnt[PH_BUCKET];
   const int blk = blockIdx.x;
   if (blk >= blk_prefix[n_buckets]) return;  // block-uniform
@@ -531,11 +539,12 @@ __global__ __launch_bounds__(PHH_THREADS) void ph_hist_kernel(const unsigned sho
     for (int64_t t = a0 + n_vec * 8 + threadIdx.x; t < e1; t += PHH_THREADS) atomicAdd(&s_cnt[bucketed[t]], 1u);  // tail
   }
   __syncthreads();
-  unsigned* out = partial + (int64_t)blk * PH_BUCKET;
-  for (int c = threadIdx.x; c < PH_BUCKET; c += PHH_THREADS) out[c] = s_cnt[c];
+  // two counters per 4-byte store
+  unsigned* out = reinterpret_cast<unsigned*>(partial + (int64_t)blk * PH_BUCKET);
+  for (int c = threadIdx.x; c < PH_BUCKET / 2; c += PHH_THREADS) out[c] = s_cnt[2 * c] | (s_cnt[2 * c + 1] << 16);
 }
 
-__global__ __launch_bounds__(256) void ph_reduce_kernel(const unsigned* __restrict__ partial, const int32_t* __restrict__ blk_prefix, int32_t n_cols,
+__global__ __launch_bounds__(256) void ph_reduce_kernel(const unsigned short* __restrict__ partial, const int32_t* __restrict__ blk_prefix, int32_t n_cols,
                                                         int32_t* __restrict__ counts) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= n_cols) return;
@@ -551,9 +560,9 @@ int64_t column_counts_scratch_bytes(int64_t nnz, int32_t n_cols) {
   const int64_t n_buckets = ((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS;
   const int64_t n_parts = (nnz + PH_PART - 1) / PH_PART;
   const int64_t m = n_buckets * n_parts;
-  const int64_t max_blocks = n_buckets + (nnz + PH_CHUNK - 1) / PH_CHUNK;
+  const int64_t max_blocks = n_buckets + (nnz + ph_chunk(nnz) - 1) / ph_chunk(nnz);
   auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
-  return al(m * 4) + al((m + 1) * 8) + al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8) + al(nnz * 2 + 16) + al((n_buckets + 1) * 4) + al(max_blocks * PH_BUCKET * 4);
+  return al(m * 4) + al((m + 1) * 8) + al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8) + al(nnz * 2 + 16) + al((n_buckets + 1) * 4) + al(max_blocks * PH_BUCKET * 2);
 }
 
 hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_idx, int64_t nnz, const int64_t* nnz_dev, int32_t n_cols,
@@ -561,21 +570,22 @@ hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_i
   const int n_buckets = (int)(((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS);
   const int64_t n_parts = (nnz + PH_PART - 1) / PH_PART;
   const int64_t m = (int64_t)n_buckets * n_parts;
-  const int64_t max_blocks = n_buckets + (nnz + PH_CHUNK - 1) / PH_CHUNK;
+  const int chunk = ph_chunk(nnz);
+  const int64_t max_blocks = n_buckets + (nnz + chunk - 1) / chunk;
   auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
   int32_t* part_counts = reinterpret_cast<int32_t*>(scratch); scratch += al(m * 4);
   int64_t* offsets = reinterpret_cast<int64_t*>(scratch); scratch += al((m + 1) * 8);
   int64_t* tile_sums = reinterpret_cast<int64_t*>(scratch); scratch += al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8);
   unsigned short* bucketed = reinterpret_cast<unsigned short*>(scratch); scratch += al(nnz * 2 + 16);
   int32_t* blk_prefix = reinterpret_cast<int32_t*>(scratch); scratch += al(((int64_t)n_buckets + 1) * 4);
-  unsigned* partial = reinterpret_cast<unsigned*>(scratch);
+  unsigned short* partial = reinterpret_cast<unsigned short*>(scratch);
   const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
   hipLaunchKernelGGL(ph_count_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, part_counts, vec_ok);
   hipError_t e = launch_scan_i32(st, part_counts, m, offsets, tile_sums);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(ph_scatter_kernel, dim3((unsigned)n_parts), dim3(PHS_THREADS), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, offsets, bucketed, vec_ok);
-  hipLaunchKernelGGL(ph_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, offsets, n_buckets, n_parts, blk_prefix);
-  hipLaunchKernelGGL(ph_hist_kernel, dim3((unsigned)max_blocks), dim3(PHH_THREADS), 0, st, bucketed, offsets, n_buckets, n_parts, blk_prefix, partial);
+  hipLaunchKernelGGL(ph_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, offsets, n_buckets, n_parts, blk_prefix, chunk);
+  hipLaunchKernelGGL(ph_hist_kernel, dim3((unsigned)max_blocks), dim3(PHH_THREADS), 0, st, bucketed, offsets, n_buckets, n_parts, blk_prefix, partial, chunk);
   hipLaunchKernelGGL(ph_reduce_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, partial, blk_prefix, n_cols, counts);
   return hipGetLastError();
 }
