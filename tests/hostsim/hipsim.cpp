@@ -68,6 +68,9 @@ void* guard_alloc(size_t n) {
   mprotect(m + pages, GUARD_PAGE, PROT_NONE);
   char* p = m + pages - body;
   memset(m, 0xA5, pages - body);  // whatever precedes the buffer is not zero either
+  // fresh device memory is NOT zero on hardware (it may hold whatever this or another process freed): ints of 0x7f7f7f7f index far
+  // out of any buffer, so a kernel that uses unwritten memory as an index or a length faults here instead of once in a while there
+  memset(p, 0x7f, body);
   std::lock_guard<std::mutex> lk(g_guard_mu);
   g_guard[p] = {m, pages + GUARD_PAGE};
   return p;
@@ -92,6 +95,7 @@ char* arena_place(char* base, size_t off, size_t bytes, size_t* new_off) {
   const uintptr_t end = (lo + body + GUARD_PAGE - 1) & ~(uintptr_t)(GUARD_PAGE - 1);
   mprotect(reinterpret_cast<void*>(end), GUARD_PAGE, PROT_NONE);
   *new_off = (size_t)(end + GUARD_PAGE - reinterpret_cast<uintptr_t>(base));
+  memset(reinterpret_cast<char*>(end - body), 0x7f, body);  // scratch handed out again: poisoned like fresh memory (see guard_alloc)
   return reinterpret_cast<char*>(end - body);
 }
 
