@@ -19,6 +19,8 @@ def sim_lib():
     """The kernel sources compiled against the TEST-ONLY host simulator (logic checks on CPU; never a parity claim)."""
     from hostsim import build_sim
     from universal_recommender_amd import _lib
+    if os.environ.get("HIPSIM_VARIANT") == "bounds":      # tests/test_sim_guard.py: LDS array indices checked
+        return _lib.load(build_sim.build_bounds())
     return _lib.load(build_sim.build())
 
 

@@ -30,6 +30,25 @@ def build(force: bool = False) -> str:
     return OUT
 
 
+OUT_BOUNDS = os.path.join(HERE, "_build", "liburcco_hostsim_bounds.so")
+
+
+def build_bounds(force: bool = False) -> str:
+    """The same build with -fsanitize=bounds,object-size: every index into a `__shared__` array (a static array of known size
+    here) is checked.  On the GPU an out-of-range LDS access through a ds_ instruction is silently dropped, through a flat
+    instruction it is a memory aperture violation; in the plain simulator it would scribble over a neighbouring static."""
+    if not force and os.path.exists(OUT_BOUNDS) and all(os.path.getmtime(OUT_BOUNDS) >= os.path.getmtime(d) for d in DEPS):
+        return OUT_BOUNDS
+    os.makedirs(os.path.dirname(OUT_BOUNDS), exist_ok=True)
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off", "-fno-strict-aliasing", "-pthread",
+           "-fsanitize=bounds,object-size", "-fno-sanitize-recover=all", "-I", os.path.join(HERE, "include"), "-Wno-unknown-pragmas"]
+    for s in SOURCES:
+        cmd += ["-x", "c++", s]
+    cmd += ["-ldl", "-lubsan", "-o", OUT_BOUNDS]
+    subprocess.check_call(cmd)
+    return OUT_BOUNDS
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
 

@@ -14,8 +14,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_guarded(mode: str, files):
-    env = dict(os.environ, HIPSIM_GUARD=mode)
+def run_guarded(mode: str, files, **extra):
+    env = dict(os.environ, HIPSIM_GUARD=mode, **extra)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", *files], cwd=ROOT, env=env, capture_output=True, text=True)
     assert r.returncode == 0, f"HIPSIM_GUARD={mode}: rc {r.returncode}\n{r.stdout[-3000:]}\n{r.stderr[-2000:]}"
 
@@ -49,3 +49,9 @@ def test_kernels_and_context_under_guard_pages_aligned(sim_lib):
 
 def test_kernels_under_guard_pages_exact(sim_lib):
     run_guarded("2", ["tests/test_sim_kernel_logic.py", "tests/test_sim_properties.py"])
+
+
+def test_kernels_with_lds_array_bounds_checked(sim_lib):
+    """The kernel sources once more with -fsanitize=bounds (every index into a `__shared__` array checked; an out-of-range LDS
+    access is dropped silently by ds_ instructions and is a memory aperture violation through flat ones), on top of guard pages."""
+    run_guarded("1", ["tests/test_sim_kernel_logic.py"], HIPSIM_VARIANT="bounds")
