@@ -36,9 +36,10 @@ def guarded_tensor(lib, n, dtype):
     lib.hipsim_guard_malloc.argtypes = [C.c_size_t]
     lib.hipsim_guard_release.argtypes = [C.c_void_p]
     nbytes = max(int(n), 1) * item
-    body = (nbytes + 15) & ~15 if os.environ.get("HIPSIM_GUARD") != "2" else (nbytes + 3) & ~3
+    mode = os.environ.get("HIPSIM_GUARD")
+    body = nbytes if mode == "3" else ((nbytes + 15) & ~15 if mode != "2" else (nbytes + 3) & ~3)
     ptr = lib.hipsim_guard_malloc(nbytes)
-    buf = (C.c_uint8 * nbytes).from_address(ptr + (body - nbytes))  # the requested bytes END where the allocation ends
+    buf = (C.c_uint8 * nbytes).from_address(ptr + (body - nbytes))  # the requested bytes END where the allocation ends (mode 3: START behind a guard page)
     arr = np.frombuffer(buf, dtype=np.uint8)
     t = torch.from_numpy(arr).view(dtype)[: int(n)]
     weakref.finalize(arr, lib.hipsim_guard_release, ptr)

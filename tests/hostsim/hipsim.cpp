@@ -60,7 +60,23 @@ size_t guard_align() {  // HIPSIM_GUARD=2: buffers end to 4 bytes at the guard p
   return a;
 }
 }  // namespace
+namespace {
+bool guard_before() {  // HIPSIM_GUARD=3: buffers START at a page boundary behind a PROT_NONE page (buffer[-1], tile_sums[t - 1] at t = 0, ...)
+  static const bool b = [] { const char* e = getenv("HIPSIM_GUARD"); return e && *e == '3'; }();
+  return b;
+}
+}  // namespace
 void* guard_alloc(size_t n) {
+  if (guard_before()) {
+    const size_t pages = (n + GUARD_PAGE - 1) & ~(GUARD_PAGE - 1);
+    char* m = static_cast<char*>(mmap(nullptr, pages + GUARD_PAGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+    if (m == MAP_FAILED) return nullptr;
+    mprotect(m, GUARD_PAGE, PROT_NONE);
+    memset(m + GUARD_PAGE, 0x7f, pages);
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guard[m + GUARD_PAGE] = {m, pages + GUARD_PAGE};
+    return m + GUARD_PAGE;
+  }
   const size_t body = (n + guard_align() - 1) & ~(guard_align() - 1);
   const size_t pages = (body + GUARD_PAGE - 1) & ~(GUARD_PAGE - 1);
   char* m = static_cast<char*>(mmap(nullptr, pages + GUARD_PAGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
@@ -90,6 +106,15 @@ void arena_unguard(void* base, size_t cap) {
   if (e > b) mprotect(b, (size_t)(e - b), PROT_READ | PROT_WRITE);
 }
 char* arena_place(char* base, size_t off, size_t bytes, size_t* new_off) {
+  if (guard_before()) {
+    const uintptr_t guard = (reinterpret_cast<uintptr_t>(base) + off + GUARD_PAGE - 1) & ~(uintptr_t)(GUARD_PAGE - 1);
+    mprotect(reinterpret_cast<void*>(guard), GUARD_PAGE, PROT_NONE);
+    char* p = reinterpret_cast<char*>(guard + GUARD_PAGE);
+    const size_t rounded = (bytes + 15) & ~(size_t)15;
+    memset(p, 0x7f, rounded);
+    *new_off = (size_t)(guard + GUARD_PAGE + rounded - reinterpret_cast<uintptr_t>(base));
+    return p;
+  }
   const size_t body = (bytes + guard_align() - 1) & ~(guard_align() - 1);
   const uintptr_t lo = reinterpret_cast<uintptr_t>(base) + off;
   const uintptr_t end = (lo + body + GUARD_PAGE - 1) & ~(uintptr_t)(GUARD_PAGE - 1);

@@ -4,7 +4,9 @@ output tensor ENDING at a PROT_NONE page (tests/hostsim/hipsim.cpp: HIPSIM_GUARD
 of a buffer -- a vector load over the tail, row_ptr[n_rows + 1], an upper-bound launch that forgets its live length -- dies
 with SIGSEGV here; on the GPU the same overrun only faults when the neighbouring page happens to be unmapped (which is how
 such bugs survive ordinary runs and then kill a profiled one).  HIPSIM_GUARD=1 keeps buffer starts 16-byte aligned (vector
-paths), =2 ends buffers to 4 bytes at the guard page (scalar paths, exact to one int32)."""
+paths), =2 ends buffers to 4 bytes at the guard page (scalar paths, exact to one int32), =3 guards the page BEFORE every buffer.
+In every mode fresh memory and scratch handed out again are poisoned (0x7f bytes), so a kernel that consumes memory nobody wrote
+uses an index ~2^31 elements away and faults too."""
 import os
 import subprocess
 import sys
@@ -49,6 +51,12 @@ def test_kernels_and_context_under_guard_pages_aligned(sim_lib):
 
 def test_kernels_under_guard_pages_exact(sim_lib):
     run_guarded("2", ["tests/test_sim_kernel_logic.py", "tests/test_sim_properties.py"])
+
+
+def test_kernels_and_context_with_a_guard_page_before_every_buffer(sim_lib):
+    """HIPSIM_GUARD=3: buffers START at a page boundary behind a PROT_NONE page -- buffer[-1], prefix[t - 1] at t = 0, a sentinel -1 used
+    as an index (the one fault address recorded on hardware was the last page below a 2 MiB boundary)."""
+    run_guarded("3", ["tests/test_sim_kernel_logic.py", "tests/test_sim_context.py"])
 
 
 def test_kernels_with_lds_array_bounds_checked(sim_lib):

@@ -14,6 +14,7 @@
 // Wave = 64 lanes everywhere.  Wave-level primitives (__shfl*, __ballot) are only ever executed under
 // wave-uniform control flow.
 #include "cco_kernels.h"
+#include <atomic>
 
 #include <cstdio>
 #include <cstdlib>
@@ -2777,8 +2778,8 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
 // resident blocks per CU of each LDS-accumulator kernel (registers / LDS decide), so that the persistent grids fill
 // the chip exactly once
 static int blocks_per_cu(int bin) {
-  static int cache[7] = {0, 0, 0, 0, 0, 0, 0};
-  if (cache[bin] == 0) {
+  static std::atomic<int> cache[7];  // zero-initialised; a racing first call computes the same value twice
+  if (cache[bin].load(std::memory_order_relaxed) == 0) {
     int n = 0;
     hipError_t e = hipErrorUnknown;
     if (bin == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_micro_kernel, 256, 0);
@@ -2788,9 +2789,9 @@ static int blocks_per_cu(int bin) {
     if (bin == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<512, E2S, URCCO_U_H>, 512, 0);
     if (bin == 5) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2, URCCO_U_C>, 1024, 0);
     if (bin == 6) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<1024, E2, URCCO_U_C, true>, 1024, 0);
-    cache[bin] = (e == hipSuccess && n > 0) ? n : 1;
+    cache[bin].store((e == hipSuccess && n > 0) ? n : 1, std::memory_order_relaxed);
   }
-  return cache[bin];
+  return cache[bin].load(std::memory_order_relaxed);
 }
 
 hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, int bin) {
@@ -2801,17 +2802,19 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
   // of the other event types' streams in -- a grid that exactly fills the chip locks them out until it ends (measured:
   // single-block kernels of another stream waited 0.2 ms).  3.5-3.7 -> 3.2-3.3 ms per build of config 3; 3x, 4x and 8x
   // measured no better than 1x (profiles/r02_grid_factor_sweep.log).
-  static int factor[7] = {0, 0, 0, 0, 0, 0, 2};
-  if (factor[0] == 0) {
-    const int dflt[6] = {2, 2, 2, 2, 2, 2};
-    for (int b = 0; b < 6; ++b) factor[b] = dflt[b];
-    if (const char* e = getenv("URCCO_GRID_FACTORS")) {
-      int v[6];
-      if (sscanf(e, "%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6)
-        for (int b = 0; b < 6; ++b)
-          if (v[b] >= 1 && v[b] <= 64) factor[b] = v[b];
+  struct Factors {  // initialised once, thread-safely: every event type's enqueueing thread comes through here in the first build
+    int f[7] = {2, 2, 2, 2, 2, 2, 2};
+    Factors() {
+      if (const char* e = getenv("URCCO_GRID_FACTORS")) {
+        int v[6];
+        if (sscanf(e, "%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6)
+          for (int b = 0; b < 6; ++b)
+            if (v[b] >= 1 && v[b] <= 64) f[b] = v[b];
+      }
     }
-  }
+  };
+  static const Factors factors;
+  const int* factor = factors.f;
   auto grid = [&](int b) { return dim3((unsigned)(n_cu * blocks_per_cu(b)) * (unsigned)factor[b]); };
   switch (bin) {
     case 0: hipLaunchKernelGGL(cco_rows_micro_kernel, grid(0), dim3(256), 0, st, args); break;
