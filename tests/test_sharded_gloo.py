@@ -1,6 +1,6 @@
 """The N > 1 path on CPU: world_size-2 and -3 `gloo` process groups drive the library's multi-rank build
-(urcco_context_build_device: user-range shards, count all-reduces, all-gather-v of the down-sampled shards, work-balanced
-item ranges) end to end, the collectives going through the urcco_collectives callbacks instead of RCCL.  Compute underneath is the
+(urcco_context_build_device: user-range shards, count all-reduces, all-gather-v of the down-sampled shards, all-to-all-v of the
+primary's CSC fragments, work-balanced item ranges) end to end, the collectives going through the urcco_collectives callbacks instead of RCCL.  Compute underneath is the
 kernel sources on the TEST-ONLY host simulator; the result must equal the single-process oracle exactly the way the
 single-GPU path does -- i.e. the sharding is invisible."""
 import os
@@ -75,7 +75,7 @@ def _worker(rank, world, port, uneven, q):
         q.put((rank, "fail: " + traceback.format_exc(), None))
 
 
-@pytest.mark.parametrize("world,uneven", [(2, False), (2, True), (3, False), (2, "empty"), (2, "skew5")])
+@pytest.mark.parametrize("world,uneven", [(2, False), (2, True), (3, False), (4, False), (2, "empty"), (2, "skew5")])
 def test_sharded_equals_single_process_oracle(world, uneven, sim_lib):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -137,7 +137,7 @@ def test_context_reuse_and_stream_modes(sim_lib):
     context_reuse_case(sim_lib, torch.device("cpu"))
 
 
-@pytest.mark.parametrize("n_gpus,primary", [(2, "fragments"), (3, "fragments"), (2, "gathered")])
+@pytest.mark.parametrize("n_gpus,primary", [(2, "fragments"), (3, "fragments"), (5, "fragments"), (2, "gathered")])
 def test_one_process_drives_several_gpus(sim_lib, n_gpus, primary, monkeypatch):
     """n_gpus ranks in ONE process (what the JVM host does; here simulated devices, collectives looped back in-process
     through the urcco_collectives callbacks): the device-resident build on user-range shards and the host-level build
