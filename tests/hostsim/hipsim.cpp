@@ -222,17 +222,31 @@ void run_block(BlockCtx* c, dim3 block) {
   if ((int)c->fibers.size() < T) c->fibers.resize((size_t)T);
   for (int t = 0; t < T; ++t) prepare(c->fibers[(size_t)t]);
   int live = T;
+  // HIPSIM_ORDER: the order in which the WAVES of a block get their turn between two rendezvous -- any order is a schedule the hardware
+  // may produce.  The default (ascending) hides a missing __syncthreads() whenever the producer is the lower wave, which is also the
+  // order hardware mostly happens to run in: exactly the bug that survives ordinary runs.  "reverse" = descending, "rotate" = a
+  // different first wave every round.  Lanes inside a wave keep their order (they run in lock step on hardware).
+  static const int order_mode = [] {
+    const char* e = getenv("HIPSIM_ORDER");
+    return !e ? 0 : (!strcmp(e, "reverse") ? 1 : (!strcmp(e, "rotate") ? 2 : 0));
+  }();
+  const int n_waves = (T + 63) / 64;
+  unsigned round = 0;
   while (live > 0) {
-    for (int t = 0; t < T; ++t) {
-      Fiber& f = c->fibers[(size_t)t];
-      if (f.state != RUNNABLE) continue;
-      c->cur = t;
-      tIdx.x = (unsigned)t % block.x;
-      tIdx.y = ((unsigned)t / block.x) % block.y;
-      tIdx.z = (unsigned)t / (block.x * block.y);
-      hipsim_switch(&c->sched_sp, f.sp);
-      if (f.state == DONE) --live;
+    for (int wi = 0; wi < n_waves; ++wi) {
+      const int w = order_mode == 1 ? n_waves - 1 - wi : (order_mode == 2 ? (int)((wi + round * 7 + 1) % (unsigned)n_waves) : wi);
+      for (int t = w * 64; t < T && t < (w + 1) * 64; ++t) {
+        Fiber& f = c->fibers[(size_t)t];
+        if (f.state != RUNNABLE) continue;
+        c->cur = t;
+        tIdx.x = (unsigned)t % block.x;
+        tIdx.y = ((unsigned)t / block.x) % block.y;
+        tIdx.z = (unsigned)t / (block.x * block.y);
+        hipsim_switch(&c->sched_sp, f.sp);
+        if (f.state == DONE) --live;
+      }
     }
+    ++round;
     if (live == 0) break;
     bool resolved = false;
     for (int w0 = 0; w0 < T; w0 += 64) {

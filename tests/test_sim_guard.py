@@ -59,6 +59,13 @@ def test_kernels_and_context_with_a_guard_page_before_every_buffer(sim_lib):
     run_guarded("3", ["tests/test_sim_kernel_logic.py", "tests/test_sim_context.py"])
 
 
+def test_kernels_with_the_waves_of_a_block_scheduled_in_reverse(sim_lib):
+    """HIPSIM_ORDER=reverse: between two rendezvous the highest wave of a block runs first.  The default ascending order hides a
+    missing __syncthreads() whenever the producing wave has the lower index -- which is also how hardware mostly happens to
+    schedule, i.e. the kind of bug that survives ordinary runs and strikes once in a while."""
+    run_guarded("1", ["tests/test_sim_kernel_logic.py", "tests/test_sim_properties.py"], HIPSIM_ORDER="reverse")
+
+
 def test_kernels_with_lds_array_bounds_checked(sim_lib):
     """The kernel sources once more with -fsanitize=bounds (every index into a `__shared__` array checked; an out-of-range LDS
     access is dropped silently by ds_ instructions and is a memory aperture violation through flat ones), on top of guard pages."""
