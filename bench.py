@@ -539,18 +539,23 @@ def supervise():
     a GPU memory fault raised while the inputs were still being generated (twice under rocprofv3, once plain; never reproduced on
     demand, profiles/r03_rocprofv3_stats_failure.txt).  The child does ALL the work and prints the line; if it dies of a signal before
     printing one, it is started ONCE more and the line says so (`attempts`, `first_attempt`) -- nothing is measured or averaged
-    across attempts."""
+    across attempts.  A child that dies of a signal AFTER its (flushed) line -- i.e. while tearing down -- has reported: its line is relayed
+    with `child_exit` saying so."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--child"]
     first = None
     for attempt in (1, 2):
         r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        if r.returncode == 0 and lines:
+        if lines and (r.returncode == 0 or r.returncode < 0):
+            # the line is printed (and flushed) after every measurement and check and before the teardown: a child that dies of a signal
+            # AFTER it has reported died while releasing its GPU state -- recorded, not hidden
             out = json.loads(lines[-1])
             out["attempts"] = attempt
             if first:
                 out["first_attempt"] = first
+            if r.returncode != 0:
+                out["child_exit"] = f"signal {-r.returncode} after the line was printed (during teardown)"
             print(json.dumps(out), flush=True)
             return 0
         first = f"child exited with {r.returncode}" + (" (signal %d)" % -r.returncode if r.returncode < 0 else "") + " before printing a result"
@@ -732,7 +737,8 @@ def main():
                                                                  "note": "same build, indicator rows as unordered top-k sets (no ranking pass): what the JNI shim asks for; not the headline value"},
     }
     line.update(extras)
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)   # flushed before any teardown: a process that dies later (abort() does not flush stdio) has still reported
+    mark("line printed; tearing down")
     job.close()
     if world > 1 and not args.single_process:
         dist.destroy_process_group()

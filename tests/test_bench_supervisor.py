@@ -65,3 +65,14 @@ def test_ordinary_failures_are_not_retried(tmp_path):
 def test_two_signals_fail_the_run(tmp_path):
     r = run_supervised(tmp_path, "import os; os.abort()")
     assert r.returncode != 0 and "signal 6" in r.stderr and not r.stdout.strip()
+
+
+def test_a_child_that_dies_after_reporting_has_reported(tmp_path):
+    r = run_supervised(tmp_path, """
+        import json, os
+        print(json.dumps({"metric": "cooccurrence_pairs_per_s", "value": 3.0}), flush=True)
+        os.abort()                           # a fault while the process tears its GPU state down
+    """)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] == 3.0 and line["attempts"] == 1 and "signal 6" in line["child_exit"]
