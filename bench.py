@@ -538,14 +538,19 @@ def supervise():
     """One-process runs measure in a child: three times in round 3 a config-4-sized process on the gpurun pool died at start-up of
     a GPU memory fault raised while the inputs were still being generated (twice under rocprofv3, once plain; never reproduced on
     demand, profiles/r03_rocprofv3_stats_failure.txt).  The child does ALL the work and prints the line; if it dies of a signal before
-    printing one, it is started ONCE more and the line says so (`attempts`, `first_attempt`) -- nothing is measured or averaged
-    across attempts.  A child that dies of a signal AFTER its (flushed) line -- i.e. while tearing down -- has reported: its line is relayed
+    printing one, it is started once more, and a third time without the secondary legs (`--no-extras`); the line says so
+    (`attempts`, `first_attempt`, `extras_skipped`) -- nothing is measured or averaged across attempts.  A child that dies of a signal AFTER its (flushed) line -- i.e. while tearing down -- has reported: its line is relayed
     with `child_exit` saying so."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--child"]
     first = None
-    for attempt in (1, 2):
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    for attempt in (1, 2, 3):
+        # a third and last attempt leaves the secondary legs out (host level, row scan, LLR rate, config-3 object): the headline
+        # measurement, its roofline and the cpu_baseline do not depend on them
+        lean = attempt == 3 and "--no-extras" not in cmd
+        if attempt == 3 and not lean:
+            break
+        r = subprocess.run(cmd + (["--no-extras"] if lean else []), stdout=subprocess.PIPE, text=True)
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
         if lines and (r.returncode == 0 or r.returncode < 0):
             # the line is printed (and flushed) after every measurement and check and before the teardown: a child that dies of a signal
@@ -554,12 +559,15 @@ def supervise():
             out["attempts"] = attempt
             if first:
                 out["first_attempt"] = first
+            if lean:
+                out["extras_skipped"] = "third attempt after two that died of a signal: run with --no-extras"
             if r.returncode != 0:
                 out["child_exit"] = f"signal {-r.returncode} after the line was printed (during teardown)"
             print(json.dumps(out), flush=True)
             return 0
-        first = f"child exited with {r.returncode}" + (" (signal %d)" % -r.returncode if r.returncode < 0 else "") + " before printing a result"
-        print(f"[bench] attempt {attempt}: {first}", file=sys.stderr, flush=True)
+        died = f"child exited with {r.returncode}" + (" (signal %d)" % -r.returncode if r.returncode < 0 else "") + " before printing a result"
+        first = first or died
+        print(f"[bench] attempt {attempt}: {died}", file=sys.stderr, flush=True)
         if r.returncode >= 0:   # an ordinary failure (assertion, bad argument, pairs mismatch): retrying would only hide it
             break
     raise SystemExit(f"bench.py: {first}")

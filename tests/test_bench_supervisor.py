@@ -62,9 +62,27 @@ def test_ordinary_failures_are_not_retried(tmp_path):
     assert len([f for f in os.listdir(tmp_path) if f.startswith("ran_")]) == 1       # an assertion / mismatch is reported, not retried
 
 
-def test_two_signals_fail_the_run(tmp_path):
-    r = run_supervised(tmp_path, "import os; os.abort()")
+def test_three_signals_fail_the_run_and_the_third_attempt_is_lean(tmp_path):
+    r = run_supervised(tmp_path, """
+        import os, sys
+        open("args_%d" % len([f for f in os.listdir(".") if f.startswith("args_")]), "w").write(" ".join(sys.argv[1:]))
+        os.abort()
+    """)
     assert r.returncode != 0 and "signal 6" in r.stderr and not r.stdout.strip()
+    args = [open(os.path.join(tmp_path, f)).read() for f in sorted(os.listdir(tmp_path)) if f.startswith("args_")]
+    assert len(args) == 3 and "--no-extras" not in args[0] and "--no-extras" not in args[1] and args[2].endswith("--no-extras")
+
+
+def test_the_lean_third_attempt_is_disclosed(tmp_path):
+    r = run_supervised(tmp_path, """
+        import json, os, sys
+        if "--no-extras" not in sys.argv:
+            os.abort()
+        print(json.dumps({"metric": "cooccurrence_pairs_per_s", "value": 4.0}))
+    """)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["attempts"] == 3 and "extras_skipped" in line and "signal 6" in line["first_attempt"]
 
 
 def test_a_child_that_dies_after_reporting_has_reported(tmp_path):
