@@ -12,6 +12,11 @@ if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    try:  # a GPU fault aborts the process; with ~100 GB mapped the core dump alone took ten minutes on a gpurun box
+        import resource
+        resource.setrlimit(resource.RLIMIT_CORE, (0, 0))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
