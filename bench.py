@@ -534,45 +534,6 @@ def mark(what: str):
     print(f"[bench {time.strftime('%H:%M:%S')}] {what}", file=sys.stderr, flush=True)
 
 
-def supervise():
-    """One-process runs measure in a child: three times in round 3 a config-4-sized process on the gpurun pool died at start-up of
-    a GPU memory fault raised while the inputs were still being generated (twice under rocprofv3, once plain; never reproduced on
-    demand, profiles/r03_rocprofv3_stats_failure.txt).  The child does ALL the work and prints the line; if it dies of a signal before
-    printing one, it is started once more, and a third time without the secondary legs (`--no-extras`); the line says so
-    (`attempts`, `first_attempt`, `extras_skipped`) -- nothing is measured or averaged across attempts.  A child that dies of a signal AFTER its (flushed) line -- i.e. while tearing down -- has reported: its line is relayed
-    with `child_exit` saying so."""
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--child"]
-    first = None
-    for attempt in (1, 2, 3):
-        # a third and last attempt leaves the secondary legs out (host level, row scan, LLR rate, config-3 object): the headline
-        # measurement, its roofline and the cpu_baseline do not depend on them
-        lean = attempt == 3 and "--no-extras" not in cmd
-        if attempt == 3 and not lean:
-            break
-        r = subprocess.run(cmd + (["--no-extras"] if lean else []), stdout=subprocess.PIPE, text=True)
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        if lines and (r.returncode == 0 or r.returncode < 0):
-            # the line is printed (and flushed) after every measurement and check and before the teardown: a child that dies of a signal
-            # AFTER it has reported died while releasing its GPU state -- recorded, not hidden
-            out = json.loads(lines[-1])
-            out["attempts"] = attempt
-            if first:
-                out["first_attempt"] = first
-            if lean:
-                out["extras_skipped"] = "third attempt after two that died of a signal: run with --no-extras"
-            if r.returncode != 0:
-                out["child_exit"] = f"signal {-r.returncode} after the line was printed (during teardown)"
-            print(json.dumps(out), flush=True)
-            return 0
-        died = f"child exited with {r.returncode}" + (" (signal %d)" % -r.returncode if r.returncode < 0 else "") + " before printing a result"
-        first = first or died
-        print(f"[bench] attempt {attempt}: {died}", file=sys.stderr, flush=True)
-        if r.returncode >= 0:   # an ordinary failure (assertion, bad argument, pairs mismatch): retrying would only hide it
-            break
-    raise SystemExit(f"bench.py: {first}")
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -591,15 +552,14 @@ def main():
                     help="A/B (N > 1 path): the primary's CSC from a pass of every rank over the whole gathered A' (rounds 1-2) instead of fragments")
     ap.add_argument("--timed-only", action="store_true", help="stop after the timed region (timeline captures)")
     ap.add_argument("--seed", type=int, default=20260925)
-    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
-    try:  # a GPU fault aborts the process; with ~100 GB mapped the core dump alone took ten minutes on a gpurun box
+    # No restart logic: round 3's supervisor (a child re-run after a death by signal) is gone with the fault it papered over -- a
+    # missing barrier in the top-k select, cco_kernels.hip "SHARE && T != WAVE" (DESIGN.md section 7).  A process that dies fails the run.
+    try:  # a GPU fault aborts the process; with ~100 GB mapped a core dump alone would take ten minutes on a gpurun box
         import resource
         resource.setrlimit(resource.RLIMIT_CORE, (0, 0))
     except Exception:
         pass
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.child and not args.timed_only and not os.environ.get("URCCO_BENCH_NO_SUPERVISOR"):
-        return supervise()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -679,7 +639,7 @@ def main():
                                         "own evaluation is cheaper (per-item entropies hoisted, xLogX from two tables): the SpGEMM classes are far from fp64-bound"}
         if not args.no_cpu_baseline:
             mark("cpu_baseline (C oracle on the host cores)")
-            cpu_baseline = cpu_oracle_leg(host, cfg.n_users, args.seed, pairs, runs=1 if workload != "config3" else 5)
+            cpu_baseline = cpu_oracle_leg(host, cfg.n_users, args.seed, pairs, runs=3 if workload != "config3" else 5)   # warm-up + median
         del host
         job.host_data = None
         if not args.no_extras and workload != "config3":

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define URCCO_VERSION 301 /* 0.3.1 */
+#define URCCO_VERSION 302 /* 0.3.2 */
 
 typedef enum urcco_status {
   URCCO_OK = 0,
@@ -155,9 +155,12 @@ typedef struct urcco_context urcco_context;
 
 /* Replacement for the built-in RCCL collectives (the CPU test-suite runs the multi-rank build over `gloo` through this;
  * product callers pass NULL).  `rank` = global rank of the calling GPU; calls between group_start and group_end are
- * one collective each across all ranks and may complete at group_end.  stream = the HIP stream the buffers are
- * produced / consumed on.  Return 0 on success. */
+ * one collective each across all ranks and may complete at group_end -- the offset / count arrays handed to a callback stay
+ * valid until that group_end returns (the data buffers until the stream has passed the collective).  stream = the HIP stream the
+ * buffers are produced / consumed on.  Return 0 on success. */
 typedef struct urcco_collectives {
+  size_t struct_size; /* sizeof(urcco_collectives) of the header the CALLER was compiled against (since 302): a struct shorter than
+                         the library's is rejected by urcco_context_create instead of being read past its end */
   void* user;
   int (*group_start)(void* user);
   int (*group_end)(void* user);
@@ -272,11 +275,17 @@ enum {
 int urcco_session_set_timing(urcco_session* s, int32_t enable);
 /* Profiling aid: kernel ablation switches; results are meaningless when non-zero.  0 in production.
  * SpGEMM rows: 1 = gather only, 2 = no LLR, 4 = no top-k, 8 = no select, 16 = no rank / output.
- * CSR row scan: 32 = cheap hash, 64 = no threshold gather, 128 = no entry -> row lookup. */
+ * CSR row scan: 32 = cheap hash, 64 = no threshold gather, 128 = no entry -> row lookup.
+ * Test hooks of the top-k select (tests/test_gpu_parity.py::test_select_overlay_race_*): 131072 = the first wave of every multi-wave
+ * team sleeps before it reads the select histogram, 262144 = skip the barrier in front of the ambiguous-set copy-out (round 3's race). */
 int urcco_session_set_debug(urcco_session* s, int32_t flags);
 int urcco_session_get_timings(urcco_session* s, double* ms /*[URCCO_N_STAGES]*/, int64_t* launches /*[URCCO_N_STAGES]*/);
 /* bytes of device scratch currently held */
 int64_t urcco_session_scratch_bytes(const urcco_session* s);
+/* Fault-hunting aid.  With URCCO_DEBUG_MARKS=1 in the environment every launch group of every session leaves "begun" /
+ * "finished" marks in pinned host memory (stream-ordered); this prints them to stderr (the library's own SIGABRT handler does
+ * the same when the HSA runtime aborts the process on a GPU memory fault).  Without the variable it prints nothing. */
+void urcco_debug_dump_marks(void);
 
 /* numNonZeroElementsPerColumn: counts[n_cols] = occurrences of each column id in col_idx[0..nnz).
  * counts is overwritten. */

@@ -42,6 +42,7 @@ struct JNIEnv {
   virtual ~JNIEnv() {}
   virtual jclass FindClass(const char* name) = 0;
   virtual jint ThrowNew(jclass cls, const char* msg) = 0;
+  virtual jboolean ExceptionCheck() = 0;
   virtual jsize GetArrayLength(jarray a) = 0;
   virtual jobject GetObjectArrayElement(jobjectArray a, jsize i) = 0;
   virtual void SetObjectArrayElement(jobjectArray a, jsize i, jobject v) = 0;

@@ -30,12 +30,16 @@ struct FakeEnv : JNIEnv {
   int critical = 0;          // primitive arrays currently held critically
   int violations = 0;        // JNI calls made inside a critical section
   std::string pending;       // message of the pending exception ("" = none)
+  int fail_pin_after = -1;   // >= 0: the (fail_pin_after + 1)-th GetPrimitiveArrayCritical fails, leaving an OutOfMemoryError pending
+  int pins = 0;
+  int pending_violations = 0;  // JNI calls that may throw, made with an exception already pending (-Xcheck:jni aborts on them)
   template <typename T> T* keep(T* o) { heap.push_back(o); return o; }
   ~FakeEnv() override { for (_jobject* o : heap) delete o; }
   void call() { if (critical > 0) ++violations; }
 
-  jclass FindClass(const char* name) override { call(); Cls* c = keep(new Cls()); c->name = name; return c; }
-  jint ThrowNew(jclass, const char* msg) override { call(); pending = msg ? msg : "(null)"; return 0; }
+  jclass FindClass(const char* name) override { call(); if (!pending.empty()) ++pending_violations; Cls* c = keep(new Cls()); c->name = name; return c; }
+  jint ThrowNew(jclass, const char* msg) override { call(); if (!pending.empty()) ++pending_violations; pending = msg ? msg : "(null)"; return 0; }
+  jboolean ExceptionCheck() override { return pending.empty() ? 0 : 1; }  // allowed with an exception pending, and inside a critical section
   jsize GetArrayLength(jarray a) override {
     call();
     if (auto* x = dynamic_cast<IntArr*>(a)) return (jsize)x->v.size();
@@ -63,6 +67,10 @@ struct FakeEnv : JNIEnv {
     memcpy(static_cast<DoubleArr*>(a)->v.data() + s, b, sizeof(jdouble) * (size_t)n);
   }
   void* GetPrimitiveArrayCritical(jarray a, jboolean* c) override {  // allowed inside a critical section
+    if (fail_pin_after >= 0 && pins++ == fail_pin_after) {
+      pending = "java.lang.OutOfMemoryError";
+      return nullptr;
+    }
     ++critical;
     if (c) *c = 0;
     if (auto* x = dynamic_cast<IntArr*>(a)) return x->v.data();
@@ -91,6 +99,7 @@ int fake_jvm_cross_occurrence(int n, const int64_t* n_rows, const int64_t* n_col
                               int64_t** out_row_ptr, int32_t** out_col_idx, double** out_llr, int64_t* out_nnz, int64_t* out_rows, char* err,
                               int err_cap) {
   FakeEnv env;
+  if (const char* e = getenv("FAKE_JVM_FAIL_PIN_AFTER")) env.fail_pin_after = atoi(e);
   ObjArr* rps = env.keep(new ObjArr());
   ObjArr* cis = env.keep(new ObjArr());
   LongArr* nc = env.keep(new LongArr());
@@ -110,8 +119,9 @@ int fake_jvm_cross_occurrence(int n, const int64_t* n_rows, const int64_t* n_col
     ml->v.push_back(min_llr[d]);
   }
   jobjectArray res = Java_com_actionml_urcco_Native_crossOccurrenceDownsampled(&env, nullptr, rps, cis, nc, mr, mi, ml, seed, device, n_gpus);
-  if (env.violations > 0 || env.critical != 0) {
-    snprintf(err, (size_t)err_cap, "JNI rule violated: %d call(s) inside a critical section, %d array(s) still held", env.violations, env.critical);
+  if (env.violations > 0 || env.critical != 0 || env.pending_violations > 0) {
+    snprintf(err, (size_t)err_cap, "JNI rule violated: %d call(s) inside a critical section, %d array(s) still held, %d throwing call(s) with an exception pending",
+             env.violations, env.critical, env.pending_violations);
     return 2;
   }
   if (!env.pending.empty() || !res) {

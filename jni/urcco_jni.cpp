@@ -91,7 +91,9 @@ JNIEXPORT jobjectArray JNICALL Java_com_actionml_urcco_Native_crossOccurrenceDow
     if (ds[(size_t)d].matrix.row_ptr) env->ReleasePrimitiveArrayCritical(rp[(size_t)d], (void*)ds[(size_t)d].matrix.row_ptr, JNI_ABORT);
   }
   if (null_array) {
-    throw_runtime(env, "urcco: the JVM could not pin an input array");
+    // GetPrimitiveArrayCritical returned NULL: the JVM has (normally) left an OutOfMemoryError pending, and no JNI call that may
+    // throw -- FindClass, ThrowNew -- is allowed with an exception pending (-Xcheck:jni aborts on it): let that one propagate
+    if (!env->ExceptionCheck()) throw_runtime(env, "urcco: the JVM could not pin an input array");
     return nullptr;
   }
   if (st == URCCO_OK) st = urcco_cross_occurrence_finish(out.data(), n, nullptr);

@@ -154,3 +154,40 @@ def test_model_documents_match_the_oracle_and_the_reference_document_shape(sim_l
     n = model.save(str(tmp_path / "model.ndjson"))
     out = [json.loads(l) for l in open(tmp_path / "model.ndjson")]
     assert n == len(docs) and len(out) == 2 * n and out[0]["index"]["_id"] == out[1]["id"]
+
+
+def test_extract_jvalue_types_dates_and_ranks_before_indexing(sim_lib, tmp_path):
+    """URModel.extractJvalue (URModel.scala:126-140, applied at :67-74 with URAlgorithm's dateNames, :264-267): the handmade
+    engine names `available` / `expires` / `date` as date properties -- their ISO strings become dates, a ranking field that
+    arrives as a string becomes a double, lists map element-wise, everything else passes through."""
+    from datetime import datetime, timezone
+    from universal_recommender_amd.data_source import DataSource, DataSourceParams
+    from universal_recommender_amd.preparator import Preparator
+    from universal_recommender_amd.ur_algorithm import URAlgorithm, URAlgorithmParams
+    from universal_recommender_amd.ur_model import URModel, extractJvalue
+    engine = json.load(open("/root/reference/examples/handmade-engine.json")) if os.path.exists("/root/reference/examples/handmade-engine.json") else None
+    doc, by_event, _, items = _load("handmade.json")
+    eng = {"datasource": {"params": doc["datasource_params"]}, "algorithms": [{"name": "ur", "params": dict(doc["algorithm_params"], availableDateName="available",
+                                                                                                      expireDateName="expires", dateName="date")}]}
+    if engine is not None:   # the committed parameters are the reference's (tests/golden/make_golden.py); here also its date names, when the reference is at hand
+        rp = [a for a in engine["algorithms"] if a["name"] == "ur"][0]["params"]
+        assert (rp["availableDateName"], rp["expireDateName"], rp["dateName"]) == ("available", "expires", "date")
+    ap = URAlgorithmParams.from_engine_json(eng)
+    ap.seed = 1
+    algo = URAlgorithm(ap, library=sim_lib)
+    assert algo.dateNames == ["date", "available", "expires"]
+    lines = [",".join(e) for e in doc["events"]] + [f"{i},$set,{p}" for i, p in doc["sets"]]
+    model = algo.train(Preparator().prepare(DataSource(DataSourceParams.from_engine_json(eng)).readTraining(lines)))
+    model.propertiesMaps.append({"Iphone 4": {"available": "2016-03-02T12:00:00.000-08:00", "expires": ["2017-01-01T00:00:00Z"], "popRank": "3.5", "hotRank": 2,
+                                              "defaultRank": "4.0", "title": "2016-03-02T12:00:00Z"}})
+    d = {x["id"]: x for x in model.documents(algo.dateNames)}["Iphone 4"]
+    assert d["available"] == datetime(2016, 3, 2, 20, 0, tzinfo=timezone.utc) and d["expires"] == [datetime(2017, 1, 1, tzinfo=timezone.utc)]
+    assert d["popRank"] == 3.5 and isinstance(d["popRank"], float) and d["hotRank"] == 2
+    assert d["defaultRank"] == "4.0" and d["title"] == "2016-03-02T12:00:00Z"     # neither a date name nor a ranking field: untouched
+    assert d["view"] == ["Soap", "Tablets"]                                        # indicator lists are lists of strings: untouched
+    plain = {x["id"]: x for x in model.documents()}["Iphone 4"]                    # no dateNames: strings stay strings, ranks still become doubles
+    assert plain["available"] == "2016-03-02T12:00:00.000-08:00" and plain["popRank"] == 3.5
+    assert extractJvalue(["t"], "t", [["2016-03-02"]])[0][0].year == 2016 and extractJvalue([], "n", True) is True
+    model.save(str(tmp_path / "m.ndjson"), algo.dateNames)
+    saved = {json.loads(l)["id"]: json.loads(l) for l in list(open(tmp_path / "m.ndjson"))[1::2]}
+    assert saved["Iphone 4"]["available"] == "2016-03-02T20:00:00.000Z" and saved["Iphone 4"]["popRank"] == 3.5

@@ -69,6 +69,15 @@ def shim_case(jvm):
     assert st == 1 and "invalid entries" in msg, (st, msg)
     st, msg, _ = run_shim(jvm, mats[:1], [O.DatasetParams(0, 10, None)], 1)
     assert st == 1 and "positive" in msg, (st, msg)
+    # the JVM cannot pin an array (GetPrimitiveArrayCritical -> NULL, OutOfMemoryError pending): everything pinned so far is
+    # released and the pending error propagates -- no FindClass / ThrowNew on top of it (-Xcheck:jni aborts on that)
+    for k in (0, 1, 2):
+        os.environ["FAKE_JVM_FAIL_PIN_AFTER"] = str(k)
+        try:
+            st, msg, _ = run_shim(jvm, mats[:2], params[:2], 1)
+        finally:
+            del os.environ["FAKE_JVM_FAIL_PIN_AFTER"]
+        assert st == 1 and msg == "java.lang.OutOfMemoryError", (k, st, msg)
     assert jvm.fake_jvm_device_count() >= 1
     jvm.fake_jvm_shutdown()
     st, msg, out = run_shim(jvm, mats[:2], params[:2], 7)              # the context is re-created after shutdown

@@ -493,3 +493,17 @@ def test_row_scan_large_matrix_edges(sim_session, mode):
         assert np.array_equal(out.row_ptr.cpu().numpy(), ref.row_ptr)
         assert np.array_equal(out.col_idx.cpu().numpy()[:ref.nnz], ref.col_idx)
         assert np.array_equal(post.cpu().numpy()[:m.n_cols], O.column_counts(ref))
+
+
+def test_select_ambiguous_set_overlays_the_histograms(sim_session):
+    """The workload of the round-3 race (tests/race_negative_control.py): 120 candidates tied at the top LLR (+ 100 weaker ones) per row in the 256-thread
+    small-block class, whose LDS layout overlays the ambiguous set on the select histograms.  The simulator runs the waves of a
+    team one after the other between rendezvous, so it cannot show the race itself (the -m gpu tests do, with a wave delayed on
+    hardware); here the logic of the path -- and of the barrier round 4 added -- is checked with exact ids, delay hook on."""
+    import race_negative_control as nc
+    sim_session.set_debug(131072)
+    try:
+        _, _, stats = compare_with_oracle(sim_session, nc.workload(), [P(), P()], 77, exact_ids=True)
+    finally:
+        sim_session.set_debug(0)
+    assert all(int(s[0][1 + 2]) == nc.N_ROWS_SMALL_BLOCK for s in stats)

@@ -1,0 +1,214 @@
+// Scattered-access microbenchmarks behind the round-4 designs of the CSR row scan and the SpGEMM:
+//   gather_u8 / gather_u32   per-lane random loads from a table in global memory, with a fraction of the lanes active per
+//                            load instruction: is the cost of a gather per INSTRUCTION or per ACTIVE LANE?
+//   lds_u8 / lds_u32         the same lookups against a table in LDS
+//   rows48                   random B'-row reads (48-byte rows of a 1 GiB array): a known byte count to calibrate FETCH_SIZE on
+//                            (rocprofv3 --pmc FETCH_SIZE -- gather_microbench rows48), MI355X_MICROARCH.md "HBM"
+// hipcc --offload-arch=gfx950 -O3 -o tools/_build/gather_microbench tools/gather_microbench.hip
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ __forceinline__ unsigned mix(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+
+// Every thread: ITERS rounds of K loads; load q of a round is issued only by lanes whose coin for (round, q) is below `active256`.
+template <typename T, int K>
+__global__ __launch_bounds__(256) void gather_kernel(const T* __restrict__ tab, unsigned mask, int iters, unsigned active256, unsigned long long* __restrict__ out) {
+  const unsigned gid = blockIdx.x * 256 + threadIdx.x;
+  unsigned s = mix(gid * 2654435761u + 12345u);
+  unsigned long long acc = 0;
+  for (int it = 0; it < iters; ++it) {
+    unsigned idx[K];
+    bool on[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      s = s * 1664525u + 1013904223u;
+      const unsigned r = mix(s);
+      idx[q] = r & mask;
+      on[q] = ((r >> 24) & 255u) < active256;
+    }
+    unsigned v[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) v[q] = on[q] ? (unsigned)tab[idx[q]] : 0u;
+#pragma unroll
+    for (int q = 0; q < K; ++q) acc += v[q];
+  }
+  if (acc == 0x123456789abcull) out[0] = acc;
+}
+
+// The same against LDS: the block first copies `lds_bytes` of the table into LDS.
+template <typename T, int K>
+__global__ __launch_bounds__(1024) void lds_kernel(const T* __restrict__ tab, int lds_elems, int iters, unsigned long long* __restrict__ out) {
+  extern __shared__ unsigned char s_raw[];
+  T* s_tab = reinterpret_cast<T*>(s_raw);
+  for (int i = threadIdx.x; i < lds_elems; i += blockDim.x) s_tab[i] = tab[i];
+  __syncthreads();
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned s = mix(gid * 2654435761u + 12345u);
+  const unsigned mask = (unsigned)lds_elems - 1u;
+  unsigned long long acc = 0;
+  for (int it = 0; it < iters; ++it) {
+    unsigned v[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      s = s * 1664525u + 1013904223u;
+      v[q] = (unsigned)s_tab[mix(s) & mask];
+    }
+#pragma unroll
+    for (int q = 0; q < K; ++q) acc += v[q];
+  }
+  if (acc == 0x123456789abcull) out[0] = acc;
+}
+
+// Control: the index arithmetic alone.
+template <int K>
+__global__ __launch_bounds__(256) void alu_kernel(int iters, unsigned long long* __restrict__ out) {
+  const unsigned gid = blockIdx.x * 256 + threadIdx.x;
+  unsigned s = mix(gid * 2654435761u + 12345u);
+  unsigned long long acc = 0;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      s = s * 1664525u + 1013904223u;
+      acc += mix(s) & 0xffffu;
+    }
+  }
+  if (acc == 0x123456789abcull) out[0] = acc;
+}
+
+// rows48: `lanes_per_row` lanes read one row of `row_words` consecutive 4-byte words starting at a random row of the array
+// (rows are row_words * 4 bytes apart: a 48-byte row straddles a 128-byte line 3 times in 8).
+__global__ __launch_bounds__(256) void rows_kernel(const int* __restrict__ arr, unsigned n_rows, int row_words, int lanes_log2, int rows_per_group, unsigned long long* __restrict__ out) {
+  const unsigned gid = blockIdx.x * 256 + threadIdx.x;
+  const unsigned grp = gid >> lanes_log2, gl = gid & ((1u << lanes_log2) - 1u);
+  unsigned long long acc = 0;
+  for (int r = 0; r < rows_per_group; ++r) {
+    const unsigned row = mix(grp * 2654435761u + (unsigned)r * 40503u + 7u) % n_rows;
+    const int* p = arr + (size_t)row * (size_t)row_words;
+    for (int w = (int)gl; w < row_words; w += 1 << lanes_log2) acc += (unsigned)p[w];
+  }
+  if (acc == 0x123456789abcull) out[0] = acc;
+}
+
+static float time_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
+
+int main(int argc, char** argv) {
+  const std::string only = argc > 1 ? argv[1] : "all";
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  const int n_cu = prop.multiProcessorCount;
+  unsigned long long* out;
+  CK(hipMalloc(&out, 64));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int blocks = n_cu * 8 * 4;  // 8 blocks of 256 per CU resident, four rounds
+  constexpr int K = 8;
+  const int iters = 64;
+  const double loads = (double)blocks * 256 * iters * K;
+
+  if (only == "all" || only == "alu") {
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(alu_kernel<K>, dim3(blocks), dim3(256), 0, 0, iters, out);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      if (rep) printf("{\"test\": \"alu_only\", \"ms\": %.4f, \"G_slots_per_s\": %.1f}\n", time_ms(e0, e1), loads / time_ms(e0, e1) / 1e6);
+    }
+  }
+  if (only == "all" || only == "gather") {
+    for (size_t tab_bytes : {(size_t)256 << 10, (size_t)2 << 20, (size_t)16 << 20}) {
+      unsigned char* tab;
+      CK(hipMalloc(&tab, tab_bytes));
+      CK(hipMemset(tab, 1, tab_bytes));
+      for (int width : {1, 4}) {
+        for (unsigned act : {256u, 128u, 64u, 16u, 4u}) {
+          float ms = 0;
+          for (int rep = 0; rep < 2; ++rep) {
+            CK(hipEventRecord(e0));
+            if (width == 1)
+              hipLaunchKernelGGL((gather_kernel<unsigned char, K>), dim3(blocks), dim3(256), 0, 0, tab, (unsigned)(tab_bytes - 1), iters, act, out);
+            else
+              hipLaunchKernelGGL((gather_kernel<unsigned, K>), dim3(blocks), dim3(256), 0, 0, reinterpret_cast<unsigned*>(tab), (unsigned)(tab_bytes / 4 - 1), iters, act, out);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            ms = time_ms(e0, e1);
+          }
+          printf("{\"test\": \"gather_u%d\", \"table_KB\": %zu, \"active_frac\": %.4f, \"ms\": %.4f, \"G_slots_per_s\": %.1f, \"G_active_lookups_per_s\": %.1f, \"cycles_per_wave_instr_per_cu\": %.1f}\n",
+                 width * 8, tab_bytes >> 10, act / 256.0, ms, loads / ms / 1e6, loads * (act / 256.0) / ms / 1e6, ms * 1e-3 * 2.4e9 * n_cu / (loads / 64));
+        }
+      }
+      CK(hipFree(tab));
+    }
+  }
+  if (only == "all" || only == "lds") {
+    unsigned char* tab;
+    CK(hipMalloc(&tab, 128 << 10));
+    CK(hipMemset(tab, 1, 128 << 10));
+    for (int lds_kb : {32, 64, 128}) {
+      for (int width : {1, 4}) {
+        const int threads = 1024;
+        const int lblocks = n_cu * 4;
+        const int liters = 256;
+        const double lloads = (double)lblocks * threads * liters * K;
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+          CK(hipEventRecord(e0));
+          if (width == 1) {
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_kernel<unsigned char, K>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb << 10));
+            hipLaunchKernelGGL((lds_kernel<unsigned char, K>), dim3(lblocks), dim3(threads), (size_t)lds_kb << 10, 0, tab, lds_kb << 10, liters, out);
+          } else {
+            CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lds_kernel<unsigned, K>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb << 10));
+            hipLaunchKernelGGL((lds_kernel<unsigned, K>), dim3(lblocks), dim3(threads), (size_t)lds_kb << 10, 0, reinterpret_cast<unsigned*>(tab), (lds_kb << 10) / 4, liters, out);
+          }
+          CK(hipGetLastError());
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          ms = time_ms(e0, e1);
+        }
+        printf("{\"test\": \"lds_u%d\", \"lds_KB\": %d, \"threads\": %d, \"ms\": %.4f, \"G_lookups_per_s\": %.1f, \"cycles_per_wave_instr_per_cu\": %.1f}\n", width * 8, lds_kb, threads, ms,
+               lloads / ms / 1e6, ms * 1e-3 * 2.4e9 * n_cu / (lloads / 64));
+      }
+    }
+    CK(hipFree(tab));
+  }
+  if (only == "all" || only == "rows48" || only == "rows64" || only == "rows128") {
+    const size_t bytes = (size_t)1 << 30;
+    int* arr;
+    CK(hipMalloc(&arr, bytes));
+    CK(hipMemset(arr, 1, bytes));
+    for (int row_words : {12, 16, 32}) {
+      if (only == "rows48" && row_words != 12) continue;
+      if (only == "rows64" && row_words != 16) continue;
+      if (only == "rows128" && row_words != 32) continue;
+      for (int lanes_log2 : {0, 2, 4}) {
+        if (only != "all" && lanes_log2 != 0) continue;
+        const unsigned n_rows = (unsigned)(bytes / (size_t)(row_words * 4));
+        const int rows_per_group = 16;
+        const int rblocks = n_cu * 8 * 8;
+        const double rows = (double)rblocks * 256 / (1 << lanes_log2) * rows_per_group;
+        float ms = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+          CK(hipEventRecord(e0));
+          hipLaunchKernelGGL(rows_kernel, dim3(rblocks), dim3(256), 0, 0, arr, n_rows, row_words, lanes_log2, rows_per_group, out);
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          ms = time_ms(e0, e1);
+        }
+        printf("{\"test\": \"rows\", \"row_bytes\": %d, \"lanes_per_row\": %d, \"rows\": %.0f, \"algorithmic_bytes_per_launch\": %.0f, \"ms\": %.4f, \"M_rows_per_s\": %.1f, \"alg_GBps\": %.1f}\n",
+               row_words * 4, 1 << lanes_log2, rows, rows * row_words * 4, ms, rows / ms / 1e3, rows * row_words * 4 / ms / 1e6);
+      }
+    }
+    CK(hipFree(arr));
+  }
+  return 0;
+}

@@ -56,8 +56,12 @@ ALL_TO_ALL_V_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.POIN
 
 
 class Collectives(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("group_start", GROUP_FN), ("group_end", GROUP_FN), ("all_reduce_sum", ALL_REDUCE_FN),
+    """urcco_collectives; the constructor takes the members after struct_size (which it fills in)."""
+    _fields_ = [("struct_size", C.c_size_t), ("user", C.c_void_p), ("group_start", GROUP_FN), ("group_end", GROUP_FN), ("all_reduce_sum", ALL_REDUCE_FN),
                 ("all_gather_v", ALL_GATHER_V_FN), ("all_to_all_v", ALL_TO_ALL_V_FN)]
+
+    def __init__(self, user=None, *callbacks):
+        super().__init__(C.sizeof(Collectives), user, *callbacks)
 
 
 class CommConfig(C.Structure):
@@ -123,6 +127,7 @@ SYMBOLS = {
     "urcco_session_scratch_bytes": (C.c_int64, [_p]),
     "urcco_session_set_timing": (C.c_int, [_p, C.c_int32]),
     "urcco_session_set_debug": (C.c_int, [_p, C.c_int32]),
+    "urcco_debug_dump_marks": (None, []),
     "urcco_session_get_timings": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "urcco_dev_column_counts": (C.c_int, [_p, C.c_int64, _p, C.c_int32, _p]),
     "urcco_dev_downsample": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int64, C.c_int32, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,

@@ -1857,6 +1857,20 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 // from the row's work (1.25 x the expected distinct columns per pass must fit) and doubles whenever a pass still overflows --
 // at the latest when ceil(n_cols / P) columns are GUARANTEED to fit, so every row ends.  Round 2 served these rows from dense
 // counters in global memory (n_cols x 16 B of scratch per resident block, L2 atomics): 35.9 ms for 16K rows of config 5.
+// entries of the xLogX tables every block keeps in LDS (cco_device.h: XlxLds); 0 = every lookup goes to the global tables (round 3)
+#ifndef URCCO_XLX_LDS
+#define URCCO_XLX_LDS 0
+#endif
+constexpr int XLX_LDS = URCCO_XLX_LDS;
+template <int N>
+__device__ __forceinline__ void fill_xlx_lds(double* s_xlx, double* s_xlx_hi, const CcoArgs& a, int n_threads) {
+  for (int x = threadIdx.x; x < N; x += n_threads) {
+    s_xlx[x] = a.xlx_tab[x];
+    s_xlx_hi[x] = a.xlx_hi[x];
+  }
+  __syncthreads();
+}
+
 template <int T, int E, int U, bool MP = false>
 __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T == 256 && E == 4096 ? 7 : 1))) void cco_rows_kernel(CcoArgs a, int bin) {
   constexpr int BLOCK = T < 256 ? 256 : T;
@@ -1903,6 +1917,10 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   __shared__ unsigned s_mpflag;                    // MP: a pass overflowed its table
   __shared__ unsigned long long s_runk[MP ? 2 * MP_KMAX : 1];  // MP: the row's running top k (two buffers: a merge reads one, writes the other)
   __shared__ unsigned s_runc[MP ? 2 * MP_KMAX : 1];
+  constexpr int XL = T == 1024 ? 0 : XLX_LDS;  // the whole-CU classes have no LDS to spare (a 128 KB table); their rows are few
+  __shared__ double s_xlx[XL > 0 ? XL : 1], s_xlx_hi[XL > 0 ? XL : 1];
+  if (XL > 0) fill_xlx_lds<XL>(s_xlx, s_xlx_hi, a, BLOCK);
+  const XlxLds xl{s_xlx, s_xlx_hi, XL};
 
   const int team = TEAMS == 1 ? 0 : uni((int)threadIdx.x / T);  // a team is one wave (T == 64) or the whole block
   const int tl = threadIdx.x % T;
@@ -2125,9 +2143,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             unsigned long long key = 0ull;
             if (!(a.exclude_self && j == i)) {
               const double llr = (a.debug & 2) ? (double)k11
-                                               : llr_from_entropies_tab(row_entropy, column_entropy_tab((long long)cbj[x], xlx_n, a.n_users, a.xlx_tab, a.xlx_hi), xlx_n, k11,
-                                                                        ca - k11, (long long)cbj[x] - k11, a.n_users - ca - (long long)cbj[x] + k11, a.xlx_tab, a.n_users,
-                                                                        a.xlx_hi);
+                                               : llr_from_entropies_tab_l(row_entropy, column_entropy_tab_l((long long)cbj[x], xlx_n, a.n_users, xl, a.xlx_tab, a.xlx_hi), xlx_n, k11,
+                                                                          ca - k11, (long long)cbj[x] - k11, a.n_users - ca - (long long)cbj[x] + k11, xl, a.xlx_tab, a.n_users,
+                                                                          a.xlx_hi);
               if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
             }
             kk[t] = key;
@@ -2242,6 +2260,16 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             list_n = uni(sel_res[0]);
           }
           first_pass = false;
+          // test hook (tests/test_gpu_parity.py::test_select_overlay_race_*): the team's FIRST wave -- it owns the lowest table entries, the
+          // ones a tie at the cut selects -- dawdles before it reads the histogram, so that its siblings are far ahead of it: the
+          // interleaving the round-3 race needed, made certain
+          if (T != WAVE && (a.debug & 131072) && tl / WAVE == 0) {
+#ifdef HIPSIM_HOST_BUILD
+            __builtin_amdgcn_s_sleep(127);
+#else
+            asm volatile("s_sleep 127\n\ts_sleep 127" ::: "memory");  // "memory": the histogram reads below must not be hoisted above the nap
+#endif
+          }
           {  // every wave locates the digit that holds the cut: lane l owns the four bins of digit group 63 - l (the highest
              // digits sit in the lowest lanes, so that the count of everything above a group is a PREFIX sum over lanes)
             const int grp = WAVE - 1 - lane;
@@ -2278,6 +2306,14 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
           }
           if (prev_cnt <= (unsigned)SEL_AMB) {
             // finish: copy out the members of the cut bin (they match the prefix through digit p) ...
+            // In the SHARE layout amb_key / amb_col OVERLAY the three rotating histograms.  Every wave has run the digit search above for
+            // itself, at its own pace: a wave that arrives here first must not write the ambiguous set over histogram words a sibling has
+            // yet to read (or is still clearing).  Round 3 shipped without this barrier: the 256-thread small-block class -- the only
+            // multi-wave class with the overlay -- then cut a row's top k at a threshold computed from clobbered counts: one or two
+            // entries lost at the cut in ~1 build of 50 on config 4, now and then a garbage column and a wild store (the GPU memory
+            // fault of profiles/r03_rocprofv3_stats_failure.txt; found by tools/race_hunt.py, profiles/r04_race_hunt.log).  prev_cnt is
+            // team-uniform, so every wave takes the barrier.  (debug 262144 skips it: the regression test's negative control.)
+            if (SHARE && T != WAVE && !(a.debug & 262144)) team_sync<T>();
             const unsigned n_scan2 = have_list ? list_n : D;
             for (unsigned base = 0; base < n_scan2; base += T) {
               const unsigned idx = base + (unsigned)tl;
@@ -2438,6 +2474,9 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
   __shared__ unsigned s_tab[TEAMS * MICRO_WORDS];
   __shared__ long long s_ustart[TEAMS * WAVE];
   __shared__ unsigned s_uoff[TEAMS * (WAVE + 1)];
+  __shared__ double s_xlx[XLX_LDS > 0 ? XLX_LDS : 1], s_xlx_hi[XLX_LDS > 0 ? XLX_LDS : 1];
+  if (XLX_LDS > 0) fill_xlx_lds<XLX_LDS>(s_xlx, s_xlx_hi, a, 256);
+  const XlxLds xl{s_xlx, s_xlx_hi, XLX_LDS};
   // (moving the row id, bounds and counts to scalar registers as in cco_rows_kernel was measured 12 % SLOWER here: the kernel
   // argument block alone keeps ~60 SGPRs live and the extra scalars spill to VGPR lanes)
   const int team = threadIdx.x / WAVE;
@@ -2540,8 +2579,8 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
       if (!(a.exclude_self && j == i)) {
         const long long cbj = (a.debug & 512) ? 100ll : (use16 ? (long long)a.cnt_b16[j] : (long long)a.cnt_b[j]);
         const double llr = (a.debug & 2) ? (double)k11
-                                         : llr_from_entropies_tab(row_entropy, column_entropy_tab(cbj, xlx_n, a.n_users, a.xlx_tab, a.xlx_hi), xlx_n, k11, ca - k11,
-                                                                  cbj - k11, a.n_users - ca - cbj + k11, a.xlx_tab, a.n_users, a.xlx_hi);
+                                         : llr_from_entropies_tab_l(row_entropy, column_entropy_tab_l(cbj, xlx_n, a.n_users, xl, a.xlx_tab, a.xlx_hi), xlx_n, k11, ca - k11,
+                                                                    cbj - k11, a.n_users - ca - cbj + k11, xl, a.xlx_tab, a.n_users, a.xlx_hi);
         if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
           mk = (unsigned long long)__double_as_longlong(llr);
           mc = j;

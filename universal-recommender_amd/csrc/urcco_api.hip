@@ -8,10 +8,114 @@
 
 using namespace urcco_detail;
 
+#include <signal.h>
+#include <unistd.h>
+
+#include <mutex>
+
 namespace urcco_detail {
 char* err_buf() {
   static thread_local char buf[512] = "";
   return buf;
+}
+
+// ---- fault-hunting aids (urcco_internal.h: URCCO_DEBUG_MARKS / URCCO_DEBUG_POISON) ----------------------------------
+const DebugCfg& debug_cfg() {
+  static const DebugCfg cfg = [] {
+    DebugCfg c;
+    const char* m = getenv("URCCO_DEBUG_MARKS");
+    const char* p = getenv("URCCO_DEBUG_POISON");
+    c.marks = m && *m && *m != '0';
+    c.poison = p && *p && *p != '0';
+    return c;
+  }();
+  return cfg;
+}
+
+namespace {
+__global__ void debug_mark_kernel(unsigned* slot, unsigned value) {
+  __hip_atomic_store(slot, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+constexpr int MARK_SESSIONS = 64;
+struct MarkSlot { unsigned* marks; void* stream; int device; };
+MarkSlot g_mark_slots[MARK_SESSIONS];  // read by the signal handler: plain array, entries published by their `marks` pointer
+std::mutex g_mark_mu;
+struct sigaction g_prev_abrt;
+void put(const char* s) { (void)!write(2, s, strlen(s)); }
+void put_u(unsigned long long v, int base = 10) {
+  char b[24];
+  int n = 0;
+  do { const int d = (int)(v % (unsigned)base); b[n++] = (char)(d < 10 ? '0' + d : 'a' + d - 10); v /= (unsigned)base; } while (v && n < 23);
+  char o[24];
+  for (int i = 0; i < n; ++i) o[i] = b[n - 1 - i];
+  o[n] = 0;
+  put(o);
+}
+const char* const STAGE_NAME[URCCO_N_STAGES] = {"column_counts", "downsample_flags", "downsample_scan", "downsample_compact", "transpose", "row_work", "binning",
+                                               "entropy", "cco_bin0", "cco_bin1", "cco_bin2", "cco_bin3", "cco_bin4", "cco_bin5", "cco_bin6", "compact_indicators"};
+void dump_marks(const char* why) {  // async-signal-safe: write(2) only
+  put("[urcco marks] "); put(why); put(": last launch groups per session (ordinal:stage begun / finished)\n");
+  for (int i = 0; i < MARK_SESSIONS; ++i) {
+    unsigned* m = g_mark_slots[i].marks;
+    if (!m) continue;
+    const unsigned b = __atomic_load_n(&m[0], __ATOMIC_RELAXED), f = __atomic_load_n(&m[1], __ATOMIC_RELAXED);
+    put("[urcco marks]   session "); put_u((unsigned)i); put(" dev "); put_u((unsigned)g_mark_slots[i].device);
+    put(" stream 0x"); put_u((unsigned long long)(uintptr_t)g_mark_slots[i].stream, 16);
+    put(": begun "); put_u(b >> 8); put(":"); put((b & 255u) < URCCO_N_STAGES ? STAGE_NAME[b & 255u] : "?");
+    put("  finished "); put_u(f >> 8); put(":"); put((f & 255u) < URCCO_N_STAGES ? STAGE_NAME[f & 255u] : "?");
+    put(b == f ? "  (idle)\n" : "  <-- IN FLIGHT\n");
+  }
+}
+void on_abort(int sig) {
+  dump_marks("SIGABRT");
+  sigaction(SIGABRT, &g_prev_abrt, nullptr);
+  raise(sig);
+}
+}  // namespace
+
+void debug_register(urcco_session* s) {
+  if (!debug_cfg().marks) return;
+  std::lock_guard<std::mutex> g(g_mark_mu);
+  static bool installed = false;
+  if (!installed) {
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_handler = on_abort;
+    sigaction(SIGABRT, &sa, &g_prev_abrt);
+    installed = true;
+  }
+  unsigned* m = nullptr;
+  if (hipHostMalloc((void**)&m, 64, 0) != hipSuccess || !m) return;
+  m[0] = m[1] = 0u;
+  for (int i = 0; i < MARK_SESSIONS; ++i)
+    if (!g_mark_slots[i].marks) {
+      g_mark_slots[i].stream = (void*)s->stream;
+      g_mark_slots[i].device = s->device;
+      __atomic_store_n(&g_mark_slots[i].marks, m, __ATOMIC_RELEASE);
+      s->marks = m;
+      return;
+    }
+  (void)hipHostFree(m);
+}
+void debug_unregister(urcco_session* s) {
+  if (!s->marks) return;
+  std::lock_guard<std::mutex> g(g_mark_mu);
+  for (int i = 0; i < MARK_SESSIONS; ++i)
+    if (g_mark_slots[i].marks == s->marks) __atomic_store_n(&g_mark_slots[i].marks, (unsigned*)nullptr, __ATOMIC_RELEASE);
+  (void)hipHostFree(s->marks);
+  s->marks = nullptr;
+}
+void debug_mark(urcco_session* s, int which, int stage) {
+  if (which == 0) ++s->mark_seq;
+  hipLaunchKernelGGL(debug_mark_kernel, dim3(1), dim3(1), 0, s->stream, s->marks + which, (s->mark_seq << 8) | (unsigned)(stage & 255));
+}
+void debug_poison(void* p, size_t bytes, hipStream_t st, bool async) {
+#ifdef HIPSIM_HOST_BUILD
+  if (hipsim::guard_on()) return;  // the simulator's own guard mode poisons (and keeps PROT_NONE pages inside the arena)
+#endif
+  if (!p || !bytes) return;
+  if (async) (void)hipMemsetAsync(p, 0x7f, bytes, st);
+  else (void)hipMemset(p, 0x7f, bytes);
 }
 }  // namespace urcco_detail
 
@@ -41,6 +145,10 @@ const char* urcco_status_string(int status) {
   }
 }
 
+void urcco_debug_dump_marks(void) {
+  if (debug_cfg().marks) dump_marks("dump");
+}
+
 int urcco_session_create(int32_t device, void* stream, urcco_session** out) {
   if (!out) return fail(URCCO_BAD_ARG, "urcco_session_create: out is NULL");
   *out = nullptr;
@@ -60,6 +168,7 @@ int urcco_session_create(int32_t device, void* stream, urcco_session** out) {
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) s->n_cu = prop.multiProcessorCount;
+  debug_register(s);
   *out = s;
   return URCCO_OK;
 }
@@ -68,6 +177,7 @@ void urcco_session_destroy(urcco_session* s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   (void)hipStreamSynchronize(s->stream);
+  debug_unregister(s);
   if (s->arena) (void)hipFree(s->arena);
   if (s->xlx_tab) (void)hipFree(s->xlx_tab);
   if (s->xlx_hi) (void)hipFree(s->xlx_hi);

@@ -103,6 +103,7 @@ struct DBuf {  // device buffer that only grows (hipFree synchronises the device
 #endif
     HIPC(hipMalloc((void**)&p, want * sizeof(T)));
     cap = want;
+    if (debug_cfg().poison) debug_poison(p, want * sizeof(T), nullptr, false);
     return URCCO_OK;
   }
   void release() {
@@ -819,6 +820,10 @@ int exchange_phase(urcco_context* c, int d, const std::vector<DsParams>& ps, int
       URC(D.f_ent.ensure((size_t)ents + 4));
     }
   }
+  // offsets / counts of the fragment all-to-all-v: one set per local device, alive until group_end (a collectives callback may
+  // keep the pointers until its group ends -- include/urcco.h)
+  struct A2A { std::vector<int64_t> so, sc, ro, rc, eso, esc, ero, erc; };
+  std::vector<A2A> a2a(c->devs.size());
   URC(c->group_start());
   for (DevState& D : c->devs) {
     URC(set_dev(D));
@@ -831,7 +836,9 @@ int exchange_phase(urcco_context* c, int d, const std::vector<DsParams>& ps, int
       // for this GPU's range, one fragment behind the other in rank order
       const int64_t lb = fp->wire16 ? 2 : 4;
       const int64_t n_range = D.item_hi - D.item_lo;
-      std::vector<int64_t> so((size_t)W), sc((size_t)W), ro((size_t)W), rc((size_t)W), eso((size_t)W), esc((size_t)W), ero((size_t)W), erc((size_t)W);
+      A2A& x = a2a[(size_t)(&D - c->devs.data())];
+      std::vector<int64_t>&so = x.so, &sc = x.sc, &ro = x.ro, &rc = x.rc, &eso = x.eso, &esc = x.esc, &ero = x.ero, &erc = x.erc;
+      for (std::vector<int64_t>* v : {&so, &sc, &ro, &rc, &eso, &esc, &ero, &erc}) v->assign((size_t)W, 0);
       int64_t e_at = 0;
       const int64_t* mine = fp->cpb.data() + (size_t)D.rank * (size_t)(W + 1);
       for (int q = 0; q < W; ++q) {
@@ -1050,6 +1057,11 @@ int stage_copy(StageRing& ring, hipStream_t st, void* dst, const void* src, size
 }
 
 std::mutex g_default_mu;
+// The one-shot entry points share ONE process-wide context: a build occupies it from its stage to its finish.  A second thread's
+// stage waits here for the first thread's finish (round 3 dropped the lock between the two halves: the second stage then failed with
+// "previous staged build has not been finished" or, with different options, destroyed the context under the pending build -- ADVICE r03).
+std::condition_variable g_default_cv;
+bool g_default_busy = false;
 urcco_context* g_default_ctx = nullptr;
 int g_default_n_gpus = -1, g_default_device = -1, g_default_mode = -1, g_default_flags = 0;
 
@@ -1108,6 +1120,10 @@ int urcco_context_create(const urcco_options* options, const urcco_comm_config* 
     if (c->first_rank < 0 || c->first_rank + n_local > c->world) return fail(URCCO_BAD_ARG, "ranks [%d, %d) outside a world of %d", c->first_rank, c->first_rank + n_local, c->world);
     if (comm && comm->collectives) {
       const urcco_collectives* k = comm->collectives;
+      // a host built against an older header hands in a shorter struct: reading its missing tail would yield a garbage function pointer
+      if (k->struct_size < sizeof(urcco_collectives))
+        return fail(URCCO_BAD_ARG, "urcco_collectives.struct_size is %zu, this library's struct has %zu bytes (ABI %d): rebuild the host against include/urcco.h", k->struct_size,
+                    sizeof(urcco_collectives), URCCO_VERSION);
       if (!k->group_start || !k->group_end || !k->all_reduce_sum || !k->all_gather_v) return fail(URCCO_BAD_ARG, "urcco_collectives: every callback must be set");
       c->cb = *k;
       c->have_cb = true;
@@ -1508,6 +1524,8 @@ int urcco_shutdown(void) {
   std::lock_guard<std::mutex> g(g_default_mu);
   if (g_default_ctx) urcco_context_destroy(g_default_ctx);
   g_default_ctx = nullptr;
+  g_default_busy = false;  // a staged build nobody finished went with the context
+  g_default_cv.notify_all();
   pinned_pool().trim();
   return URCCO_OK;
 }
@@ -1542,10 +1560,13 @@ static int default_context(const urcco_options* options, urcco_context** out) {
 int urcco_cross_occurrence_stage(const urcco_dataset* datasets, int32_t n_datasets, int32_t random_seed, const urcco_options* options) {
   return guarded([&]() -> int {
     err_buf()[0] = 0;
-    std::lock_guard<std::mutex> g(g_default_mu);
+    std::unique_lock<std::mutex> g(g_default_mu);
+    g_default_cv.wait(g, [] { return !g_default_busy; });
     urcco_context* c = nullptr;
     URC(default_context(options, &c));
-    return urcco_context_stage(c, datasets, n_datasets, random_seed);
+    const int st = urcco_context_stage(c, datasets, n_datasets, random_seed);
+    g_default_busy = st == URCCO_OK;  // released by the matching urcco_cross_occurrence_finish
+    return st;
   });
 }
 
@@ -1556,7 +1577,10 @@ int urcco_cross_occurrence_finish(urcco_indicators* out, int32_t n_datasets, urc
     std::lock_guard<std::mutex> g(g_default_mu);
     if (!g_default_ctx || !g_default_ctx->pending) return fail(URCCO_BAD_ARG, "urcco_cross_occurrence_finish: nothing staged");
     if (g_default_ctx->pending->n_ds != n_datasets) return fail(URCCO_BAD_ARG, "urcco_cross_occurrence_finish: %d datasets were staged, out holds %d", g_default_ctx->pending->n_ds, n_datasets);
-    return urcco_context_finish(g_default_ctx, out, stats);
+    const int st = urcco_context_finish(g_default_ctx, out, stats);  // consumes the pending build whatever its outcome
+    g_default_busy = false;
+    g_default_cv.notify_one();
+    return st;
   });
 }
 

@@ -13,6 +13,7 @@
 #include "../../include/urcco.h"
 #include "cco_kernels.h"
 
+struct urcco_session;
 namespace urcco_detail {
 
 char* err_buf();  // thread-local message buffer of urcco_last_error (512 bytes)
@@ -57,6 +58,20 @@ inline int guarded(F&& body) {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Fault-hunting aids, off unless the environment asks (read once; urcco_api.hip):
+//   URCCO_DEBUG_MARKS=1   flight recorder: every launch group of every session writes "begun" / "finished" marks (build ordinal, stage)
+//                         into pinned host memory, in stream order; a SIGABRT handler (the HSA runtime aborts the process on a GPU
+//                         memory fault) prints every session's last marks, so the launch groups in flight at the fault are known
+//   URCCO_DEBUG_POISON=1  every fresh device allocation of the library and the WHOLE scratch arena at every reserve() are filled with
+//                         0x7f bytes (stream-ordered): a kernel that consumes memory nobody wrote meets an index ~2^31 elements away
+//                         (or a 64-bit offset beyond the address space) instead of a stale but plausible value
+struct DebugCfg { bool marks = false, poison = false; };
+const DebugCfg& debug_cfg();
+void debug_mark(urcco_session* s, int which /*0: begun, 1: finished*/, int stage);
+void debug_register(urcco_session* s);
+void debug_unregister(urcco_session* s);
+void debug_poison(void* p, size_t bytes, hipStream_t st, bool async);
+
 inline int ceil_log2_i64(int64_t v) {
   int l = 0;
   while (((int64_t)1 << l) < v) ++l;
@@ -65,7 +80,6 @@ inline int ceil_log2_i64(int64_t v) {
 
 }  // namespace urcco_detail
 
-struct urcco_session;
 namespace urcco_detail {
 // urcco_dev_cco_rows with one secondary's share of a fused expand preparation handed in (both NULL: it prepares its own)
 int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a, const int64_t* a_col_ptr, const int32_t* a_row_idx, int64_t nnz_a_bound,
@@ -96,6 +110,8 @@ struct urcco_session {
   double* xlx_hi = nullptr;   // xLogX(N - d) for the N of the last build
   long long xlx_hi_n = -1;
   int debug = 0;              // kernel ablation switches (profiling only)
+  unsigned* marks = nullptr;  // URCCO_DEBUG_MARKS: pinned host words [0] last launch group begun, [1] last finished ((ordinal << 8) | stage)
+  unsigned mark_seq = 0;
   int unordered_rows = 0;     // URCCO_FLAG_UNORDERED_ROWS of the owning context
   // optional per-stage HIP-event timing (bench.py's roofline numbers)
   bool timing = false;
@@ -113,6 +129,8 @@ struct urcco_session {
     return e;
   }
   void begin(int stage) noexcept {
+    cur_stage = stage;
+    if (marks) debug_mark(this, 0, stage);
     if (!timing) return;
     try {
       recs.reserve(recs.size() + 1);
@@ -128,7 +146,9 @@ struct urcco_session {
     open_rec = true;
   }
   bool open_rec = false;
+  int cur_stage = 0;
   void end() noexcept {
+    if (marks) debug_mark(this, 1, cur_stage);
     if (!timing || !open_rec || recs.empty()) return;
     (void)hipEventRecord(recs.back().e1, stream);
     open_rec = false;
@@ -152,7 +172,10 @@ struct urcco_session {
       bytes += 64 * hipsim::GUARD_PAGE;  // callers that reserve raw byte counts (one block carved by the launcher) do not go through need()
     }
 #endif
-    if (bytes <= arena_cap) return URCCO_OK;
+    if (bytes <= arena_cap) {
+      if (debug_cfg().poison) debug_poison(arena, arena_cap, stream, true);  // what the previous stage left behind is not an input of this one
+      return URCCO_OK;
+    }
     if (arena) {
       HIPC(hipStreamSynchronize(stream));
       HIPC(hipFree(arena));
@@ -162,6 +185,7 @@ struct urcco_session {
     const size_t want = align_up(bytes + bytes / 4, (size_t)1 << 20);
     HIPC(hipMalloc((void**)&arena, want));
     arena_cap = want;
+    if (debug_cfg().poison) debug_poison(arena, arena_cap, stream, true);
     return URCCO_OK;
   }
   template <typename T>

@@ -21,6 +21,10 @@ from .indexed_dataset import BiDictionary
 class RankingFieldName:
     UserRank, UniqueRank, PopRank, TrendRank, HotRank, UnknownRank = "userRank", "uniqueRank", "popRank", "trendRank", "hotRank", "unknownRank"
 
+    @staticmethod
+    def toSeq():   # PopModel.scala:39
+        return [RankingFieldName.UserRank, RankingFieldName.UniqueRank, RankingFieldName.PopRank, RankingFieldName.TrendRank, RankingFieldName.HotRank]
+
 
 class RankingType:
     Popular, Trending, Hot, UserDefined, Random = "popular", "trending", "hot", "userDefined", "random"

@@ -36,34 +36,68 @@ class RankingParams:
     duration: Optional[str] = None
 
 
-_DURATION_UNITS = {"d": 86400, "day": 86400, "days": 86400, "h": 3600, "hour": 3600, "hours": 3600, "min": 60, "minute": 60, "minutes": 60,
-                   "s": 1, "sec": 1, "second": 1, "seconds": 1}
+# scala.concurrent.duration.Duration's unit words (Duration.scala: timeUnitLabels -- every label, its plural, and the short forms)
+_NS = {"d": 86400 * 10**9, "day": 86400 * 10**9, "h": 3600 * 10**9, "hr": 3600 * 10**9, "hour": 3600 * 10**9, "m": 60 * 10**9, "min": 60 * 10**9, "minute": 60 * 10**9,
+       "s": 10**9, "sec": 10**9, "second": 10**9, "ms": 10**6, "milli": 10**6, "millis": 10**6, "millisecond": 10**6,
+       "µs": 10**3, "micro": 10**3, "micros": 10**3, "microsecond": 10**3, "ns": 1, "nano": 1, "nanos": 1, "nanosecond": 1}
+_DURATION_NS = dict(_NS)
+_DURATION_NS.update({k + "s": v for k, v in _NS.items() if len(k) > 2 and not k.endswith("s")})   # "days", "hours", "seconds", "milliseconds", ...
 
 
 def duration_seconds(text: str) -> int:
-    """scala.concurrent.duration.Duration("3650 days").toSeconds.toInt (URAlgorithm.scala:542-543) for the units engine.json
-    files use."""
-    parts = text.strip().split()
-    if len(parts) == 1:     # "90days"
-        num = parts[0].rstrip("abcdefghijklmnopqrstuvwxyz")
-        parts = [num, parts[0][len(num):]]
-    if len(parts) != 2 or parts[1].lower() not in _DURATION_UNITS:
+    """scala.concurrent.duration.Duration("3650 days").toSeconds.toInt (URAlgorithm.scala:542-543): number and unit with or
+    without a blank between them, every unit Duration accepts (d/day .. ns/nanosecond, plurals), truncation towards zero by
+    toSeconds and the 32-bit wrap of Long.toInt."""
+    t = text.strip()
+    i = 0
+    while i < len(t) and (t[i].isdigit() or t[i] in "+-.eE"):
+        i += 1
+    num, unit = t[:i], t[i:].strip().lower()
+    if not num or unit not in _DURATION_NS:
         raise ValueError(f"bad duration {text!r}")
-    return int(float(parts[0]) * _DURATION_UNITS[parts[1].lower()])
+    try:
+        ns = int(num) * _DURATION_NS[unit]
+    except ValueError:
+        ns = int(float(num) * _DURATION_NS[unit])
+    secs = abs(ns) // 10**9 * (1 if ns >= 0 else -1)
+    return (secs + 2**31) % 2**32 - 2**31
+
+
+_ISO_RE = None
 
 
 def _iso_ms(text: Optional[str]) -> Optional[int]:
-    """ISODateTimeFormat.dateTimeParser (PopModel.scala:66-74); a bad date falls back to `now` there: None here."""
+    """ISODateTimeFormat.dateTimeParser().parseDateTime (PopModel.scala:66-74): date, optional 'T' time with any number of
+    fraction digits, optional offset ('Z', +hh:mm, +hhmm, +hh); extended and basic (yyyyMMdd'T'HHmmss) forms.  A string without
+    an offset is read in the DEFAULT time zone, as Joda does (the JVM's user.timezone == this process's local zone).  A bad
+    date falls back to `now` in the reference, after a warning: None (and the same warning) here."""
+    global _ISO_RE
     if not text:
         return None
-    from datetime import datetime, timezone
+    import re
+    from datetime import datetime, timedelta, timezone
+    if _ISO_RE is None:
+        _ISO_RE = re.compile(r"^(\d{4})-?(\d{2})?-?(\d{2})?(?:T(\d{2})?:?(\d{2})?:?(\d{2})?(?:[.,](\d+))?)?(Z|[+-]\d{2}(?::?\d{2})?)?$")
+    m = _ISO_RE.match(text.strip())
     try:
-        d = datetime.fromisoformat(text.replace("Z", "+00:00"))
-    except ValueError:
+        if not m:
+            raise ValueError(text)
+        y, mo, da, hh, mi, ss, frac, off = m.groups()
+        d = datetime(int(y), int(mo or 1), int(da or 1), int(hh or 0), int(mi or 0), int(ss or 0))
+        ms = int((frac + "000")[:3]) if frac else 0
+        if off is None:
+            base = d.astimezone()            # naive -> the process's local zone (Joda: DateTimeZone.getDefault)
+        elif off == "Z":
+            base = d.replace(tzinfo=timezone.utc)
+        else:
+            sign = -1 if off[0] == "-" else 1
+            digits = off[1:].replace(":", "")
+            base = d.replace(tzinfo=timezone(sign * timedelta(hours=int(digits[:2]), minutes=int(digits[2:4] or 0))))
+        return int(base.timestamp()) * 1000 + ms
+    except (ValueError, OverflowError):
+        import logging
+        logging.getLogger("universal_recommender_amd").warning("bad date %r: falling back to now (PopModel.scala:70)", text)
         return None
-    if d.tzinfo is None:
-        d = d.replace(tzinfo=timezone.utc)
-    return int(d.timestamp() * 1000)
 
 
 @dataclass
@@ -88,6 +122,9 @@ class URAlgorithmParams:
     indicators: Optional[List[IndicatorParams]] = None
     seed: Optional[int] = None
     rankings: Optional[List[RankingParams]] = None      # :159
+    availableDateName: Optional[str] = None   # :160-162: item properties that hold dates (URModel.extractJvalue turns them into dates)
+    expireDateName: Optional[str] = None
+    dateName: Optional[str] = None
     numGPUs: Optional[int] = None      # additive key: GPUs of the node the CCO build may use; absent = 1, 0 = every visible one
     ccoBackend: Optional[str] = None   # additive key: "hip" (default) or "mahout" (the host falls back to the reference path: not available here)
 
@@ -103,6 +140,7 @@ class URAlgorithmParams:
             rankings=None if rk is None else [RankingParams(r.get("name"), r.get("type"), r.get("eventNames"), r.get("offsetDate"), r.get("endDate"),
                                                             r.get("duration")) for r in rk],
             numGPUs=p.get("numGPUs"), ccoBackend=p.get("ccoBackend"),
+            availableDateName=p.get("availableDateName"), expireDateName=p.get("expireDateName"), dateName=p.get("dateName"),
             appName=p.get("appName", ""), indexName=p.get("indexName", ""), typeName=p.get("typeName", ""),
             recsModel=p.get("recsModel"), eventNames=p.get("eventNames"),
             maxEventsPerEventType=p.get("maxEventsPerEventType"), maxCorrelatorsPerEventType=p.get("maxCorrelatorsPerEventType"),
@@ -136,6 +174,15 @@ class URAlgorithm:
         if ap.numGPUs is not None and ap.numGPUs < 0:
             raise ValueError("numGPUs must be >= 0 (0 = every visible GPU)")
         self.numGPUs = 1 if ap.numGPUs is None else int(ap.numGPUs)
+
+    @property
+    def dateNames(self) -> List[str]:
+        """:264-267: Seq(dateName, availableDateName, expireDateName).flatten.distinct -- what calcAll hands to URModel.save."""
+        out: List[str] = []
+        for n in (self.ap.dateName, self.ap.availableDateName, self.ap.expireDateName):
+            if n is not None and n not in out:
+                out.append(n)
+        return out
 
     @property
     def rankingsParams(self) -> List[RankingParams]:
