@@ -368,3 +368,59 @@ def test_stage_finish_protocol(sim_lib):
     assert lib.urcco_cross_occurrence_downsampled(arr, n, 3, C.byref(bad_opts), junk, None) == _lib.BAD_ARG
     assert all(not junk[d].row_ptr and junk[d].nnz == 0 for d in range(n))
     lib.urcco_shutdown()
+
+
+def test_one_shot_calls_from_two_threads_serialise(sim_lib):
+    """The one-shot entry points share one process-wide context; a build occupies it from its stage to its finish (the
+    lock was dropped between the two halves, so a second thread's stage failed -- or, with different options, destroyed the context
+    under the first thread's pending build).  Two threads now call urcco_cross_occurrence_downsampled at once, with DIFFERENT flags
+    (each call re-creates the default context): both must succeed and equal the oracle."""
+    import ctypes as C
+    import threading
+    from universal_recommender_amd import _lib
+    lib = sim_lib
+    lib.urcco_shutdown()
+    rng = np.random.default_rng(77)
+    jobs = []
+    for t in range(2):
+        mats = [rand_csr(rng, 3000, 400, 8, zipf_s=1.1), rand_csr(rng, 3000, 250, 12)]
+        jobs.append((mats, 11 + t, _lib.FLAG_UNORDERED_ROWS if t else 0))
+    results, errors = {}, {}
+
+    def run(t):
+        mats, seed, flags = jobs[t]
+        n = len(mats)
+        arr = (_lib.Dataset * n)()
+        for d, m in enumerate(mats):
+            arr[d].matrix.n_rows, arr[d].matrix.n_cols = m.n_rows, m.n_cols
+            arr[d].matrix.row_ptr, arr[d].matrix.col_idx = m.row_ptr.ctypes.data, m.col_idx.ctypes.data
+            arr[d].max_elements_per_row, arr[d].max_interesting_elements = 500, 50
+        opts = _lib.Options(device=0, row_rate_mode=0, n_gpus=1, flags=flags)
+        for rep in range(3):
+            out = (_lib.Indicators * n)()
+            st = lib.urcco_cross_occurrence_downsampled(arr, n, seed, C.byref(opts), out, None)
+            if st != _lib.OK:
+                errors[t] = (st, lib.urcco_last_error())
+                return
+            got = []
+            for d in range(n):
+                o = out[d]
+                nnz = int(o.nnz)
+                got.append((np.ctypeslib.as_array(o.row_ptr, shape=(o.n_rows + 1,)).copy(), np.ctypeslib.as_array(o.col_idx, shape=(max(nnz, 1),))[:nnz].copy(),
+                            np.ctypeslib.as_array(o.llr, shape=(max(nnz, 1),))[:nnz].copy()))
+            lib.urcco_free_indicators(out, n)
+            results[t] = got
+
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    assert not any(th.is_alive() for th in threads), "a one-shot call never returned"
+    assert not errors, errors
+    from helpers import sort_rows
+    for t, (mats, seed, flags) in enumerate(jobs):
+        ref = O.cross_occurrence_downsampled(mats, [P()] * len(mats), seed)
+        for got, r in zip(results[t], ref):
+            check_indicators(sort_rows(got) if flags else got, r)
+    lib.urcco_shutdown()

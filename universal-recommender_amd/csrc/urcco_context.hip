@@ -1062,6 +1062,7 @@ std::mutex g_default_mu;
 // "previous staged build has not been finished" or, with different options, destroyed the context under the pending build -- ADVICE r03).
 std::condition_variable g_default_cv;
 bool g_default_busy = false;
+std::thread::id g_default_owner;  // the thread whose staged build occupies the context
 urcco_context* g_default_ctx = nullptr;
 int g_default_n_gpus = -1, g_default_device = -1, g_default_mode = -1, g_default_flags = 0;
 
@@ -1561,11 +1562,15 @@ int urcco_cross_occurrence_stage(const urcco_dataset* datasets, int32_t n_datase
   return guarded([&]() -> int {
     err_buf()[0] = 0;
     std::unique_lock<std::mutex> g(g_default_mu);
+    // the same thread staging twice is a protocol error (waiting for itself would never end); another thread's build is waited for
+    if (g_default_busy && g_default_owner == std::this_thread::get_id())
+      return fail(URCCO_BAD_ARG, "urcco_cross_occurrence_stage: the previous staged build has not been finished");
     g_default_cv.wait(g, [] { return !g_default_busy; });
     urcco_context* c = nullptr;
     URC(default_context(options, &c));
     const int st = urcco_context_stage(c, datasets, n_datasets, random_seed);
     g_default_busy = st == URCCO_OK;  // released by the matching urcco_cross_occurrence_finish
+    if (g_default_busy) g_default_owner = std::this_thread::get_id();
     return st;
   });
 }
