@@ -48,7 +48,7 @@ static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorNoDevice = 100, hipErrorInvalidDevice = 101, hipErrorInvalidHandle = 400,
+enum { hipErrorNotReady = 600, hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1, hipErrorNoDevice = 100, hipErrorInvalidDevice = 101, hipErrorInvalidHandle = 400,
        hipErrorUnknown = 999 };
 // Devices are modelled as far as the host code can get them wrong: every thread has a current device, streams and events
 // belong to the device that was current when they were created, an event may only be recorded on a stream of its own device
@@ -293,6 +293,7 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t st = nullptr) 
   return hipSuccess;
 }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }  // the simulator executes synchronously: every recorded event has completed
 static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
   *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
   return hipSuccess;

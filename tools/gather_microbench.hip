@@ -21,6 +21,28 @@ __device__ __forceinline__ unsigned mix(unsigned x) {
 }
 
 // Every thread: ITERS rounds of K loads; load q of a round is issued only by lanes whose coin for (round, q) is below `active256`.
+// the same with every lane of a wave inside a window of `window` consecutive entries (window = 1: one address for the whole wave):
+// what the SpGEMM's score phase does when it reads xLogX at k11 (a handful of small integers) and at cA - k11
+template <typename T, int K>
+__global__ __launch_bounds__(256) void window_kernel(const T* __restrict__ tab, unsigned mask, int iters, unsigned window, unsigned long long* __restrict__ out) {
+  const unsigned gid = blockIdx.x * 256 + threadIdx.x;
+  unsigned s = mix(gid * 2654435761u + 12345u);
+  unsigned sw = mix((gid >> 6) * 40503u + 7u);  // per wave
+  unsigned long long acc = 0;
+  for (int it = 0; it < iters; ++it) {
+    unsigned v[K];
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      s = s * 1664525u + 1013904223u;
+      sw = sw * 1664525u + 1013904223u;
+      v[q] = (unsigned)tab[((mix(sw) & mask) & ~(window - 1u)) + (mix(s) & (window - 1u))];
+    }
+#pragma unroll
+    for (int q = 0; q < K; ++q) acc += v[q];
+  }
+  if (acc == 0x123456789abcull) out[0] = acc;
+}
+
 template <typename T, int K>
 __global__ __launch_bounds__(256) void gather_kernel(const T* __restrict__ tab, unsigned mask, int iters, unsigned active256, unsigned long long* __restrict__ out) {
   const unsigned gid = blockIdx.x * 256 + threadIdx.x;
@@ -149,6 +171,25 @@ int main(int argc, char** argv) {
       }
       CK(hipFree(tab));
     }
+  }
+  if (only == "all" || only == "window") {
+    double* tab;
+    const size_t n = 4096;  // the xLogX table: 32 KB of doubles
+    CK(hipMalloc(&tab, n * 8));
+    CK(hipMemset(tab, 0, n * 8));
+    for (unsigned window : {1u, 4u, 16u, 64u, 512u, 4096u}) {
+      float ms = 0;
+      for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((window_kernel<double, K>), dim3(blocks), dim3(256), 0, 0, tab, (unsigned)(n - 1), iters, window, out);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        ms = time_ms(e0, e1);
+      }
+      printf("{\"test\": \"window_f64_32KB_table\", \"lanes_within_entries\": %u, \"ms\": %.4f, \"G_lookups_per_s\": %.1f, \"cycles_per_wave_instr_per_cu\": %.1f}\n", window, ms,
+             loads / ms / 1e6, ms * 1e-3 * 2.4e9 * n_cu / (loads / 64));
+    }
+    CK(hipFree(tab));
   }
   if (only == "all" || only == "lds") {
     unsigned char* tab;

@@ -88,43 +88,16 @@ __device__ __forceinline__ double column_entropy_tab(long long cb, double xlx_n,
                                                      const double* __restrict__ xlx_hi) {
   return (xlx_n - x_log_x_tab(cb, xlx_tab)) - x_log_x_hi(n_users - cb, n_users, xlx_hi, xlx_tab);
 }
+// ... or, for the counts the interaction cut leaves (below the table size), from the per-build table of that very expression
+__device__ __forceinline__ double column_entropy_of(long long cb, double xlx_n, long long n_users, const double* __restrict__ xlx_tab,
+                                                    const double* __restrict__ xlx_hi, const double* __restrict__ col_ent) {
+  return (col_ent != nullptr && cb < (long long)XLX_TABLE) ? col_ent[cb] : column_entropy_tab(cb, xlx_n, n_users, xlx_tab, xlx_hi);
+}
 __device__ __forceinline__ double llr_from_entropies_tab(double row_entropy, double column_entropy, double xlx_n, long long k11, long long k12,
                                                          long long k21, long long k22, const double* __restrict__ xlx_tab,
                                                          long long n_users, const double* __restrict__ xlx_hi) {
   const double matrix_entropy =
       (((xlx_n - x_log_x_tab(k11, xlx_tab)) - x_log_x_tab(k12, xlx_tab)) - x_log_x_tab(k21, xlx_tab)) - x_log_x_hi(k22, n_users, xlx_hi, xlx_tab);
-  const double s = row_entropy + column_entropy;
-  if (s < matrix_entropy) return 0.0; /* round off error */
-  return 2.0 * (s - matrix_entropy);
-}
-
-// The same lookups with the HEAD of both tables resident in LDS (round 4).  A candidate's score reads xLogX at k21 = cB - k11, at
-// k22 (through N - k22 = cA + cB - k11), at cB and at N - cB: four 8-byte gathers whose addresses differ from lane to lane, and a
-// scattered global load costs the CU's address unit ~2 cycles per ACTIVE LANE whatever the table's size
-// (profiles/r04_gather_microbench.json) -- the SpGEMM classes were bound by exactly that unit.  After the interaction cut the
-// arguments are below a few hundred: XL entries of each table in LDS (same bits: copied from the global tables) serve them from
-// the LDS pipe (~10x the lookup rate); larger arguments fall back to the global table, then to the logarithm.
-struct XlxLds {
-  const double* tab;  // LDS: xlx_tab[0 .. n)
-  const double* hi;   // LDS: xlx_hi[0 .. n)
-  int n;
-};
-__device__ __forceinline__ double x_log_x_tab_l(long long x, const XlxLds& l, const double* __restrict__ xlx_tab) {
-  return x < (long long)l.n ? l.tab[x] : x_log_x_tab(x, xlx_tab);
-}
-__device__ __forceinline__ double x_log_x_hi_l(long long x, long long n_users, const XlxLds& l, const double* __restrict__ xlx_hi, const double* __restrict__ xlx_tab) {
-  const long long d = n_users - x;
-  return (d >= 0 && d < (long long)l.n) ? l.hi[d] : x_log_x_hi(x, n_users, xlx_hi, xlx_tab);
-}
-__device__ __forceinline__ double column_entropy_tab_l(long long cb, double xlx_n, long long n_users, const XlxLds& l, const double* __restrict__ xlx_tab,
-                                                       const double* __restrict__ xlx_hi) {
-  return (xlx_n - x_log_x_tab_l(cb, l, xlx_tab)) - x_log_x_hi_l(n_users - cb, n_users, l, xlx_hi, xlx_tab);
-}
-__device__ __forceinline__ double llr_from_entropies_tab_l(double row_entropy, double column_entropy, double xlx_n, long long k11, long long k12, long long k21,
-                                                           long long k22, const XlxLds& l, const double* __restrict__ xlx_tab, long long n_users,
-                                                           const double* __restrict__ xlx_hi) {
-  const double matrix_entropy = (((xlx_n - x_log_x_tab_l(k11, l, xlx_tab)) - x_log_x_tab_l(k12, l, xlx_tab)) - x_log_x_tab_l(k21, l, xlx_tab)) -
-                                x_log_x_hi_l(k22, n_users, l, xlx_hi, xlx_tab);
   const double s = row_entropy + column_entropy;
   if (s < matrix_entropy) return 0.0; /* round off error */
   return 2.0 * (s - matrix_entropy);

@@ -39,6 +39,7 @@ struct CcoArgs {
   const double* xlx_n;       // [1] xLogX(N)
   const double* xlx_tab;     // [XLX_TABLE_HOST] xLogX of small integers
   const double* xlx_hi;      // [XLX_TABLE_HOST] xLogX(n_users - d): the k22 term without a logarithm
+  const double* col_ent;     // [XLX_TABLE_HOST] columnEntropy of a column with d interactions, for the N of the build (behind xlx_hi in the same allocation)
   int32_t debug;             // ablation switches for profiling (0 in production): 1 = gather only, 2 = no LLR, 4 = no top-k
   long long n_users;
   int32_t n_cols_b;
@@ -137,7 +138,7 @@ hipError_t launch_pop_counts(hipStream_t st, int n_cu, int64_t n, const int32_t*
                              const int64_t* bounds, int32_t* counts);
 
 hipError_t launch_xlx_table(hipStream_t st, double* tab);
-hipError_t launch_xlx_hi_table(hipStream_t st, double* tab, long long n_users);
+hipError_t launch_xlx_hi_table(hipStream_t st, double* tab /*[2 * XLX_TABLE_HOST]: xlx_hi, then col_ent*/, const double* xlx_tab, long long n_users);
 hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, double* xlx_n);
 // out16[i] = counts[i] (low 16 bits); bad[0] = number of counts that do not fit
 hipError_t launch_narrow_counts(hipStream_t st, int n_cu, const int32_t* counts, int32_t n, unsigned short* out16, int32_t* bad);

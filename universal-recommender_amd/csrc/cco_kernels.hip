@@ -1325,13 +1325,20 @@ hipError_t launch_xlx_table(hipStream_t st, double* tab) {
   hipLaunchKernelGGL(xlx_table_kernel, dim3(XLX_TABLE / 256), dim3(256), 0, st, tab);
   return hipGetLastError();
 }
-// tab[d] = xLogX(n_users - d), d < XLX_TABLE (entries with n_users - d < 0 are never read)
-__global__ __launch_bounds__(256) void xlx_hi_table_kernel(double* __restrict__ tab, long long n_users) {
+// tab[d] = xLogX(n_users - d), d < XLX_TABLE (entries with n_users - d < 0 are never read); behind it
+// tab[XLX_TABLE + c] = columnEntropy of a column with c interactions = entropy(c, N - c), evaluated by column_entropy_tab -- the very
+// expression the row kernels evaluated per candidate until round 4 (two scattered 8-byte table reads and two subtractions; now one read:
+// the CU's address unit, not the arithmetic, is what a candidate's score costs -- profiles/r04_gather_microbench.json)
+__global__ __launch_bounds__(256) void xlx_hi_table_kernel(double* __restrict__ tab, const double* __restrict__ xlx_tab, long long n_users) {
   const int d = blockIdx.x * 256 + threadIdx.x;
-  if (d < XLX_TABLE) tab[d] = n_users - d >= 0 ? x_log_x(n_users - (long long)d) : 0.0;
+  if (d >= XLX_TABLE) return;
+  tab[d] = n_users - d >= 0 ? x_log_x(n_users - (long long)d) : 0.0;
+  // columnEntropy(c) reads xlx_hi[c] = xLogX(N - c): the value this thread has just produced (x_log_x_hi falls back to the same formula)
+  const double hi = n_users - d >= 0 ? x_log_x(n_users - (long long)d) : 0.0;
+  tab[XLX_TABLE + d] = d <= n_users ? (x_log_x(n_users) - x_log_x_tab((long long)d, xlx_tab)) - hi : 0.0;
 }
-hipError_t launch_xlx_hi_table(hipStream_t st, double* tab, long long n_users) {
-  hipLaunchKernelGGL(xlx_hi_table_kernel, dim3(XLX_TABLE / 256), dim3(256), 0, st, tab, n_users);
+hipError_t launch_xlx_hi_table(hipStream_t st, double* tab, const double* xlx_tab, long long n_users) {
+  hipLaunchKernelGGL(xlx_hi_table_kernel, dim3(XLX_TABLE / 256), dim3(256), 0, st, tab, xlx_tab, n_users);
   return hipGetLastError();
 }
 
@@ -1857,20 +1864,6 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 // from the row's work (1.25 x the expected distinct columns per pass must fit) and doubles whenever a pass still overflows --
 // at the latest when ceil(n_cols / P) columns are GUARANTEED to fit, so every row ends.  Round 2 served these rows from dense
 // counters in global memory (n_cols x 16 B of scratch per resident block, L2 atomics): 35.9 ms for 16K rows of config 5.
-// entries of the xLogX tables every block keeps in LDS (cco_device.h: XlxLds); 0 = every lookup goes to the global tables (round 3)
-#ifndef URCCO_XLX_LDS
-#define URCCO_XLX_LDS 0
-#endif
-constexpr int XLX_LDS = URCCO_XLX_LDS;
-template <int N>
-__device__ __forceinline__ void fill_xlx_lds(double* s_xlx, double* s_xlx_hi, const CcoArgs& a, int n_threads) {
-  for (int x = threadIdx.x; x < N; x += n_threads) {
-    s_xlx[x] = a.xlx_tab[x];
-    s_xlx_hi[x] = a.xlx_hi[x];
-  }
-  __syncthreads();
-}
-
 template <int T, int E, int U, bool MP = false>
 __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T == 256 && E == 4096 ? 7 : 1))) void cco_rows_kernel(CcoArgs a, int bin) {
   constexpr int BLOCK = T < 256 ? 256 : T;
@@ -1917,10 +1910,6 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   __shared__ unsigned s_mpflag;                    // MP: a pass overflowed its table
   __shared__ unsigned long long s_runk[MP ? 2 * MP_KMAX : 1];  // MP: the row's running top k (two buffers: a merge reads one, writes the other)
   __shared__ unsigned s_runc[MP ? 2 * MP_KMAX : 1];
-  constexpr int XL = T == 1024 ? 0 : XLX_LDS;  // the whole-CU classes have no LDS to spare (a 128 KB table); their rows are few
-  __shared__ double s_xlx[XL > 0 ? XL : 1], s_xlx_hi[XL > 0 ? XL : 1];
-  if (XL > 0) fill_xlx_lds<XL>(s_xlx, s_xlx_hi, a, BLOCK);
-  const XlxLds xl{s_xlx, s_xlx_hi, XL};
 
   const int team = TEAMS == 1 ? 0 : uni((int)threadIdx.x / T);  // a team is one wave (T == 64) or the whole block
   const int tl = threadIdx.x % T;
@@ -2143,9 +2132,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             unsigned long long key = 0ull;
             if (!(a.exclude_self && j == i)) {
               const double llr = (a.debug & 2) ? (double)k11
-                                               : llr_from_entropies_tab_l(row_entropy, column_entropy_tab_l((long long)cbj[x], xlx_n, a.n_users, xl, a.xlx_tab, a.xlx_hi), xlx_n, k11,
-                                                                          ca - k11, (long long)cbj[x] - k11, a.n_users - ca - (long long)cbj[x] + k11, xl, a.xlx_tab, a.n_users,
-                                                                          a.xlx_hi);
+                                               : llr_from_entropies_tab(row_entropy, column_entropy_of((long long)cbj[x], xlx_n, a.n_users, a.xlx_tab, a.xlx_hi, a.col_ent), xlx_n, k11,
+                                                                        ca - k11, (long long)cbj[x] - k11, a.n_users - ca - (long long)cbj[x] + k11, a.xlx_tab, a.n_users,
+                                                                        a.xlx_hi);
               if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
             }
             kk[t] = key;
@@ -2474,9 +2463,6 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
   __shared__ unsigned s_tab[TEAMS * MICRO_WORDS];
   __shared__ long long s_ustart[TEAMS * WAVE];
   __shared__ unsigned s_uoff[TEAMS * (WAVE + 1)];
-  __shared__ double s_xlx[XLX_LDS > 0 ? XLX_LDS : 1], s_xlx_hi[XLX_LDS > 0 ? XLX_LDS : 1];
-  if (XLX_LDS > 0) fill_xlx_lds<XLX_LDS>(s_xlx, s_xlx_hi, a, 256);
-  const XlxLds xl{s_xlx, s_xlx_hi, XLX_LDS};
   // (moving the row id, bounds and counts to scalar registers as in cco_rows_kernel was measured 12 % SLOWER here: the kernel
   // argument block alone keeps ~60 SGPRs live and the extra scalars spill to VGPR lanes)
   const int team = threadIdx.x / WAVE;
@@ -2579,8 +2565,8 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
       if (!(a.exclude_self && j == i)) {
         const long long cbj = (a.debug & 512) ? 100ll : (use16 ? (long long)a.cnt_b16[j] : (long long)a.cnt_b[j]);
         const double llr = (a.debug & 2) ? (double)k11
-                                         : llr_from_entropies_tab_l(row_entropy, column_entropy_tab_l(cbj, xlx_n, a.n_users, xl, a.xlx_tab, a.xlx_hi), xlx_n, k11, ca - k11,
-                                                                    cbj - k11, a.n_users - ca - cbj + k11, xl, a.xlx_tab, a.n_users, a.xlx_hi);
+                                         : llr_from_entropies_tab(row_entropy, column_entropy_of(cbj, xlx_n, a.n_users, a.xlx_tab, a.xlx_hi, a.col_ent), xlx_n, k11, ca - k11,
+                                                                  cbj - k11, a.n_users - ca - cbj + k11, a.xlx_tab, a.n_users, a.xlx_hi);
         if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
           mk = (unsigned long long)__double_as_longlong(llr);
           mc = j;
@@ -2670,7 +2656,7 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
         const long long k11 = atomicExch(&cnt[j], 0);  // exactly one lane claims (and clears) each column
         if (k11 > 0 && !(a.exclude_self && j == i)) {
           const long long cbj = a.cnt_b[j];
-          const double llr = llr_from_entropies_tab(row_entropy, column_entropy_tab(cbj, xlx_n, a.n_users, a.xlx_tab, a.xlx_hi), xlx_n, k11, ca - k11, cbj - k11,
+          const double llr = llr_from_entropies_tab(row_entropy, column_entropy_of(cbj, xlx_n, a.n_users, a.xlx_tab, a.xlx_hi, a.col_ent), xlx_n, k11, ca - k11, cbj - k11,
                                                     a.n_users - ca - cbj + k11, a.xlx_tab, a.n_users, a.xlx_hi);
           if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
             const int pos = atomicAdd(&s_ncand, 1);

@@ -428,9 +428,9 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
     HIPC(hipMalloc((void**)&s->xlx_tab, sizeof(double) * urcco::XLX_TABLE_HOST));
     HIPC(urcco::launch_xlx_table(s->stream, s->xlx_tab));
   }
-  if (!s->xlx_hi) HIPC(hipMalloc((void**)&s->xlx_hi, sizeof(double) * urcco::XLX_TABLE_HOST));
+  if (!s->xlx_hi) HIPC(hipMalloc((void**)&s->xlx_hi, sizeof(double) * 2 * urcco::XLX_TABLE_HOST));  // xLogX(N - d), then columnEntropy(c)
   if (s->xlx_hi_n != n_users) {
-    HIPC(urcco::launch_xlx_hi_table(s->stream, s->xlx_hi, n_users));
+    HIPC(urcco::launch_xlx_hi_table(s->stream, s->xlx_hi, s->xlx_tab, n_users));
     s->xlx_hi_n = n_users;
   }
   const int64_t n_tiles = ((int64_t)n + urcco::BIN_TILE - 1) / urcco::BIN_TILE;
@@ -478,7 +478,7 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
   urcco::CcoArgs a;
   a.bin_rows = bin_rows; a.bin_off = bin_off;
   a.a_col_ptr = a_col_ptr; a.pstart = pstart; a.wp = wp; a.b_col_idx = b_col_idx;
-  a.cnt_a = counts_a; a.cnt_b = counts_b; a.ent_a = ent_a; a.cnt_b16 = cnt_b16; a.cnt16_bad = cnt16_bad; a.xlx_n = xlx_n; a.xlx_tab = s->xlx_tab; a.xlx_hi = s->xlx_hi; a.debug = s->debug;
+  a.cnt_a = counts_a; a.cnt_b = counts_b; a.ent_a = ent_a; a.cnt_b16 = cnt_b16; a.cnt16_bad = cnt16_bad; a.xlx_n = xlx_n; a.xlx_tab = s->xlx_tab; a.xlx_hi = s->xlx_hi; a.col_ent = s->xlx_hi + urcco::XLX_TABLE_HOST; a.debug = s->debug;
   a.n_users = n_users; a.n_cols_b = n_cols_b; a.item_lo = item_lo; a.exclude_self = exclude_self ? 1 : 0; a.k = k;
   a.has_min_llr = has_min_llr ? 1 : 0; a.min_llr = min_llr; a.count_bits = count_bits;
   a.col_bytes = n_cols_b <= (1 << 8) ? 1 : (n_cols_b <= (1 << 16) ? 2 : (n_cols_b <= (1 << 24) ? 3 : 4));

@@ -377,6 +377,11 @@ struct PendingBuild {
   int build_st = URCCO_OK;
   std::string build_msg;
   bool build_deferred = false;  // several GPUs / exchange path: the build is issued by urcco_context_finish
+  // one GPU: every event type's results are brought to the host by the thread that enqueued its chain, the moment the chain ends --
+  // under the uploads and the SpGEMMs of the other event types (pinned blocks of the process-wide pool; handed out by finish)
+  std::vector<urcco_indicators> res;
+  std::vector<char> res_done;
+  void* stats_block = nullptr;  // pinned int64 [(URCCO_STATS_LEN + 1) * n_ds]: per-event statistics, then nnz' of B_d
   HostTrace trace;
   ~PendingBuild();
 };
@@ -526,6 +531,7 @@ int stage_rows(DevState& D, EvState& E, EvState& A, int d, const DsParams& pa, c
 // then lets a kernel consume the matrix.  The primary's chain and A'A thus run under the upload of the larger secondaries.
 struct InputGate {
   const HostTrace* trace = nullptr;
+  std::function<int(int)> after_chain;  // called by the thread that has just enqueued event type d's chain (see PendingBuild::res)
   std::vector<std::promise<int>> staged;
   std::vector<std::shared_future<int>> fut;
   std::vector<char> released;
@@ -576,7 +582,10 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
   // (start, length) record per user and writes every secondary's pstart / plen (one scattered sector per CSC entry instead of one
   // line per entry AND event type).  It runs on the first secondary's stream once every secondary has been sampled and A'
   // transposed; the primary's own A'A does not wait for it.  (debug 4096: every event type prepares its own, as in round 2.)
-  bool fuse = n_ds >= 3 && n_ds - 1 <= urcco::EXPAND_MULTI_MAX && !(c->debug & 4096);
+  // Not under the host level's gate: there the secondaries land one after the other over tens of milliseconds, and a pass that needs
+  // ALL of them sampled would hold every A'B_d back until the last upload has finished (measured on config 4, round 4: view's matrices
+  // landed at 63 ms, its chain was enqueued at 102 ms -- the fused pass saves 2 ms of GPU time and cost 40 ms of wall time).
+  bool fuse = n_ds >= 3 && n_ds - 1 <= urcco::EXPAND_MULTI_MAX && !(c->debug & 4096) && gate == nullptr;
   for (int d = 1; d < n_ds; ++d) fuse = fuse && sh[(size_t)d].nnz < ((int64_t)1 << 32);
   std::vector<std::promise<int>> sampled((size_t)n_ds);
   std::vector<std::shared_future<int>> sampled_f((size_t)n_ds);
@@ -622,6 +631,7 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
     E.b_nnz_bound = sh[(size_t)d].nnz;
     URC(stage_rows(D, E, A, d, ps_[0], ps_[(size_t)d], n_users, sh[0].nnz, fuse));
     if (gate && gate->trace) gate->trace->mark("chain enqueued", d);
+    if (gate && gate->after_chain) URC(gate->after_chain(d));
     return URCCO_OK;
   };
   // one enqueueing thread per secondary (see above); host-side hand-offs make sure an event has been RECORDED before a stream is
@@ -676,6 +686,7 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
     A.b_nnz_bound = sh[0].nnz;
     st = stage_rows(D, A, A, 0, ps_[0], ps_[0], n_users, sh[0].nnz);
     if (gate && gate->trace) gate->trace->mark("chain enqueued", 0);
+    if (st == URCCO_OK && gate && gate->after_chain) st = gate->after_chain(0);
   }
   for (std::thread& t : workers) t.join();
   if (st != URCCO_OK) return st;
@@ -1018,6 +1029,44 @@ PendingBuild::~PendingBuild() {
     for (size_t d = 0; d < gate->staged.size(); ++d)
       if (!gate->released[d]) gate->release((int)d, URCCO_INTERNAL);  // a builder still waiting must not wait forever
   if (builder.joinable()) builder.join();
+  for (urcco_indicators& o : res)  // results finish never handed out
+    for (void* p : {(void*)o.row_ptr, (void*)o.col_idx, (void*)o.llr})
+      if (p) (void)pinned_pool().put(p);
+  if (stats_block) (void)pinned_pool().put(stats_block);
+}
+
+// One event type's indicator matrix device -> pinned host memory, by the thread that enqueued its chain (single-GPU host level): the
+// slice's row_ptr and the statistics first, then -- its stream drained, the size known -- exactly nnz entries.
+int download_event(urcco_context* c, PendingBuild* pb, int d) {
+  DevState& D = c->devs[0];
+  URC(set_dev(D));
+  EvState& E = D.ev[(size_t)d];
+  urcco_indicators& o = pb->res[(size_t)d];
+  const int32_t n = D.item_hi - D.item_lo;  // one rank: every item row
+  int64_t* h_stats = static_cast<int64_t*>(pb->stats_block) + (size_t)d * URCCO_STATS_LEN;
+  int64_t* h_sampled = static_cast<int64_t*>(pb->stats_block) + (size_t)pb->n_ds * URCCO_STATS_LEN + (size_t)d;
+  o.n_rows = n;
+  o.n_cols = pb->ps[(size_t)d].n_cols;
+  o.row_ptr = (int64_t*)pinned_pool().get(sizeof(int64_t) * ((size_t)n + 1));
+  if (!o.row_ptr) return fail(URCCO_OOM_HOST, "pinned indicator row_ptr");
+  o.row_ptr[0] = 0;
+  if (n > 0) HIPC(hipMemcpyAsync(o.row_ptr + 1, E.c_rp.p + 1, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, E.s->stream));
+  HIPC(hipMemcpyAsync(h_stats, E.stats.p, sizeof(int64_t) * URCCO_STATS_LEN, hipMemcpyDeviceToHost, E.s->stream));
+  HIPC(hipMemcpyAsync(h_sampled, E.s_rp.p + pb->n_users, sizeof(int64_t), hipMemcpyDeviceToHost, E.s->stream));
+  HIPC(hipStreamSynchronize(E.s->stream));
+  pb->trace.mark("indicator row_ptr on the host", d);
+  o.nnz = n > 0 ? o.row_ptr[n] : 0;
+  o.col_idx = (int32_t*)pinned_pool().get(sizeof(int32_t) * (size_t)(o.nnz ? o.nnz : 1));
+  o.llr = (double*)pinned_pool().get(sizeof(double) * (size_t)(o.nnz ? o.nnz : 1));
+  if (!o.col_idx || !o.llr) return fail(URCCO_OOM_HOST, "pinned indicator arrays");
+  if (o.nnz > 0) {
+    HIPC(hipMemcpyAsync(o.col_idx, E.c_idx.p, sizeof(int32_t) * (size_t)o.nnz, hipMemcpyDeviceToHost, E.s->stream));
+    HIPC(hipMemcpyAsync(o.llr, E.c_llr.p, sizeof(double) * (size_t)o.nnz, hipMemcpyDeviceToHost, E.s->stream));
+    HIPC(hipStreamSynchronize(E.s->stream));
+  }
+  pb->trace.mark("indicator entries on the host", d);
+  pb->res_done[(size_t)d] = 1;
+  return URCCO_OK;
 }
 
 // pageable host memory -> device through the GPU's pinned ring, `max_threads` copy threads; every chunk's H2D is enqueued
@@ -1367,13 +1416,25 @@ int urcco_context_stage(urcco_context* c, const urcco_dataset* datasets, int32_t
       P->gate.reset(new InputGate(n_ds));
       P->gate->trace = &trace;
       PendingBuild* pb = P.get();
+      pb->res.assign((size_t)n_ds, urcco_indicators{});
+      pb->res_done.assign((size_t)n_ds, 0);
+      pb->stats_block = pinned_pool().get(sizeof(int64_t) * (URCCO_STATS_LEN + 1) * (size_t)n_ds);
+      if (!pb->stats_block) return fail(URCCO_OOM_HOST, "pinned statistics block");
+      memset(pb->stats_block, 0, sizeof(int64_t) * (URCCO_STATS_LEN + 1) * (size_t)n_ds);
+      pb->gate->after_chain = [c, pb](int d) { return download_event(c, pb, d); };
       pb->builder = std::thread([c, pb] {
         pb->build_st = guarded([&] { return run_build(c, pb->sh, pb->ps, pb->n_users, pb->seed, nullptr, pb->gate.get()); });
         if (pb->build_st != URCCO_OK) pb->build_msg = err_buf();
       });
       int stage_st = URCCO_OK;
       std::string stage_msg;
-      for (int d = 0; d < n_ds; ++d) {
+      // upload order: the primary, then the secondaries from the largest down -- the heaviest A'B_d starts first and runs under the
+      // remaining uploads, and what is still to come when the link goes quiet is the smallest chain and its few results (round 3
+      // staged in index order: on config 4 the largest secondary's SpGEMM and 2.2 GB of finished results waited behind the uploads)
+      std::vector<int> order((size_t)n_ds);
+      for (int d = 0; d < n_ds; ++d) order[(size_t)d] = d;
+      std::stable_sort(order.begin() + 1, order.end(), [&](int a, int b) { return P->nnz_raw[(size_t)a] > P->nnz_raw[(size_t)b]; });
+      for (int d : order) {
         if (stage_st == URCCO_OK) {
           stage_st = guarded([&] { return stage_event(d); });
           if (stage_st != URCCO_OK) stage_msg = err_buf();
@@ -1429,6 +1490,25 @@ int urcco_context_finish(urcco_context* c, urcco_indicators* out, urcco_dataset_
       if (P->builder.joinable()) P->builder.join();
       trace.mark("build enqueued");
       if (P->build_st != URCCO_OK) return fail(P->build_st, "%s", P->build_msg.c_str());
+      if (!P->res.empty()) {  // one GPU: every event type's thread has already brought its results over (download_event)
+        const int64_t* hs = static_cast<const int64_t*>(P->stats_block);
+        for (int d = 0; d < n_ds; ++d) {
+          if (!P->res_done[(size_t)d]) return fail(URCCO_INTERNAL, "event type %d: results were not downloaded", d);
+          out[d] = P->res[(size_t)d];
+          P->res[(size_t)d] = urcco_indicators{};  // the blocks now belong to the caller
+          if (stats) {
+            urcco_dataset_stats& st = stats[d];
+            const int64_t* h = hs + (size_t)d * URCCO_STATS_LEN;
+            st.nnz_raw = P->nnz_raw[(size_t)d];
+            st.nnz_out = out[d].nnz;
+            st.pairs = h[0];
+            for (int b = 0; b < URCCO_N_BINS; ++b) st.rows_by_bin[b] = h[1 + (size_t)b];
+            st.nnz_sampled = hs[(size_t)n_ds * URCCO_STATS_LEN + (size_t)d];
+          }
+        }
+        trace.mark("return");
+        return URCCO_OK;
+      }
     }
     // ---- results: row_ptr of every GPU's slice first (small), then exactly nnz entries each
     const int32_t n_items_a = (int32_t)ps[0].n_cols;
@@ -1463,7 +1543,30 @@ int urcco_context_finish(urcco_context* c, urcco_indicators* out, urcco_dataset_
         HIPC(hipEventRecord(E.ev_rp, E.s->stream));
       }
     }
-    for (int d = 0; d < n_ds; ++d) {
+    // The entries of an event type leave the moment ITS row_ptr has arrived, in the order the event types finish -- not in
+    // index order: round 3 waited for event 1 (the heaviest: `view`) before it even asked for the rows of events 2.., which had been
+    // ready for tens of milliseconds on config 4 (their 2.2 GB now cross the link under view's SpGEMM).
+    std::vector<char> fetched((size_t)n_ds, 0);
+    for (int done = 0; done < n_ds; ++done) {
+      int d = -1;
+      for (unsigned spin = 0; d < 0; ++spin) {
+        for (int e = 0; e < n_ds && d < 0; ++e) {
+          if (fetched[(size_t)e]) continue;
+          bool ready = true;
+          for (size_t g = 0; g < L && ready; ++g) {
+            URC(set_dev(c->devs[g]));
+            const hipError_t q = hipEventQuery(c->devs[g].ev[(size_t)e].ev_rp);
+            if (q == hipErrorNotReady) ready = false;
+            else if (q != hipSuccess) return hip_fail(q, "hipEventQuery(ev_rp)");
+          }
+          if (ready) d = e;
+        }
+        if (d < 0) {
+          if (spin < 64) std::this_thread::yield();
+          else std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+      }
+      fetched[(size_t)d] = 1;
       urcco_indicators& o = out[d];
       std::vector<int64_t> base(L + 1, 0);
       for (size_t g = 0; g < L; ++g) {
