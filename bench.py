@@ -59,6 +59,19 @@ NAMES = {"config3": "config3: synthetic 1M users x 200K items, Zipf-1.0, purchas
          "config5": "config5: synthetic 10M x 2M skewed (top 0.1 % of the items = 40 % of the interactions, 1 % heavy users x50), 5 event types, indicators form"}
 
 
+def kernel_source_id() -> str:
+    """Identity of the kernel sources the in-tree library is built from: sha256 over csrc/*, first 16 hex digits.  The PMC traffic file
+    under profiles/ records the id it was collected on (tools/r04_measure.sh); a file with another id is not quoted."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "universal-recommender_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes(stage: str, f: dict) -> float:
     """Algorithmic HBM bytes of one launch of a stage (int32 indices, implicit values; L2-resident gathers
     of per-column counts are not counted).  f = per-event-type facts."""
@@ -501,14 +514,20 @@ def measure(job: Job, args, full: bool):
     dominant = max(timed, key=lambda k: timed[k]["ms_per_step"])
     dk = timed[dominant]
     launches = max(dk["launches_per_step"], 1)
-    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot wrap the process it runs in)
+    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot wrap the process it runs in).  The file must have
+    # been collected on THESE kernel sources (kernel_source_id), else no traffic is quoted (round 3 quoted a stale one).
     traffic, traffic_src = None, None
-    for tpath in (os.path.join(ROOT, "profiles", f"r03_hbm_traffic_pmc_{job.workload}.json"),):
+    for tpath in (os.path.join(ROOT, "profiles", f"r04_hbm_traffic_pmc_{job.workload}.json"),):
         if world == 1 and n_local == 1 and args.scale == 1.0 and os.path.exists(tpath) and dominant in STAGE_TO_KERNEL:
-            tk = json.load(open(tpath))["kernels"].get(STAGE_TO_KERNEL[dominant])
+            tj = json.load(open(tpath))
+            if tj.get("kernel_source_id") != kernel_source_id():
+                traffic_src = f"{os.path.relpath(tpath, ROOT)} was collected on kernel sources {tj.get('kernel_source_id')}, this library is {kernel_source_id()}: not quoted"
+                continue
+            tk = tj["kernels"].get(STAGE_TO_KERNEL[dominant])
             if tk and "hbm_bytes_per_launch" in tk:
                 traffic = tk["hbm_bytes_per_launch"]
-                traffic_src = os.path.relpath(tpath, ROOT) + " ((2*FETCH_SIZE + WRITE_SIZE) KB -> bytes, two separate --pmc passes on this workload)"
+                traffic_src = (os.path.relpath(tpath, ROOT) + f" (kernel sources {tj['kernel_source_id']}; ({tk['fetch_factor']} * FETCH_SIZE + WRITE_SIZE) KB -> bytes, two separate --pmc "
+                               f"passes on this workload; FETCH_SIZE factor: {tk['fetch_factor_kind']}, profiles/r04_fetch_size_calibration.json)")
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": dk["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(dk["GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "bytes_per_launch": round(dk["alg_MB_per_step"] * 1e6 / launches), "avg_launch_ms": round(dk["ms_per_step"] / launches, 4)}

@@ -174,9 +174,18 @@ def test_one_process_drives_several_gpus(sim_lib, n_gpus, primary, monkeypatch):
             check_indicators((rp, np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])), r, exact_ids=True)
             assert sum(int(ind.stats[0]) for ind in res[d]) == r.pairs
             full = O.downsample(mats[d], O.column_counts(mats[d]), 2024, params[d].max_elements_per_row)
-            for ind in res[d]:                                            # every GPU holds the whole down-sampled B
-                assert np.array_equal(ind.sampled_row_ptr.numpy(), full.row_ptr)
-                assert np.array_equal(ind.sampled_col_idx.numpy()[:full.nnz], full.col_idx)
+            for ind in res[d]:
+                if primary == "gathered":                                 # every GPU holds the whole down-sampled B
+                    assert np.array_equal(ind.sampled_row_ptr.numpy(), full.row_ptr)
+                    assert np.array_equal(ind.sampled_col_idx.numpy()[:full.nnz], full.col_idx)
+                else:       # row-filtered exchange: a GPU holds the rows of the users its item range touches -- whole -- and empty rows for the others
+                    rp_g, ci_g = ind.sampled_row_ptr.numpy(), ind.sampled_col_idx.numpy()
+                    lens_g, lens_f = np.diff(rp_g), np.diff(full.row_ptr)
+                    assert np.all((lens_g == lens_f) | (lens_g == 0))
+                    held = np.nonzero(lens_g)[0]
+                    assert np.array_equal(ci_g[:rp_g[-1]], np.concatenate([full.col_idx[full.row_ptr[u]:full.row_ptr[u + 1]] for u in held] + [np.zeros(0, np.int32)]))
+                    if n_gpus >= 3 and d == 1:
+                        assert 0 < held.size < np.count_nonzero(lens_f), "the filter must drop some rows and keep some"
         # host level on the same context
         n = len(mats)
         arr = (_lib.Dataset * n)()
@@ -197,16 +206,23 @@ def test_one_process_drives_several_gpus(sim_lib, n_gpus, primary, monkeypatch):
             assert stats[d].pairs == r.pairs and stats[d].nnz_out == nnz and stats[d].nnz_raw == mats[d].nnz
         sim_lib.urcco_free_indicators(out, n)
         assert coll.error is None
-        # what travelled: the primary's CSC as an all-to-all of fragments (16-bit column lengths, then entries), row lengths as 16 bits
+        # what travelled
         a2a = [e for e in coll.log if e[0] == "aa"]
         if primary == "fragments":
-            assert len(a2a) == 2 * 2 * n_gpus                            # two builds x (lengths, entries) x ranks
-            assert sum(a2a[0][2]) == 2 * mats[0].n_cols                  # rank 0 sends every column's length once, as uint16
+            # per build and rank: the primary's CSC as fragments (16-bit column lengths, then entries) + per event type the row-filtered
+            # exchange (masked row lengths to every destination, then the rows a destination may see)
+            assert len(a2a) == 2 * n_gpus * (2 + 2 * len(mats))
+            assert any(e[1] == 0 and sum(e[2]) == 2 * mats[0].n_cols for e in a2a)   # rank 0 sends every column's length once, as uint16
+            assert a2a[0] == ("aa", 0, (2 * 100,) * n_gpus)                          # rank 0's 100 masked row lengths to every rank, as uint16
             sampled = O.downsample(mats[0], O.column_counts(mats[0]), 2024, params[0].max_elements_per_row)
-            assert sum(sum(e[2]) for e in a2a[n_gpus:2 * n_gpus]) == 4 * sampled.nnz   # the entries of A' cross the wire exactly once
+            cols0 = [sum(e[2]) for e in a2a[n_gpus:2 * n_gpus]]                      # A' rows as packed per destination (first event type, first build)
+            assert 4 * sampled.nnz <= sum(cols0) + 4 * int((np.diff(sampled.row_ptr) == 0).sum()) and sum(cols0) <= n_gpus * 4 * sampled.nnz
+            if n_gpus >= 3:
+                assert sum(cols0) < n_gpus * 4 * sampled.nnz, "not every row goes to every rank"
+            assert not any(e[0] == "ag" and e[2] == 4 * sampled.nnz for e in coll.log)   # no all-gather of whole matrices any more
         else:
             assert not a2a
-        assert any(e[0] == "ag" and e[2] == 2 * 100 for e in coll.log)     # rank 0's 100 row lengths of one event type, as uint16
+            assert any(e[0] == "ag" and e[2] == 2 * 100 for e in coll.log)     # rank 0's 100 row lengths of one event type, as uint16
     finally:
         ctx.close()
 
@@ -250,10 +266,10 @@ def test_exchange_falls_back_to_32_bit_lengths(sim_lib, monkeypatch):
             check_indicators((full_rp, np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])), r, exact_ids=True)
         assert coll.error is None
         a2a = [e for e in coll.log if e[0] == "aa"]
-        assert sum(a2a[0][2]) == 4 * n_a                                   # int32 column lengths
-        ag = [e for e in coll.log if e[0] == "ag"]
-        assert any(e[1] == 0 and e[2] == 2 * 72_000 for e in ag)           # the primary's row lengths as uint16 ...
-        assert any(e[1] == 0 and e[2] == 4 * 72_000 for e in ag)           # ... the secondary's as int32
+        assert any(e[1] == 0 and sum(e[2]) == 4 * n_a for e in a2a)        # the fragments' column lengths as int32
+        assert not any(e[1] == 0 and sum(e[2]) == 2 * n_a for e in a2a)
+        assert any(e[1] == 0 and e[2] == (2 * 72_000,) * n_gpus for e in a2a)   # the primary's (masked) row lengths as uint16 ...
+        assert any(e[1] == 0 and e[2] == (4 * 72_000,) * n_gpus for e in a2a)   # ... the secondary's as int32
     finally:
         ctx.close()
 
@@ -424,3 +440,53 @@ def test_one_shot_calls_from_two_threads_serialise(sim_lib):
         for got, r in zip(results[t], ref):
             check_indicators(sort_rows(got) if flags else got, r)
     lib.urcco_shutdown()
+
+
+def test_row_filtered_exchange_volume_at_8_ranks(sim_lib, monkeypatch):
+    """at 8 ranks a rank must receive clearly less than the all-gather of every down-sampled matrix.  BASELINE config 4's
+    generator at 1/100 (100K users, 5 event types), 8 simulated GPUs in one process, the collectives' log as the wire: with the
+    row-filtered exchange (default) every rank receives <= 0.6 x what the all-gather form (debug 16384) delivers to it -- B' rows travel
+    only to the ranks whose item range their user touches -- and both builds equal the oracle."""
+    from universal_recommender_amd import sharded, synth
+    from universal_recommender_amd.device import Context
+    W = 8
+    monkeypatch.setenv("HIPSIM_DEVICE_COUNT", str(W))
+    cfg = synth.config4(0.01)
+    data = synth.generate(cfg)
+    mats = [O.Csr(cfg.n_users, nc, rp, ci) for (_, nc, rp, ci) in data]
+    params = [P()] * len(mats)
+    ref = O.cross_occurrence_downsampled(mats, params, 7)
+    cuts = [cfg.n_users * g // W for g in range(W + 1)]
+    shards = [[to_dev(O.Csr(hi - lo, m.n_cols, m.row_ptr[lo:hi + 1] - m.row_ptr[lo], m.col_idx[m.row_ptr[lo]:m.row_ptr[hi]]), "cpu")
+               for lo, hi in zip(cuts, cuts[1:])] for m in mats]
+    received = {}
+    for mode, debug in (("filtered", 0), ("all-gather", 16384)):
+        coll = sharded.TorchCollectives(W, list(range(W)))
+        ctx = Context(torch.device("cpu"), sim_lib, n_gpus=W, collectives=coll)
+        try:
+            ctx.set_debug(debug)
+            ctx.build(shards, to_params(params), 7, cfg.n_users, cuts[:-1])
+            res = ctx.results()
+            for d, r in enumerate(ref):
+                parts = [ind.to_host() for ind in res[d]]
+                lens = np.concatenate([np.diff(p[0]) for p in parts])
+                rp = np.zeros(lens.size + 1, np.int64)
+                np.cumsum(lens, out=rp[1:])
+                check_indicators((rp, np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])), r)
+                assert sum(int(ind.stats[0]) for ind in res[d]) == r.pairs
+            assert coll.error is None
+            recv = np.zeros(W, np.int64)
+            for e in coll.log:
+                if e[0] == "aa":                      # (kind, sender, bytes to every destination)
+                    for q, b in enumerate(e[2]):
+                        if q != e[1]:
+                            recv[q] += b
+                elif e[0] == "ag":                    # (kind, sender, bytes contributed): every other rank receives them
+                    recv += e[2]
+                    recv[e[1]] -= e[2]
+            received[mode] = recv
+        finally:
+            ctx.close()
+    ratio = received["filtered"] / received["all-gather"]
+    assert np.all(ratio <= 0.6), (ratio, received)
+    assert np.all(ratio >= 0.15), ratio       # sanity: it still receives the rows it multiplies with

@@ -121,6 +121,34 @@ __global__ __launch_bounds__(256) void rows_kernel(const int* __restrict__ arr, 
   if (acc == 0x123456789abcull) out[0] = acc;
 }
 
+// rows_dep: as rows_kernel with one lane per row, but every load's address depends on the value of the previous one (the array
+// holds zeros): the row is walked one word after the other, each load issued when its predecessor has returned -- the SpGEMM's
+// expand loop (load a column index, insert it, load the next).  rows_kernel issues its 12 loads back to back: they all miss.
+__global__ __launch_bounds__(256) void rows_dep_kernel(const int* __restrict__ arr, unsigned n_rows, int row_words, int rows_per_lane, unsigned long long* __restrict__ out) {
+  const unsigned gid = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long acc = 0;
+  for (int r = 0; r < rows_per_lane; ++r) {
+    const unsigned row = mix(gid * 2654435761u + (unsigned)r * 40503u + 7u) % n_rows;
+    const int* p = arr + (size_t)row * (size_t)row_words;
+    int v = 0;
+    for (int w = 0; w < row_words; ++w) {
+      v = p[w + v];
+      acc += (unsigned)v;
+    }
+  }
+  if (acc == 0x123456789abcull) out[0] = acc;
+}
+
+// stream: the wide coalesced read (16 B per lane) the guide's FETCH_SIZE correction is stated for -- the reference point of the calibration
+__global__ __launch_bounds__(256) void stream_kernel(const int4* __restrict__ arr, size_t n_vec, unsigned long long* __restrict__ out) {
+  unsigned acc = 0;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < n_vec; v += (size_t)gridDim.x * 256) {
+    const int4 x = arr[v];
+    acc += (unsigned)(x.x ^ x.y ^ x.z ^ x.w);
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
 static float time_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; CK(hipEventElapsedTime(&ms, a, b)); return ms; }
 
 int main(int argc, char** argv) {
@@ -221,6 +249,43 @@ int main(int argc, char** argv) {
       }
     }
     CK(hipFree(tab));
+  }
+  if (only == "all" || only == "stream") {
+    const size_t bytes = (size_t)1 << 30;
+    int4* arr;
+    CK(hipMalloc(&arr, bytes));
+    CK(hipMemset(arr, 1, bytes));
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(stream_kernel, dim3(n_cu * 16), dim3(256), 0, 0, arr, bytes / 16, out);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      ms = time_ms(e0, e1);
+    }
+    printf("{\"test\": \"stream\", \"algorithmic_bytes_per_launch\": %zu, \"ms\": %.4f, \"GBps\": %.1f}\n", bytes, ms, bytes / ms / 1e6);
+    CK(hipFree(arr));
+  }
+  if (only == "all" || only == "rows48dep") {
+    const size_t bytes = (size_t)1 << 30;
+    int* arr;
+    CK(hipMalloc(&arr, bytes));
+    CK(hipMemset(arr, 0, bytes));
+    const int row_words = 12, rows_per_lane = 16;
+    const unsigned n_rows = (unsigned)(bytes / (size_t)(row_words * 4));
+    const int rblocks = n_cu * 8 * 8;
+    const double rows = (double)rblocks * 256 * rows_per_lane;
+    float ms = 0;
+    for (int rep = 0; rep < 2; ++rep) {
+      CK(hipEventRecord(e0));
+      hipLaunchKernelGGL(rows_dep_kernel, dim3(rblocks), dim3(256), 0, 0, arr, n_rows, row_words, rows_per_lane, out);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      ms = time_ms(e0, e1);
+    }
+    printf("{\"test\": \"rows_dep\", \"row_bytes\": 48, \"lanes_per_row\": 1, \"rows\": %.0f, \"algorithmic_bytes_per_launch\": %.0f, \"ms\": %.4f, \"M_rows_per_s\": %.1f, \"alg_GBps\": %.1f}\n",
+           rows, rows * row_words * 4, ms, rows / ms / 1e3, rows * row_words * 4 / ms / 1e6);
+    CK(hipFree(arr));
   }
   if (only == "all" || only == "rows48" || only == "rows64" || only == "rows128") {
     const size_t bytes = (size_t)1 << 30;

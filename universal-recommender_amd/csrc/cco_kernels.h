@@ -122,6 +122,14 @@ hipError_t launch_csr_from_pairs(hipStream_t st, int n_cu, int64_t n, const int3
 // len[n_rows] = row lengths, len16 (nullable) = the same as uint16; sizes (nullable) = {n_rows, nnz, rows longer than 65535}
 constexpr int EXCH_SIZES = 3;
 hipError_t launch_row_lengths(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, int32_t* len, unsigned short* len16, int64_t* sizes);
+// row-filtered exchange (cco_kernels.hip): per-user masks of the ranks whose item range a row of A' touches, per-destination masked row
+// lengths + their scan + the totals per destination, and the packing of the rows per destination
+hipError_t launch_need_mask(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* a_row_ptr, const int32_t* a_col_idx, const int32_t* bounds, int world,
+                            unsigned long long* mask);
+hipError_t launch_masked_lengths(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const unsigned long long* mask, int world, int32_t* mlen, int64_t* off,
+                                 int64_t* tile_sums, int64_t* to_nnz);
+hipError_t launch_pack_rows(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, const unsigned long long* mask, int world,
+                            const int64_t* off, int32_t* pack);
 hipError_t launch_scan_u16(hipStream_t st, const unsigned short* in, int64_t n, int64_t* out, int64_t* tile_sums);
 // CSC fragments of the primary (multi-GPU): the record a rank publishes ((2 * world + 3) int64) and the merge of received fragments
 hipError_t launch_frag_record(hipStream_t st, int32_t world, const int32_t* bounds, const int64_t* l_cp, const int32_t* bad, int64_t* rec);

@@ -2990,6 +2990,94 @@ hipError_t launch_scan_u16(hipStream_t st, const unsigned short* in, int64_t n, 
   return launch_scan(st, LoadU16{in}, n, out, tile_sums);
 }
 
+// --------------------------------------------------------------------------------------------
+// Row-filtered exchange of the down-sampled matrices (round 4).  Rank q multiplies the CSC of ITS item range of A' with B': it
+// reads B' row u only for users that hold an item of that range -- ~40 % of all users at 8 ranks.  Which users those are is known
+// to the rank that owns them (it holds their rows of A' and every rank holds the bounds): no request travels.  Per user a mask
+// of the ranks that need it; per event type the shard's rows are then packed per destination and sent by all-to-all-v -- a row
+// nobody's range touches is not sent at all, and a destination receives a length of 0 for a row it does not need (the rebuilt
+// matrix keeps every user's row, empty where it was not sent: the SpGEMM never looks those up).
+//   need_mask        mask[u] bit q: row u of A' (shard) holds a column of [bounds[q], bounds[q + 1])            (W <= 64)
+//   masked_lengths   mlen[q * n + u] = mask[u] bit q ? len(row u of B') : 0     -> scan -> where every sent row starts, and
+//   peer_totals      to_nnz[q] = column indices destined for rank q
+//   pack_rows        the rows, destination-major, in user order (16 lanes per user)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void need_mask_kernel(int64_t n_rows, const int64_t* __restrict__ a_rp, const int32_t* __restrict__ a_ci,
+                                                        const int32_t* __restrict__ bounds, int world, unsigned long long* __restrict__ mask) {
+  __shared__ int s_b[65];
+  for (int t = threadIdx.x; t <= world; t += 256) s_b[t] = bounds[t];
+  __syncthreads();
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < n_rows; u += (int64_t)gridDim.x * 256) {
+    unsigned long long m = 0ull;
+    for (int64_t p = a_rp[u]; p < a_rp[u + 1]; ++p) {
+      const int c = a_ci[p];
+      int lo = 0, hi = world;  // last q with bounds[q] <= c  (bounds[0] = 0 <= c < bounds[world])
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (s_b[mid] <= c) lo = mid; else hi = mid;
+      }
+      m |= 1ull << lo;
+    }
+    mask[u] = m;
+  }
+}
+hipError_t launch_need_mask(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* a_row_ptr, const int32_t* a_col_idx, const int32_t* bounds, int world,
+                            unsigned long long* mask) {
+  if (world > 64) return hipErrorInvalidValue;
+  if (n_rows == 0) return hipSuccess;
+  int64_t blocks = (n_rows + 255) / 256;
+  if (blocks > (int64_t)n_cu * 8) blocks = (int64_t)n_cu * 8;
+  hipLaunchKernelGGL(need_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, a_row_ptr, a_col_idx, bounds, world, mask);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void masked_lengths_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const unsigned long long* __restrict__ mask, int world,
+                                                             int32_t* __restrict__ mlen) {
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < n_rows; u += (int64_t)gridDim.x * 256) {
+    const int32_t l = (int32_t)(rp[u + 1] - rp[u]);
+    const unsigned long long m = mask[u];
+    for (int q = 0; q < world; ++q) mlen[(int64_t)q * n_rows + u] = ((m >> q) & 1ull) ? l : 0;
+  }
+}
+__global__ void peer_totals_kernel(int world, int64_t n_rows, const int64_t* __restrict__ off, int64_t* __restrict__ to_nnz) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < world) to_nnz[q] = off[(int64_t)(q + 1) * n_rows] - off[(int64_t)q * n_rows];
+}
+// mlen [world * n_rows] int32, off [world * n_rows + 1] int64 (exclusive scan of mlen), to_nnz [world]; tile_sums: scan scratch for world * n_rows values
+hipError_t launch_masked_lengths(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const unsigned long long* mask, int world, int32_t* mlen, int64_t* off,
+                                 int64_t* tile_sums, int64_t* to_nnz) {
+  if (n_rows > 0) {
+    int64_t blocks = (n_rows + 255) / 256;
+    if (blocks > (int64_t)n_cu * 8) blocks = (int64_t)n_cu * 8;
+    hipLaunchKernelGGL(masked_lengths_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, row_ptr, mask, world, mlen);
+  }
+  hipError_t e = launch_scan_i32(st, mlen, (int64_t)world * n_rows, off, tile_sums);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(peer_totals_kernel, dim3((unsigned)((world + 63) / 64)), dim3(64), 0, st, world, n_rows, off, to_nnz);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, const unsigned long long* __restrict__ mask,
+                                                        int world, const int64_t* __restrict__ off, int32_t* __restrict__ pack) {
+  const int gl = threadIdx.x & 15;
+  for (int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; u < n_rows; u += ((int64_t)gridDim.x * 256) >> 4) {
+    const unsigned long long m = mask[u];
+    if (m == 0ull) continue;
+    const int64_t s = rp[u], e = rp[u + 1];
+    for (int q = 0; q < world; ++q) {
+      if (!((m >> q) & 1ull)) continue;
+      const int64_t dst = off[(int64_t)q * n_rows + u];
+      for (int64_t p = s + gl; p < e; p += 16) pack[dst + (p - s)] = ci[p];
+    }
+  }
+}
+hipError_t launch_pack_rows(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, const unsigned long long* mask, int world,
+                            const int64_t* off, int32_t* pack) {
+  if (n_rows == 0) return hipSuccess;
+  int64_t blocks = (n_rows * 16 + 255) / 256;
+  if (blocks > (int64_t)n_cu * 16) blocks = (int64_t)n_cu * 16;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, row_ptr, col_idx, mask, world, off, pack);
+  return hipGetLastError();
+}
+
 // rec[0 .. W] = entry offsets of the local CSC at the range bounds, rec[W + 1 .. 2W + 1] = the bounds,
 // rec[2W + 2] = local column lengths that do not fit 16 bits
 __global__ void frag_record_kernel(int32_t world, const int32_t* __restrict__ bounds, const int64_t* __restrict__ l_cp, const int32_t* __restrict__ bad,
