@@ -345,10 +345,19 @@ class Job:
         self.exchange = world > 1 or n_local > 1 or args.force_exchange
         self.base_flags = (_lib.FLAG_FORCE_EXCHANGE if args.force_exchange else 0)
         flags = self.base_flags | (_lib.FLAG_SINGLE_STREAM if args.single_stream else 0)
-        if single_process:
-            self.ctx = Context(devs[0], library, n_local, flags)      # ncclCommInitAll inside the library when n_local > 1
-        else:
-            self.ctx = sharded.make_context(devs[0], library, flags=flags)
+        # RCCL may greet on the C-level stdout when the first communicator comes up (version / host / library path): stdout carries
+        # ONE JSON line, so file descriptor 1 points at stderr while the context is created
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if single_process:
+                self.ctx = Context(devs[0], library, n_local, flags)      # ncclCommInitAll inside the library when n_local > 1
+            else:
+                self.ctx = sharded.make_context(devs[0], library, flags=flags)
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         if args.gathered_primary:
             self.ctx.set_debug(8192)
 
