@@ -1421,8 +1421,8 @@ hipError_t launch_expand_prepare(hipStream_t st, int n_cu, const int64_t* a_col_
 // --------------------------------------------------------------------------------------------
 // Expand preparation for SEVERAL event types at once.  expand_prepare gathers two row_ptr words of B per CSC entry of A' -- one
 // scattered 64-byte line per entry and event type, the whole cost of the kernel (0.93 ms per event type on config 4: 40M entries,
-// a 40 MB table, fabric-bound).  The secondaries' (start, length) pairs are first interleaved per user -- T[u][d] = {start32, len32},
-// 32 bytes per user for four secondaries: ONE sector -- so that a CSC entry's single gather serves every event type.
+// a 40 MB table, fabric-bound).  The secondaries' row pointers are first interleaved per user (32 bits each) so that a CSC entry's single
+// gather -- 32 consecutive bytes for four secondaries -- serves every event type.
 // --------------------------------------------------------------------------------------------
 struct ExpandMultiArgs {
   const int64_t* b_rp[EXPAND_MULTI_MAX];
@@ -1430,46 +1430,60 @@ struct ExpandMultiArgs {
   int32_t* plen[EXPAND_MULTI_MAX];
   int n;
 };
-__global__ __launch_bounds__(256) void expand_pack_kernel(ExpandMultiArgs a, int64_t n_rows_b, uint2* __restrict__ T) {
-  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < n_rows_b; u += (int64_t)gridDim.x * 256)
-    for (int d = 0; d < a.n; ++d) {
-      const int64_t s = a.b_rp[d][u], e = a.b_rp[d][u + 1];
-      T[u * a.n + d] = make_uint2((unsigned)s, (unsigned)(e - s));
-    }
+// Round 4: the table holds only the STARTS -- T[u][d] = row_ptr_d[u] as 32 bits, u = 0 .. n_rows (the interleaved, narrowed row pointers
+// of the secondaries) -- and a length is the next user's start minus this one's: the two records a CSC entry reads are adjacent (32 bytes
+// for four secondaries, as before), but the table is HALF the size: 160 MB instead of 320 MB for config 4's 10M users, inside the 256 MiB
+// Infinity Cache the gathers otherwise spill from.
+__global__ __launch_bounds__(256) void expand_pack_kernel(ExpandMultiArgs a, int64_t n_rows_b, unsigned* __restrict__ T) {
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u <= n_rows_b; u += (int64_t)gridDim.x * 256)
+    for (int d = 0; d < a.n; ++d) T[u * a.n + d] = (unsigned)a.b_rp[d][u];
 }
 template <int N>
 __global__ __launch_bounds__(256) void expand_prepare_multi_kernel(const int64_t* __restrict__ a_cp, int32_t n_items_a, const int32_t* __restrict__ a_ri,
-                                                                   const uint2* __restrict__ T, int64_t cap, ExpandMultiArgs a) {
+                                                                   const unsigned* __restrict__ T, int64_t cap, ExpandMultiArgs a) {
   const int64_t nnz = a_cp[n_items_a];
   int64_t lim = (nnz / SCAN_TILE + 1) * SCAN_TILE;  // the scans skip tiles that start at or beyond nnz
   if (lim > cap) lim = cap;
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t p0 = (int64_t)blockIdx.x * 256 + threadIdx.x; p0 < lim; p0 += stride * 2) {  // two entries per thread and round: both gathers in flight
     int u[2];
-    uint2 v[2][N];
+    unsigned v[2][2 * N];  // starts of user u, then of user u + 1: 2 N consecutive words
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int64_t p = p0 + q * stride;
       u[q] = p < nnz ? a_ri[p] : -1;
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < 2; ++q) {
+      if (u[q] >= 0) {
+        const unsigned* t = T + (int64_t)u[q] * N;
+        if (N == 4) {  // 16-byte aligned: two 16-byte loads
+          const uint4 x = *reinterpret_cast<const uint4*>(t), y = *reinterpret_cast<const uint4*>(t + 4);
+          v[q][0] = x.x; v[q][1] = x.y; v[q][2] = x.z; v[q][3] = x.w;
+          v[q][4 % (2 * N)] = y.x; v[q][5 % (2 * N)] = y.y; v[q][6 % (2 * N)] = y.z; v[q][7 % (2 * N)] = y.w;
+        } else {
 #pragma unroll
-      for (int d = 0; d < N; ++d) v[q][d] = u[q] >= 0 ? T[(int64_t)u[q] * N + d] : make_uint2(0u, 0u);
+          for (int d = 0; d < 2 * N; ++d) v[q][d] = t[d];
+        }
+      } else {
+#pragma unroll
+        for (int d = 0; d < 2 * N; ++d) v[q][d] = 0u;
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int64_t p = p0 + q * stride;
       if (p < lim) {
 #pragma unroll
         for (int d = 0; d < N; ++d) {
-          a.pstart[d][p] = (int64_t)v[q][d].x;
-          a.plen[d][p] = (int32_t)v[q][d].y;
+          a.pstart[d][p] = (int64_t)v[q][d];
+          a.plen[d][p] = (int32_t)(v[q][N + d] - v[q][d]);
         }
       }
     }
   }
 }
-// pstart[d][cap], plen[d][cap] for n <= EXPAND_MULTI_MAX event types (every B must hold fewer than 2^32 entries); T: n_rows_b * n uint2
+// pstart[d][cap], plen[d][cap] for n <= EXPAND_MULTI_MAX event types (every B must hold fewer than 2^32 entries); T: (n_rows_b + 1) * n words of 32 bits
 hipError_t launch_expand_prepare_multi(hipStream_t st, int n_cu, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx, int n,
                                        const int64_t* const* b_row_ptr, int64_t n_rows_b, int64_t cap, int64_t* const* pstart, int32_t* const* plen, void* T) {
   if (n < 1 || n > EXPAND_MULTI_MAX) return hipErrorInvalidValue;
@@ -1484,11 +1498,11 @@ hipError_t launch_expand_prepare_multi(hipStream_t st, int n_cu, const int64_t* 
   int64_t nb = (n_rows_b + 255) / 256;
   if (nb > (int64_t)n_cu * 8) nb = (int64_t)n_cu * 8;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(expand_pack_kernel, dim3((unsigned)nb), dim3(256), 0, st, a, n_rows_b, static_cast<uint2*>(T));
+  hipLaunchKernelGGL(expand_pack_kernel, dim3((unsigned)nb), dim3(256), 0, st, a, n_rows_b, static_cast<unsigned*>(T));
   int64_t blocks = (cap + 511) / 512;
   const int64_t lim = (int64_t)n_cu * 16;
   if (blocks > lim) blocks = lim;
-  const uint2* Tc = static_cast<const uint2*>(T);
+  const unsigned* Tc = static_cast<const unsigned*>(T);
   switch (n) {
     case 1: hipLaunchKernelGGL(expand_prepare_multi_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, Tc, cap, a); break;
     case 2: hipLaunchKernelGGL(expand_prepare_multi_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, a_col_ptr, n_items_a, a_row_idx, Tc, cap, a); break;

@@ -507,8 +507,8 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
 int expand_multi(urcco_session* s, int n, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx, int64_t cap, const int64_t* const* b_row_ptr,
                  int64_t n_users, int64_t* const* pstart, int32_t* const* plen) {
   if (!s || n < 1 || n > urcco::EXPAND_MULTI_MAX || !a_col_ptr || cap < 0) return fail(URCCO_BAD_ARG, "expand_multi: bad argument");
-  URC(s->reserve(urcco_session::need((size_t)n_users * (size_t)n, 8) + 256));
-  void* T = s->take<unsigned long long>((size_t)n_users * (size_t)n);
+  URC(s->reserve(urcco_session::need(((size_t)n_users + 2) * (size_t)n, 4) + 256));
+  void* T = s->take<unsigned>(((size_t)n_users + 2) * (size_t)n);  // n_users + 1 records of n starts (+ one record of slack: the last user's 2 n-word read)
   s->begin(URCCO_STAGE_ROW_WORK);
   HIPC(urcco::launch_expand_prepare_multi(s->stream, s->n_cu, a_col_ptr, n_items_a, a_row_idx, n, b_row_ptr, n_users, cap, pstart, plen, T));
   s->end();
