@@ -55,6 +55,18 @@ def _worker(rank, world, port, uneven, q):
         else:
             cuts = [n_users * r // world for r in range(world + 1)]
         lo, hi = cuts[rank], cuts[rank + 1]
+        if uneven == "rebuild":
+            # three builds on ONE context, the middle one smaller and with other cuts and another seed: every buffer of the exchange
+            # (masks, masked lengths, packed rows, fragments) is reused at a different size and must not leak anything from the build before
+            small = [O.Csr(400, m.n_cols, m.row_ptr[:401].copy(), m.col_idx[:m.row_ptr[400]].copy()) for m in mats]
+            for ms, seed, cs in ((mats, 5, cuts), (small, 6, [0, 150, 400] if world == 2 else [400 * r // world for r in range(world + 1)]), (mats, 7, cuts)):
+                l2, h2 = cs[rank], cs[rank + 1]
+                sh2 = [O.Csr(h2 - l2, m.n_cols, m.row_ptr[l2:h2 + 1] - m.row_ptr[l2], m.col_idx[m.row_ptr[l2]:m.row_ptr[h2]]) for m in ms]
+                r2 = sharded.cross_occurrence_sharded(ctx, [to_dev(s, "cpu") for s in sh2], to_params(params), seed, ms[0].n_rows, l2)
+                f2 = sharded.gather_indicators_to_host(r2)
+                ref2 = O.cross_occurrence_downsampled(ms, params, seed)
+                for got, r in zip(f2, ref2):
+                    check_indicators(got, r, exact_ids=True)
         shards = [O.Csr(hi - lo, m.n_cols, m.row_ptr[lo:hi + 1] - m.row_ptr[lo], m.col_idx[m.row_ptr[lo]:m.row_ptr[hi]]) for m in mats]
         res = sharded.cross_occurrence_sharded(ctx, [to_dev(s, "cpu") for s in shards], to_params(params), 2024, n_users, lo)
         full = sharded.gather_indicators_to_host(res)
@@ -75,7 +87,7 @@ def _worker(rank, world, port, uneven, q):
         q.put((rank, "fail: " + traceback.format_exc(), None))
 
 
-@pytest.mark.parametrize("world,uneven", [(2, False), (2, True), (3, False), (4, False), (2, "empty"), (2, "skew5")])
+@pytest.mark.parametrize("world,uneven", [(2, False), (2, True), (3, False), (4, False), (2, "empty"), (2, "skew5"), (2, "rebuild"), (3, "rebuild")])
 def test_sharded_equals_single_process_oracle(world, uneven, sim_lib):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
