@@ -1867,6 +1867,9 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 #ifndef URCCO_G_BLOCK
 #define URCCO_G_BLOCK 1
 #endif
+#ifndef URCCO_SWEEP_SHARED
+#define URCCO_SWEEP_SHARED 1  // classes other than the 256-thread ones find the key bytes all candidates share with a sweep before the select
+#endif
 #ifndef URCCO_G_CU
 #define URCCO_G_CU 1
 #endif
@@ -2209,11 +2212,40 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
         unsigned need = (unsigned)a.k;
         if (a.col_bytes < 4) thr_ncol = 0xffffffffu << (8 * a.col_bytes);  // digits of ~col above the highest used byte are all ones
         int p0 = 0;  // first key byte that differs between candidates
-        if (SKIP_SHARED) {
+        if (!SKIP_SHARED && URCCO_SWEEP_SHARED) {
+          // The classes that do not track the shared key bytes while they score (registers) find them here, with one cheap sweep over
+          // the keys (an AND and an OR per key, no histogram, no atomics): the LLRs of a row share their sign / exponent byte, so the
+          // select's first pass -- a full histogram sweep plus a digit search -- found one bin holding everything and was wasted.
+          kand = ~0ull;
+          kor = 0ull;
+          for (unsigned base = 0; base < D; base += T) {  // scalar loop control
+            const unsigned t = base + (unsigned)tl;
+            const unsigned long long key = t < D ? kk[t] : 0ull;
+            if (key != 0ull) {
+              kand &= key;
+              kor |= key;
+            }
+          }
 #pragma unroll
-          for (int w = 0; w < NW; ++w) {
-            kand &= s_kbits[2 * w];
-            kor |= s_kbits[2 * w + 1];
+          for (int msk = 1; msk < WAVE; msk <<= 1) {
+            kand &= shfl_xor_u64(kand, msk);
+            kor |= shfl_xor_u64(kor, msk);
+          }
+          if (T != WAVE) {
+            if (lane == 0) {
+              s_kbits[2 * (tl / WAVE)] = kand;
+              s_kbits[2 * (tl / WAVE) + 1] = kor;
+            }
+            team_sync<T>();
+          }
+        }
+        if (SKIP_SHARED || URCCO_SWEEP_SHARED) {
+          if (T != WAVE) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+              kand &= s_kbits[2 * w];
+              kor |= s_kbits[2 * w + 1];
+            }
           }
           const unsigned long long kdiff = kand ^ kor;
           p0 = kdiff == 0ull ? 8 : (__clzll((long long)kdiff) >> 3);
