@@ -139,6 +139,31 @@ __global__ __launch_bounds__(256) void rows_dep_kernel(const int* __restrict__ a
   if (acc == 0x123456789abcull) out[0] = acc;
 }
 
+// rowsfit: rows_kernel over three placements of the SAME number of 48-byte rows -- dense (a row straddles a 128-byte line 11 times
+// in 32), no line straddle (every row inside a 2x slack region, moved up to the next line start when it would cross one: what a
+// "loose" B' layout computable from the ordinary prefix sum would give), and 64-byte slots (no straddle of 64-byte sectors either).
+// Is the unit of the random-row cost the 128-byte line, the 64-byte sector, or the request?
+__global__ __launch_bounds__(256) void rows_layout_kernel(const int* __restrict__ arr, unsigned n_rows, int row_words, int lanes_log2, int rows_per_group, int layout, unsigned long long* __restrict__ out) {
+  const unsigned gid = blockIdx.x * 256 + threadIdx.x;
+  const unsigned grp = gid >> lanes_log2, gl = gid & ((1u << lanes_log2) - 1u);
+  unsigned long long acc = 0;
+  for (int r = 0; r < rows_per_group; ++r) {
+    const unsigned row = mix(grp * 2654435761u + (unsigned)r * 40503u + 7u) % n_rows;
+    size_t start;
+    if (layout == 0) {
+      start = (size_t)row * (size_t)row_words;
+    } else if (layout == 1) {
+      const size_t s2 = 2 * (size_t)row * (size_t)row_words;
+      start = ((s2 & 31) + (size_t)row_words <= 32) ? s2 : ((s2 + 31) & ~(size_t)31);
+    } else {
+      start = (size_t)row * 16;
+    }
+    const int* p = arr + start;
+    for (int w = (int)gl; w < row_words; w += 1 << lanes_log2) acc += (unsigned)p[w];
+  }
+  if (acc == 0x123456789abcull) out[0] = acc;
+}
+
 // stream: the wide coalesced read (16 B per lane) the guide's FETCH_SIZE correction is stated for -- the reference point of the calibration
 __global__ __launch_bounds__(256) void stream_kernel(const int4* __restrict__ arr, size_t n_vec, unsigned long long* __restrict__ out) {
   unsigned acc = 0;
@@ -312,6 +337,32 @@ int main(int argc, char** argv) {
         }
         printf("{\"test\": \"rows\", \"row_bytes\": %d, \"lanes_per_row\": %d, \"rows\": %.0f, \"algorithmic_bytes_per_launch\": %.0f, \"ms\": %.4f, \"M_rows_per_s\": %.1f, \"alg_GBps\": %.1f}\n",
                row_words * 4, 1 << lanes_log2, rows, rows * row_words * 4, ms, rows / ms / 1e3, rows * row_words * 4 / ms / 1e6);
+      }
+    }
+    CK(hipFree(arr));
+  }
+  if (only == "all" || only == "rowsfit") {
+    const size_t bytes = (size_t)2 << 30;
+    int* arr;
+    CK(hipMalloc(&arr, bytes));
+    CK(hipMemset(arr, 1, bytes));
+    const int row_words = 12;
+    const unsigned n_rows = (unsigned)(((size_t)1 << 30) / (size_t)(row_words * 4));
+    for (int lanes_log2 : {0, 2}) {
+      for (int layout : {0, 1, 2}) {
+        const int rows_per_group = 16;
+        const int rblocks = n_cu * 8 * (lanes_log2 ? 32 : 8);
+        const double rows = (double)rblocks * 256 / (1 << lanes_log2) * rows_per_group;
+        float ms = 0;
+        for (int rep = 0; rep < 3; ++rep) {
+          CK(hipEventRecord(e0));
+          hipLaunchKernelGGL(rows_layout_kernel, dim3(rblocks), dim3(256), 0, 0, arr, n_rows, row_words, lanes_log2, rows_per_group, layout, out);
+          CK(hipEventRecord(e1));
+          CK(hipEventSynchronize(e1));
+          ms = time_ms(e0, e1);
+        }
+        printf("{\"test\": \"rowsfit\", \"row_bytes\": 48, \"layout\": \"%s\", \"lanes_per_row\": %d, \"rows\": %.0f, \"ms\": %.4f, \"M_rows_per_s\": %.1f, \"alg_GBps\": %.1f}\n",
+               layout == 0 ? "dense" : (layout == 1 ? "no_line_straddle_2x_slack" : "64B_slots"), 1 << lanes_log2, rows, ms, rows / ms / 1e3, rows * row_words * 4 / ms / 1e6);
       }
     }
     CK(hipFree(arr));
