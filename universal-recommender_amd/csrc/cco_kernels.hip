@@ -1767,6 +1767,15 @@ __device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int coun
   return ok;
 }
 
+// "This prefetched register is needed now": an empty asm that reads it makes the compiler place the wait for its load HERE -- ahead
+// of the stores that follow -- instead of at its first use in the next row, where the wait would also cover every store issued in
+// between (the memory counter retires in order) and so expose the write latency of the row's output at the top of the next row.
+#ifdef HIPSIM_HOST_BUILD
+#define URCCO_SETTLE(x) ((void)(x))
+#else
+#define URCCO_SETTLE(x) asm volatile("" : "+v"(x) : : "memory")  // "memory": the stores that follow must not be scheduled above it
+#endif
+
 // LDS hand-off inside ONE wave: DS operations of a wave execute in program order, so a compiler-level fence is all that
 // is needed between a lane's write and another lane's read.
 __device__ __forceinline__ void wave_sync() {
@@ -2530,45 +2539,70 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
   unsigned long long cand_acc = 0ull;  // candidates scored by this wave (statistics)
 
   int li = blockIdx.x * TEAMS + team;
-  int i_nx = 0;
-  int64_t cs_nx = 0, ce_nx = 0;
-  if (li < list_n) {
-    i_nx = a.bin_rows[list_start + li];
-    cs_nx = a.a_col_ptr[i_nx];
-    ce_nx = a.a_col_ptr[i_nx + 1];
+  if (li >= list_n) return;  // (wave-level synchronisation only: a wave without rows may leave)
+  // The row loop is a chain of dependent gathers (row id -> CSC bounds -> per-user operands -> B' columns -> column counts), and
+  // the memory counter retires IN ORDER: a wave that waits for any load waits for every older one, and for every older store.  So
+  //  * every link of the chain is issued at the TOP of a row, for the rows ahead -- the row id three rows ahead, the CSC bounds two,
+  //    the operands one -- where the wait for this row's B' columns (the one unavoidable long wait) covers them all;
+  //  * they are issued unconditionally (a branch with loads in it makes the compiler wait for everything where the paths join): list
+  //    positions past the end re-read the last row, lanes beyond a row's users its last user;
+  //  * nothing is touched where it is loaded (a conversion next to a load is a wait for it), and everything is collected
+  //    (URCCO_SETTLE) just before the row's output stores, so that the next row never waits behind those stores.
+  // Round 4 found the rounds 1-3 form of this loop waiting three times per row for loads it had issued as "prefetches".
+  const int stride = total_teams;
+  auto row_at = [&](int l) { return a.bin_rows[list_start + (l < list_n ? l : list_n - 1)]; };
+  const unsigned* wp32 = reinterpret_cast<const unsigned*>(a.wp);  // low words: a row only uses differences (<= 64) between its own entries
+  const unsigned* cnt_words = use16 ? reinterpret_cast<const unsigned*>(a.cnt_b16) : reinterpret_cast<const unsigned*>(a.cnt_b);  // the column counts, read a word at a time
+  int i_cur = row_at(li);              // this row
+  int i_n1 = row_at(li + stride);      // the next one: id ...
+  int i_n2 = row_at(li + 2 * stride);  // (two ahead: id only)
+  int64_t cs1 = a.a_col_ptr[i_n1], ce1 = a.a_col_ptr[i_n1 + 1];  // ... and CSC bounds
+  // operands of the row about to be processed; wp[cs] is what lane 0 reads as its user's entry
+  unsigned pf_w1, pf_wp;
+  int64_t pf_start;
+  int pf_ca;  // as loaded: widened where it is used
+  double pf_ent;
+  int n_cur;  // users of the row about to be processed
+  {
+    const int64_t cs0 = a.a_col_ptr[i_cur], ce0 = a.a_col_ptr[i_cur + 1];
+    n_cur = (int)(ce0 - cs0);
+    const int64_t pl = lane < n_cur ? cs0 + lane : ce0 - 1;
+    pf_w1 = wp32[2 * ce0];
+    pf_wp = wp32[2 * pl];
+    pf_start = a.pstart[pl];
+    pf_ca = a.cnt_a[i_cur];
+    pf_ent = a.ent_a[i_cur];
   }
-  // operands of the row about to be processed, loaded one row ahead (the row loop is a chain of dependent gathers)
-  int64_t pf_w0 = 0, pf_w1 = 0, pf_wp = 0, pf_start = 0;
-  long long pf_ca = 0;
-  double pf_ent = 0.0;
-  if (li < list_n) {
-    pf_w0 = a.wp[cs_nx];
-    pf_w1 = a.wp[ce_nx];
-    if (cs_nx + lane < ce_nx) {
-      pf_wp = a.wp[cs_nx + lane];
-      pf_start = a.pstart[cs_nx + lane];
-    }
-    pf_ca = a.cnt_a[i_nx];
-    pf_ent = a.ent_a[i_nx];
-  }
-  for (; li < list_n; li += total_teams) {  // each wave runs its own row loop: wave-level sync only
-    const int i = i_nx;
-    const int64_t cs = cs_nx, ce = ce_nx;
-    const bool has_next = li + total_teams < list_n;
-    if (has_next) {  // the next row's id and CSC bounds travel while this row is processed
-      i_nx = a.bin_rows[list_start + li + total_teams];
-      cs_nx = a.a_col_ptr[i_nx];
-      ce_nx = a.a_col_ptr[i_nx + 1];
-    }
-    const int64_t w0 = pf_w0;
-    const unsigned total = (unsigned)(pf_w1 - w0);  // <= 64 by the binning rule
-    const bool owns_user = cs + lane < ce;
-    const long long ca = pf_ca;
+  // (collected here as at the end of every row: with a load still pending on ONE way into the loop header the compiler waits there
+  // for everything in flight on every pass)
+  URCCO_SETTLE(pf_w1); URCCO_SETTLE(pf_wp); URCCO_SETTLE(pf_start); URCCO_SETTLE(pf_ca); URCCO_SETTLE(pf_ent);
+  URCCO_SETTLE(cs1); URCCO_SETTLE(ce1); URCCO_SETTLE(i_n2);
+  for (; li < list_n; li += stride) {  // each wave runs its own row loop: wave-level sync only
+    const int i = i_cur;
+    // this row's operands leave their registers ...
+    const unsigned w0 = wave_read_lane(pf_wp, 0);  // wp[cs]
+    const unsigned total = pf_w1 - w0;  // <= 64 by the binning rule
+    const bool owns_user = lane < n_cur;
+    const long long ca = (long long)pf_ca;
     const double row_entropy = pf_ent;
+    const int64_t my_start = owns_user ? pf_start : 0;
+    const unsigned my_off = owns_user ? pf_wp - w0 : total;
+    // ... and the rows ahead take them: id of row + 3, bounds of row + 2, operands of row + 1
+    int i_n3 = row_at(li + 3 * stride);
+    int64_t cs2 = a.a_col_ptr[i_n2], ce2 = a.a_col_ptr[i_n2 + 1];
+    n_cur = (int)(ce1 - cs1);
+    {
+      const int64_t pl = lane < n_cur ? cs1 + lane : ce1 - 1;
+      pf_w1 = wp32[2 * ce1];
+      pf_wp = wp32[2 * pl];
+      pf_start = a.pstart[pl];
+      pf_ca = a.cnt_a[i_n1];
+      pf_ent = a.ent_a[i_n1];
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) tab[lane + q * WAVE] = 0u;
-    ustart[lane] = owns_user ? pf_start : 0;
-    uoff[lane] = owns_user ? (unsigned)(pf_wp - w0) : total;
+    ustart[lane] = my_start;
+    uoff[lane] = my_off;
     if (lane == 0) uoff[WAVE] = total;
     wave_sync();
     if ((unsigned)lane < total) {
@@ -2582,16 +2616,6 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
       if (!(a.debug & 1) && !tab_insert(tab, jj + 1u, cb, 255u, 24, ident)) atomicAdd(a.err, 1ull);
     }
     wave_sync();
-    if (has_next) {  // next row's operands (its CSC bounds arrived during the insert phase)
-      pf_w0 = a.wp[cs_nx];
-      pf_w1 = a.wp[ce_nx];
-      if (cs_nx + lane < ce_nx) {
-        pf_wp = a.wp[cs_nx + lane];
-        pf_start = a.pstart[cs_nx + lane];
-      }
-      pf_ca = a.cnt_a[i_nx];
-      pf_ent = a.ent_a[i_nx];
-    }
     unsigned D = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -2604,12 +2628,19 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
     wave_sync();
     unsigned long long mk = 0ull;
     int mc = 0x7fffffff;
-    if ((unsigned)lane < D) {
-      const unsigned vv = cand[lane];
+    const bool is_cand = (unsigned)lane < D;
+    unsigned vv = 0u, cb_raw = 0u;
+    if (is_cand) {  // the count gather is issued -- ONE 4-byte load whichever width the counts have (two alternative loads meet in a
+                    // copy, and a copy next to a load is a wait) -- and nothing reads it before the block below
+      vv = cand[lane];
+      const int j = (int)(vv >> cb) - 1;
+      cb_raw = cnt_words[use16 ? j >> 1 : j];
+    }
+    if (is_cand) {
       const int j = (int)(vv >> cb) - 1;
       const long long k11 = (long long)(vv & cmask);
       if (!(a.exclude_self && j == i)) {
-        const long long cbj = (a.debug & 512) ? 100ll : (use16 ? (long long)a.cnt_b16[j] : (long long)a.cnt_b[j]);
+        const long long cbj = (a.debug & 512) ? 100ll : (long long)(use16 ? ((j & 1) ? cb_raw >> 16 : cb_raw & 0xffffu) : cb_raw);
         const double llr = (a.debug & 2) ? (double)k11
                                          : llr_from_entropies_tab(row_entropy, column_entropy_of(cbj, xlx_n, a.n_users, a.xlx_tab, a.xlx_hi, a.col_ent), xlx_n, k11, ca - k11,
                                                                   cbj - k11, a.n_users - ca - cbj + k11, a.xlx_tab, a.n_users, a.xlx_hi);
@@ -2623,8 +2654,13 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
     wave_sync();
     const unsigned long long valid_mask = __ballot(mk != 0ull);
     const int n_valid = __popcll(valid_mask);
+    auto settle_prefetch = [&]() {  // the next row's operands have had the score phase to arrive: collect them before the output stores
+      URCCO_SETTLE(pf_w1); URCCO_SETTLE(pf_wp); URCCO_SETTLE(pf_start); URCCO_SETTLE(pf_ca); URCCO_SETTLE(pf_ent);
+      URCCO_SETTLE(cs2); URCCO_SETTLE(ce2); URCCO_SETTLE(i_n3);
+    };
     if (a.unordered && n_valid <= a.k && !(a.debug & 4)) {  // every candidate is emitted: no ranking needed (wave-uniform)
       const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
+      settle_prefetch();
       if (mk != 0ull) {
         const int pos = __popcll(valid_mask & lt);
         a.out_idx[obase + pos] = mc;
@@ -2644,12 +2680,20 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
         srt_key[rank] = mk;
       }
       wave_sync();
+      settle_prefetch();
       if ((unsigned)lane < n_out) {
         a.out_idx[obase + lane] = (int)srt_col[lane];
         a.out_llr[obase + lane] = __longlong_as_double((long long)srt_key[lane]);
       }
       if (lane == 0) a.out_count[i - a.item_lo] = (int)n_out;
+    } else {
+      settle_prefetch();
     }
+    i_cur = i_n1;
+    i_n1 = i_n2;
+    i_n2 = i_n3;
+    cs1 = cs2;
+    ce1 = ce2;
     wave_sync();
   }
   if (a.cand && lane == 0 && cand_acc != 0ull) atomicAdd(&a.cand[(blockIdx.x * TEAMS + team) & (CAND_SLOTS - 1)], cand_acc);
