@@ -1815,6 +1815,12 @@ __device__ __forceinline__ int64_t uni(int64_t v) {
 }
 // value of lane l (wave-uniform l): one v_readlane, no LDS
 __device__ __forceinline__ unsigned wave_read_lane(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+// 64-bit value of lane l (wave-uniform l).  One wave operation per source line: the test simulator keys them by line.
+__device__ __forceinline__ int64_t wave_read_lane64(int64_t v, int l) {
+  const unsigned lo = wave_read_lane((unsigned)(unsigned long long)v, l);
+  const unsigned hi = wave_read_lane((unsigned)((unsigned long long)v >> 32), l);
+  return (int64_t)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
 // number of set bits of m below this lane
 __device__ __forceinline__ unsigned lanes_below(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
@@ -1963,37 +1969,65 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
 
   // T == 64: teams are independent waves (wave-level sync only).  T > 64: one team per block, loop is block-uniform.
   int li = blockIdx.x * TEAMS + team;
-  int i_nx = 0;
-  int64_t cs_nx = 0, ce_nx = 0;
-  if (li < list_n) {
-    i_nx = uni(a.bin_rows[list_start + li]);
-    cs_nx = uni(a.a_col_ptr[i_nx]);
-    ce_nx = uni(a.a_col_ptr[i_nx + 1]);
+  if (li >= list_n) return;  // team-uniform (a block for T > 64, a wave -- which only ever synchronises with itself -- for T == 64)
+  // The chain row id -> CSC bounds -> first-chunk operands, as in the micro class (see there: the memory counter retires in order):
+  // every link is issued at the TOP of a row for the rows ahead (ids of the next three rows, bounds two rows ahead, operands one),
+  // unconditionally (list positions past the end re-read the last row), into VECTOR registers -- uniform values packed by lane: one
+  // register carries three row ids, one pair both bounds of a row -- and read into scalars (readlane / readfirstlane) only where they
+  // are consumed, a row later; URCCO_SETTLE collects them after the score phase, ahead of every store of the row's output.
+  // (Rounds 1-3: readfirstlane next to each of these loads = a wait for it, twice in a row at the top of every row and once more
+  // on the first-chunk operands.)
+  const int S = total_teams;
+  auto pos_of = [&](int l) { return list_start + (l < list_n ? l : list_n - 1); };
+  const unsigned* wp32 = reinterpret_cast<const unsigned*>(a.wp);  // low words: a chunk only uses differences between its own entries
+  const int lane3 = lane < 3 ? lane : 2;
+  int idv = a.bin_rows[pos_of(li + lane3 * S)];  // lanes 0, 1, 2: ids of this row and the next two
+  int64_t cs_c, ce_c;                             // this row's CSC bounds (scalars)
+  int64_t bnd_b;                                  // the next row's: lane 0 start, lane 1 end
+  {
+    const int id0 = (int)wave_read_lane((unsigned)idv, 0);
+    const int id1 = (int)wave_read_lane((unsigned)idv, 1);
+    cs_c = uni(a.a_col_ptr[id0]);
+    ce_c = uni(a.a_col_ptr[id0 + 1]);
+    bnd_b = a.a_col_ptr[id1 + (lane & 1)];
   }
-  // first-chunk operands of the row about to be processed (loaded one row ahead, see the end of step 4)
-  int64_t pf_w0 = 0, pf_w1 = 0, pf_wp = 0, pf_start = 0;
-  if (li < list_n) {
-    const int64_t c1 = cs_nx + T < ce_nx ? cs_nx + T : ce_nx;
-    pf_w0 = uni(a.wp[cs_nx]);
-    pf_w1 = uni(a.wp[c1]);
-    if (cs_nx + tl < c1) {
-      pf_wp = a.wp[cs_nx + tl];
-      pf_start = a.pstart[cs_nx + tl];
-    }
+  // first-chunk operands of the row about to be processed (low words of the work prefix)
+  unsigned pf_w0, pf_w1, pf_wp;
+  int64_t pf_start;
+  {
+    const int64_t c1 = cs_c + T < ce_c ? cs_c + T : ce_c;
+    const int64_t pl = cs_c + tl < c1 ? cs_c + tl : c1 - 1;
+    pf_w0 = wp32[2 * cs_c];
+    pf_w1 = wp32[2 * c1];
+    pf_wp = wp32[2 * pl];
+    pf_start = a.pstart[pl];
   }
-  for (; li < list_n; li += total_teams) {
-    const int i = i_nx;
-    const int64_t cs = cs_nx, ce = ce_nx;
-    const bool has_next = li + total_teams < list_n;
-    if (has_next) {  // the next row's row id and CSC bounds travel while this row is processed
-      i_nx = uni(a.bin_rows[list_start + li + total_teams]);
-      cs_nx = uni(a.a_col_ptr[i_nx]);
-      ce_nx = uni(a.a_col_ptr[i_nx + 1]);
+  URCCO_SETTLE(idv); URCCO_SETTLE(bnd_b); URCCO_SETTLE(pf_w0); URCCO_SETTLE(pf_w1); URCCO_SETTLE(pf_wp); URCCO_SETTLE(pf_start);
+  int64_t cs_n = 0, ce_n = 0, bnd_c = 0;  // next row's bounds as scalars / the bounds two rows ahead in flight: rotated by the loop's increment
+  for (; li < list_n; li += S, cs_c = cs_n, ce_c = ce_n, bnd_b = bnd_c) {
+    const int i = (int)wave_read_lane((unsigned)idv, 0);
+    const int id2 = (int)wave_read_lane((unsigned)idv, 2);
+    const int64_t cs = cs_c, ce = ce_c;
+    cs_n = wave_read_lane64(bnd_b, 0);
+    ce_n = wave_read_lane64(bnd_b, 1);
+    // this row's first-chunk operands leave their registers ...
+    const unsigned row_w0 = uni(pf_w0), row_w1 = uni(pf_w1);
+    const unsigned my_wp = pf_wp;
+    const int64_t my_start = pf_start;
+    // ... and the rows ahead take them
+    idv = a.bin_rows[pos_of(li + (1 + lane3) * S)];
+    bnd_c = a.a_col_ptr[id2 + (lane & 1)];
+    if (!MP) {  // (the multi-pass rows re-read every chunk once per pass: no prefetched first chunk)
+      const int64_t c1 = cs_n + T < ce_n ? cs_n + T : ce_n;
+      const int64_t pl = cs_n + tl < c1 ? cs_n + tl : c1 - 1;
+      pf_w0 = wp32[2 * cs_n];
+      pf_w1 = wp32[2 * c1];
+      pf_wp = wp32[2 * pl];
+      pf_start = a.pstart[pl];
     }
     // MP: number of passes 2^mp_s, current pass mp_q, entries of the running top k and which of its two buffers is current
     int mp_s = 0;
     unsigned mp_q = 0u, n_run = 0u, run_cur = 0u;
-    bool nx_fetched = false;
     if (MP) {
       const long long w_row = (long long)(uni(a.wp[ce]) - uni(a.wp[cs]));
       const long long ca_row = a.cnt_a[i];
@@ -2026,12 +2060,12 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
     for (int64_t c0 = cs; c0 < ce; c0 += T) {  // team-uniform
       const int64_t c1 = c0 + T < ce ? c0 + T : ce;
       const bool pre = !MP && c0 == cs;  // the first chunk's operands were prefetched
-      const int64_t w0 = pre ? pf_w0 : uni(a.wp[c0]);
-      const unsigned total = (unsigned)((pre ? pf_w1 : uni(a.wp[c1])) - w0);
+      const unsigned w0 = pre ? row_w0 : uni(wp32[2 * c0]);  // low words: the differences below are < 2^32
+      const unsigned total = (pre ? row_w1 : uni(wp32[2 * c1])) - w0;
       const int64_t p = c0 + tl;
       if (p < c1) {
-        ustart[tl] = pre ? pf_start : a.pstart[p];
-        uoff[tl] = (unsigned)((pre ? pf_wp : a.wp[p]) - w0);
+        ustart[tl] = pre ? my_start : a.pstart[p];
+        uoff[tl] = (pre ? my_wp : wp32[2 * p]) - w0;
       } else {
         uoff[tl] = total;
       }
@@ -2175,16 +2209,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
         }
       }
     }
-    if (has_next && !nx_fetched) {  // the next row's first-chunk operands travel while this row is ranked
-      nx_fetched = true;
-      const int64_t c1 = cs_nx + T < ce_nx ? cs_nx + T : ce_nx;
-      pf_w0 = a.wp[cs_nx];
-      pf_w1 = a.wp[c1];
-      if (cs_nx + tl < c1) {
-        pf_wp = a.wp[cs_nx + tl];
-        pf_start = a.pstart[cs_nx + tl];
-      }
-    }
+    // what was issued at the top of the row has had the expand and score phases to arrive: collected ahead of the row's output stores
+    URCCO_SETTLE(idv); URCCO_SETTLE(bnd_c);
+    if (!MP) { URCCO_SETTLE(pf_w0); URCCO_SETTLE(pf_w1); URCCO_SETTLE(pf_wp); URCCO_SETTLE(pf_start); }
     if (SKIP_SHARED) {
 #pragma unroll
       for (int msk = 1; msk < WAVE; msk <<= 1) {
