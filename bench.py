@@ -310,6 +310,95 @@ def scipy_leg(data, n_users, seed):
                       "scipy.sparse A.T @ A + vectorised numpy LLR + argpartition top-k, single thread"}
 
 
+EMU_PHASES = [("input (counts + row scan on the user shard)", ["column_counts", "downsample_flags", "downsample_scan", "downsample_compact"]),
+              ("own-shard transposition + fragment merge", ["transpose"]),
+              ("exchange side (row lengths, need masks, masked lengths, packing, row_ptr rebuild)", ["exchange"]),
+              ("expand preparation (row work)", ["row_work"]),
+              ("binning + entropies", ["binning", "entropy"]),
+              ("SpGEMM + LLR + top-k (item range)", BIN_STAGES),
+              ("indicator compaction", ["compact_indicators"])]
+
+
+def emulate_ranks_leg(library, dev, workload, W, args):
+    """Per-rank critical path of a W-rank build measured on ONE GPU (readiness, not a scaling curve).  The W ranks of the
+    job live in this process on this GPU (URCCO_FLAG_EMULATE_RANKS: one stream, every kernel alone on the device; collectives = device-to-
+    device copies through DeviceLoopbackCollectives), the build is the real W-rank build -- user-range input phase, work-balanced item
+    ranges from partition_dev, own-shard transposition + fragment merge, row-filtered all-to-all-v, fused expand, item-range SpGEMM --
+    and every rank's HIP-event stage times are read separately.  What it cannot see: xGMI time, host enqueue time, overlap between streams."""
+    from universal_recommender_amd import _lib, sharded, synth
+    from universal_recommender_amd.device import Context, DatasetParams, DevCsr
+    cfg = {"config3": synth.config3, "config4": synth.config4, "config5": synth.config5}[workload](args.scale)
+    cuts = [cfg.n_users * g // W for g in range(W + 1)]
+    per_rank = [synth.generate_device(cfg, dev, cuts[g], cuts[g + 1]) for g in range(W)]
+    shards = [[DevCsr(cuts[g + 1] - cuts[g], per_rank[g][d][1], per_rank[g][d][2], per_rank[g][d][3], int(per_rank[g][d][2][-1].item())) for g in range(W)]
+              for d in range(len(cfg.events))]
+    params = [DatasetParams(500, 50, None) for _ in shards]
+    builds = max(2, min(args.steps, 5))
+
+    def run(n_ranks, sh, bases):
+        coll = sharded.DeviceLoopbackCollectives(n_ranks, dev) if n_ranks > 1 else None
+        flags = (_lib.FLAG_EMULATE_RANKS if n_ranks > 1 else _lib.FLAG_SINGLE_STREAM)
+        ctx = Context(dev, library, n_ranks, flags, collectives=coll)
+        try:
+            ctx.build(sh, params, args.seed, cfg.n_users, bases)
+            ctx.synchronize()
+            ctx.set_timing(True)
+            t0 = time.perf_counter()
+            for _ in range(builds):
+                ctx.build(sh, params, args.seed, cfg.n_users, bases)
+            ctx.synchronize()
+            wall = (time.perf_counter() - t0) / builds * 1e3
+            tms = [ctx.get_timings_gpu(g) for g in range(n_ranks)]
+            ctx.set_timing(False)
+            res = ctx.results()
+            pairs = [[int(ind.stats[0]) for ind in row] for row in res]          # [event type][rank]
+            rows = [[ind.item_hi - ind.item_lo for ind in row] for row in res]
+            if coll is not None and coll.error is not None:
+                raise coll.error
+            recv = [b / (builds + 1) for b in coll.bytes_received] if coll is not None else [0]
+            return tms, pairs, rows, recv, wall
+        finally:
+            ctx.close()
+
+    tms, pairs, rows, recv, wall_w = run(W, shards, cuts[:-1])
+    # the same job on one rank (whole matrices = the shards' rows back to back), event types serialised on one stream: the N = 1 reference
+    whole = []
+    for d in range(len(cfg.events)):
+        rp = [shards[d][0].row_ptr] + [shards[d][g].row_ptr[1:] + sum(shards[d][q].nnz_bound for q in range(g)) for g in range(1, W)]
+        whole.append([DevCsr(cfg.n_users, shards[d][0].n_cols, torch.cat(rp), torch.cat([shards[d][g].col_idx[: shards[d][g].nnz_bound] for g in range(W)]),
+                             sum(shards[d][g].nnz_bound for g in range(W)))])
+    tms1, pairs1, _, _, wall_1 = run(1, whole, [0])
+    assert sum(sum(p) for p in pairs) == sum(sum(p) for p in pairs1), "the W-rank build and the one-rank build form different numbers of pairs"
+
+    def ms(t, names):
+        return sum(t[n][0] for n in names if n in t) / builds
+    phases = {}
+    tot_rank = [0.0] * W
+    for title, names in EMU_PHASES:
+        per = [ms(t, names) for t in tms]
+        for g in range(W):
+            tot_rank[g] += per[g]
+        mean = sum(per) / W
+        phases[title] = {"per_rank_ms": [round(x, 3) for x in per], "max_ms": round(max(per), 3), "mean_ms": round(mean, 3),
+                         "max_over_mean": round(max(per) / mean, 3) if mean > 0 else None, "one_rank_ms": round(ms(tms1[0], names), 3)}
+    one = sum(v["one_rank_ms"] for v in phases.values())
+    pr = [sum(pairs[d][g] for d in range(len(pairs))) for g in range(W)]
+    out = {"what": f"EMULATED on one GPU, xGMI not included: the {W} ranks of a {workload} build run one after the other on this device (URCCO_FLAG_EMULATE_RANKS); "
+                   "per-rank sums of HIP-event stage times, averaged over %d builds" % builds,
+           "workload": workload, "scale": args.scale, "ranks": W, "phases": phases,
+           "rank_total_ms": [round(x, 3) for x in tot_rank], "max_rank_ms": round(max(tot_rank), 3), "mean_rank_ms": round(sum(tot_rank) / W, 3),
+           "max_over_mean": round(max(tot_rank) / (sum(tot_rank) / W), 3),
+           "one_rank_serialised_ms": round(one, 3),
+           "implied_compute_only_speedup": round(one / max(tot_rank), 3),
+           "ideal_speedup_if_balanced": round(one / (sum(tot_rank) / W), 3),
+           "pairs_per_rank": pr, "pairs_max_over_mean": round(max(pr) / (sum(pr) / W), 4),
+           "item_rows_per_rank": [r for r in rows[0]],
+           "bytes_received_per_rank_MB": [round(b / 1e6, 1) for b in recv],
+           "xgmi_ms_at_300GBps_per_rank": [round(b / 300e9 * 1e3, 3) for b in recv],
+           "wall_ms_per_build": {"emulated_W_ranks_sequential_incl_python_collectives": round(wall_w, 2), "one_rank_single_stream": round(wall_1, 2)}}
+    return out
+
+
 class Job:
     """One workload resident on this process's GPU(s) + its context: warm-up, timed region, the optional extra passes."""
 
@@ -476,7 +565,7 @@ def measure(job: Job, args, full: bool):
     items = n_items_a * len(cfg.events)
     ms_per_step = elapsed / args.steps * 1e3
     value = pairs / (elapsed / args.steps)
-    nnz_sampled = [int(ind.sampled_row_ptr[-1]) for ind in inds]
+    nnz_sampled = [ind.nnz_sampled_global() for ind in inds]  # the whole matrix over all ranks (the row-filtered exchange leaves a rank only its rows)
     nnz_raw_local = [sum(s.nnz_bound for s in row) for row in job.shards]
     item_range = [inds[0].item_lo, inds[0].item_hi]
     out = {"elapsed": elapsed, "ms_per_step": ms_per_step, "value": value, "pairs": pairs, "pairs_per_event": pairs_per_event, "stats": stats,
@@ -580,6 +669,8 @@ def main():
                     help="A/B (N > 1 path): the primary's CSC from a pass of every rank over the whole gathered A' (rounds 1-2) instead of fragments")
     ap.add_argument("--timed-only", action="store_true", help="stop after the timed region (timeline captures)")
     ap.add_argument("--seed", type=int, default=20260925)
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="measurement mode: the per-rank critical path of a W-rank build on ONE GPU (prints its own JSON object, not the bench line)")
     args = ap.parse_args()
     # No restart logic: round 3's supervisor (a child re-run after a death by signal) is gone with the fault it papered over -- a
     # missing barrier in the top-k select, cco_kernels.hip "SHARE && T != WAVE" (DESIGN.md section 7).  A process that dies fails the run.
@@ -623,6 +714,10 @@ def main():
         if world > 1 and not args.single_process:
             dist.barrier()
     library = _lib.load(os.environ.get("URCCO_LIB", _lib.DEFAULT_PATH))   # URCCO_LIB: A/B runs of two builds on one box
+    if args.emulate_ranks > 1:
+        wl = "config4" if args.workload == "auto" else args.workload
+        print(json.dumps(emulate_ranks_leg(library, dev, wl, args.emulate_ranks, args)), flush=True)
+        return
 
     workload = args.workload if args.workload != "auto" else "config4"
     mark(f"generating {workload} on the device")

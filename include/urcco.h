@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define URCCO_VERSION 302 /* 0.3.2 */
+#define URCCO_VERSION 303 /* 0.3.3: urcco_dev_result.sampled_nnz_total */
 
 typedef enum urcco_status {
   URCCO_OK = 0,
@@ -79,6 +79,13 @@ typedef struct urcco_options {
                                        computeSimilarities returns -- a sparse vector has no score order, the reference sorts
                                        later (toStringMapRDD, package.scala:102) and a JNI host re-inserts by index anyway.
                                        Saves the in-kernel ranking pass.  Default off: rows ordered (llr desc, col asc). */
+
+#define URCCO_FLAG_EMULATE_RANKS 8  /* MEASUREMENT ONLY (bench.py --emulate-ranks): the context's n_gpus ranks all run on the ONE device
+                                       `device`, one after the other on a single stream (every kernel alone on the GPU), so that the per-rank
+                                       critical path of a W-rank build -- user-range input phase, own-shard transposition, masks, packing,
+                                       fragment merge, fused expand, item-range SpGEMM -- can be timed without W GPUs.  Needs caller-supplied
+                                       collectives (urcco_comm_config.collectives; RCCL cannot put two ranks on one device) and the device
+                                       level (urcco_context_build_device).  Results are the real W-rank results; xGMI time is not in them. */
 
 /* One returned IndexedDataset: rows = items of the primary matrix A (rowIDs = A.columnIDs), columns = items
  * of B_i (columnIDs = B_i.columnIDs), values = raw LLR.  Inside a row entries are ordered (llr desc, col asc)
@@ -224,9 +231,17 @@ typedef struct urcco_dev_result {
   const int32_t* col_idx;
   const double* llr;
   const int64_t* stats;    /* URCCO_STATS_LEN, see urcco_dev_cco_rows */
-  const int64_t* sampled_row_ptr; /* the down-sampled B this GPU multiplied with (whole matrix), sampled_rows + 1 */
+  /* The down-sampled B this GPU multiplied with, sampled_rows + 1 row pointers.  One rank: the whole matrix.  Several ranks: a row per
+   * user of the job, but (row-filtered exchange, the default) only the rows of users holding an item of THIS rank's item range are
+   * filled -- every other row is empty, and sampled_row_ptr[sampled_rows] is this rank's filtered entry count, not the matrix's.  Debug
+   * bit 16384 (urcco_context_set_debug) exchanges every row instead.  The exchange is also unfiltered when the job has more than 64
+   * ranks or runs on caller-supplied collectives without all_to_all_v. */
+  const int64_t* sampled_row_ptr;
   const int32_t* sampled_col_idx;
   int64_t sampled_rows;
+  /* entries of the WHOLE down-sampled matrix, over all ranks (host-known after the exchange); -1 on a one-rank build, where the host
+   * never reads a size back: there it equals sampled_row_ptr[sampled_rows] on the device */
+  int64_t sampled_nnz_total;
 } urcco_dev_result;
 /* input_stream (nullable hipStream_t): the stream the shards were produced on -- the build waits for it on the device.
  * out[d * local_gpus + g].  Returns after ENQUEUEING (except for the one blocking read of range bounds / shard sizes
@@ -238,6 +253,8 @@ int urcco_context_synchronize(urcco_context* ctx);               /* the host wai
 /* per-stage timing / ablation switches of every session of the context (see urcco_session_set_timing / _set_debug) */
 int urcco_context_set_timing(urcco_context* ctx, int32_t enable);
 int urcco_context_get_timings(urcco_context* ctx, double* ms, int64_t* launches);
+/* the same for ONE local GPU (rank first_rank + local_gpu): what bench.py --emulate-ranks reads per rank */
+int urcco_context_get_timings_gpu(urcco_context* ctx, int32_t local_gpu, double* ms, int64_t* launches);
 int urcco_context_set_debug(urcco_context* ctx, int32_t flags);
 int urcco_context_set_flags(urcco_context* ctx, int32_t flags); /* URCCO_FLAG_* */
 
@@ -253,7 +270,7 @@ int urcco_session_synchronize(urcco_session* s);
 /* Per-stage device timing with HIP events on the session's stream (what bench.py's roofline numbers are made of).
  * set_timing resets the accumulators; get_timings synchronises and returns, per stage id, the summed event time
  * in ms and the number of timed launches. */
-#define URCCO_N_STAGES 16
+#define URCCO_N_STAGES 17
 enum {
   URCCO_STAGE_COLUMN_COUNTS = 0,
   URCCO_STAGE_DOWNSAMPLE_FLAGS = 1,
@@ -270,7 +287,8 @@ enum {
   URCCO_STAGE_CCO_BIN4 = 12, /* half-CU-LDS rows            */
   URCCO_STAGE_CCO_BIN5 = 13, /* CU-LDS accumulator rows     */
   URCCO_STAGE_CCO_BIN6 = 14, /* global accumulator rows     */
-  URCCO_STAGE_COMPACT_INDICATORS = 15
+  URCCO_STAGE_COMPACT_INDICATORS = 15,
+  URCCO_STAGE_EXCHANGE = 16 /* several ranks only: row lengths, need masks, masked lengths, packing per destination, row_ptr rebuild of what was received */
 };
 int urcco_session_set_timing(urcco_session* s, int32_t enable);
 /* Profiling aid: kernel ablation switches; results are meaningless when non-zero.  0 in production.

@@ -44,6 +44,7 @@ struct alignas(16) uint4 { unsigned x, y, z, w; };
 struct alignas(8) int2 { int x, y; };
 struct alignas(8) uint2 { unsigned x, y; };
 static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 static inline int2 make_int2(int x, int y) { return int2{x, y}; }
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 

@@ -175,6 +175,8 @@ def test_one_process_drives_several_gpus(sim_lib, n_gpus, primary, monkeypatch):
             assert sum(int(ind.stats[0]) for ind in res[d]) == r.pairs
             full = O.downsample(mats[d], O.column_counts(mats[d]), 2024, params[d].max_elements_per_row)
             for ind in res[d]:
+                #  the size of the WHOLE down-sampled matrix comes from the library's own total, whatever this GPU holds of it
+                assert ind.sampled_nnz_total == full.nnz and ind.nnz_sampled_global() == full.nnz
                 if primary == "gathered":                                 # every GPU holds the whole down-sampled B
                     assert np.array_equal(ind.sampled_row_ptr.numpy(), full.row_ptr)
                     assert np.array_equal(ind.sampled_col_idx.numpy()[:full.nnz], full.col_idx)
@@ -490,3 +492,49 @@ def test_row_filtered_exchange_volume_at_8_ranks(sim_lib, monkeypatch):
     ratio = received["filtered"] / received["all-gather"]
     assert np.all(ratio <= 0.6), (ratio, received)
     assert np.all(ratio >= 0.15), ratio       # sanity: it still receives the rows it multiplies with
+
+
+def test_emulated_ranks_on_one_device(sim_lib):
+    """URCCO_FLAG_EMULATE_RANKS (bench.py --emulate-ranks): W ranks of a job on ONE device and one stream, collectives looped back through
+    views on the library's buffers.  The build is the real W-rank build -- fragments, row-filtered exchange, fused expand, work-balanced
+    ranges -- so every rank's rows must equal the oracle, and every rank reports its own stage timings."""
+    from universal_recommender_amd import _lib, sharded, synth
+    from universal_recommender_amd.device import Context
+    W = 4
+    cfg = synth.config4(0.004)
+    data = synth.generate(cfg)
+    mats = [O.Csr(cfg.n_users, nc, rp, ci) for (_, nc, rp, ci) in data]
+    params = [P(60, 12)] * len(mats)
+    ref = O.cross_occurrence_downsampled(mats, params, 11)
+    cuts = [cfg.n_users * g // W for g in range(W + 1)]
+    shards = [[to_dev(O.Csr(hi - lo, m.n_cols, m.row_ptr[lo:hi + 1] - m.row_ptr[lo], m.col_idx[m.row_ptr[lo]:m.row_ptr[hi]]), "cpu")
+               for lo, hi in zip(cuts, cuts[1:])] for m in mats]
+    with pytest.raises(_lib.UrccoError):      # RCCL cannot put two ranks on one device: the flag needs caller-supplied collectives
+        Context(torch.device("cpu"), sim_lib, n_gpus=W, flags=_lib.FLAG_EMULATE_RANKS)
+    coll = sharded.DeviceLoopbackCollectives(W, "cpu")
+    ctx = Context(torch.device("cpu"), sim_lib, n_gpus=W, flags=_lib.FLAG_EMULATE_RANKS, collectives=coll)
+    try:
+        assert ctx.n_local == W
+        ctx.set_timing(True)
+        for _ in range(2):                     # the second build reuses every buffer
+            ctx.build(shards, to_params(params), 11, cfg.n_users, cuts[:-1])
+            res = ctx.results()
+            assert coll.error is None
+            for d, r in enumerate(ref):
+                parts = [ind.to_host() for ind in res[d]]
+                assert res[d][0].item_lo == 0 and res[d][-1].item_hi == mats[0].n_cols
+                assert all(a.item_hi == b.item_lo for a, b in zip(res[d], res[d][1:]))
+                lens = np.concatenate([np.diff(p[0]) for p in parts])
+                rp = np.zeros(lens.size + 1, np.int64)
+                np.cumsum(lens, out=rp[1:])
+                check_indicators((rp, np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])), r)
+                assert sum(int(ind.stats[0]) for ind in res[d]) == r.pairs
+                assert all(ind.sampled_nnz_total == O.downsample(mats[d], O.column_counts(mats[d]), 11, 60).nnz for ind in res[d])
+        per_rank = [ctx.get_timings_gpu(g) for g in range(W)]
+        total = ctx.get_timings()
+        for name in ("column_counts", "downsample_flags", "transpose", "exchange", "cco_rows_micro", "compact_indicators"):
+            assert all(t[name][1] > 0 for t in per_rank), name                      # every rank ran the stage ...
+            assert sum(t[name][1] for t in per_rank) == total[name][1], name        # ... and the per-rank views add up to the context's
+        assert all(b > 0 for b in coll.bytes_received)
+    finally:
+        ctx.close()

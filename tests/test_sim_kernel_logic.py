@@ -128,9 +128,15 @@ def test_partition_balances_work(sim_session):
         assert pref[bounds[p]] >= total * p // 8 and (bounds[p] == 0 or pref[bounds[p] - 1] < total * p // 8)
 
 
+def test_partitioned_column_counts_bucket_contiguous_layout(sim_session, monkeypatch):
+    """The same with URCCO_COLCOUNT_GLOBAL_LAYOUT=1: the bucket-contiguous form (rounds 1-4; still what catalogues beyond 4M columns take)."""
+    monkeypatch.setenv("URCCO_COLCOUNT_GLOBAL_LAYOUT", "1")
+    test_partitioned_column_counts_large_matrix(sim_session)
+
+
 def test_partitioned_column_counts_large_matrix(sim_session):
     """>= 2^20 interactions take the atomic-free partition/dense-LDS histogram (raw counts and, after compaction, the
-    post-sampling counts whose length only the device knows)."""
+    post-sampling counts whose length only the device knows): the part-local layout of round 5."""
     rng = np.random.default_rng(10)
     m = rand_csr(rng, 70000, 100_000, 18, zipf_s=1.0)
     assert m.nnz >= (1 << 20)
@@ -167,11 +173,21 @@ def test_partitioned_column_counts_big_chunks_and_hot_columns(sim_session, monke
     ref = O.column_counts(m)
     assert ref[17] == n_users and ref[8200] == n_users
     d = to_dev(m, sim_session.device)
+    monkeypatch.setenv("URCCO_COLCOUNT_GLOBAL_LAYOUT", "1")
     for big in ("1000000", "2000000000"):
         monkeypatch.setenv("URCCO_PH_CHUNK_BIG_NNZ", big)
         cnt = sim_session.column_counts(d.col_idx, m.nnz, m.n_cols)
         sim_session.synchronize()
         assert np.array_equal(cnt.cpu().numpy(), ref), big
+    # the part-local layout: a hot column is one bucket's slice of EVERY part (ranks inside a lane-private copy reach their 10-bit
+    # limit when a copy's 1024 ids share a bucket), a length that is not a multiple of the part, and a last bucket of 3616 columns
+    monkeypatch.setenv("URCCO_COLCOUNT_GLOBAL_LAYOUT", "0")
+    cnt = sim_session.column_counts(d.col_idx, m.nnz, m.n_cols)
+    one = O.Csr(1, 36_384, np.array([0, 1 << 20], np.int64), np.full(1 << 20, 20_001, np.int32))  # (not a legal CSR row: the histogram does not care)
+    cnt_one = sim_session.column_counts(to_dev(one, sim_session.device).col_idx, one.nnz, one.n_cols)
+    sim_session.synchronize()
+    assert np.array_equal(cnt.cpu().numpy(), ref)
+    assert int(cnt_one[20_001]) == (1 << 20) and int(cnt_one.sum()) == (1 << 20)
 
 
 def test_large_matrix_full_pipeline(sim_session):

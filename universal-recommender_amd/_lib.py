@@ -17,14 +17,15 @@ OK, BAD_ARG, OOM_HOST, OOM_DEVICE, HIP_ERROR, INTERNAL, NO_DEVICE, RCCL_ERROR = 
 FLAG_SINGLE_STREAM = 1
 FLAG_FORCE_EXCHANGE = 2
 FLAG_UNORDERED_ROWS = 4
+FLAG_EMULATE_RANKS = 8
 UNIQUE_ID_BYTES = 128
 ROW_RATE_MAHOUT_INT_DIV = 0
 ROW_RATE_FRACTIONAL = 1
-N_STAGES = 16
+N_STAGES = 17
 N_BINS = 7
 STATS_LEN = 32
 STAGE_NAMES = ["column_counts", "downsample_flags", "downsample_scan", "downsample_compact", "transpose", "row_work", "binning",
-               "entropy", "cco_rows_micro", "cco_rows_wave", "cco_rows_block_small", "cco_rows_block", "cco_rows_cu_half", "cco_rows_cu", "cco_rows_global", "compact_indicators"]
+               "entropy", "cco_rows_micro", "cco_rows_wave", "cco_rows_block_small", "cco_rows_block", "cco_rows_cu_half", "cco_rows_cu", "cco_rows_global", "compact_indicators", "exchange"]
 
 
 class UrccoError(RuntimeError):
@@ -79,7 +80,8 @@ class DevDataset(C.Structure):
 
 class DevResult(C.Structure):
     _fields_ = [("item_lo", C.c_int32), ("item_hi", C.c_int32), ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("llr", C.c_void_p),
-                ("stats", C.c_void_p), ("sampled_row_ptr", C.c_void_p), ("sampled_col_idx", C.c_void_p), ("sampled_rows", C.c_int64)]
+                ("stats", C.c_void_p), ("sampled_row_ptr", C.c_void_p), ("sampled_col_idx", C.c_void_p), ("sampled_rows", C.c_int64),
+                ("sampled_nnz_total", C.c_int64)]
 
 
 class Indicators(C.Structure):
@@ -119,6 +121,7 @@ SYMBOLS = {
     "urcco_context_synchronize": (C.c_int, [_p]),
     "urcco_context_set_timing": (C.c_int, [_p, C.c_int32]),
     "urcco_context_get_timings": (C.c_int, [_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "urcco_context_get_timings_gpu": (C.c_int, [_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "urcco_context_set_debug": (C.c_int, [_p, C.c_int32]),
     "urcco_context_set_flags": (C.c_int, [_p, C.c_int32]),
     "urcco_session_create": (C.c_int, [C.c_int32, _p, C.POINTER(_p)]),

@@ -556,31 +556,252 @@ __global__ __launch_bounds__(256) void ph_reduce_kernel(const unsigned short* __
   counts[j] = (int32_t)sum;
 }
 
+// --------------------------------------------------------------------------------------------
+// K1c  part-local form of the partitioned histogram (round 5; catalogues of up to PL_MAX_BUCKETS * 16384 columns).
+// The form above reads the column indices twice (count, then scatter) and scans a (bucket x part) table in between, because a
+// bucket's ids are to lie contiguously in memory: ~13.5 bytes moved per 4-byte interaction.  Here a part of PL_PART
+// interactions is read ONCE into registers, ranked inside its bucket while it is counted (one returning LDS atomic per id on a
+// lane-private copy of the bucket counters), grouped by bucket in LDS and written where it lies -- part p's ids at
+// bucketed[p * PL_PART ...), whole lines -- together with the (transposed) table of where each bucket's slice starts inside the
+// part.  The histogram block of (bucket, part range) then walks that range's slices: 4 B read + 2 B written + 2 B read per
+// interaction, no count pass, no scan, no block map.
+//   partition  one block per part          ids -> 14-bit in-bucket ids grouped by bucket, loc_t[b][p] = start of bucket b in part p
+//   hist       one block per (bucket, s)   dense 64 KiB LDS counters over the slices of parts [s, s + 1) * pp, 32-bit partials
+//   reduce     counts[col] = sum over the bucket's S partials
+// --------------------------------------------------------------------------------------------
+constexpr int PL_BITS = 14;
+constexpr int PL_BUCKET = 1 << PL_BITS;
+constexpr int PL_PART = 16384;
+constexpr int PL_THREADS = 512;
+constexpr int PL_PER_THREAD = PL_PART / PL_THREADS;  // 32 ids in registers
+constexpr int PL_MAX_BUCKETS = 256;                  // the packed (bucket, id, rank) word has 8 bits for the bucket
+constexpr int PL_COPIES = 16;                        // lane-private counter copies: a copy sees PL_PART / 16 = 1024 ids -> ranks fit 10 bits
+static_assert(PL_PER_THREAD % 4 == 0 && PL_PART / PL_COPIES <= 1024 && PL_THREADS % PL_COPIES == 0, "packed word: 8 + 14 + 10 bits");
+
+__global__ __launch_bounds__(PL_THREADS, 6) void pl_partition_kernel(const int32_t* __restrict__ ci, int64_t nnz_host, const int64_t* __restrict__ nnz_dev,
+                                                                  int n_buckets, int64_t n_parts, unsigned short* __restrict__ bucketed,
+                                                                  unsigned short* __restrict__ loc_t, int vec_ok) {
+  __shared__ int s_cnt[PL_COPIES * PL_MAX_BUCKETS];  // counts, then the start of every (copy, bucket) run inside the staging array
+  __shared__ uint4 s_stage4[PL_PART / 8];  // (16-byte aligned: the part leaves in 16-byte stores)
+  __shared__ long long s_wave[PL_THREADS / WAVE];
+  unsigned short* s_stage = reinterpret_cast<unsigned short*>(s_stage4);
+  const int64_t nnz = nnz_dev ? *nnz_dev : nnz_host;
+  const int64_t e0 = (int64_t)blockIdx.x * PL_PART;
+  const int64_t e1 = e0 + PL_PART < nnz ? e0 + PL_PART : nnz;
+  if (e0 >= e1) {  // a part beyond the device-side length: every slice is empty (block-uniform)
+    for (int b = threadIdx.x; b <= n_buckets; b += PL_THREADS) loc_t[(int64_t)b * n_parts + blockIdx.x] = 0;
+    return;
+  }
+  for (int b = threadIdx.x; b < PL_COPIES * n_buckets; b += PL_THREADS) s_cnt[b] = 0;
+  __syncthreads();
+  int* mine = s_cnt + (threadIdx.x & (PL_COPIES - 1)) * n_buckets;
+  const int n = (int)(e1 - e0);
+  auto live = [&](int q) { return (q >> 2) * (PL_THREADS * 4) + (int)threadIdx.x * 4 + (q & 3) < n; };  // register q holds an entry of the part
+  unsigned w[PL_PER_THREAD];  // the column, then (bucket << 24) | (id << 10) | rank inside (copy, bucket)
+#pragma unroll
+  for (int r = 0; r < PL_PER_THREAD / 4; ++r) {  // all loads of the part are issued before the first atomic
+    const int64_t e = e0 + (int64_t)r * (PL_THREADS * 4) + (int64_t)threadIdx.x * 4;
+    int4 x = make_int4(0, 0, 0, 0);
+    if (vec_ok && e + 3 < e1) {
+      x = *reinterpret_cast<const int4*>(ci + e);
+    } else {
+      if (e < e1) x.x = ci[e];
+      if (e + 1 < e1) x.y = ci[e + 1];
+      if (e + 2 < e1) x.z = ci[e + 2];
+      if (e + 3 < e1) x.w = ci[e + 3];
+    }
+    w[4 * r] = (unsigned)x.x; w[4 * r + 1] = (unsigned)x.y; w[4 * r + 2] = (unsigned)x.z; w[4 * r + 3] = (unsigned)x.w;
+  }
+#pragma unroll
+  for (int q = 0; q < PL_PER_THREAD; ++q) {
+    if (live(q)) {
+      const unsigned b = w[q] >> PL_BITS;
+      const unsigned rank = (unsigned)atomicAdd(&mine[b], 1);
+      w[q] = (b << 24) | ((w[q] & (PL_BUCKET - 1)) << 10) | rank;
+    }
+  }
+  __syncthreads();
+  {  // exclusive prefix over (bucket, copy), bucket-major: where every run starts; the bucket starts go out as loc_t[b][part]
+    const int b = threadIdx.x;  // n_buckets <= PL_MAX_BUCKETS <= PL_THREADS: one round
+    long long tot = 0;
+    if (b < n_buckets) {
+#pragma unroll
+      for (int k = 0; k < PL_COPIES; ++k) tot += s_cnt[k * n_buckets + b];
+    }
+    long long all;
+    const long long ex = block_exclusive_scan<PL_THREADS>(tot, s_wave, &all);
+    if (b < n_buckets) {
+      int run = (int)ex;
+      loc_t[(int64_t)b * n_parts + blockIdx.x] = (unsigned short)run;
+#pragma unroll
+      for (int k = 0; k < PL_COPIES; ++k) {  // (read a second time rather than held across the scan: 16 registers less)
+        const int c = s_cnt[k * n_buckets + b];
+        s_cnt[k * n_buckets + b] = run;
+        run += c;
+      }
+    }
+    if (b == n_buckets) loc_t[(int64_t)b * n_parts + blockIdx.x] = (unsigned short)all;  // <= PL_PART = 16384
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PL_PER_THREAD; ++q) {
+    if (live(q)) s_stage[mine[w[q] >> 24] + (int)(w[q] & 1023u)] = (unsigned short)((w[q] >> 10) & (PL_BUCKET - 1));
+  }
+  __syncthreads();
+  // the part leaves as it lies: 16-byte stores (bucketed + e0 is 32 KiB-aligned relative to the array's 256-byte-aligned base)
+  uint4* dst = reinterpret_cast<uint4*>(bucketed + e0);
+  for (int v = threadIdx.x; v * 8 < n; v += PL_THREADS) dst[v] = s_stage4[v];  // the last vector may carry up to 7 stale ids: inside the part's own 32 KiB, never read
+}
+
+constexpr int PLH_THREADS = 1024;
+// LPS lanes walk one slice together, 16 ids (two 16-byte loads) per lane and step.  A slice of a 2M-column catalogue holds ~130 ids:
+// with 16 lanes per slice a step covers 256 and half of the lanes idle through the masked atomics; fewer lanes per slice waste less
+// but touch more parts (pages) per load instruction.  Measured on config 4's five raw matrices (profiles/r05_colcount_variants.log):
+// 16 / 8 / 4 lanes 3.07 / 3.02 / 3.19 ms, the bucket-contiguous form 3.45.  dbg (URCCO_PL_DEBUG, profiling only): 1 = no LDS atomics,
+// 2 = no loads -- which is how the same log prices the pass: without the atomics 1.76 ms, with neither 1.37: the RANDOM LDS atomics
+// (~1.1 lane updates per clock and CU: ~58 cycles per wave instruction against 4.6 for conflict-free addresses) are what the histogram
+// costs, not its loads -- the same bound the bucket-contiguous form sits on.
+template <int LPS>
+__global__ __launch_bounds__(PLH_THREADS) void pl_hist_kernel(const unsigned short* __restrict__ bucketed, const unsigned short* __restrict__ loc_t,
+                                                              int n_buckets, int64_t n_parts, int S, int32_t n_cols, unsigned* __restrict__ partial, int dbg) {
+  __shared__ unsigned s_cnt[PL_BUCKET];
+  // bucket fastest: the blocks resident at any time read ALL buckets' slices of a few part ranges -- a dense window of the array
+  const int b = (int)(blockIdx.x % (unsigned)n_buckets), s = (int)(blockIdx.x / (unsigned)n_buckets);
+  const int width = (int)((int64_t)n_cols - ((int64_t)b << PL_BITS) < PL_BUCKET ? (int64_t)n_cols - ((int64_t)b << PL_BITS) : PL_BUCKET);  // columns of this bucket
+  for (int c = threadIdx.x; c < width; c += PLH_THREADS) s_cnt[c] = 0u;
+  __syncthreads();
+  const int64_t pp = (n_parts + S - 1) / S;
+  const int64_t p0 = (int64_t)s * pp, p1 = p0 + pp < n_parts ? p0 + pp : n_parts;
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+  const unsigned short* lo_t = loc_t + (int64_t)b * n_parts;
+  const unsigned short* hi_t = loc_t + (int64_t)(b + 1) * n_parts;
+  // Steps are aligned to 8 ids; ids of a step outside [lo, hi) -- the neighbouring buckets' -- are masked (the array has 64 bytes of slack
+  // behind it).  (Measured: one WAVE per slice with 2-byte loads -- a chain of short waits -- took 2x the bucket-contiguous form; one
+  // LANE per slice -- 64 parts, i.e. 64 pages, per load instruction -- 2.4x.)
+  constexpr int SPR = WAVE / LPS;  // slices per wave and round
+  constexpr int GP = 16;           // parts per group (a wave takes groups round robin; lane l < GP holds the bounds of part g + l)
+  static_assert(GP % SPR == 0 && SPR <= GP, "rounds per group");
+  const int sub = lane / LPS, sl = lane % LPS;
+  const int64_t gstep = (int64_t)(PLH_THREADS / WAVE) * GP;
+  unsigned fake = 0u;
+  int64_t g = p0 + (int64_t)wave * GP;
+  unsigned lo_n = 0u, hi_n = 0u;  // the NEXT group's bounds travel while this group's slices are counted
+  if (g < p1 && lane < GP && g + lane < p1) {
+    lo_n = lo_t[g + lane];
+    hi_n = hi_t[g + lane];
+  }
+  for (; g < p1; g += gstep) {  // wave-uniform
+    const unsigned lo = lo_n, hi = hi_n;
+    lo_n = 0u;
+    hi_n = 0u;
+    if (g + gstep < p1 && lane < GP && g + gstep + lane < p1) {
+      lo_n = lo_t[g + gstep + lane];
+      hi_n = hi_t[g + gstep + lane];
+    }
+    const int rounds = (int)(p1 - g < GP ? (p1 - g + SPR - 1) / SPR : GP / SPR);
+    for (int r = 0; r < rounds; ++r) {  // wave-uniform
+      const int pj = SPR * r + sub;  // (parts past the range carry lo == hi == 0)
+      const unsigned lo_j = (unsigned)__shfl((int)lo, pj);
+      const unsigned hi_j = (unsigned)__shfl((int)hi, pj);
+      const unsigned short* src = bucketed + (g + pj) * PL_PART;
+      for (unsigned base = (lo_j & ~7u) + 16u * (unsigned)sl; base < hi_j; base += 16u * LPS) {
+        uint4 x0 = make_uint4(base, base + 2u, base + 4u, base + 6u), x1 = x0;
+        if (!(dbg & 2)) {
+          x0 = *reinterpret_cast<const uint4*>(src + base);
+          x1 = *reinterpret_cast<const uint4*>(src + base + 8);
+        }
+        const unsigned wds[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        if (dbg & 1) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) fake ^= wds[k];
+          continue;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const unsigned t = base + 2u * k;
+          if (t >= lo_j && t < hi_j) atomicAdd(&s_cnt[wds[k] & (PL_BUCKET - 1)], 1u);
+          if (t + 1u >= lo_j && t + 1u < hi_j) atomicAdd(&s_cnt[(wds[k] >> 16) & (PL_BUCKET - 1)], 1u);
+        }
+      }
+    }
+  }
+  if ((dbg & 1) && fake == 0x9e3779b9u) s_cnt[0] = 1u;
+  __syncthreads();
+  unsigned* out = partial + ((int64_t)b * S + s) * PL_BUCKET;
+  for (int c = threadIdx.x; c < width; c += PLH_THREADS) out[c] = s_cnt[c];
+}
+
+__global__ __launch_bounds__(256) void pl_reduce_kernel(const unsigned* __restrict__ partial, int S, int32_t n_cols, int32_t* __restrict__ counts) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_cols) return;
+  const int64_t b = j >> PL_BITS;
+  const int c = (int)(j & (PL_BUCKET - 1));
+  unsigned sum = 0;
+  for (int s = 0; s < S; ++s) sum += partial[(b * S + s) * PL_BUCKET + c];
+  counts[j] = (int32_t)sum;
+}
+
+// histogram blocks per bucket: a few thousand blocks in all, each with at least a handful of parts
+static inline int pl_splits(int n_buckets, int64_t n_parts) {
+  int64_t S = (2048 + n_buckets - 1) / n_buckets;
+  if (S > n_parts / 4) S = n_parts / 4;
+  if (S < 1) S = 1;
+  return (int)S;
+}
+static inline bool pl_applies(int32_t n_cols) {
+  const char* e = getenv("URCCO_COLCOUNT_GLOBAL_LAYOUT");  // A/B and test knob: the bucket-contiguous form above
+  if (e && *e == '1') return false;
+  return (((int64_t)n_cols + PL_BUCKET - 1) >> PL_BITS) <= PL_MAX_BUCKETS;
+}
+
 int64_t column_counts_scratch_bytes(int64_t nnz, int32_t n_cols) {
+  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  if (nnz >= PH_MIN_NNZ && pl_applies(n_cols)) {
+    const int64_t n_buckets = ((int64_t)n_cols + PL_BUCKET - 1) >> PL_BITS;
+    const int64_t n_parts = (nnz + PL_PART - 1) / PL_PART;
+    return al(n_parts * PL_PART * 2 + 64) + al((n_buckets + 1) * n_parts * 2) + al(n_buckets * pl_splits((int)n_buckets, n_parts) * (int64_t)PL_BUCKET * 4);
+  }
   if (nnz < PH_MIN_NNZ || (((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS) > PH_MAX_BUCKETS) return 0;
   const int64_t n_buckets = ((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS;
   const int64_t n_parts = (nnz + PH_PART - 1) / PH_PART;
   const int64_t m = n_buckets * n_parts;
   const int64_t max_blocks = n_buckets + (nnz + ph_chunk(nnz) - 1) / ph_chunk(nnz);
-  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
   return al(m * 4) + al((m + 1) * 8) + al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8) + al(nnz * 2 + 16) + al((n_buckets + 1) * 4) + al(max_blocks * PH_BUCKET * 2);
 }
 
 hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_idx, int64_t nnz, const int64_t* nnz_dev, int32_t n_cols,
                                             int32_t* counts, char* scratch) {
+  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
+  if (pl_applies(n_cols)) {
+    const int n_buckets = (int)(((int64_t)n_cols + PL_BUCKET - 1) >> PL_BITS);
+    const int64_t n_parts = (nnz + PL_PART - 1) / PL_PART;
+    const int S = pl_splits(n_buckets, n_parts);
+    unsigned short* bucketed = reinterpret_cast<unsigned short*>(scratch); scratch += al(n_parts * PL_PART * 2 + 64);
+    unsigned short* loc_t = reinterpret_cast<unsigned short*>(scratch); scratch += al(((int64_t)n_buckets + 1) * n_parts * 2);
+    unsigned* partial = reinterpret_cast<unsigned*>(scratch);
+    hipLaunchKernelGGL(pl_partition_kernel, dim3((unsigned)n_parts), dim3(PL_THREADS), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, bucketed, loc_t, vec_ok);
+    const char* de = getenv("URCCO_PL_DEBUG");   // profiling only: 1 = no LDS atomics, 2 = no loads (the counts are then meaningless)
+    const char* le = getenv("URCCO_PL_LANES");   // A/B: lanes per slice (16, 8 or 4)
+    const int dbg = de && *de ? atoi(de) : 0, lps = le && *le ? atoi(le) : 8;
+    const dim3 hg((unsigned)(n_buckets * S)), hb(PLH_THREADS);
+    if (lps == 4) hipLaunchKernelGGL((pl_hist_kernel<4>), hg, hb, 0, st, bucketed, loc_t, n_buckets, n_parts, S, n_cols, partial, dbg);
+    else if (lps == 8) hipLaunchKernelGGL((pl_hist_kernel<8>), hg, hb, 0, st, bucketed, loc_t, n_buckets, n_parts, S, n_cols, partial, dbg);
+    else hipLaunchKernelGGL((pl_hist_kernel<16>), hg, hb, 0, st, bucketed, loc_t, n_buckets, n_parts, S, n_cols, partial, dbg);
+    hipLaunchKernelGGL(pl_reduce_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, partial, S, n_cols, counts);
+    return hipGetLastError();
+  }
   const int n_buckets = (int)(((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS);
   const int64_t n_parts = (nnz + PH_PART - 1) / PH_PART;
   const int64_t m = (int64_t)n_buckets * n_parts;
   const int chunk = ph_chunk(nnz);
   const int64_t max_blocks = n_buckets + (nnz + chunk - 1) / chunk;
-  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
   int32_t* part_counts = reinterpret_cast<int32_t*>(scratch); scratch += al(m * 4);
   int64_t* offsets = reinterpret_cast<int64_t*>(scratch); scratch += al((m + 1) * 8);
   int64_t* tile_sums = reinterpret_cast<int64_t*>(scratch); scratch += al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8);
   unsigned short* bucketed = reinterpret_cast<unsigned short*>(scratch); scratch += al(nnz * 2 + 16);
   int32_t* blk_prefix = reinterpret_cast<int32_t*>(scratch); scratch += al(((int64_t)n_buckets + 1) * 4);
   unsigned short* partial = reinterpret_cast<unsigned short*>(scratch);
-  const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
   hipLaunchKernelGGL(ph_count_kernel, dim3((unsigned)n_parts), dim3(256), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, part_counts, vec_ok);
   hipError_t e = launch_scan_i32(st, part_counts, m, offsets, tile_sums);
   if (e != hipSuccess) return e;

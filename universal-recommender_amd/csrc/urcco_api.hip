@@ -52,7 +52,7 @@ void put_u(unsigned long long v, int base = 10) {
   put(o);
 }
 const char* const STAGE_NAME[URCCO_N_STAGES] = {"column_counts", "downsample_flags", "downsample_scan", "downsample_compact", "transpose", "row_work", "binning",
-                                               "entropy", "cco_bin0", "cco_bin1", "cco_bin2", "cco_bin3", "cco_bin4", "cco_bin5", "cco_bin6", "compact_indicators"};
+                                               "entropy", "cco_bin0", "cco_bin1", "cco_bin2", "cco_bin3", "cco_bin4", "cco_bin5", "cco_bin6", "compact_indicators", "exchange"};
 void dump_marks(const char* why) {  // async-signal-safe: write(2) only
   put("[urcco marks] "); put(why); put(": last launch groups per session (ordinal:stage begun / finished)\n");
   for (int i = 0; i < MARK_SESSIONS; ++i) {

@@ -273,11 +273,12 @@ struct DevWorkers {
   bool stop = false;
   std::vector<int> status;
   std::vector<std::string> message;
+  bool sequential = false;  // URCCO_FLAG_EMULATE_RANKS: the ranks share one device and one stream; their phases are enqueued one after the other
 
   void start(size_t n) {
     status.assign(n, URCCO_OK);
     message.assign(n, std::string());
-    if (n <= 1) return;
+    if (n <= 1 || sequential) return;
     for (size_t g = 0; g < n; ++g)
       threads.emplace_back([this, g] {
         uint64_t seen = 0;
@@ -304,6 +305,10 @@ struct DevWorkers {
   int run(const std::function<int(size_t)>& f) {
     const size_t n = status.size();
     if (n <= 1) return n == 1 ? f(0) : URCCO_OK;
+    if (sequential) {
+      for (size_t g = 0; g < n; ++g) URC(f(g));
+      return URCCO_OK;
+    }
     {
       std::lock_guard<std::mutex> lk(mu);
       job = &f;
@@ -415,6 +420,8 @@ struct urcco_context {
   int copy_threads = 4;
   std::unique_ptr<PendingBuild> pending;  // between urcco_context_stage and urcco_context_finish
 
+  hipStream_t emu_stream = nullptr;  // URCCO_FLAG_EMULATE_RANKS: the one stream every session of every rank runs on
+  bool emulate() const { return (flags & URCCO_FLAG_EMULATE_RANKS) != 0; }
   bool exchange() const { return world > 1 || (flags & URCCO_FLAG_FORCE_EXCHANGE); }
   bool single_stream() const { return (flags & URCCO_FLAG_SINGLE_STREAM) != 0; }
 
@@ -480,7 +487,7 @@ int ensure_events(urcco_context* c, DevState& D, int n_ds) {
   URC(set_dev(D));
   while ((int)D.sessions.size() < n_ds) {
     urcco_session* s = nullptr;
-    URC(urcco_session_create(D.device, nullptr, &s));
+    URC(urcco_session_create(D.device, c->emulate() ? (void*)c->emu_stream : nullptr, &s));
     s->debug = c->debug;
     s->timing = c->timing;
     s->unordered_rows = (c->flags & URCCO_FLAG_UNORDERED_ROWS) ? 1 : 0;
@@ -741,7 +748,9 @@ int filtered_sizes(urcco_context* c, DevState& D, int d, const Shard& s) {
   URC(E.mtmp.ensure((size_t)W * n / urcco::SCAN_TILE + 4));
   URC(E.to_nnz.ensure((size_t)W * (size_t)W));
   if (E.s != D.ev[0].s) HIPC(hipStreamWaitEvent(E.s->stream, D.need_ready, 0));
+  E.s->begin(URCCO_STAGE_EXCHANGE);
   HIPC(urcco::launch_masked_lengths(E.s->stream, D.n_cu, s.n_rows, E.s_rp.p, D.need.p, W, E.mlen.p, E.moff.p, E.mtmp.p, E.to_nnz.p + (size_t)W * (size_t)D.rank));
+  E.s->end();
   return URCCO_OK;
 }
 // ... and the tiny all-gather of those totals (W int64 per rank), on event d's stream
@@ -796,7 +805,9 @@ int input_phase(urcco_context* c, int d, const std::vector<std::vector<Shard>>& 
     URC(E.deg.ensure((size_t)s.n_rows + 1));
     URC(E.deg16.ensure((size_t)s.n_rows + 8));
     URC(E.sizes.ensure((size_t)XS * (size_t)c->world));
+    E.s->begin(URCCO_STAGE_EXCHANGE);
     HIPC(urcco::launch_row_lengths(E.s->stream, D.n_cu, s.n_rows, E.s_rp.p, E.deg.p, E.deg16.p, E.sizes.p + XS * D.rank));
+    E.s->end();
   }
   std::vector<int64_t> off((size_t)c->world), cnt((size_t)c->world, 8 * XS);
   for (int r = 0; r < c->world; ++r) off[(size_t)r] = 8 * XS * (int64_t)r;
@@ -920,8 +931,10 @@ int exchange_phase(urcco_context* c, int d, const std::vector<std::vector<Shard>
       URC(set_dev(D));
       EvState& E = D.ev[(size_t)d];
       const Shard& s = sh[(size_t)d][g];
+      E.s->begin(URCCO_STAGE_EXCHANGE);
       HIPC(urcco::launch_pack_rows(E.s->stream, D.n_cu, s.n_rows, E.s_rp.p, E.s_ci.p, D.need.p, W, E.moff.p, E.pack.p));
       if (deg16 && s.n_rows > 0) HIPC(urcco::launch_narrow_counts(E.s->stream, D.n_cu, E.mlen.p, (int32_t)((int64_t)W * s.n_rows), E.mlen16.p, E.mlen_bad.p));
+      E.s->end();
       return URCCO_OK;
     }));
   }
@@ -986,8 +999,10 @@ int exchange_phase(urcco_context* c, int d, const std::vector<std::vector<Shard>
   for (DevState& D : c->devs) {
     URC(set_dev(D));
     EvState& E = D.ev[(size_t)d];
+    E.s->begin(URCCO_STAGE_EXCHANGE);
     if (deg16) HIPC(urcco::launch_scan_u16(E.s->stream, E.f_deg16.p, rows, E.f_rp.p, E.scan_tmp.p));
     else HIPC(urcco::launch_scan_i32(E.s->stream, E.f_deg.p, rows, E.f_rp.p, E.scan_tmp.p));
+    E.s->end();
     E.b_rp = E.f_rp.p;
     E.b_ci = E.f_ci.p;
     E.b_rows = rows;
@@ -1041,10 +1056,14 @@ int build_sharded(urcco_context* c, const std::vector<std::vector<Shard>>& sh, c
       URC(D.bounds.ensure((size_t)W + 1));
       URC(D.rec.ensure((size_t)R * (size_t)W));
       URC(urcco_dev_transpose(A.s, s.n_rows, A.s_rp.p, A.s_ci.p, s.nnz, n_items_a, D.l_cnt.p, 0, n_items_a, D.l_cp.p, D.l_ri.p));
+      A.s->begin(URCCO_STAGE_EXCHANGE);
       HIPC(urcco::launch_narrow_counts(A.s->stream, D.n_cu, D.l_cnt.p, n_items_a, D.len16.p, D.len_bad.p));
+      A.s->end();
       // identical bounds on every rank: the same scan + split of the same summed key; they stay on the device
       URC(urcco_detail::partition_dev(A.s, n_items_a, D.work.p, W, D.bounds.p, nullptr));
+      A.s->begin(URCCO_STAGE_EXCHANGE);
       HIPC(urcco::launch_frag_record(A.s->stream, W, D.bounds.p, D.l_cp.p, D.len_bad.p, D.rec.p + (size_t)R * (size_t)D.rank));
+      A.s->end();
       return URCCO_OK;
     }));
     std::vector<int64_t> off((size_t)W), cnt((size_t)W, 8 * (int64_t)R);
@@ -1062,7 +1081,9 @@ int build_sharded(urcco_context* c, const std::vector<std::vector<Shard>>& sh, c
         EvState& A = D.ev[0];
         const Shard& s = sh[0][g];
         URC(D.need.ensure((size_t)s.n_rows + 1));
+        A.s->begin(URCCO_STAGE_EXCHANGE);
         HIPC(urcco::launch_need_mask(A.s->stream, D.n_cu, s.n_rows, A.s_rp.p, A.s_ci.p, D.bounds.p, W, D.need.p));
+        A.s->end();
         HIPC(hipEventRecord(D.need_ready, A.s->stream));
         return filtered_sizes(c, D, 0, s);
       }));
@@ -1308,6 +1329,7 @@ void urcco_context_destroy(urcco_context* c) {
     D.need.release();
     for (urcco_session* s : D.sessions) urcco_session_destroy(s);
   }
+  if (c->emu_stream) (void)hipStreamDestroy(c->emu_stream);
   c->rings.clear();
   delete c;
 }
@@ -1322,7 +1344,13 @@ int urcco_context_create(const urcco_options* options, const urcco_comm_config* 
     const int first = options ? options->device : 0;
     int n_local = options ? options->n_gpus : 0;
     if (first < 0 || first >= n_dev) return fail(URCCO_BAD_ARG, "device %d out of range [0,%d)", first, n_dev);
-    if (n_local < 0 || first + n_local > n_dev) return fail(URCCO_BAD_ARG, "n_gpus %d from device %d: only %d device(s) visible", n_local, first, n_dev);
+    const bool emulate = options && (options->flags & URCCO_FLAG_EMULATE_RANKS);
+    if (emulate) {  // measurement only: n_gpus ranks on the one device `first`, see include/urcco.h
+      if (n_local < 1) return fail(URCCO_BAD_ARG, "URCCO_FLAG_EMULATE_RANKS: n_gpus must name the number of ranks to emulate");
+      if (!comm || !comm->collectives) return fail(URCCO_BAD_ARG, "URCCO_FLAG_EMULATE_RANKS needs caller-supplied collectives (RCCL cannot put two ranks on one device)");
+    } else if (n_local < 0 || first + n_local > n_dev) {
+      return fail(URCCO_BAD_ARG, "n_gpus %d from device %d: only %d device(s) visible", n_local, first, n_dev);
+    }
     if (n_local == 0) n_local = n_dev - first;
     const int mode = options ? options->row_rate_mode : URCCO_ROW_RATE_MAHOUT_INT_DIV;
     if (mode != URCCO_ROW_RATE_MAHOUT_INT_DIV && mode != URCCO_ROW_RATE_FRACTIONAL) return fail(URCCO_BAD_ARG, "unknown row_rate_mode %d", mode);
@@ -1345,10 +1373,15 @@ int urcco_context_create(const urcco_options* options, const urcco_comm_config* 
     c->devs.resize((size_t)n_local);
     for (int g = 0; g < n_local; ++g) {
       DevState& D = c->devs[(size_t)g];
-      D.device = first + g;
+      D.device = emulate ? first : first + g;
       D.rank = c->first_rank + g;
       hipDeviceProp_t prop;
       if (hipGetDeviceProperties(&prop, D.device) == hipSuccess && prop.multiProcessorCount > 0) D.n_cu = prop.multiProcessorCount;
+    }
+    if (emulate) {
+      HIPC(hipSetDevice(first));
+      HIPC(hipStreamCreate(&c->emu_stream));
+      c->workers->sequential = true;
     }
     c->workers->start((size_t)n_local);
     const unsigned hc = std::thread::hardware_concurrency();
@@ -1386,6 +1419,7 @@ int urcco_context_set_flags(urcco_context* c, int32_t flags) {
   if (!c) return fail(URCCO_BAD_ARG, "context is NULL");
   if (!c->have_cb && !c->rccl && c->world == 1 && (flags & URCCO_FLAG_FORCE_EXCHANGE))
     return fail(URCCO_BAD_ARG, "URCCO_FLAG_FORCE_EXCHANGE must be given to urcco_context_create (the communicator is created there)");
+  if ((flags ^ c->flags) & URCCO_FLAG_EMULATE_RANKS) return fail(URCCO_BAD_ARG, "URCCO_FLAG_EMULATE_RANKS must be given to urcco_context_create");
   c->flags = flags;
   return URCCO_OK;
 }
@@ -1421,6 +1455,21 @@ int urcco_context_get_timings(urcco_context* c, double* ms, int64_t* launches) {
       URC(urcco_session_get_timings(s, m, n));
       for (int i = 0; i < URCCO_N_STAGES; ++i) { ms[i] += m[i]; launches[i] += n[i]; }
     }
+  }
+  return URCCO_OK;
+}
+
+int urcco_context_get_timings_gpu(urcco_context* c, int32_t g, double* ms, int64_t* launches) {
+  CallerDevice restore;
+  if (!c || !ms || !launches || g < 0 || (size_t)g >= c->devs.size()) return fail(URCCO_BAD_ARG, "urcco_context_get_timings_gpu: bad argument");
+  for (int i = 0; i < URCCO_N_STAGES; ++i) { ms[i] = 0; launches[i] = 0; }
+  DevState& D = c->devs[(size_t)g];
+  HIPC(hipSetDevice(D.device));
+  for (urcco_session* s : D.sessions) {
+    double m[URCCO_N_STAGES];
+    int64_t n[URCCO_N_STAGES];
+    URC(urcco_session_get_timings(s, m, n));
+    for (int i = 0; i < URCCO_N_STAGES; ++i) { ms[i] += m[i]; launches[i] += n[i]; }
   }
   return URCCO_OK;
 }
@@ -1479,6 +1528,7 @@ int urcco_context_build_device(urcco_context* c, const urcco_dev_dataset* datase
         r.item_lo = D.item_lo; r.item_hi = D.item_hi;
         r.row_ptr = E.c_rp.p; r.col_idx = E.c_idx.p; r.llr = E.c_llr.p; r.stats = E.stats.p;
         r.sampled_row_ptr = E.b_rp; r.sampled_col_idx = E.b_ci; r.sampled_rows = E.b_rows;
+        r.sampled_nnz_total = c->exchange() && (size_t)d < c->h_sizes.size() ? c->h_sizes[(size_t)d] : -1;
       }
     return URCCO_OK;
   });

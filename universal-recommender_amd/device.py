@@ -46,8 +46,16 @@ class DevIndicators:
     col_idx: torch.Tensor   # int32 [n * k] (first row_ptr[-1] live)
     llr: torch.Tensor       # float64 [n * k]
     stats: torch.Tensor     # int64 [STATS_LEN]: pairs, then rows / pairs / users / emitted entries per accumulator bin
-    sampled_row_ptr: Optional[torch.Tensor] = None  # row_ptr of the down-sampled B (its last entry = nnz')
-    sampled_col_idx: Optional[torch.Tensor] = None  # col_idx of the down-sampled B (first nnz' entries live)
+    sampled_row_ptr: Optional[torch.Tensor] = None  # row_ptr of the down-sampled B this GPU multiplied with (several ranks: only the rows its
+                                                    # item range touches are filled, include/urcco.h urcco_dev_result)
+    sampled_col_idx: Optional[torch.Tensor] = None  # col_idx of the same (first sampled_row_ptr[-1] entries live)
+    sampled_nnz_total: int = -1                     # entries of the WHOLE down-sampled matrix over all ranks (-1: one rank, = sampled_row_ptr[-1])
+
+    def nnz_sampled_global(self) -> int:
+        """nnz' of the whole matrix: the library's host-side total when the build exchanged, else the (whole) matrix this GPU holds."""
+        if self.sampled_nnz_total >= 0:
+            return int(self.sampled_nnz_total)
+        return int(self.sampled_row_ptr[-1]) if self.sampled_row_ptr is not None and self.sampled_row_ptr.numel() else 0
 
     def to_host(self):
         if self.row_ptr.numel() == 0:
@@ -203,8 +211,8 @@ def _to_i32(seed: int) -> int:
     return s - (1 << 32) if s >= (1 << 31) else s
 
 
-_TYPESTR = {torch.int32: "<i4", torch.int64: "<i8", torch.float64: "<f8"}
-_CTYPE = {torch.int32: C.c_int32, torch.int64: C.c_int64, torch.float64: C.c_double}
+_TYPESTR = {torch.int32: "<i4", torch.int64: "<i8", torch.float64: "<f8", torch.uint8: "|u1"}
+_CTYPE = {torch.int32: C.c_int32, torch.int64: C.c_int64, torch.float64: C.c_double, torch.uint8: C.c_uint8}
 
 
 class _RawDeviceArray:
@@ -239,7 +247,8 @@ class Context:
         if self.device.type == "cuda":
             index = self.device.index if self.device.index is not None else torch.cuda.current_device()
             self.device = torch.device("cuda", index)
-        self.devices = [torch.device("cuda", index + g) if self.device.type == "cuda" else self.device for g in range(max(n_gpus, 1))]
+        emulate = bool(flags & _lib.FLAG_EMULATE_RANKS)  # measurement only: every rank on the ONE device (include/urcco.h)
+        self.devices = [torch.device("cuda", index + (0 if emulate else g)) if self.device.type == "cuda" else self.device for g in range(max(n_gpus, 1))]
         opts = _lib.Options(device=index, row_rate_mode=row_rate_mode, n_gpus=n_gpus, flags=flags)
         comm = None
         self._collectives = collectives
@@ -301,6 +310,13 @@ class Context:
         ms = (C.c_double * _lib.N_STAGES)()
         n = (C.c_int64 * _lib.N_STAGES)()
         self._check(self.lib.urcco_context_get_timings(self.handle, ms, n))
+        return {_lib.STAGE_NAMES[i]: (ms[i], n[i]) for i in range(_lib.N_STAGES) if _lib.STAGE_NAMES[i]}
+
+    def get_timings_gpu(self, local_gpu: int):
+        """The stage timings of ONE local GPU (rank first_rank + local_gpu)."""
+        ms = (C.c_double * _lib.N_STAGES)()
+        n = (C.c_int64 * _lib.N_STAGES)()
+        self._check(self.lib.urcco_context_get_timings_gpu(self.handle, int(local_gpu), ms, n))
         return {_lib.STAGE_NAMES[i]: (ms[i], n[i]) for i in range(_lib.N_STAGES) if _lib.STAGE_NAMES[i]}
 
     def build(self, shards: Sequence[Sequence[DevCsr]], params: Sequence[DatasetParams], seed: int, n_users_total: Optional[int] = None,
@@ -369,7 +385,8 @@ class Context:
                 s_nnz = int(s_rp[-1]) if s_rp.numel() else 0
                 row.append(DevIndicators(r.item_lo, r.item_hi, n_cols[d], ks[d], _view(r.row_ptr, n + 1, torch.int64, dev),
                                          _view(r.col_idx, max(n * ks[d], 1), torch.int32, dev), _view(r.llr, max(n * ks[d], 1), torch.float64, dev),
-                                         _view(r.stats, _lib.STATS_LEN, torch.int64, dev), s_rp, _view(r.sampled_col_idx, max(s_nnz, 1), torch.int32, dev)))
+                                         _view(r.stats, _lib.STATS_LEN, torch.int64, dev), s_rp, _view(r.sampled_col_idx, max(s_nnz, 1), torch.int32, dev),
+                                         int(r.sampled_nnz_total)))
             res.append(row)
         return res
 

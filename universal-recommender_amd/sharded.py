@@ -154,6 +154,65 @@ class TorchCollectives:
                     C.memmove(recv + roff[p], pieces[(p, r)], rcnt[p])
 
 
+class DeviceLoopbackCollectives(TorchCollectives):
+    """urcco_collectives for URCCO_FLAG_EMULATE_RANKS (bench.py --emulate-ranks, tests): every rank of the job lives in this process on
+    ONE GPU, so a collective is a handful of device-to-device copies through zero-copy views on the library's buffers.  The device is
+    drained before and after (the library enqueues on its own stream, torch on its own): measurement plumbing, not a data path."""
+
+    def __init__(self, world: int, device):
+        super().__init__(world, list(range(world)), None)
+        self.device = torch.device(device)
+        self.bytes_received = [0] * world   # per rank, over the builds so far: what xGMI would have carried to it
+
+    def _group_end(self, user):
+        if self.depth == 1 and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        rc = super()._group_end(user)
+        if self.depth == 0 and self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        return rc
+
+    def _v(self, ptr, n, dtype=torch.uint8):
+        from .device import _view
+        return _view(ptr, n, dtype, self.device)
+
+    def _run_all_reduce(self, ops):
+        views = []
+        for r in self.local:
+            _, buf, count, dtype = ops[r]
+            self.log.append(("ar", r, count * (4 if dtype == 0 else 8)))
+            views.append(self._v(buf, count, torch.int32 if dtype == 0 else torch.int64))
+        total = views[0].clone()
+        for v in views[1:]:
+            total += v
+        for r, v in zip(self.local, views):
+            v.copy_(total)
+            self.bytes_received[r] += 2 * v.numel() * v.element_size() * (self.world - 1) // self.world   # reduce-scatter + all-gather
+
+    def _run_all_gather_v(self, ops):
+        for r in self.local:
+            _, send, recv, off, cnt = ops[r]
+            self.log.append(("ag", r, cnt[r]))
+            for p in range(self.world):
+                src = ops[p][1]
+                if cnt[p] > 0 and recv + off[p] != src:
+                    self._v(recv + off[p], cnt[p]).copy_(self._v(src, cnt[p]))
+                if p != r:
+                    self.bytes_received[r] += cnt[p]
+
+    def _run_all_to_all_v(self, ops):
+        for r in self.local:
+            _, send, soff, scnt, recv, roff, rcnt = ops[r]
+            self.log.append(("aa", r, tuple(scnt)))
+            for p in range(self.world):
+                _, send_p, soff_p, scnt_p, _, _, _ = ops[p]
+                assert scnt_p[r] == rcnt[p], f"rank {p} sends {scnt_p[r]} bytes to rank {r}, {rcnt[p]} expected"
+                if rcnt[p] > 0:
+                    self._v(recv + roff[p], rcnt[p]).copy_(self._v(send_p + soff_p[r], rcnt[p]))
+                if p != r:
+                    self.bytes_received[r] += rcnt[p]
+
+
 def make_context(device, library=None, group=None, flags: int = 0, row_rate_mode: int = _lib.ROW_RATE_MAHOUT_INT_DIV) -> Context:
     """The urcco_context of THIS rank of a one-process-per-GPU job (`group` = its torch.distributed group)."""
     device = torch.device(device)
@@ -181,7 +240,7 @@ def cross_occurrence_sharded(ctx: Context, shards: Sequence[DevCsr], params: Seq
     inds = [r[0] for r in ctx.results()]
     if ctx.collectives_error() is not None:
         raise ctx.collectives_error()
-    return ShardedResult(inds, [], [int(i.sampled_row_ptr[-1]) if i.sampled_row_ptr.numel() else 0 for i in inds])
+    return ShardedResult(inds, [], [i.nnz_sampled_global() for i in inds])
 
 
 def gather_item_ranges(res: ShardedResult, n_items_a: int, group=None) -> List[int]:
