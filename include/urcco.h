@@ -45,6 +45,11 @@ typedef enum urcco_status {
 /* D9: how sampleDownAndBinarize's perRowSampleRate is evaluated */
 #define URCCO_ROW_RATE_MAHOUT_INT_DIV 0 /* Int / Int as in Mahout 0.13.0: rows with more than max non-zeros are dropped */
 #define URCCO_ROW_RATE_FRACTIONAL 1     /* min(max, n) / n in floating point */
+/* The down-sampling RNG (oracle decision D10: the reference pins none -- Mahout draws from a java.util.Random per Spark partition), OR-ed
+ * into row_rate_mode wherever that travels (urcco_options.row_rate_mode, urcco_dev_downsample): a stateless uniform keyed by
+ * (seed, global row, column), identical in oracle/cco_oracle.{py,c} and on the device. */
+#define URCCO_RNG_SPLITMIX53 0         /* 64-bit splitmix finaliser, 53-bit uniform (default) */
+#define URCCO_RNG_MIX32 0x100          /* 32-bit: column xor (row, seed) key, two-round multiply-xorshift; ~10 instead of ~25 instructions per interaction */
 
 /* One IndexedDataset.matrix (user x item, binary), rows = the shared user dictionary
  * (Preparator.scala:44-87).  row_ptr has n_rows + 1 entries; col_idx is sorted and unique inside a row. */
@@ -68,7 +73,7 @@ typedef struct urcco_dataset {
 
 typedef struct urcco_options {
   int32_t device;        /* HIP device ordinal of the first GPU */
-  int32_t row_rate_mode; /* URCCO_ROW_RATE_* */
+  int32_t row_rate_mode; /* URCCO_ROW_RATE_* | URCCO_RNG_* */
   int32_t n_gpus;        /* GPUs of THIS process to use, starting at `device`; 0 = every visible one (engine.json "numGPUs") */
   int32_t flags;         /* URCCO_FLAG_* */
   int32_t reserved[4];
@@ -392,6 +397,7 @@ int urcco_dev_pop_counts(urcco_session* s, int64_t n_events, const int32_t* item
 int urcco_dev_llr(urcco_session* s, int64_t n, const int64_t* with_a, const int64_t* with_b, const int64_t* with_ab,
                   const int64_t* n_users, double* out);
 int urcco_dev_u01(urcco_session* s, int64_t n, int32_t seed, const int32_t* row, const int32_t* col, double* out);
+int urcco_dev_u01_rng(urcco_session* s, int64_t n, int32_t seed, const int32_t* row, const int32_t* col, int32_t rng /* URCCO_RNG_* */, double* out);
 
 /* ---- DEVICE level: Preparator (reference src/main/scala/Preparator.scala:44-87, :102-158, :160-214) -------------
  * Dictionaries and binary CSR matrices from event streams of 64-bit keys resident in HBM (the host hashes its id

@@ -67,6 +67,7 @@ struct FakeEnv : JNIEnv {
     memcpy(static_cast<DoubleArr*>(a)->v.data() + s, b, sizeof(jdouble) * (size_t)n);
   }
   void* GetPrimitiveArrayCritical(jarray a, jboolean* c) override {  // allowed inside a critical section
+    if (!pending.empty()) ++pending_violations;  // ... but not with an exception pending (the shim kept pinning after a failed pin)
     if (fail_pin_after >= 0 && pins++ == fail_pin_after) {
       pending = "java.lang.OutOfMemoryError";
       return nullptr;

@@ -70,9 +70,18 @@ JNIEXPORT jobjectArray JNICALL Java_com_actionml_urcco_Native_crossOccurrenceDow
   // only then does the shim wait for the model (urcco_cross_occurrence_finish) -- the JVM's garbage collector is locked out for
   // the duration of a memcpy-speed pass over the inputs, not for the build and the download of the results.  No JNI call is
   // made between the first Get...Critical and the last Release...Critical.
+  // (a NULL return leaves an OutOfMemoryError pending, and GetPrimitiveArrayCritical is itself a call -Xcheck:jni flags with an
+  // exception pending: the loop stops at the first failure, the arrays behind it stay unpinned -- their pointers NULL, which the
+  // release loop skips)
+  for (jsize d = 0; d < n; ++d) {
+    ds[(size_t)d].matrix.row_ptr = nullptr;
+    ds[(size_t)d].matrix.col_idx = nullptr;
+  }
   for (jsize d = 0; d < n; ++d) {
     ds[(size_t)d].matrix.row_ptr = (const int64_t*)env->GetPrimitiveArrayCritical(rp[(size_t)d], nullptr);
+    if (!ds[(size_t)d].matrix.row_ptr) break;
     ds[(size_t)d].matrix.col_idx = (const int32_t*)env->GetPrimitiveArrayCritical(ci[(size_t)d], nullptr);
+    if (!ds[(size_t)d].matrix.col_idx && ci_len[(size_t)d] > 0) break;
   }
   urcco_options opt = {};
   opt.device = device;

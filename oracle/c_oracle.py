@@ -20,6 +20,9 @@ i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
 f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 
 
+RNG_MIX32 = 0x100   # OR-ed into row_rate_mode: the 32-bit form of the down-sampling RNG (cco_oracle.c ORC_RNG_MIX32)
+
+
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "cco_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
@@ -38,6 +41,10 @@ def lib():
         L.orc_llr.argtypes = [C.c_int64] * 4
         L.orc_u01.restype = C.c_double
         L.orc_u01.argtypes = [C.c_uint32] * 3
+        L.orc_u01_mix32.restype = C.c_double
+        L.orc_u01_mix32.argtypes = [C.c_uint32] * 3
+        L.orc_mix32.restype = C.c_uint32
+        L.orc_mix32.argtypes = [C.c_uint32] * 3
         L.orc_column_counts.restype = None
         L.orc_column_counts.argtypes = [C.c_int64, i32p, C.c_int32, i32p]
         L.orc_downsample.restype = C.c_int64

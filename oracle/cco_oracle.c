@@ -24,6 +24,7 @@
 
 #define ORC_ROW_RATE_MAHOUT_INT_DIV 0
 #define ORC_ROW_RATE_FRACTIONAL 1
+#define ORC_RNG_MIX32 0x100 /* OR-ed into row_rate_mode: the 32-bit form of the down-sampling RNG (D10 b) instead of the 53-bit one */
 
 /* ---- LogLikelihood.java ---------------------------------------------------------------- */
 static inline double x_log_x(int64_t x) { return x == 0 ? 0.0 : (double)x * log((double)x); }
@@ -56,6 +57,16 @@ double orc_u01(uint32_t seed, uint32_t row, uint32_t col) {
   return (double)(x >> 11) * (1.0 / 9007199254740992.0);
 }
 
+/* D10 (b), ORC_RNG_MIX32: identical to cco_oracle.py::mix32 / u01_mix32 */
+uint32_t orc_mix32(uint32_t seed, uint32_t row, uint32_t col) {
+  uint32_t x = col ^ (row * 0x9E3779B1u + seed * 0x85EBCA77u + 0xC2B2AE3Du);
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15; x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+double orc_u01_mix32(uint32_t seed, uint32_t row, uint32_t col) { return (double)orc_mix32(seed, row, col) * (1.0 / 4294967296.0); }
+
 void orc_column_counts(int64_t nnz, const int32_t* col_idx, int32_t n_cols, int32_t* counts) {
   memset(counts, 0, sizeof(int32_t) * (size_t)n_cols);
   for (int64_t e = 0; e < nnz; ++e) counts[col_idx[e]]++;
@@ -64,12 +75,12 @@ void orc_column_counts(int64_t nnz, const int32_t* col_idx, int32_t n_cols, int3
 /* keep decision of sampleDownAndBinarize for one interaction (r = global row index) */
 static inline int orc_keep(uint32_t seed, int64_t r, int32_t j, int64_t n_row, const int32_t* raw_counts, int32_t max_n, int row_rate_mode) {
   int64_t capped = n_row < max_n ? n_row : max_n;
-  double per_row = row_rate_mode == ORC_ROW_RATE_MAHOUT_INT_DIV ? (double)(capped / n_row) /* Int / Int (D9) */
-                                                                : (double)capped / (double)n_row;
+  double per_row = (row_rate_mode & 0xff) == ORC_ROW_RATE_MAHOUT_INT_DIV ? (double)(capped / n_row) /* Int / Int (D9) */
+                                                                         : (double)capped / (double)n_row;
   double n_thing = (double)raw_counts[j];
   double per_thing = (n_thing < (double)max_n ? n_thing : (double)max_n) / n_thing;
   double rate = per_row < per_thing ? per_row : per_thing;
-  return orc_u01(seed, (uint32_t)r, (uint32_t)j) <= rate;
+  return ((row_rate_mode & ORC_RNG_MIX32) ? orc_u01_mix32(seed, (uint32_t)r, (uint32_t)j) : orc_u01(seed, (uint32_t)r, (uint32_t)j)) <= rate;
 }
 
 /* sampleDownAndBinarize.  raw_counts = column counts of the RAW matrix (all users, D11).

@@ -31,7 +31,8 @@ REFERENCE-UNPINNED decisions (no reference test observes them; this oracle is th
   D7  top-k boundary ties -> (score desc, column index asc)
   D8  integer ids = first appearance in the event stream
   D9  row sample rate: Mahout's Int/Int division (rows over the cap are dropped) [switchable]
-  D10 down-sample RNG: stateless hash u01(seed,row,col) instead of per-Spark-block java.util.Random
+  D10 down-sample RNG: stateless hash u01(seed,row,col) instead of per-Spark-block java.util.Random [switchable: the 64-bit
+      splitmix finaliser (53-bit uniform, default) or a 32-bit two-round multiply-xorshift (RNG_MIX32) -- neither is closer to Mahout]
   D11 sampling uses raw column counts, LLR uses post-sampling counts
   D12 minLLR applied before the k cap           D13 indicators matched to event matrices by position
   D14 seed: Long -> .toInt truncation
@@ -100,6 +101,32 @@ def u01(seed: int, row: int, col: int) -> float:
     x = (x * 0x94D049BB133111EB) & MASK64
     x ^= x >> 31
     return (x >> 11) * (1.0 / 9007199254740992.0)
+
+
+RNG_SPLITMIX53 = 0      # D10 (a), the default: u01 above
+RNG_MIX32 = 0x100       # D10 (b): u01_mix32 below.  OR-ed into the row-rate mode (one "mode" integer travels through the path)
+
+
+def mix32(seed: int, row: int, col: int) -> int:
+    """32-bit uniform keyed by (seed,row,col): x = col ^ (row * 0x9E3779B1 + seed * 0x85EBCA77 + 0xC2B2AE3D), then the two-round
+    multiply-xorshift finaliser ("lowbias32").  Identical in oracle/cco_oracle.c (orc_mix32) and csrc/cco_device.h (mix32)."""
+    m = 0xFFFFFFFF
+    x = (col & m) ^ (((row & m) * 0x9E3779B1 + (seed & m) * 0x85EBCA77 + 0xC2B2AE3D) & m)
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & m
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & m
+    x ^= x >> 16
+    return x
+
+
+def u01_mix32(seed: int, row: int, col: int) -> float:
+    return mix32(seed, row, col) * (1.0 / 4294967296.0)
+
+
+def u01_of(mode: int, seed: int, row: int, col: int) -> float:
+    """The uniform the down-sampling draws under `mode` (ROW_RATE_* | RNG_*)."""
+    return u01_mix32(seed, row, col) if mode & RNG_MIX32 else u01(seed, row, col)
 
 
 def seed_to_int(seed: int) -> int:
@@ -216,14 +243,14 @@ def sample_down_and_binarize(rows: Sequence[Sequence[int]], ncol: int, seed: int
         n_row = len(row)
         kept: List[int] = []
         if n_row > 0:
-            if row_rate_mode == ROW_RATE_MAHOUT_INT_DIV:
+            if (row_rate_mode & 0xFF) == ROW_RATE_MAHOUT_INT_DIV:
                 per_row_rate = float(min(max_num_interactions, n_row) // n_row)   # Int / Int (D9)
             else:
                 per_row_rate = min(max_num_interactions, n_row) / n_row
             for j in row:
                 n_thing = float(num_interactions[j])
                 per_thing_rate = min(float(max_num_interactions), n_thing) / n_thing
-                if u01(seed, row_base + r, j) <= min(per_row_rate, per_thing_rate):
+                if u01_of(row_rate_mode, seed, row_base + r, j) <= min(per_row_rate, per_thing_rate):
                     kept.append(j)
         out.append(kept)
     return out

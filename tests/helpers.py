@@ -108,13 +108,58 @@ def compare_with_oracle(sess, mats, params, seed, mode=0, item_lo=0, item_hi=Non
     return out, ref, stats
 
 
-def compare_with_oracle_large(sess, mats, params, seed, mode=0, threads=None, dev_mats=None, via_context=False, flags=0):
+class RanksOfAJob:
+    """The per-rank outputs of ONE event type of a multi-rank build (disjoint, consecutive item ranges) seen as one indicator matrix."""
+
+    def __init__(self, parts):
+        assert parts[0].item_lo == 0 and all(a.item_hi == b.item_lo for a, b in zip(parts, parts[1:])), "the ranks' item ranges do not tile the items"
+        self.parts = parts
+        self.stats = torch.stack([p.stats.cpu() for p in parts]).sum(0)
+
+    def to_host(self):
+        hosts = [p.to_host() for p in self.parts]
+        lens = np.concatenate([np.diff(h[0]) for h in hosts])
+        rp = np.zeros(lens.size + 1, np.int64)
+        np.cumsum(lens, out=rp[1:])
+        return rp, np.concatenate([h[1] for h in hosts]), np.concatenate([h[2] for h in hosts])
+
+    def check_sampled(self, b):
+        for p in self.parts:
+            check_sampled_rows(p, b)
+
+
+def check_sampled_rows(o, b):
+    """The down-sampled B a GPU multiplied with, after an exchange: every row either whole (bit for bit) or -- row-filtered exchange: no
+    item of this GPU's range among the user's primary items -- empty; the library's own total is the whole matrix's."""
+    rp_g = o.sampled_row_ptr.cpu().numpy()
+    lens_g, lens_f = np.diff(rp_g), np.diff(b.row_ptr)
+    assert lens_g.shape == lens_f.shape and np.all((lens_g == lens_f) | (lens_g == 0)), "a down-sampled row arrived neither whole nor empty"
+    held = lens_g > 0
+    ci_g = o.sampled_col_idx[: int(rp_g[-1])].cpu().numpy()
+    assert np.array_equal(ci_g, b.col_idx[np.repeat(held, lens_f)]), "down-sampled col_idx of the rows this GPU holds differs"
+    assert o.sampled_nnz_total in (-1, b.nnz), (o.sampled_nnz_total, b.nnz)
+
+
+def shard_rows(dev_mats, W):
+    """User-range shards of device-resident matrices: [event type][rank] (views; row_ptr re-based to 0)."""
+    n = dev_mats[0].n_rows
+    cuts = [n * g // W for g in range(W + 1)]
+    out = []
+    for m in dev_mats:
+        e = [int(m.row_ptr[c].item()) for c in cuts]
+        out.append([D.DevCsr(cuts[g + 1] - cuts[g], m.n_cols, m.row_ptr[cuts[g]:cuts[g + 1] + 1] - e[g], m.col_idx[e[g]:max(e[g + 1], e[g] + 1)], e[g + 1] - e[g])
+                    for g in range(W)])
+    return out, cuts
+
+
+def compare_with_oracle_large(sess, mats, params, seed, mode=0, threads=None, dev_mats=None, via_context=False, flags=0, also=()):
     """compare_with_oracle for workloads of 10^8..10^9 pairs: the C oracle runs on every host core, one event type at a
     time (its strided outputs are freed before the next), and the down-sampled matrices themselves -- row_ptr AND
     col_idx -- are compared bit for bit before the indicator rows (every row) are.  `dev_mats`: the same matrices already
     resident in HBM (inputs generated on the device).  `via_context`: run the build through urcco_context_build_device (the
-    entry point bench.py times) instead of the session-level stage calls.  Returns per event
-    (stats vector, rows needing the k-boundary tie rule)."""
+    entry point bench.py times) instead of the session-level stage calls.  `also`: (label, per-event outputs) of OTHER builds of the same
+    job -- the exchange route, the ranks of an emulated multi-rank build -- checked against the same oracle pass (the oracle is what a
+    test at this size costs).  Returns per event (stats vector, rows needing the k-boundary tie rule)."""
     threads = threads or min(os.cpu_count() or 1, O.lib().orc_max_threads())
     ctx = None
     if dev_mats is None:
@@ -141,6 +186,16 @@ def compare_with_oracle_large(sess, mats, params, seed, mode=0, threads=None, de
             assert int(st[1 + 4 * 7]) == 0, "LDS accumulator overflow reported"
             _, ties = check_indicators(o.to_host(), ref)
             res.append((st.copy(), ties))
+            for label, outs in also:
+                x = outs[d]
+                xs = x.stats.cpu().numpy()
+                assert int(xs[0]) == ref.pairs, f"{label}, event {d}: pairs {int(xs[0])} vs oracle {ref.pairs}"
+                assert int(xs[1 + 4 * 7]) == 0, f"{label}: LDS accumulator overflow reported"
+                if hasattr(x, "check_sampled"):
+                    x.check_sampled(b)
+                else:
+                    check_sampled_rows(x, b)
+                check_indicators(x.to_host(), ref)
             del ref, b
     finally:
         if ctx is not None:

@@ -71,7 +71,19 @@ def test_full_config4_every_row(gpu_session):
     cfg = synth.config4(1.0)
     dev_mats, mats = device_generated(cfg, gpu_session.device)
     assert mats[0].n_rows == 10_000_000 and mats[0].n_cols == 2_000_000 and len(mats) == 5
-    _, res = compare_with_oracle_large(gpu_session, mats, [P()] * 5, 20260925, dev_mats=dev_mats, via_context=True)
+    # the same job through the EXCHANGE route at full size -- URCCO_FLAG_FORCE_EXCHANGE: a one-rank RCCL communicator, count
+    # all-reduces, work-balanced ranges, own-shard transposition + fragment merge, need masks, packing, the row-filtered all-to-all-v, the
+    # fused expand of the sharded path -- against the same oracle pass, every row
+    from helpers import to_params
+    from universal_recommender_amd import _lib
+    from universal_recommender_amd import device as D
+    ctx_x = D.Context(gpu_session.device, gpu_session.lib, 1, _lib.FLAG_FORCE_EXCHANGE, 0)
+    try:
+        out_x = D.cross_occurrence_context(ctx_x, dev_mats, to_params([P()] * 5), 20260925)
+        _, res = compare_with_oracle_large(gpu_session, mats, [P()] * 5, 20260925, dev_mats=dev_mats, via_context=True, also=[("exchange route", out_x)])
+    finally:
+        out_x = None
+        ctx_x.close()
     rows_by_bin = np.sum([st[1:8] for st, _ in res], axis=0)
     assert sum(int(st[0]) for st, _ in res) > 1_000_000_000 and rows_by_bin[:6].min() > 0, rows_by_bin
 
@@ -86,7 +98,26 @@ def test_full_config5_every_row(gpu_session):
     cfg = synth.config5(1.0)
     dev_mats, mats = device_generated(cfg, gpu_session.device)
     assert max(int(np.diff(m.row_ptr).max()) for m in mats) > 500
-    _, res = compare_with_oracle_large(gpu_session, mats, [P()] * 5, 20260925, dev_mats=dev_mats, via_context=True)
+    # the same job as EIGHT ranks (BASELINE config 5: "8 x MI355X") on this one GPU -- URCCO_FLAG_EMULATE_RANKS, the real
+    # 8-rank build with its collectives looped back on the device -- every rank's rows of the skewed catalogue against the same oracle pass
+    from helpers import RanksOfAJob, shard_rows, to_params
+    from universal_recommender_amd import _lib, sharded
+    from universal_recommender_amd import device as D
+    W = 8
+    shards, cuts = shard_rows(dev_mats, W)
+    coll = sharded.DeviceLoopbackCollectives(W, gpu_session.device)
+    ctx8 = D.Context(gpu_session.device, gpu_session.lib, W, _lib.FLAG_EMULATE_RANKS, collectives=coll)
+    try:
+        ctx8.build(shards, to_params([P()] * 5), 20260925, cfg.n_users, cuts[:-1])
+        res8 = ctx8.results()
+        assert coll.error is None
+        _, res = compare_with_oracle_large(gpu_session, mats, [P()] * 5, 20260925, dev_mats=dev_mats, via_context=True,
+                                           also=[("8 emulated ranks", [RanksOfAJob(row) for row in res8])])
+        work = np.array([sum(int(res8[d][g].stats[0]) for d in range(5)) for g in range(W)], np.float64)
+        assert work.max() / work.mean() < 1.05, work           # work-balanced item ranges under the skew
+    finally:
+        res8 = None
+        ctx8.close()
     rows_by_bin = np.sum([st[1:8] for st, _ in res], axis=0)
     assert rows_by_bin[6] > 1000, rows_by_bin                   # the heavy-row class carries real work here
 

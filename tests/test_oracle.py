@@ -18,7 +18,7 @@ def _py_ids(m: O.Csr):
     return PO.IndexedDataset(_py_rows(m), PO.BiDictionary([f"u{i}" for i in range(m.n_rows)]), PO.BiDictionary([f"i{j}" for j in range(m.n_cols)]))
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, O.RNG_MIX32, 1 | O.RNG_MIX32])
 @pytest.mark.parametrize("seed", [0, 0xdeadbeef, -7])
 def test_c_oracle_equals_python_oracle(mode, seed):
     rng = np.random.default_rng(abs(seed) % 1000 + mode)
@@ -38,6 +38,73 @@ def test_rng_is_the_same_stream_in_both_restatements():
         assert O.lib().orc_u01(int(s), int(r), int(c)) == PO.u01(int(s), int(r), int(c))
     u = np.array([PO.u01(1, r, 7) for r in range(20000)])
     assert 0.0 <= u.min() and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.01
+
+
+def np_mix32(seed, row, col):
+    """cco_oracle.mix32 vectorised (uint32 arithmetic wraps like the C)."""
+    with np.errstate(over="ignore"):
+        row, col = np.asarray(row, np.uint32), np.asarray(col, np.uint32)
+        x = col ^ (row * np.uint32(0x9E3779B1) + np.uint32((int(seed) & 0xFFFFFFFF) * 0x85EBCA77 + 0xC2B2AE3D & 0xFFFFFFFF))
+        x ^= x >> np.uint32(16)
+        x *= np.uint32(0x7FEB352D)
+        x ^= x >> np.uint32(15)
+        x *= np.uint32(0x846CA68B)
+        x ^= x >> np.uint32(16)
+    return x
+
+
+def test_mix32_is_the_same_stream_in_both_restatements():
+    """The 32-bit form of the down-sampling RNG (D10 b, RNG_MIX32): C == Python == the vectorised form the statistics below use."""
+    rng = np.random.default_rng(6)
+    trip = rng.integers(0, 2**32, (2000, 3))
+    L = O.lib()
+    for s, r, c in trip:
+        assert L.orc_mix32(int(s), int(r), int(c)) == PO.mix32(int(s), int(r), int(c))
+        assert L.orc_u01_mix32(int(s), int(r), int(c)) == PO.u01_mix32(int(s), int(r), int(c)) == PO.mix32(int(s), int(r), int(c)) / 4294967296.0
+    for s in (0, 1, 0xdeadbeef):
+        assert np.array_equal(np_mix32(s, trip[:, 1], trip[:, 2]), np.array([PO.mix32(s, int(r), int(c)) for _, r, c in trip], np.uint32))
+
+
+def test_mix32_statistics_at_config4_scale():
+    """the cheap RNG must sample like a uniform.  On the (row, column) domain of BASELINE config 4 -- 10M users x 2M
+    items -- with the keep rule `u01 <= rate`:  per-column keep rates inside binomial bounds for hot columns (rates 500 / count from
+    2e-5 to 0.9, 200K draws each), uniform bytes (chi-square), avalanche (one flipped input bit flips ~16 output bits), and independence
+    across seeds and across neighbouring rows / columns (correlation of keep decisions)."""
+    rng = np.random.default_rng(41)
+    n = 200_000
+    worst = 0.0
+    for col, rate in [(1_234_567, 500 / 23_000_000), (17, 500 / 1_000_000), (1_999_999, 500 / 40_000), (65_536, 0.11), (424_242, 0.5), (3, 0.9)]:
+        rows = rng.choice(10_000_000, n, replace=False)          # the users that hold this hot column
+        for seed in (1, 20260925):
+            kept = int((np_mix32(seed, rows, col).astype(np.float64) / 4294967296.0 <= rate).sum())
+            z = (kept - n * rate) / np.sqrt(n * rate * (1 - rate))
+            worst = max(worst, abs(z))
+    assert worst < 4.5, worst                                      # 12 draws: |z| < 4.5 fails a true uniform once in ~10^5 runs
+    # uniformity of every output byte over a dense block of the domain (consecutive rows x consecutive columns: the worst case for a weak mixer)
+    r, c = np.meshgrid(np.arange(5_000_000, 5_002_048, dtype=np.uint32), np.arange(1_000_000, 1_001_024, dtype=np.uint32), indexing="ij")
+    h = np_mix32(7, r.ravel(), c.ravel())
+    for byte in range(4):
+        cnt = np.bincount((h >> np.uint32(8 * byte)) & np.uint32(255), minlength=256).astype(np.float64)
+        chi2 = ((cnt - h.size / 256) ** 2 / (h.size / 256)).sum()
+        assert chi2 < 255 + 5 * np.sqrt(2 * 255), (byte, chi2)     # chi-square with 255 degrees of freedom: mean 255, sd 22.6
+    # avalanche: flipping one bit of the row, the column or the seed flips half of the output bits on average
+    rows, cols = rng.integers(0, 10_000_000, 20000).astype(np.uint32), rng.integers(0, 2_000_000, 20000).astype(np.uint32)
+    base = np_mix32(99, rows, cols)
+    pop = lambda x: np.unpackbits(x.view(np.uint8)).sum() / x.size
+    for bit in range(0, 24, 3):
+        assert 14.5 < pop(base ^ np_mix32(99, rows ^ np.uint32(1 << bit), cols)) < 17.5, bit
+    for bit in range(0, 21, 3):
+        assert 14.5 < pop(base ^ np_mix32(99, rows, cols ^ np.uint32(1 << bit))) < 17.5, bit
+    for bit in range(0, 32, 5):
+        assert 14.5 < pop(base ^ np_mix32(99 ^ (1 << bit), rows, cols)) < 17.5, bit
+    # independence: keep decisions of two seeds, of a row and its neighbour, of a column and its neighbour are uncorrelated
+    m = 2_000_000
+    rows, cols = rng.integers(0, 10_000_000, m).astype(np.uint32), rng.integers(0, 2_000_000, m).astype(np.uint32)
+    k = lambda s, rr, cc: (np_mix32(s, rr, cc) < np.uint32(0x40000000)).astype(np.float64)   # rate 1/4
+    a = k(5, rows, cols)
+    for other in (k(6, rows, cols), k(5, rows + np.uint32(1), cols), k(5, rows, cols + np.uint32(1)), k(5, rows ^ np.uint32(0x10000), cols)):
+        corr = np.corrcoef(a, other)[0, 1]
+        assert abs(corr) < 5 / np.sqrt(m), corr
 
 
 def test_counts_against_scipy():

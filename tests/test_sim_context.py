@@ -538,3 +538,38 @@ def test_emulated_ranks_on_one_device(sim_lib):
         assert all(b > 0 for b in coll.bytes_received)
     finally:
         ctx.close()
+
+
+def test_eight_ranks_and_the_exchange_route_on_config5_skew_every_row(sim_session):
+    """The CPU-suite twin of tests/test_gpu_scale.py::test_full_config4_every_row / test_full_config5_every_row (VERDICT r04 #4): BASELINE
+    config 5's generator (hot head, heavy users; 1/250 of the users, item spaces 1/50) built three ways -- one rank, one rank through the
+    exchange route (URCCO_FLAG_FORCE_EXCHANGE), eight emulated ranks -- and every row of every build checked against ONE oracle pass,
+    the rows a rank holds of the down-sampled matrices included."""
+    from helpers import RanksOfAJob, compare_with_oracle_large, shard_rows
+    from universal_recommender_amd import _lib, sharded, synth
+    from universal_recommender_amd import device as D
+    cfg = synth.config5(0.004, item_scale=0.02)
+    mats = [O.Csr(cfg.n_users, nc, rp, ci) for (_, nc, rp, ci) in synth.generate(cfg)]
+    assert max(int(np.diff(m.row_ptr).max()) for m in mats) > 60
+    params = [P(60, 12)] * len(mats)
+    dev_mats = [to_dev(m, "cpu") for m in mats]
+    W = 8
+    shards, cuts = shard_rows(dev_mats, W)
+    coll8 = sharded.DeviceLoopbackCollectives(W, "cpu")
+    ctx8 = D.Context(torch.device("cpu"), sim_session.lib, W, _lib.FLAG_EMULATE_RANKS, collectives=coll8)
+    coll1 = sharded.TorchCollectives(1, [0])
+    ctx_x = D.Context(torch.device("cpu"), sim_session.lib, 1, _lib.FLAG_FORCE_EXCHANGE, collectives=coll1)
+    try:
+        ctx8.build(shards, to_params(params), 77, cfg.n_users, cuts[:-1])
+        res8 = ctx8.results()
+        out_x = D.cross_occurrence_context(ctx_x, dev_mats, to_params(params), 77)
+        assert coll8.error is None and coll1.error is None
+        _, res = compare_with_oracle_large(sim_session, mats, params, 77, dev_mats=dev_mats, via_context=True, threads=4,
+                                           also=[("8 emulated ranks", [RanksOfAJob(row) for row in res8]), ("exchange route", out_x)])
+        work = np.array([sum(int(res8[d][g].stats[0]) for d in range(len(mats))) for g in range(W)], np.float64)
+        assert work.max() / work.mean() < 1.25, work      # work-balanced item ranges (a small job: coarse)
+        assert sum(int(st[0]) for st, _ in res) == int(work.sum())
+    finally:
+        res8 = out_x = None
+        ctx8.close()
+        ctx_x.close()

@@ -117,6 +117,31 @@ def test_unaligned_col_idx_takes_scalar_path(sim_session):
     assert np.array_equal(post.cpu().numpy()[:m.n_cols], O.column_counts(ref))
 
 
+def test_downsampling_under_the_32_bit_rng(sim_session):
+    """URCCO_RNG_MIX32 (decision D10 b): the same builds with the 32-bit down-sampling RNG OR-ed into the row-rate mode -- device and oracle
+    draw the same stream, both row-rate modes, the one-byte threshold prefixes (ties on the prefix fall back to the full 32-bit threshold),
+    rows beyond the interaction cap (fractional row rate: their own threshold), a sharded row_base."""
+    from oracle import c_oracle
+    R = c_oracle.RNG_MIX32
+    rng = np.random.default_rng(21)
+    a, b, c = rand_csr(rng, 4000, 900, 12, zipf_s=1.1), rand_csr(rng, 4000, 2500, 30), rand_csr(rng, 4000, 12, 3, empty_frac=0.2)
+    for mode in (R, R | 1):
+        compare_with_oracle(sim_session, [a, b, c], [P(20, 10), P(25, 12), P(500, 50)], 3, mode)
+    m = rand_csr(rng, 70000, 90_000, 17, zipf_s=1.0)       # >= 2^20 interactions: the tiled row scan, many thresholds per prefix value
+    assert m.nnz >= (1 << 20)
+    d = to_dev(m, sim_session.device)
+    cnt = sim_session.column_counts(d.col_idx, m.nnz, m.n_cols)
+    for mode, base in ((R, 0), (R | 1, 123_456_789)):
+        out, post = sim_session.downsample(d, m.nnz, cnt, 11, 9, mode, base)
+        sim_session.synchronize()
+        ref = O.downsample(m, O.column_counts(m), 11, 9, mode, base)
+        ref53 = O.downsample(m, O.column_counts(m), 11, 9, mode & 1, base)
+        assert np.array_equal(out.row_ptr.cpu().numpy(), ref.row_ptr) and np.array_equal(out.col_idx.cpu().numpy()[:ref.nnz], ref.col_idx)
+        assert np.array_equal(post.cpu().numpy()[:m.n_cols], O.column_counts(ref))
+        assert not np.array_equal(ref.row_ptr, ref53.row_ptr)                    # a different stream ...
+        assert abs(ref.nnz - ref53.nnz) < 6 * np.sqrt(ref53.nnz)                  # ... that keeps as many interactions
+
+
 def test_partition_balances_work(sim_session):
     rng = np.random.default_rng(9)
     work = guarded(torch.from_numpy(rng.zipf(1.5, 5000).astype(np.int64)).to(sim_session.device))

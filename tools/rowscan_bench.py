@@ -17,6 +17,7 @@ from universal_recommender_amd.device import DevCsr, DeviceSession  # noqa: E402
 sim = "--sim" in sys.argv
 hbm = "--hbm" in sys.argv     # one matrix far beyond the Infinity Cache: config 3's `view` generator with 8M users (what bench.py's csr_row_scan_hbm_resident runs)
 c4 = "--config4" in sys.argv  # the five matrices of BASELINE config 4, generated on the device
+mode = _lib.RNG_MIX32 if "--rng32" in sys.argv else 0  # the 32-bit form of the down-sampling RNG (URCCO_RNG_MIX32)
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 scale = float(argv[0]) if len(argv) > 0 else 1.0
 flags = [int(x) for x in argv[1].split(",")] if len(argv) > 1 else [0, 32, 64, 128, 224]
@@ -46,12 +47,12 @@ for f in flags:
     line = []
     for i, (m, raw) in enumerate(zip(mats, raws)):
         for _ in range(2):
-            out, post = sess.downsample(m, m.nnz_bound, raw, 1, 500)
+            out, post = sess.downsample(m, m.nnz_bound, raw, 1, 500, mode)
         sync()
         sess.set_timing(True)
         t0 = time.perf_counter()
         for _ in range(reps):
-            out, post = sess.downsample(m, m.nnz_bound, raw, 1, 500)
+            out, post = sess.downsample(m, m.nnz_bound, raw, 1, 500, mode)
         sync()
         wall = (time.perf_counter() - t0) / reps * 1e3
         tm = sess.get_timings()
@@ -61,5 +62,5 @@ for f in flags:
         kept = int(out.row_ptr[-1].item())
         alg = m.nnz_bound * 4 + kept * 4 + (m.n_rows + 1) * 16
         line.append(f"m{i}: nnz={m.nnz_bound} kept={kept} scan={scan:.4f} ms = " + "+".join(f"{x:.4f}" for x in parts) + f" ({alg / scan / 1e6:.0f} GB/s) wall={wall:.3f}")
-    print(f"debug={f}: " + " | ".join(line), flush=True)
+    print(f"debug={f}{' rng32' if mode else ''}: " + " | ".join(line), flush=True)
 sess.set_debug(0)

@@ -21,6 +21,8 @@ FLAG_EMULATE_RANKS = 8
 UNIQUE_ID_BYTES = 128
 ROW_RATE_MAHOUT_INT_DIV = 0
 ROW_RATE_FRACTIONAL = 1
+RNG_SPLITMIX53 = 0      # the down-sampling RNG (oracle decision D10), OR-ed into the row-rate mode
+RNG_MIX32 = 0x100
 N_STAGES = 17
 N_BINS = 7
 STATS_LEN = 32
@@ -146,6 +148,7 @@ SYMBOLS = {
     "urcco_dev_pop_counts": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), _p]),
     "urcco_dev_llr": (C.c_int, [_p, C.c_int64, _p, _p, _p, _p, _p]),
     "urcco_dev_u01": (C.c_int, [_p, C.c_int64, C.c_int32, _p, _p, _p]),
+    "urcco_dev_u01_rng": (C.c_int, [_p, C.c_int64, C.c_int32, _p, _p, C.c_int32, _p]),
     "urcco_dev_dictionary_build": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int32, _p, C.POINTER(_p), C.POINTER(C.c_int64)]),
     "urcco_dev_dictionary_lookup": (C.c_int, [_p, _p, C.c_int64, _p, _p, _p]),
     "urcco_dev_dictionary_verify": (C.c_int, [_p, _p, C.c_int64, _p, _p, _p, _p, C.POINTER(C.c_int64)]),

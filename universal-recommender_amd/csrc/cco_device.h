@@ -22,6 +22,22 @@ __device__ __forceinline__ double u01_hash(uint32_t seed, uint32_t row, uint32_t
   return (double)hash53(seed, row, col) * (1.0 / 9007199254740992.0);
 }
 
+// The second form of decision D10 (URCCO_RNG_MIX32; the reference pins neither: Mahout draws from a per-partition java.util.Random):
+// a 32-bit uniform keyed by (seed,row,col).  The row and the seed enter through one multiply-add each -- a key the row scan forms
+// once per tile plus one multiply per entry --, the column by xor, and the two-round multiply-xorshift finaliser ("lowbias32", bias
+// measured by its author at the level of the murmur3 finaliser) mixes the sum: 2 + 8 vector instructions per interaction where the
+// 64-bit splitmix finaliser above costs ~25 on a machine without a 64-bit integer multiplier.  u01 = h * 2^-32.
+constexpr uint32_t MIX32_ROW = 0x9E3779B1u, MIX32_SEED = 0x85EBCA77u, MIX32_ADD = 0xC2B2AE3Du;
+__device__ __forceinline__ uint32_t mix32_row_key(uint32_t seed, uint32_t row) { return row * MIX32_ROW + (seed * MIX32_SEED + MIX32_ADD); }
+__device__ __forceinline__ uint32_t mix32_finish(uint32_t x) {
+  x ^= x >> 16; x *= 0x7FEB352Du;
+  x ^= x >> 15; x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t mix32(uint32_t seed, uint32_t row, uint32_t col) { return mix32_finish(col ^ mix32_row_key(seed, row)); }
+__device__ __forceinline__ double u01_mix32(uint32_t seed, uint32_t row, uint32_t col) { return (double)mix32(seed, row, col) * (1.0 / 4294967296.0); }
+
 // Natural log of a positive, normal double (the path only ever feeds it positive integers < 2^53).
 // Classic argument-reduction + degree-14 odd polynomial in s = f/(2+f) (the algorithm of the freely
 // distributable Sun fdlibm e_log.c, error < 1 ulp); written with explicit single operations so that the

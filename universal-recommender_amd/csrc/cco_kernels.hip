@@ -661,17 +661,27 @@ constexpr int PLH_THREADS = 1024;
 // 2 = no loads -- which is how the same log prices the pass: without the atomics 1.76 ms, with neither 1.37: the RANDOM LDS atomics
 // (~1.1 lane updates per clock and CU: ~58 cycles per wave instruction against 4.6 for conflict-free addresses) are what the histogram
 // costs, not its loads -- the same bound the bucket-contiguous form sits on.
+// Buckets are split by WEIGHT: a bucket gets S blocks per average bucket weight it carries (pl_blockmap_kernel), each block an equal share of
+// the parts.  A catalogue's hottest item draws 6.6 % of a Zipf(1) matrix into ONE bucket -- 17x the average; with S blocks for every
+// bucket the few blocks of that bucket were the kernel (0.98 ms on config 4's largest matrix for 0.45 ms of evenly spread work).
 template <int LPS>
 __global__ __launch_bounds__(PLH_THREADS) void pl_hist_kernel(const unsigned short* __restrict__ bucketed, const unsigned short* __restrict__ loc_t,
-                                                              int n_buckets, int64_t n_parts, int S, int32_t n_cols, unsigned* __restrict__ partial, int dbg) {
+                                                              int n_buckets, int64_t n_parts, const int32_t* __restrict__ blk_prefix, int32_t n_cols,
+                                                              unsigned* __restrict__ partial, int dbg) {
   __shared__ unsigned s_cnt[PL_BUCKET];
-  // bucket fastest: the blocks resident at any time read ALL buckets' slices of a few part ranges -- a dense window of the array
-  const int b = (int)(blockIdx.x % (unsigned)n_buckets), s = (int)(blockIdx.x / (unsigned)n_buckets);
+  const int blk = blockIdx.x;
+  if (blk >= blk_prefix[n_buckets]) return;  // block-uniform
+  int blo = 0, bhi = n_buckets;  // last b with blk_prefix[b] <= blk
+  while (bhi - blo > 1) {
+    const int mid = (blo + bhi) >> 1;
+    if (blk_prefix[mid] <= blk) blo = mid; else bhi = mid;
+  }
+  const int b = blo, s = blk - blk_prefix[b], S = blk_prefix[b + 1] - blk_prefix[b];
   const int width = (int)((int64_t)n_cols - ((int64_t)b << PL_BITS) < PL_BUCKET ? (int64_t)n_cols - ((int64_t)b << PL_BITS) : PL_BUCKET);  // columns of this bucket
   for (int c = threadIdx.x; c < width; c += PLH_THREADS) s_cnt[c] = 0u;
   __syncthreads();
   const int64_t pp = (n_parts + S - 1) / S;
-  const int64_t p0 = (int64_t)s * pp, p1 = p0 + pp < n_parts ? p0 + pp : n_parts;
+  const int64_t p0 = (int64_t)s * pp < n_parts ? (int64_t)s * pp : n_parts, p1 = p0 + pp < n_parts ? p0 + pp : n_parts;
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
   const unsigned short* lo_t = loc_t + (int64_t)b * n_parts;
   const unsigned short* hi_t = loc_t + (int64_t)(b + 1) * n_parts;
@@ -727,27 +737,67 @@ __global__ __launch_bounds__(PLH_THREADS) void pl_hist_kernel(const unsigned sho
   }
   if ((dbg & 1) && fake == 0x9e3779b9u) s_cnt[0] = 1u;
   __syncthreads();
-  unsigned* out = partial + ((int64_t)b * S + s) * PL_BUCKET;
+  unsigned* out = partial + (int64_t)blk * PL_BUCKET;
   for (int c = threadIdx.x; c < width; c += PLH_THREADS) out[c] = s_cnt[c];
 }
 
-__global__ __launch_bounds__(256) void pl_reduce_kernel(const unsigned* __restrict__ partial, int S, int32_t n_cols, int32_t* __restrict__ counts) {
+__global__ __launch_bounds__(256) void pl_reduce_kernel(const unsigned* __restrict__ partial, const int32_t* __restrict__ blk_prefix, int32_t n_cols,
+                                                        int32_t* __restrict__ counts) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= n_cols) return;
-  const int64_t b = j >> PL_BITS;
+  const int b = (int)(j >> PL_BITS);
   const int c = (int)(j & (PL_BUCKET - 1));
   unsigned sum = 0;
-  for (int s = 0; s < S; ++s) sum += partial[(b * S + s) * PL_BUCKET + c];
+  for (int blk = blk_prefix[b]; blk < blk_prefix[b + 1]; ++blk) sum += partial[(int64_t)blk * PL_BUCKET + c];
   counts[j] = (int32_t)sum;
 }
 
-// histogram blocks per bucket: a few thousand blocks in all, each with at least a handful of parts
+// weight[b] = ids of bucket b over all parts (one block per bucket sums its slice lengths) ...
+__global__ __launch_bounds__(256) void pl_weights_kernel(const unsigned short* __restrict__ loc_t, int64_t n_parts, long long* __restrict__ weight) {
+  __shared__ long long s_wave[256 / WAVE];
+  const unsigned short* lo_t = loc_t + (int64_t)blockIdx.x * n_parts;
+  const unsigned short* hi_t = lo_t + n_parts;
+  long long sum = 0;
+  for (int64_t p = threadIdx.x; p < n_parts; p += 256) sum += (long long)hi_t[p] - (long long)lo_t[p];
+  long long tot;
+  block_exclusive_scan<256>(sum, s_wave, &tot);
+  if (threadIdx.x == 0) weight[blockIdx.x] = tot;
+}
+// ... and (single block) blk_prefix[b] = first histogram block of bucket b: S blocks per average bucket weight, at least one, at most one per part
+__global__ __launch_bounds__(SCAN_THREADS) void pl_blockmap_kernel(const long long* __restrict__ weight, int n_buckets, int64_t n_parts, int S,
+                                                                  int32_t* __restrict__ blk_prefix) {
+  __shared__ long long s_wave[SCAN_THREADS / WAVE];
+  __shared__ long long s_total;
+  {
+    const int b = threadIdx.x;  // n_buckets <= PL_MAX_BUCKETS <= SCAN_THREADS
+    long long tot;
+    block_exclusive_scan(b < n_buckets ? weight[b] : 0ll, s_wave, &tot);
+    if (threadIdx.x == 0) s_total = tot;
+  }
+  __syncthreads();
+  const long long total = s_total;
+  const int b = threadIdx.x;
+  long long v = 0;
+  if (b < n_buckets) {
+    // ceil(S * n_buckets * weight / total): the sum over the buckets is at most (S + 1) * n_buckets
+    v = total > 0 ? (weight[b] * (long long)S * n_buckets + total - 1) / total : 1;
+    if (v < 1) v = 1;
+    if (v > n_parts) v = n_parts;
+  }
+  long long tot;
+  const long long ex = block_exclusive_scan(v, s_wave, &tot);
+  if (b < n_buckets) blk_prefix[b] = (int32_t)ex;
+  if (b == 0) blk_prefix[n_buckets] = (int32_t)tot;
+}
+
+// histogram blocks per AVERAGE bucket: a few thousand blocks in all, each with at least a handful of parts
 static inline int pl_splits(int n_buckets, int64_t n_parts) {
   int64_t S = (2048 + n_buckets - 1) / n_buckets;
   if (S > n_parts / 4) S = n_parts / 4;
   if (S < 1) S = 1;
   return (int)S;
 }
+static inline int64_t pl_max_blocks(int n_buckets, int S) { return ((int64_t)S + 1) * n_buckets; }
 static inline bool pl_applies(int32_t n_cols) {
   const char* e = getenv("URCCO_COLCOUNT_GLOBAL_LAYOUT");  // A/B and test knob: the bucket-contiguous form above
   if (e && *e == '1') return false;
@@ -759,7 +809,8 @@ int64_t column_counts_scratch_bytes(int64_t nnz, int32_t n_cols) {
   if (nnz >= PH_MIN_NNZ && pl_applies(n_cols)) {
     const int64_t n_buckets = ((int64_t)n_cols + PL_BUCKET - 1) >> PL_BITS;
     const int64_t n_parts = (nnz + PL_PART - 1) / PL_PART;
-    return al(n_parts * PL_PART * 2 + 64) + al((n_buckets + 1) * n_parts * 2) + al(n_buckets * pl_splits((int)n_buckets, n_parts) * (int64_t)PL_BUCKET * 4);
+    return al(n_parts * PL_PART * 2 + 64) + al((n_buckets + 1) * n_parts * 2) + al(n_buckets * 8) + al((n_buckets + 1) * 4) +
+           al(pl_max_blocks((int)n_buckets, pl_splits((int)n_buckets, n_parts)) * (int64_t)PL_BUCKET * 4);
   }
   if (nnz < PH_MIN_NNZ || (((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS) > PH_MAX_BUCKETS) return 0;
   const int64_t n_buckets = ((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS;
@@ -779,16 +830,20 @@ hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_i
     const int S = pl_splits(n_buckets, n_parts);
     unsigned short* bucketed = reinterpret_cast<unsigned short*>(scratch); scratch += al(n_parts * PL_PART * 2 + 64);
     unsigned short* loc_t = reinterpret_cast<unsigned short*>(scratch); scratch += al(((int64_t)n_buckets + 1) * n_parts * 2);
+    long long* weight = reinterpret_cast<long long*>(scratch); scratch += al((int64_t)n_buckets * 8);
+    int32_t* blk_prefix = reinterpret_cast<int32_t*>(scratch); scratch += al(((int64_t)n_buckets + 1) * 4);
     unsigned* partial = reinterpret_cast<unsigned*>(scratch);
     hipLaunchKernelGGL(pl_partition_kernel, dim3((unsigned)n_parts), dim3(PL_THREADS), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, bucketed, loc_t, vec_ok);
+    hipLaunchKernelGGL(pl_weights_kernel, dim3((unsigned)n_buckets), dim3(256), 0, st, loc_t, n_parts, weight);
+    hipLaunchKernelGGL(pl_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, weight, n_buckets, n_parts, S, blk_prefix);
     const char* de = getenv("URCCO_PL_DEBUG");   // profiling only: 1 = no LDS atomics, 2 = no loads (the counts are then meaningless)
     const char* le = getenv("URCCO_PL_LANES");   // A/B: lanes per slice (16, 8 or 4)
     const int dbg = de && *de ? atoi(de) : 0, lps = le && *le ? atoi(le) : 8;
-    const dim3 hg((unsigned)(n_buckets * S)), hb(PLH_THREADS);
-    if (lps == 4) hipLaunchKernelGGL((pl_hist_kernel<4>), hg, hb, 0, st, bucketed, loc_t, n_buckets, n_parts, S, n_cols, partial, dbg);
-    else if (lps == 8) hipLaunchKernelGGL((pl_hist_kernel<8>), hg, hb, 0, st, bucketed, loc_t, n_buckets, n_parts, S, n_cols, partial, dbg);
-    else hipLaunchKernelGGL((pl_hist_kernel<16>), hg, hb, 0, st, bucketed, loc_t, n_buckets, n_parts, S, n_cols, partial, dbg);
-    hipLaunchKernelGGL(pl_reduce_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, partial, S, n_cols, counts);
+    const dim3 hg((unsigned)pl_max_blocks(n_buckets, S)), hb(PLH_THREADS);
+    if (lps == 4) hipLaunchKernelGGL((pl_hist_kernel<4>), hg, hb, 0, st, bucketed, loc_t, n_buckets, n_parts, blk_prefix, n_cols, partial, dbg);
+    else if (lps == 8) hipLaunchKernelGGL((pl_hist_kernel<8>), hg, hb, 0, st, bucketed, loc_t, n_buckets, n_parts, blk_prefix, n_cols, partial, dbg);
+    else hipLaunchKernelGGL((pl_hist_kernel<16>), hg, hb, 0, st, bucketed, loc_t, n_buckets, n_parts, blk_prefix, n_cols, partial, dbg);
+    hipLaunchKernelGGL(pl_reduce_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, partial, blk_prefix, n_cols, counts);
     return hipGetLastError();
   }
   const int n_buckets = (int)(((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS);
@@ -833,6 +888,7 @@ static_assert(DS_WORDS == WAVE, "one wave scans the keep words of a tile");
 static_assert((DS_TILE & (DS_TILE - 1)) == 0, "tile index by shift");
 
 constexpr int THR8_SHIFT = 45;  // one-byte threshold prefix = bits 45..52 of the 53-bit threshold (see sample_threshold_kernel)
+constexpr int THR8_SHIFT32 = 24;  // ... = bits 24..31 of the 32-bit threshold (URCCO_RNG_MIX32)
 constexpr unsigned long long RATE_ONE = 1ull << 53;  // threshold of a sample rate of 1.0 (every 53-bit hash passes)
 
 // first idx in [lo, hi] with rp[idx] > e   (rp[hi] > e guaranteed by the caller)
@@ -876,7 +932,7 @@ constexpr int DS_RUNS = DS_TILE / (DS_THREADS * DS_RUN);  // 2
 #ifndef URCCO_DS_WAVES
 #define URCCO_DS_WAVES 1  // minimum waves per SIMD the flags kernel is compiled for (A/B knob: 8 caps it at 64 VGPRs)
 #endif
-template <bool DEBUG>
+template <bool DEBUG, bool RNG32>
 __global__ __launch_bounds__(DS_THREADS, URCCO_DS_WAVES) void downsample_flags_kernel(int64_t n_rows, const int64_t* __restrict__ rp,
                                                                       const int32_t* __restrict__ ci, int64_t nnz,
                                                                       const int64_t* __restrict__ g,
@@ -952,6 +1008,7 @@ __global__ __launch_bounds__(DS_THREADS, URCCO_DS_WAVES) void downsample_flags_k
   const bool has_long = s_long != 0;
   const double dmax = (double)max_n;
   const uint32_t row0 = (uint32_t)(row_base + r_s);
+  const uint32_t key0 = mix32_row_key(seed, row0);  // RNG32: the key of row r_s + t is key0 + t * MIX32_ROW
   int kept = 0;
 #pragma unroll
   for (int gq = 0; gq < DS_RUNS; ++gq) {
@@ -979,8 +1036,9 @@ __global__ __launch_bounds__(DS_THREADS, URCCO_DS_WAVES) void downsample_flags_k
     unsigned keep_byte = 0;
 #pragma unroll
     for (int q = 0; q < DS_RUN; ++q) {
-      const unsigned long long h = (debug & 32) ? ((unsigned long long)((unsigned)cols[gq][q] * 0x9E3779B1u) << 21) : hash53(seed, row0 + (uint32_t)r_of[q], (uint32_t)cols[gq][q]);
-      const unsigned h8 = (unsigned)(h >> THR8_SHIFT), b = thr_col[q];
+      const unsigned long long h = RNG32 ? (unsigned long long)mix32_finish((uint32_t)cols[gq][q] ^ (key0 + (uint32_t)r_of[q] * MIX32_ROW))
+                                   : ((debug & 32) ? ((unsigned long long)((unsigned)cols[gq][q] * 0x9E3779B1u) << 21) : hash53(seed, row0 + (uint32_t)r_of[q], (uint32_t)cols[gq][q]));
+      const unsigned h8 = (unsigned)(h >> (RNG32 ? THR8_SHIFT32 : THR8_SHIFT)), b = thr_col[q];
       bool keep = b == 255u || h8 < b;
       if (b == 254u || (b < 254u && h8 == b)) keep = h <= thresholds[cols[gq][q]];  // 1 sampled interaction in 256: the full threshold
       keep_byte |= (keep ? 1u : 0u) << q;
@@ -991,8 +1049,9 @@ __global__ __launch_bounds__(DS_THREADS, URCCO_DS_WAVES) void downsample_flags_k
         const int64_t r = r_s + r_of[q];
         const int64_t n_row = rp[r + 1] - rp[r];
         if (n_row > (int64_t)max_n) {  // Int / Int = 0: only a hash of exactly 0 passes; fractional: min(max, n) / n
-          const unsigned long long thr_row = row_rate_mode == 0 ? 0ull : (unsigned long long)((dmax / (double)n_row) * 9007199254740992.0);
-          if (hash53(seed, row0 + (uint32_t)r_of[q], (uint32_t)cols[gq][q]) > thr_row) keep_byte &= ~(1u << q);
+          const unsigned long long thr_row = row_rate_mode == 0 ? 0ull : (unsigned long long)((dmax / (double)n_row) * (RNG32 ? 4294967296.0 : 9007199254740992.0));
+          const unsigned long long hr = RNG32 ? (unsigned long long)mix32(seed, row0 + (uint32_t)r_of[q], (uint32_t)cols[gq][q]) : hash53(seed, row0 + (uint32_t)r_of[q], (uint32_t)cols[gq][q]);
+          if (hr > thr_row) keep_byte &= ~(1u << q);
         }
       }
     }
@@ -1086,15 +1145,16 @@ __global__ __launch_bounds__(DS_THREADS) void downsample_compact_kernel(int64_t 
 //   255   perThingSampleRate = 1.0: keep                     254   always compare in full (threshold prefix >= 254)
 //   b     hash >> 45 < b: keep   > b: drop   == b: compare in full
 __global__ __launch_bounds__(256) void sample_threshold_kernel(const int32_t* __restrict__ raw_counts, int32_t n_cols, int32_t max_n,
-                                                               unsigned long long* __restrict__ thresholds, unsigned char* __restrict__ thr8) {
+                                                               unsigned long long* __restrict__ thresholds, unsigned char* __restrict__ thr8, int rng32) {
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= n_cols) return;
   const double n_thing = (double)raw_counts[j];
   const double dmax = (double)max_n;
   const bool one = n_thing <= dmax;
-  const unsigned long long thr = one ? RATE_ONE : (unsigned long long)((dmax / n_thing) * 9007199254740992.0);
+  // u01 = h * 2^-bits with an integer h < 2^bits, so u01 <= rate  <=>  h <= floor(rate * 2^bits) (the scaling is exact); RATE_ONE passes every h
+  const unsigned long long thr = one ? RATE_ONE : (unsigned long long)((dmax / n_thing) * (rng32 ? 4294967296.0 : 9007199254740992.0));
   thresholds[j] = thr;
-  const unsigned t8 = (unsigned)(thr >> THR8_SHIFT);
+  const unsigned t8 = (unsigned)(thr >> (rng32 ? THR8_SHIFT32 : THR8_SHIFT));
   thr8[j] = (unsigned char)(one ? 255u : (t8 >= 254u ? 254u : t8));
 }
 
@@ -1104,19 +1164,29 @@ hipError_t launch_downsample_flags(hipStream_t st, int n_cu, int64_t n_rows, con
                                    int32_t* post_counts, int debug) {
   if (nnz == 0) return hipSuccess;
   unsigned char* thr8 = reinterpret_cast<unsigned char*>(thresholds + n_cols);  // the scratch holds n_cols u64 + n_cols bytes
-  hipLaunchKernelGGL(sample_threshold_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, raw_counts, n_cols, max_n, thresholds, thr8);
+  const int rng32 = (row_rate_mode & 0x100) ? 1 : 0;  // URCCO_RNG_MIX32
+  row_rate_mode &= 0xff;
+  hipLaunchKernelGGL(sample_threshold_kernel, dim3((unsigned)((n_cols + 255) / 256)), dim3(256), 0, st, raw_counts, n_cols, max_n, thresholds, thr8, rng32);
   const int64_t tiles = (nnz + DS_TILE - 1) / DS_TILE;
   int64_t rblocks = (n_rows + 1 + 255) / 256;
   const int64_t rcap = (int64_t)n_cu * 8;
   if (rblocks > rcap) rblocks = rcap;
   hipLaunchKernelGGL(tile_rows_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, n_rows, row_ptr, tiles, tile_rows);
   const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
-  if (debug & (32 | 64 | 128))
-    hipLaunchKernelGGL(downsample_flags_kernel<true>, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds, thr8,
-                       seed, max_n, row_rate_mode, row_base, flags, tile_count, post_counts, vec_ok, debug);
-  else
-    hipLaunchKernelGGL(downsample_flags_kernel<false>, dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds, thr8,
+  if (debug & (32 | 64 | 128)) {
+    if (rng32)
+      hipLaunchKernelGGL((downsample_flags_kernel<true, true>), dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds, thr8,
+                         seed, max_n, row_rate_mode, row_base, flags, tile_count, post_counts, vec_ok, debug);
+    else
+      hipLaunchKernelGGL((downsample_flags_kernel<true, false>), dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds, thr8,
+                         seed, max_n, row_rate_mode, row_base, flags, tile_count, post_counts, vec_ok, debug);
+  } else if (rng32) {
+    hipLaunchKernelGGL((downsample_flags_kernel<false, true>), dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds, thr8,
                        seed, max_n, row_rate_mode, row_base, flags, tile_count, post_counts, vec_ok, 0);
+  } else {
+    hipLaunchKernelGGL((downsample_flags_kernel<false, false>), dim3((unsigned)tiles), dim3(DS_THREADS), 0, st, n_rows, row_ptr, col_idx, nnz, tile_rows, thresholds, thr8,
+                       seed, max_n, row_rate_mode, row_base, flags, tile_count, post_counts, vec_ok, 0);
+  }
   return hipGetLastError();
 }
 
@@ -3393,26 +3463,31 @@ hipError_t launch_masked_lengths(hipStream_t st, int n_cu, int64_t n_rows, const
   hipLaunchKernelGGL(peer_totals_kernel, dim3((unsigned)((world + 63) / 64)), dim3(64), 0, st, world, n_rows, off, to_nnz);
   return hipGetLastError();
 }
+// One (row, destination) pair per group of eight lanes, destinations along blockIdx.y: consecutive groups copy consecutive rows of the
+// shard to consecutive places of ONE destination's send buffer, and every pair's four operands (mask, row bounds, offset) are independent
+// loads.  (Round 4's form walked the destinations of a row one after the other inside a 16-lane group -- a dependent offset load per
+// destination, one row at a time: 263 us per event type and rank of config 4 at 8 ranks = 1.3 of a rank's 9.4 ms,
+// profiles/r05_emulated_ranks_w8_kernel_stats.csv.)
 __global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, const unsigned long long* __restrict__ mask,
                                                         int world, const int64_t* __restrict__ off, int32_t* __restrict__ pack) {
-  const int gl = threadIdx.x & 15;
-  for (int64_t u = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4; u < n_rows; u += ((int64_t)gridDim.x * 256) >> 4) {
+  const int gl = threadIdx.x & 7;
+  const int q = blockIdx.y;
+  for (int64_t u = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); u < n_rows; u += (int64_t)gridDim.x * 32) {
     const unsigned long long m = mask[u];
-    if (m == 0ull) continue;
     const int64_t s = rp[u], e = rp[u + 1];
-    for (int q = 0; q < world; ++q) {
-      if (!((m >> q) & 1ull)) continue;
-      const int64_t dst = off[(int64_t)q * n_rows + u];
-      for (int64_t p = s + gl; p < e; p += 16) pack[dst + (p - s)] = ci[p];
-    }
+    const int64_t dst = off[(int64_t)q * n_rows + u];
+    if (!((m >> q) & 1ull)) continue;
+    for (int64_t p = s + gl; p < e; p += 8) pack[dst + (p - s)] = ci[p];
   }
 }
 hipError_t launch_pack_rows(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, const unsigned long long* mask, int world,
                             const int64_t* off, int32_t* pack) {
-  if (n_rows == 0) return hipSuccess;
-  int64_t blocks = (n_rows * 16 + 255) / 256;
-  if (blocks > (int64_t)n_cu * 16) blocks = (int64_t)n_cu * 16;
-  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, row_ptr, col_idx, mask, world, off, pack);
+  if (n_rows == 0 || world <= 0) return hipSuccess;
+  int64_t blocks = (n_rows + 31) / 32;
+  const int64_t cap = ((int64_t)n_cu * 64 + world - 1) / world;  // ~64 blocks per CU over all destinations
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks, (unsigned)world), dim3(256), 0, st, n_rows, row_ptr, col_idx, mask, world, off, pack);
   return hipGetLastError();
 }
 
@@ -3575,18 +3650,18 @@ __global__ void llr_test_kernel(int64_t n, const int64_t* a, const int64_t* b, c
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = llr_full(a[i], b[i], ab[i], nu[i]);
 }
-__global__ void u01_test_kernel(int64_t n, uint32_t seed, const int32_t* row, const int32_t* col, double* out) {
+__global__ void u01_test_kernel(int64_t n, uint32_t seed, const int32_t* row, const int32_t* col, double* out, int rng32) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = u01_hash(seed, (uint32_t)row[i], (uint32_t)col[i]);
+  if (i < n) out[i] = rng32 ? u01_mix32(seed, (uint32_t)row[i], (uint32_t)col[i]) : u01_hash(seed, (uint32_t)row[i], (uint32_t)col[i]);
 }
 hipError_t launch_llr_test(hipStream_t st, int64_t n, const int64_t* a, const int64_t* b, const int64_t* ab, const int64_t* nu, double* out) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(llr_test_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, a, b, ab, nu, out);
   return hipGetLastError();
 }
-hipError_t launch_u01_test(hipStream_t st, int64_t n, uint32_t seed, const int32_t* row, const int32_t* col, double* out) {
+hipError_t launch_u01_test(hipStream_t st, int64_t n, uint32_t seed, const int32_t* row, const int32_t* col, double* out, int rng32) {
   if (n == 0) return hipSuccess;
-  hipLaunchKernelGGL(u01_test_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, seed, row, col, out);
+  hipLaunchKernelGGL(u01_test_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, seed, row, col, out, rng32);
   return hipGetLastError();
 }
 

@@ -240,7 +240,7 @@ int urcco_dev_downsample(urcco_session* s, int64_t n_rows, const int64_t* row_pt
   if (!s || n_rows < 0 || nnz < 0 || n_cols < 0 || !row_ptr || !out_row_ptr || (nnz > 0 && (!col_idx || !raw_counts || !out_col_idx)))
     return fail(URCCO_BAD_ARG, "urcco_dev_downsample: bad argument");
   if (max_elements_per_row <= 0) return fail(URCCO_BAD_ARG, "maxElementsPerRow must be positive, got %d", max_elements_per_row);
-  if (row_rate_mode != URCCO_ROW_RATE_MAHOUT_INT_DIV && row_rate_mode != URCCO_ROW_RATE_FRACTIONAL)
+  if ((row_rate_mode & ~URCCO_RNG_MIX32) != URCCO_ROW_RATE_MAHOUT_INT_DIV && (row_rate_mode & ~URCCO_RNG_MIX32) != URCCO_ROW_RATE_FRACTIONAL)
     return fail(URCCO_BAD_ARG, "unknown row_rate_mode %d", row_rate_mode);
   if (post_counts && n_cols > 0) HIPC(hipMemsetAsync(post_counts, 0, sizeof(int32_t) * (size_t)n_cols, s->stream));
   if (nnz == 0) {
@@ -654,6 +654,12 @@ int urcco_dev_llr(urcco_session* s, int64_t n, const int64_t* with_a, const int6
 int urcco_dev_u01(urcco_session* s, int64_t n, int32_t seed, const int32_t* row, const int32_t* col, double* out) {
   if (!s || n < 0) return fail(URCCO_BAD_ARG, "urcco_dev_u01: bad argument");
   HIPC(urcco::launch_u01_test(s->stream, n, (uint32_t)seed, row, col, out));
+  return URCCO_OK;
+}
+
+int urcco_dev_u01_rng(urcco_session* s, int64_t n, int32_t seed, const int32_t* row, const int32_t* col, int32_t rng, double* out) {
+  if (!s || n < 0 || (rng != URCCO_RNG_SPLITMIX53 && rng != URCCO_RNG_MIX32)) return fail(URCCO_BAD_ARG, "urcco_dev_u01_rng: bad argument");
+  HIPC(urcco::launch_u01_test(s->stream, n, (uint32_t)seed, row, col, out, rng == URCCO_RNG_MIX32 ? 1 : 0));
   return URCCO_OK;
 }
 

@@ -1353,7 +1353,7 @@ int urcco_context_create(const urcco_options* options, const urcco_comm_config* 
     }
     if (n_local == 0) n_local = n_dev - first;
     const int mode = options ? options->row_rate_mode : URCCO_ROW_RATE_MAHOUT_INT_DIV;
-    if (mode != URCCO_ROW_RATE_MAHOUT_INT_DIV && mode != URCCO_ROW_RATE_FRACTIONAL) return fail(URCCO_BAD_ARG, "unknown row_rate_mode %d", mode);
+    if ((mode & ~URCCO_RNG_MIX32) != URCCO_ROW_RATE_MAHOUT_INT_DIV && (mode & ~URCCO_RNG_MIX32) != URCCO_ROW_RATE_FRACTIONAL) return fail(URCCO_BAD_ARG, "unknown row_rate_mode %d", mode);
     std::unique_ptr<urcco_context, void (*)(urcco_context*)> c(new urcco_context(), urcco_context_destroy);
     c->row_rate_mode = mode;
     c->flags = options ? options->flags : 0;

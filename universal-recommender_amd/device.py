@@ -199,9 +199,12 @@ class DeviceSession:
         self._check(self.lib.urcco_dev_llr(self.handle, with_a.numel(), _ptr(with_a), _ptr(with_b), _ptr(with_ab), _ptr(n_users), _ptr(out)))
         return out
 
-    def u01(self, seed: int, row, col) -> torch.Tensor:
+    def u01(self, seed: int, row, col, rng: int = _lib.RNG_SPLITMIX53) -> torch.Tensor:
         out = self.empty(row.numel(), torch.float64)
-        self._check(self.lib.urcco_dev_u01(self.handle, row.numel(), _to_i32(seed), _ptr(row), _ptr(col), _ptr(out)))
+        if rng == _lib.RNG_SPLITMIX53:
+            self._check(self.lib.urcco_dev_u01(self.handle, row.numel(), _to_i32(seed), _ptr(row), _ptr(col), _ptr(out)))
+        else:
+            self._check(self.lib.urcco_dev_u01_rng(self.handle, row.numel(), _to_i32(seed), _ptr(row), _ptr(col), int(rng), _ptr(out)))
         return out
 
 
