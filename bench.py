@@ -762,7 +762,7 @@ def main():
                                         "own evaluation is cheaper (per-item entropies hoisted, xLogX from two tables): the SpGEMM classes are far from fp64-bound"}
         if not args.no_cpu_baseline:
             mark("cpu_baseline (C oracle on the host cores)")
-            cpu_baseline = cpu_oracle_leg(host, cfg.n_users, args.seed, pairs, runs=3 if workload != "config3" else 5)   # warm-up + median
+            cpu_baseline = cpu_oracle_leg(host, cfg.n_users, args.seed, pairs, runs=5)   # median of >= 5 runs after a warm-up (~14 s each on config 4)
         del host
         job.host_data = None
         if not args.no_extras and workload != "config3":

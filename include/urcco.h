@@ -148,6 +148,11 @@ void urcco_free_indicators(urcco_indicators* indicators, int32_t n);
  * it, before any fallible step: on failure the caller owns nothing and must free nothing. */
 int urcco_cross_occurrence_stage(const urcco_dataset* datasets, int32_t n_datasets, int32_t random_seed, const urcco_options* options);
 int urcco_cross_occurrence_finish(urcco_indicators* out, int32_t n_datasets, urcco_dataset_stats* stats);
+/* The process-wide context behind these calls holds ONE build at a time: a second thread's _stage waits until the first thread's
+ * _finish (at most URCCO_STAGE_WAIT_S seconds, default 600, then URCCO_INTERNAL), the same thread staging twice is URCCO_BAD_ARG.
+ * A _finish whose n_datasets differs from the staged count DISCARDS the staged build (URCCO_BAD_ARG; the context is free again), and
+ * _cancel discards a staged build nobody will finish -- a caller that gave up between the halves calls it so that others do not wait. */
+int urcco_cross_occurrence_cancel(void);
 
 /* ---- CONTEXT level: the persistent form of the host level, and the multi-GPU build ------------------------------
  * A context owns, per GPU, one HIP stream + scratch arena per event type, every intermediate and output buffer (grown

@@ -365,7 +365,27 @@ def test_stage_finish_protocol(sim_lib):
     assert lib.urcco_cross_occurrence_finish(out, n, None) == _lib.BAD_ARG          # nothing staged
     assert lib.urcco_cross_occurrence_stage(arr, n, 3, C.byref(opts)) == _lib.OK
     assert lib.urcco_cross_occurrence_stage(arr, n, 3, C.byref(opts)) == _lib.BAD_ARG   # the previous one is not finished
+    # a finish that cannot take what was staged DISCARDS it and frees the default context (the early return used to leave it
+    # occupied for good); so does urcco_cross_occurrence_cancel
     assert lib.urcco_cross_occurrence_finish(out, n - 1, None) == _lib.BAD_ARG
+    assert b"discarded" in lib.urcco_last_error()
+    assert lib.urcco_cross_occurrence_finish(out, n, None) == _lib.BAD_ARG             # nothing staged any more
+    assert lib.urcco_cross_occurrence_stage(arr, n, 3, C.byref(opts)) == _lib.OK
+    assert lib.urcco_cross_occurrence_cancel() == _lib.OK
+    assert lib.urcco_cross_occurrence_cancel() == _lib.OK                               # nothing staged: a no-op
+    assert lib.urcco_cross_occurrence_finish(out, n, None) == _lib.BAD_ARG
+    # a thread that staged and walked away: another thread's stage gives up after URCCO_STAGE_WAIT_S instead of hanging for ever
+    import threading
+    assert lib.urcco_cross_occurrence_stage(arr, n, 3, C.byref(opts)) == _lib.OK
+    os.environ["URCCO_STAGE_WAIT_S"] = "1"
+    got = []
+    try:
+        t = threading.Thread(target=lambda: got.append(lib.urcco_cross_occurrence_stage(arr, n, 3, C.byref(opts))))
+        t.start()
+        t.join(30)
+    finally:
+        del os.environ["URCCO_STAGE_WAIT_S"]
+    assert got == [_lib.INTERNAL], got
     assert lib.urcco_cross_occurrence_finish(out, n, None) == _lib.OK
     ref = O.cross_occurrence_downsampled(mats, [P()] * n, 3)
     for d, r in enumerate(ref):

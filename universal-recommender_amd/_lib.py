@@ -21,7 +21,7 @@ FLAG_EMULATE_RANKS = 8
 UNIQUE_ID_BYTES = 128
 ROW_RATE_MAHOUT_INT_DIV = 0
 ROW_RATE_FRACTIONAL = 1
-RNG_SPLITMIX53 = 0      # the down-sampling RNG (oracle decision D10), OR-ed into the row-rate mode
+RNG_SPLITMIX53 = 0      # the down-sampling RNG (decision D10 of DESIGN.md), OR-ed into the row-rate mode
 RNG_MIX32 = 0x100
 N_STAGES = 17
 N_BINS = 7
@@ -110,6 +110,7 @@ SYMBOLS = {
     "urcco_free_indicators": (None, [C.POINTER(Indicators), C.c_int32]),
     "urcco_cross_occurrence_stage": (C.c_int, [C.POINTER(Dataset), C.c_int32, C.c_int32, C.POINTER(Options)]),
     "urcco_cross_occurrence_finish": (C.c_int, [C.POINTER(Indicators), C.c_int32, C.POINTER(DatasetStats)]),
+    "urcco_cross_occurrence_cancel": (C.c_int, []),
     "urcco_context_stage": (C.c_int, [_p, C.POINTER(Dataset), C.c_int32, C.c_int32]),
     "urcco_context_finish": (C.c_int, [_p, C.POINTER(Indicators), C.POINTER(DatasetStats)]),
     "urcco_shutdown": (C.c_int, []),

@@ -149,7 +149,7 @@ hipError_t launch_xlx_table(hipStream_t st, double* tab);
 hipError_t launch_xlx_hi_table(hipStream_t st, double* tab /*[2 * XLX_TABLE_HOST]: xlx_hi, then col_ent*/, const double* xlx_tab, long long n_users);
 hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, double* xlx_n);
 // out16[i] = counts[i] (low 16 bits); bad[0] = number of counts that do not fit
-hipError_t launch_narrow_counts(hipStream_t st, int n_cu, const int32_t* counts, int32_t n, unsigned short* out16, int32_t* bad);
+hipError_t launch_narrow_counts(hipStream_t st, int n_cu, const int32_t* counts, int64_t n, unsigned short* out16, int32_t* bad);  // n: 64-bit (world x shard rows)
 
 // pstart[cap], plen[cap] (scratch), wp[cap + 1]; cap >= nnz(A'); tile_sums scratch as for scans over cap elements
 hipError_t launch_expand_prepare(hipStream_t st, int n_cu, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx,

@@ -1589,7 +1589,7 @@ hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n,
   return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void narrow_counts_kernel(const int32_t* __restrict__ counts, int32_t n, unsigned short* __restrict__ out16,
+__global__ __launch_bounds__(256) void narrow_counts_kernel(const int32_t* __restrict__ counts, int64_t n, unsigned short* __restrict__ out16,
                                                             int32_t* __restrict__ bad) {
   int over = 0;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -1599,10 +1599,10 @@ __global__ __launch_bounds__(256) void narrow_counts_kernel(const int32_t* __res
   }
   if (over) atomicAdd(bad, over);
 }
-hipError_t launch_narrow_counts(hipStream_t st, int n_cu, const int32_t* counts, int32_t n, unsigned short* out16, int32_t* bad) {
+hipError_t launch_narrow_counts(hipStream_t st, int n_cu, const int32_t* counts, int64_t n, unsigned short* out16, int32_t* bad) {
   hipError_t e = hipMemsetAsync(bad, 0, sizeof(int32_t), st);
   if (e != hipSuccess || n <= 0) return e;
-  int64_t blocks = ((int64_t)n + 255) / 256;
+  int64_t blocks = (n + 255) / 256;
   if (blocks > (int64_t)n_cu * 8) blocks = (int64_t)n_cu * 8;
   hipLaunchKernelGGL(narrow_counts_kernel, dim3((unsigned)blocks), dim3(256), 0, st, counts, n, out16, bad);
   return hipGetLastError();
@@ -3463,31 +3463,56 @@ hipError_t launch_masked_lengths(hipStream_t st, int n_cu, int64_t n_rows, const
   hipLaunchKernelGGL(peer_totals_kernel, dim3((unsigned)((world + 63) / 64)), dim3(64), 0, st, world, n_rows, off, to_nnz);
   return hipGetLastError();
 }
-// One (row, destination) pair per group of eight lanes, destinations along blockIdx.y: consecutive groups copy consecutive rows of the
-// shard to consecutive places of ONE destination's send buffer, and every pair's four operands (mask, row bounds, offset) are independent
-// loads.  (Round 4's form walked the destinations of a row one after the other inside a 16-lane group -- a dependent offset load per
-// destination, one row at a time: 263 us per event type and rank of config 4 at 8 ranks = 1.3 of a rank's 9.4 ms,
-// profiles/r05_emulated_ranks_w8_kernel_stats.csv.)
-__global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, const unsigned long long* __restrict__ mask,
-                                                        int world, const int64_t* __restrict__ off, int32_t* __restrict__ pack) {
-  const int gl = threadIdx.x & 7;
+// One block per (tile of PK_ROWS consecutive rows, destination): the tile's slice of the destination's offsets (the scanned masked
+// lengths: a row the destination does not need has length 0) and its row starts are staged in LDS, then the threads walk the tile's OUTPUT
+// entries -- consecutive lanes write consecutive words of the send buffer and, inside a row, read consecutive words of the shard; an
+// entry finds its row by a binary search of the staged offsets.  Two memory round trips per block, whatever the rows' lengths.
+// (Round 4 walked a row's destinations one after the other inside a 16-lane group, round 5's first form gave every (row, destination)
+// pair eight lanes: 1.3 and 1.45 ms per rank of config 4 at 8 ranks -- one row at a time per group, three dependent loads each:
+// profiles/r05_emulated_ranks_w8_kernel_table_config4.txt.)
+constexpr int PK_ROWS = 512;
+__global__ __launch_bounds__(256) void pack_rows_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, int world,
+                                                        const int64_t* __restrict__ off, int32_t* __restrict__ pack) {
+  __shared__ unsigned s_o[PK_ROWS + 1];  // offsets relative to the tile's first output entry
+  __shared__ long long s_src[PK_ROWS];   // where the row starts in the shard
   const int q = blockIdx.y;
-  for (int64_t u = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); u < n_rows; u += (int64_t)gridDim.x * 32) {
-    const unsigned long long m = mask[u];
-    const int64_t s = rp[u], e = rp[u + 1];
-    const int64_t dst = off[(int64_t)q * n_rows + u];
-    if (!((m >> q) & 1ull)) continue;
-    for (int64_t p = s + gl; p < e; p += 8) pack[dst + (p - s)] = ci[p];
+  const int64_t u0 = (int64_t)blockIdx.x * PK_ROWS;
+  const int nr = (int)(n_rows - u0 < PK_ROWS ? n_rows - u0 : PK_ROWS);
+  const int64_t* oq = off + (int64_t)q * n_rows + u0;  // off holds world * n_rows + 1 entries: oq[nr] exists for the last tile of the last destination too
+  const int64_t base = oq[0];
+  for (int r = threadIdx.x; r <= nr; r += 256) {
+    s_o[r] = (unsigned)(oq[r] - base);
+    if (r < nr) s_src[r] = rp[u0 + r];
+  }
+  __syncthreads();
+  const unsigned n_out = s_o[nr];
+  for (unsigned e0 = threadIdx.x; e0 < n_out; e0 += 4 * 256) {  // four entries per thread and round: their gathers travel together
+    int32_t v[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const unsigned e = e0 + (unsigned)x * 256u;
+      v[x] = 0;
+      if (e < n_out) {
+        int lo = 0, hi = nr;  // last r in [0, nr) with s_o[r] <= e  (s_o[0] = 0 <= e < s_o[nr])
+        while (hi - lo > 1) {
+          const int mid = (lo + hi) >> 1;
+          if (s_o[mid] <= e) lo = mid; else hi = mid;
+        }
+        v[x] = ci[s_src[lo] + (long long)(e - s_o[lo])];
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+      const unsigned e = e0 + (unsigned)x * 256u;
+      if (e < n_out) pack[base + e] = v[x];
+    }
   }
 }
 hipError_t launch_pack_rows(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, const unsigned long long* mask, int world,
                             const int64_t* off, int32_t* pack) {
+  (void)n_cu; (void)mask;  // (the masked lengths behind `off` already say which rows travel)
   if (n_rows == 0 || world <= 0) return hipSuccess;
-  int64_t blocks = (n_rows + 31) / 32;
-  const int64_t cap = ((int64_t)n_cu * 64 + world - 1) / world;  // ~64 blocks per CU over all destinations
-  if (blocks > cap) blocks = cap;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks, (unsigned)world), dim3(256), 0, st, n_rows, row_ptr, col_idx, mask, world, off, pack);
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((n_rows + PK_ROWS - 1) / PK_ROWS), (unsigned)world), dim3(256), 0, st, n_rows, row_ptr, col_idx, world, off, pack);
   return hipGetLastError();
 }
 

@@ -933,7 +933,7 @@ int exchange_phase(urcco_context* c, int d, const std::vector<std::vector<Shard>
       const Shard& s = sh[(size_t)d][g];
       E.s->begin(URCCO_STAGE_EXCHANGE);
       HIPC(urcco::launch_pack_rows(E.s->stream, D.n_cu, s.n_rows, E.s_rp.p, E.s_ci.p, D.need.p, W, E.moff.p, E.pack.p));
-      if (deg16 && s.n_rows > 0) HIPC(urcco::launch_narrow_counts(E.s->stream, D.n_cu, E.mlen.p, (int32_t)((int64_t)W * s.n_rows), E.mlen16.p, E.mlen_bad.p));
+      if (deg16 && s.n_rows > 0) HIPC(urcco::launch_narrow_counts(E.s->stream, D.n_cu, E.mlen.p, (int64_t)W * s.n_rows, E.mlen16.p, E.mlen_bad.p));
       E.s->end();
       return URCCO_OK;
     }));
@@ -1081,6 +1081,11 @@ int build_sharded(urcco_context* c, const std::vector<std::vector<Shard>>& sh, c
         EvState& A = D.ev[0];
         const Shard& s = sh[0][g];
         URC(D.need.ensure((size_t)s.n_rows + 1));
+        // D.need is ONE buffer per GPU: the previous build's masked_lengths / pack_rows of the other event types' streams may still read
+        // it when builds are enqueued back to back -- the primary's stream waits for their chains (ev_done is recorded at the
+        // end of every event type's chain; an event never recorded is complete)
+        for (EvState& Eo : D.ev)
+          if (&Eo != &A && Eo.ev_done) HIPC(hipStreamWaitEvent(A.s->stream, Eo.ev_done, 0));
         A.s->begin(URCCO_STAGE_EXCHANGE);
         HIPC(urcco::launch_need_mask(A.s->stream, D.n_cu, s.n_rows, A.s_rp.p, A.s_ci.p, D.bounds.p, W, D.need.p));
         A.s->end();
@@ -1844,6 +1849,16 @@ int urcco_context_cross_occurrence(urcco_context* c, const urcco_dataset* datase
   return urcco_context_finish(c, out, stats);
 }
 
+// a staged build nobody will take: finished into blocks that are released at once (the pending state is consumed whatever the outcome)
+static void discard_pending(urcco_context* c) {
+  if (!c || !c->pending) return;
+  const int n = c->pending->n_ds;
+  std::vector<urcco_indicators> tmp((size_t)n);
+  memset(tmp.data(), 0, sizeof(urcco_indicators) * (size_t)n);
+  (void)urcco_context_finish(c, tmp.data(), nullptr);
+  urcco_free_indicators(tmp.data(), n);
+}
+
 // ---- process-wide default context + the Mahout-shaped one-shot entry points ---------------------------------
 int urcco_shutdown(void) {
   std::lock_guard<std::mutex> g(g_default_mu);
@@ -1889,7 +1904,12 @@ int urcco_cross_occurrence_stage(const urcco_dataset* datasets, int32_t n_datase
     // the same thread staging twice is a protocol error (waiting for itself would never end); another thread's build is waited for
     if (g_default_busy && g_default_owner == std::this_thread::get_id())
       return fail(URCCO_BAD_ARG, "urcco_cross_occurrence_stage: the previous staged build has not been finished");
-    g_default_cv.wait(g, [] { return !g_default_busy; });
+    // (bounded: a thread that staged and then died or walked away must not hang every other caller for ever -- ADVICE r04.  The build
+    // itself never takes that long; URCCO_STAGE_WAIT_S overrides the 600 s)
+    const char* we = getenv("URCCO_STAGE_WAIT_S");
+    const long wait_s = we && *we ? atol(we) : 600;
+    if (!g_default_cv.wait_for(g, std::chrono::seconds(wait_s > 0 ? wait_s : 1), [] { return !g_default_busy; }))
+      return fail(URCCO_INTERNAL, "urcco_cross_occurrence_stage: another thread's staged build was not finished within %ld s (urcco_cross_occurrence_cancel discards it)", wait_s);
     urcco_context* c = nullptr;
     URC(default_context(options, &c));
     const int st = urcco_context_stage(c, datasets, n_datasets, random_seed);
@@ -1904,12 +1924,35 @@ int urcco_cross_occurrence_finish(urcco_indicators* out, int32_t n_datasets, urc
   return guarded([&]() -> int {
     err_buf()[0] = 0;
     std::lock_guard<std::mutex> g(g_default_mu);
-    if (!g_default_ctx || !g_default_ctx->pending) return fail(URCCO_BAD_ARG, "urcco_cross_occurrence_finish: nothing staged");
-    if (g_default_ctx->pending->n_ds != n_datasets) return fail(URCCO_BAD_ARG, "urcco_cross_occurrence_finish: %d datasets were staged, out holds %d", g_default_ctx->pending->n_ds, n_datasets);
+    if (!g_default_ctx || !g_default_ctx->pending) {
+      // nothing to hand out; if the flag is still up (the context went away under a staged build) the waiting threads must not wait for ever
+      if (g_default_busy) { g_default_busy = false; g_default_cv.notify_all(); }
+      return fail(URCCO_BAD_ARG, "urcco_cross_occurrence_finish: nothing staged");
+    }
+    if (g_default_ctx->pending->n_ds != n_datasets) {
+      // the caller cannot take what was staged: the build is DISCARDED (finished into scratch blocks that go straight back to the pool) and
+      // the default context is free again -- an early return here used to leave it occupied for good
+      const int staged = g_default_ctx->pending->n_ds;
+      discard_pending(g_default_ctx);
+      g_default_busy = false;
+      g_default_cv.notify_all();
+      return fail(URCCO_BAD_ARG, "urcco_cross_occurrence_finish: %d datasets were staged, out holds %d (the staged build was discarded)", staged, n_datasets);
+    }
     const int st = urcco_context_finish(g_default_ctx, out, stats);  // consumes the pending build whatever its outcome
     g_default_busy = false;
-    g_default_cv.notify_one();
+    g_default_cv.notify_all();
     return st;
+  });
+}
+
+int urcco_cross_occurrence_cancel(void) {
+  return guarded([&]() -> int {
+    err_buf()[0] = 0;
+    std::lock_guard<std::mutex> g(g_default_mu);
+    if (g_default_ctx && g_default_ctx->pending) discard_pending(g_default_ctx);
+    g_default_busy = false;
+    g_default_cv.notify_all();
+    return URCCO_OK;
   });
 }
 
