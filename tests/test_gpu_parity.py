@@ -26,7 +26,8 @@ def P(max_rows=500, k=50, min_llr=None):
     logic.test_small_three_events_all_modes, logic.test_hash_tables_and_all_bins, logic.test_global_accumulator_rows,
     logic.test_packed_count_overflow_goes_global, logic.test_empty_and_ragged_inputs, logic.test_item_range_slices_concatenate,
     logic.test_downsample_row_base_matches_sharded_rows, logic.test_unaligned_col_idx_takes_scalar_path,
-    logic.test_partition_balances_work, logic.test_partitioned_column_counts_large_matrix, logic.test_large_matrix_full_pipeline,
+    logic.test_partition_balances_work, logic.test_partitioned_column_counts_large_matrix, logic.test_llr_operands_beyond_the_tables,
+    logic.test_downsampling_under_the_32_bit_rng, logic.test_large_matrix_full_pipeline,
     logic.test_large_transpose_with_item_range, logic.test_all_equal_llr_ties_cut_by_column,
     logic.test_many_ties_at_the_cut_after_skipped_column_passes, logic.test_row_scan_threshold_table_forms, logic.test_global_class_ties_at_the_cut],
     ids=lambda f: f.__name__)

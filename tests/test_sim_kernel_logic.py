@@ -142,6 +142,26 @@ def test_downsampling_under_the_32_bit_rng(sim_session):
         assert abs(ref.nnz - ref53.nnz) < 6 * np.sqrt(ref53.nnz)                  # ... that keeps as many interactions
 
 
+def test_llr_operands_beyond_the_tables(sim_session):
+    """The row kernels evaluate a candidate's LLR from five table reads behind ONE range check (llr_candidate, csrc/cco_device.h); operands
+    beyond the 4096-entry tables -- a column held by 5000 of 6000 users, no interaction cut -- take the rolled general form (one copy of
+    the logarithm).  Both must give the oracle's value: A'A (the hot item's own row: cA beyond the table) and A'B (hot candidates)."""
+    rng = np.random.default_rng(33)
+    n_users = 6000
+    a = rand_csr(rng, n_users, 300, 6, zipf_s=0.7)
+    hot = np.sort(rng.choice(n_users, 5000, replace=False))
+    b0 = rand_csr(rng, n_users, 200, 4)
+    is_hot = np.zeros(n_users, bool)
+    is_hot[hot] = True
+    rows = [np.unique(np.concatenate([b0.col_idx[b0.row_ptr[u]:b0.row_ptr[u + 1]], [7] if is_hot[u] else []]).astype(np.int32)) for u in range(n_users)]
+    rp = np.zeros(n_users + 1, np.int64)
+    np.cumsum([len(r) for r in rows], out=rp[1:])
+    b = O.Csr(n_users, 200, rp, np.concatenate(rows))
+    assert O.column_counts(b)[7] >= 5000
+    _, _, stats = compare_with_oracle(sim_session, [b, a], [P(100000, 50), P(100000, 50)], 9)       # primary = the matrix with the hot column
+    _, _, stats = compare_with_oracle(sim_session, [a, b], [P(100000, 50), P(100000, 50)], 9)       # ... and as the secondary
+
+
 def test_partition_balances_work(sim_session):
     rng = np.random.default_rng(9)
     work = guarded(torch.from_numpy(rng.zipf(1.5, 5000).astype(np.int64)).to(sim_session.device))

@@ -2020,17 +2020,59 @@ __device__ __forceinline__ bool best_before(unsigned long long ka, int ca, unsig
 // ~45 % of the VALU instructions of a typical one-wave row.  Equal keys are COMMON (an LLR is a function of four small integer
 // counts), so the column comparison cannot be left to a rare path (measured: a key-only loop with a second pass for lanes that
 // saw their key twice was 8 % slower than the plain loop).
+// The single-check LLR (llr_candidate, cco_device.h) per kernel family: A/B knobs, both OFF.  Negative result of round 5
+// (profiles/r05_llr_rank_variants_ab.log): it halves the static code of every row kernel (eleven inlined logarithms become one) and removes
+// four divergent branches per candidate, and it is SLOWER -- micro class 4.73 -> 4.88 ms, one-wave class 5.98 -> 6.30 ms on config 4: the
+// rolled general form behind the one check costs the 64-VGPR classes three to six vector registers spilled to scratch in the row loop,
+// and the branches it removes were never taken (skipping cold code is free; the instruction cache was not the limit).
+#ifndef URCCO_LLR_FAST_ROWS
+#define URCCO_LLR_FAST_ROWS 0
+#endif
+#ifndef URCCO_LLR_FAST_MICRO
+#define URCCO_LLR_FAST_MICRO 0
+#endif
+template <bool FAST>
+__device__ __forceinline__ double llr_of(double row_entropy, double xlx_n, long long k11, long long ca, long long cb, long long n_users,
+                                         const double* __restrict__ xlx_tab, const double* __restrict__ xlx_hi, const double* __restrict__ col_ent) {
+  if (FAST) return llr_candidate(row_entropy, xlx_n, k11, ca, cb, n_users, xlx_tab, xlx_hi, col_ent);
+  return llr_from_entropies_tab(row_entropy, column_entropy_of(cb, xlx_n, n_users, xlx_tab, xlx_hi, col_ent), xlx_n, k11, ca - k11, cb - k11, n_users - ca - cb + k11, xlx_tab,
+                                n_users, xlx_hi);
+}
+
+// r += [(ka, ca) sorts before (mk, mc)] -- key desc, column asc -- as the final borrow of a three-word subtraction chain: [ca < mc] enters
+// (mk - ka) as its borrow, so the chain ends in [mk < ka] || ([mk == ka] && [ca < mc]).  Three subtract-with-borrow and one add-with-carry
+// per element and NO scalar instruction.  The comparison form the compiler makes of best_before -- two 64-bit compares, a 32-bit compare,
+// an s_and and an s_or per element, then the add-with-carry -- kept the CU's one scalar unit as busy as its four vector units: ~950 scalar
+// against ~1180 vector instructions per row of the one-wave class (profiles/r04_sq_counters_pmc_config4.json), half of them in these loops.
+// (__builtin_subc chains are taken apart into the same compares by the compiler: inline assembly it is.)
+#ifndef URCCO_RANK_ASM
+#define URCCO_RANK_ASM 1
+#endif
+__device__ __forceinline__ void count_if_before(unsigned& r, unsigned long long ka, unsigned ca, unsigned long long mk, unsigned mc) {
+#if defined(HIPSIM_HOST_BUILD) || !URCCO_RANK_ASM
+  r += best_before(ka, (int)ca, mk, (int)mc) ? 1u : 0u;
+#else
+  unsigned t;
+  asm("v_sub_co_u32 %1, vcc, %2, %3\n\t"
+      "v_subb_co_u32 %1, vcc, %4, %5, vcc\n\t"
+      "v_subb_co_u32 %1, vcc, %6, %7, vcc\n\t"
+      "v_addc_co_u32 %0, vcc, 0, %0, vcc"
+      : "+v"(r), "=&v"(t)
+      : "v"(ca), "v"(mc), "v"((unsigned)mk), "v"((unsigned)ka), "v"((unsigned)(mk >> 32)), "v"((unsigned)(ka >> 32))
+      : "vcc");
+#endif
+}
 template <class ColOf>
 __device__ __forceinline__ unsigned rank_by_counting(const unsigned long long* keys, unsigned n_uniform, unsigned long long mk, int mc, ColOf col_of) {
   const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)n_uniform);
-  unsigned r0 = 0, r1 = 0, r2 = 0, r3 = 0, u = 0;  // four chains: each comparison ends in one add-with-carry
+  unsigned r0 = 0, r1 = 0, r2 = 0, r3 = 0, u = 0;  // four chains
   for (; u + 4 <= n; u += 4) {
-    r0 += best_before(keys[u], col_of(u), mk, mc) ? 1u : 0u;
-    r1 += best_before(keys[u + 1], col_of(u + 1), mk, mc) ? 1u : 0u;
-    r2 += best_before(keys[u + 2], col_of(u + 2), mk, mc) ? 1u : 0u;
-    r3 += best_before(keys[u + 3], col_of(u + 3), mk, mc) ? 1u : 0u;
+    count_if_before(r0, keys[u], (unsigned)col_of(u), mk, (unsigned)mc);
+    count_if_before(r1, keys[u + 1], (unsigned)col_of(u + 1), mk, (unsigned)mc);
+    count_if_before(r2, keys[u + 2], (unsigned)col_of(u + 2), mk, (unsigned)mc);
+    count_if_before(r3, keys[u + 3], (unsigned)col_of(u + 3), mk, (unsigned)mc);
   }
-  for (; u < n; ++u) r0 += best_before(keys[u], col_of(u), mk, mc) ? 1u : 0u;
+  for (; u < n; ++u) count_if_before(r0, keys[u], (unsigned)col_of(u), mk, (unsigned)mc);
   return (r0 + r1) + (r2 + r3);
 }
 
@@ -2187,8 +2229,13 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 // from the row's work (1.25 x the expected distinct columns per pass must fit) and doubles whenever a pass still overflows --
 // at the latest when ceil(n_cols / P) columns are GUARANTEED to fit, so every row ends.  Round 2 served these rows from dense
 // counters in global memory (n_cols x 16 B of scratch per resident block, L2 atomics): 35.9 ms for 16K rows of config 5.
-template <int T, int E, int U, bool MP = false>
+// DBG: the ablation / test switches of CcoArgs::debug exist only in a second instantiation (profiling tools and the race regression tests
+// launch it); the production instantiation carries neither their branches nor the scalar register a.debug would occupy -- at eight waves
+// per SIMD a wave has 78 scalar registers and the one-wave class spilled 128 of them to vector lanes (round 5: 69 after this and the
+// single-check LLR).
+template <int T, int E, int U, bool MP = false, bool DBG = false>
 __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T == 256 && E == 4096 ? 7 : 1))) void cco_rows_kernel(CcoArgs a, int bin) {
+  const int dbg = DBG ? a.debug : 0;
   constexpr int BLOCK = T < 256 ? 256 : T;
   constexpr int TEAMS = BLOCK / T;
   constexpr int SPT = E / T;
@@ -2397,7 +2444,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
 #pragma unroll
             for (int q = 0; q < G; ++q) {
               if (on[q]) {
-                if (a.debug & 1) {  // ablation: gather only
+                if (dbg & 1) {  // ablation: gather only
                   if (jj[q] == 0xffffffffu) tab[0] = 1u;
                 } else if (MP) {
                   if ((jj[q] & mp_mask) == mp_q && !tab_insert(tab, (jj[q] >> mp_s) + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) s_mpflag = 1u;
@@ -2471,7 +2518,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
           cbj[x] = 0;
           if (vv[x] != 0u) {
             const int j = MP ? (int)((((vv[x] >> cb) - 1u) << mp_s) | mp_q) : (int)(vv[x] >> cb) - 1;
-            cbj[x] = (a.debug & 512) ? 100 : (use16 ? (int)a.cnt_b16[j] : a.cnt_b[j]);  // the ONE scattered gather per candidate (ablation 512: none)
+            cbj[x] = (dbg & 512) ? 100 : (use16 ? (int)a.cnt_b16[j] : a.cnt_b[j]);  // the ONE scattered gather per candidate (ablation 512: none)
           }
         }
 #pragma unroll
@@ -2482,10 +2529,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             const long long k11 = (long long)(vv[x] & cmask);
             unsigned long long key = 0ull;
             if (!(a.exclude_self && j == i)) {
-              const double llr = (a.debug & 2) ? (double)k11
-                                               : llr_from_entropies_tab(row_entropy, column_entropy_of((long long)cbj[x], xlx_n, a.n_users, a.xlx_tab, a.xlx_hi, a.col_ent), xlx_n, k11,
-                                                                        ca - k11, (long long)cbj[x] - k11, a.n_users - ca - (long long)cbj[x] + k11, a.xlx_tab, a.n_users,
-                                                                        a.xlx_hi);
+              const double llr = (dbg & 2) ? (double)k11
+                                               : llr_of<URCCO_LLR_FAST_ROWS != 0>(row_entropy, xlx_n, k11, ca, (long long)cbj[x], a.n_users, a.xlx_tab, a.xlx_hi, a.col_ent);
               if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
             }
             kk[t] = key;
@@ -2525,8 +2570,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
     const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
     unsigned long long thr_key = 0ull;
     unsigned thr_ncol = 0u;
-    if (!(a.debug & 4)) {
-      if (a.debug & 8) {  // ablation: no select (nothing passes)
+    if (!(dbg & 4)) {
+      if (dbg & 8) {  // ablation: no select (nothing passes)
         if (C > (unsigned)a.k) thr_key = ~0ull;
       } else if (C > (unsigned)a.k) {  // team-uniform
         // MSB-first radix select of the k-th composite, 8-bit digits, LDS histograms (three rotating 256-bin arrays of
@@ -2625,7 +2670,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
           // test hook (tests/test_gpu_parity.py::test_select_overlay_race_*): the team's FIRST wave -- it owns the lowest table entries, the
           // ones a tie at the cut selects -- dawdles before it reads the histogram, so that its siblings are far ahead of it: the
           // interleaving the round-3 race needed, made certain
-          if (T != WAVE && (a.debug & 131072) && tl / WAVE == 0) {
+          if (T != WAVE && (dbg & 131072) && tl / WAVE == 0) {
 #ifdef HIPSIM_HOST_BUILD
             __builtin_amdgcn_s_sleep(127);
 #else
@@ -2675,7 +2720,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             // entries lost at the cut in ~1 build of 50 on config 4, now and then a garbage column and a wild store (the GPU memory
             // fault of profiles/r03_rocprofv3_stats_failure.txt; found by tools/race_hunt.py, profiles/r04_race_hunt.log).  prev_cnt is
             // team-uniform, so every wave takes the barrier.  (debug 262144 skips it: the regression test's negative control.)
-            if (SHARE && T != WAVE && !(a.debug & 262144)) team_sync<T>();
+            if (SHARE && T != WAVE && !(dbg & 262144)) team_sync<T>();
             const unsigned n_scan2 = have_list ? list_n : D;
             for (unsigned base = 0; base < n_scan2; base += T) {
               const unsigned idx = base + (unsigned)tl;
@@ -2750,7 +2795,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
         }
       }
       team_sync<T>();
-      const unsigned n = (a.debug & 16) ? 0u : uni(*nsel);  // ablation 16: no ranking / output
+      const unsigned n = (dbg & 16) ? 0u : uni(*nsel);  // ablation 16: no ranking / output
       if (MP) {
         // merge the pass's <= k survivors into the running top k: every element of both lists is ranked over both (by counting),
         // the best k land in the other running buffer at their rank -- which is the output order
@@ -2831,7 +2876,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
 // --------------------------------------------------------------------------------------------
 constexpr int MICRO_WORDS = 448;
 
+template <bool DBG>
 __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
+  const int dbg = DBG ? a.debug : 0;
   constexpr int TEAMS = 256 / WAVE;
   __shared__ unsigned s_tab[TEAMS * MICRO_WORDS];
   __shared__ long long s_ustart[TEAMS * WAVE];
@@ -2931,7 +2978,7 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
       }
       const int o = lo - 1;
       const unsigned jj = (unsigned)a.b_col_idx[ustart[o] + ((unsigned)lane - uoff[o])];
-      if (!(a.debug & 1) && !tab_insert(tab, jj + 1u, cb, 255u, 24, ident)) atomicAdd(a.err, 1ull);
+      if (!(dbg & 1) && !tab_insert(tab, jj + 1u, cb, 255u, 24, ident)) atomicAdd(a.err, 1ull);
     }
     wave_sync();
     unsigned D = 0;
@@ -2958,10 +3005,9 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
       const int j = (int)(vv >> cb) - 1;
       const long long k11 = (long long)(vv & cmask);
       if (!(a.exclude_self && j == i)) {
-        const long long cbj = (a.debug & 512) ? 100ll : (long long)(use16 ? ((j & 1) ? cb_raw >> 16 : cb_raw & 0xffffu) : cb_raw);
-        const double llr = (a.debug & 2) ? (double)k11
-                                         : llr_from_entropies_tab(row_entropy, column_entropy_of(cbj, xlx_n, a.n_users, a.xlx_tab, a.xlx_hi, a.col_ent), xlx_n, k11, ca - k11,
-                                                                  cbj - k11, a.n_users - ca - cbj + k11, a.xlx_tab, a.n_users, a.xlx_hi);
+        const long long cbj = (dbg & 512) ? 100ll : (long long)(use16 ? ((j & 1) ? cb_raw >> 16 : cb_raw & 0xffffu) : cb_raw);
+        const double llr = (dbg & 2) ? (double)k11
+                                         : llr_of<URCCO_LLR_FAST_MICRO != 0>(row_entropy, xlx_n, k11, ca, cbj, a.n_users, a.xlx_tab, a.xlx_hi, a.col_ent);
         if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
           mk = (unsigned long long)__double_as_longlong(llr);
           mc = j;
@@ -2976,7 +3022,7 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
       URCCO_SETTLE(pf_w1); URCCO_SETTLE(pf_wp); URCCO_SETTLE(pf_start); URCCO_SETTLE(pf_ca); URCCO_SETTLE(pf_ent);
       URCCO_SETTLE(cs2); URCCO_SETTLE(ce2); URCCO_SETTLE(i_n3);
     };
-    if (a.unordered && n_valid <= a.k && !(a.debug & 4)) {  // every candidate is emitted: no ranking needed (wave-uniform)
+    if (a.unordered && n_valid <= a.k && !(dbg & 4)) {  // every candidate is emitted: no ranking needed (wave-uniform)
       const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
       settle_prefetch();
       if (mk != 0ull) {
@@ -2985,7 +3031,7 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
         a.out_llr[obase + pos] = __longlong_as_double((long long)mk);
       }
       if (lane == 0) a.out_count[i - a.item_lo] = n_valid;
-    } else if (!(a.debug & 4)) {
+    } else if (!(dbg & 4)) {
       const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
       const unsigned rank = mk == 0ull ? 0u : rank_by_counting(kkm, D, mk, mc, [&](unsigned u) { return (int)(cand[u] >> cb) - 1; });  // broadcast LDS reads
       // the row is put in order in LDS (the accumulator words are free again) and leaves as contiguous stores
@@ -3215,7 +3261,7 @@ static int blocks_per_cu(int bin) {
   if (cache[bin].load(std::memory_order_relaxed) == 0) {
     int n = 0;
     hipError_t e = hipErrorUnknown;
-    if (bin == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_micro_kernel, 256, 0);
+    if (bin == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_micro_kernel<false>, 256, 0);
     if (bin == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<64, E0, URCCO_U_WAVE>, 256, 0);
     if (bin == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1S, URCCO_U_BS>, 256, 0);
     if (bin == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1, URCCO_U_B>, 256, 0);
@@ -3249,15 +3295,35 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
   static const Factors factors;
   const int* factor = factors.f;
   auto grid = [&](int b) { return dim3((unsigned)(n_cu * blocks_per_cu(b)) * (unsigned)factor[b]); };
+  const bool dbgk = (args.debug & (1 | 2 | 4 | 8 | 16 | 512 | 131072 | 262144)) != 0;  // the ablation / test switches live in the DBG instantiations only
   switch (bin) {
-    case 0: hipLaunchKernelGGL(cco_rows_micro_kernel, grid(0), dim3(256), 0, st, args); break;
-    case 1: hipLaunchKernelGGL((cco_rows_kernel<64, E0, URCCO_U_WAVE>), grid(1), dim3(256), 0, st, args, 1); break;
-    case 2: hipLaunchKernelGGL((cco_rows_kernel<256, E1S, URCCO_U_BS>), grid(2), dim3(256), 0, st, args, 2); break;
-    case 3: hipLaunchKernelGGL((cco_rows_kernel<256, E1, URCCO_U_B>), grid(3), dim3(256), 0, st, args, 3); break;
-    case 4: hipLaunchKernelGGL((cco_rows_kernel<512, E2S, URCCO_U_H>), grid(4), dim3(512), 0, st, args, 4); break;
-    case 5: hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C>), grid(5), dim3(1024), 0, st, args, 5); break;
+    case 0:
+      if (dbgk) hipLaunchKernelGGL(cco_rows_micro_kernel<true>, grid(0), dim3(256), 0, st, args);
+      else hipLaunchKernelGGL(cco_rows_micro_kernel<false>, grid(0), dim3(256), 0, st, args);
+      break;
+    case 1:
+      if (dbgk) hipLaunchKernelGGL((cco_rows_kernel<64, E0, URCCO_U_WAVE, false, true>), grid(1), dim3(256), 0, st, args, 1);
+      else hipLaunchKernelGGL((cco_rows_kernel<64, E0, URCCO_U_WAVE>), grid(1), dim3(256), 0, st, args, 1);
+      break;
+    case 2:
+      if (dbgk) hipLaunchKernelGGL((cco_rows_kernel<256, E1S, URCCO_U_BS, false, true>), grid(2), dim3(256), 0, st, args, 2);
+      else hipLaunchKernelGGL((cco_rows_kernel<256, E1S, URCCO_U_BS>), grid(2), dim3(256), 0, st, args, 2);
+      break;
+    case 3:
+      if (dbgk) hipLaunchKernelGGL((cco_rows_kernel<256, E1, URCCO_U_B, false, true>), grid(3), dim3(256), 0, st, args, 3);
+      else hipLaunchKernelGGL((cco_rows_kernel<256, E1, URCCO_U_B>), grid(3), dim3(256), 0, st, args, 3);
+      break;
+    case 4:
+      if (dbgk) hipLaunchKernelGGL((cco_rows_kernel<512, E2S, URCCO_U_H, false, true>), grid(4), dim3(512), 0, st, args, 4);
+      else hipLaunchKernelGGL((cco_rows_kernel<512, E2S, URCCO_U_H>), grid(4), dim3(512), 0, st, args, 4);
+      break;
+    case 5:
+      if (dbgk) hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C, false, true>), grid(5), dim3(1024), 0, st, args, 5);
+      else hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C>), grid(5), dim3(1024), 0, st, args, 5);
+      break;
     default:
       if (args.g_blocks > 0) hipLaunchKernelGGL(cco_rows_global_kernel, dim3((unsigned)args.g_blocks), dim3(GB_THREADS), 0, st, args);
+      else if (dbgk) hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C, true, true>), grid(6), dim3(1024), 0, st, args, 6);
       else hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C, true>), grid(6), dim3(1024), 0, st, args, 6);
       break;
   }
