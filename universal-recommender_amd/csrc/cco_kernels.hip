@@ -1464,6 +1464,7 @@ __global__ __launch_bounds__(TR_THREADS) void tr_place_kernel(const unsigned sho
   const int64_t col0 = (int64_t)b << bits;
   const int64_t bs = offsets[(int64_t)b * n_parts], be_all = offsets[(int64_t)(b + 1) * n_parts];
   if (n_blk > 1) {  // block-uniform: a chunk of a heavy bucket
+    if (blockIdx.y != 0) return;  // (the column slices below belong to the single-block buckets)
     const int64_t c0 = bs + (int64_t)(blk - blk_prefix[b]) * TR_CHUNK;
     const int64_t c1 = c0 + TR_CHUNK < be_all ? c0 + TR_CHUNK : be_all;
     for (int64_t e = c0 + threadIdx.x; e < c1; e += TR_THREADS) {
@@ -1472,8 +1473,13 @@ __global__ __launch_bounds__(TR_THREADS) void tr_place_kernel(const unsigned sho
     }
     return;
   }
+  // gridDim.y blocks share a bucket, each owning a slice of its columns (round 5): every block walks the bucket's entries (2 + 4 bytes each,
+  // out of the L2 / Infinity Cache after the first) and places those of its own columns -- a bucket was ONE block walking ~80K entries four at
+  // a time, 489 blocks for 256 CUs: a latency chain (load -> LDS atomic -> store) at two blocks' worth of parallelism per CU
+  const int sub_w = (width + (int)gridDim.y - 1) / (int)gridDim.y;
+  const unsigned c_lo = (unsigned)(sub_w * (int)blockIdx.y), c_hi = c_lo + (unsigned)sub_w < (unsigned)width ? c_lo + (unsigned)sub_w : (unsigned)width;
   const int64_t base = col_ptr[col0];  // where the bucket's CSC segment starts (a bucket holds < 2^32 entries)
-  for (int c = threadIdx.x; c < width; c += TR_THREADS) s_cur[c] = col0 + c < n_cols ? (unsigned)(col_ptr[col0 + c] - base) : 0u;
+  for (unsigned c = c_lo + threadIdx.x; c < c_hi; c += TR_THREADS) s_cur[c] = col0 + c < n_cols ? (unsigned)(col_ptr[col0 + c] - base) : 0u;
   __syncthreads();
   const int64_t be = be_all;
   // four entries per thread and round: their loads are requested together (a round is a chain load -> LDS atomic -> store)
@@ -1483,12 +1489,12 @@ __global__ __launch_bounds__(TR_THREADS) void tr_place_kernel(const unsigned sho
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int64_t x = e + (int64_t)q * TR_THREADS;
-      c[q] = x < be ? (unsigned)bk_col[x] : 0u;
+      c[q] = x < be ? (unsigned)bk_col[x] : 0xffffffffu;
       r[q] = x < be ? bk_row[x] : 0;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      if (e + (int64_t)q * TR_THREADS < be) out_rows[base + atomicAdd(&s_cur[c[q]], 1u)] = r[q];
+      if (c[q] >= c_lo && c[q] < c_hi) out_rows[base + atomicAdd(&s_cur[c[q]], 1u)] = r[q];
   }
 }
 
@@ -1532,7 +1538,11 @@ hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const in
                      offsets, bk_col, bk_row);
   hipLaunchKernelGGL(tr_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, offsets, (int)n_buckets, n_parts, blk_prefix);
   const int64_t max_blocks = n_buckets + nnz / TR_CHUNK;
-  hipLaunchKernelGGL(tr_place_kernel, dim3((unsigned)max_blocks), dim3(TR_THREADS), 0, st, bk_col, bk_row, offsets, bits, (int)n_buckets, n_parts, blk_prefix, col_ptr,
+  const char* se = getenv("URCCO_TR_PLACE_SLICES");  // A/B knob: blocks per bucket of the placement pass
+  int slices = se && *se ? atoi(se) : 4;
+  if (slices < 1) slices = 1;
+  if (slices > 16) slices = 16;
+  hipLaunchKernelGGL(tr_place_kernel, dim3((unsigned)max_blocks, (unsigned)slices), dim3(TR_THREADS), 0, st, bk_col, bk_row, offsets, bits, (int)n_buckets, n_parts, blk_prefix, col_ptr,
                      n_cols, cursor, out_row_idx);
   return hipGetLastError();
 }
@@ -2082,6 +2092,36 @@ __device__ __forceinline__ unsigned rank_by_counting(const unsigned long long* k
 // without finding the key or a free slot -- impossible while the binning rule holds (the table always has room for the
 // row's distinct columns); the bound keeps a broken invariant from turning into a hung GPU and is reported through
 // stats[1 + 4 * NBINS].
+// (the micro class keeps plain argument pointers: with pointers of their own it spilled five VECTOR registers to scratch and ran 3 % slower,
+// profiles/r05_sgpr_diet_variants_ab.log)
+#ifndef URCCO_OWN_PTRS_MICRO
+#define URCCO_OWN_PTRS_MICRO 0
+#endif
+#define URCCO_PLAIN_PTR(T, name, src) T* name = (src)
+#ifndef URCCO_TAB_INSERT_V2
+#define URCCO_TAB_INSERT_V2 1
+#endif
+#if URCCO_TAB_INSERT_V2
+__device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int count_bits, unsigned mask, int hshift, bool ident) {
+  unsigned h = ident ? (key - 1u) : ((key * 0x9E3779B1u) >> hshift);
+  const unsigned fresh = (key << count_bits) | 1u;
+  // ONE loop condition and no break: with two exits and a result flag the compiler spent ~25 scalar instructions per probe on execution
+  // masks (round 5, ISA of the pair loop: the CU's single scalar unit was as loaded as its four vector units).  `left` bounds the probes
+  // (a broken binning invariant must not hang the GPU); the add for a known column is predicated, not branched around.
+  bool done;
+  unsigned left = mask + 1u;
+#pragma unroll 1
+  do {
+    const unsigned v = atomicCAS(&tab[h], 0u, fresh);
+    const bool hit = (v >> count_bits) == key;
+    if (hit) atomicAdd(&tab[h], 1u);
+    done = hit || v == 0u;
+    h = (h + 1u) & mask;
+    --left;
+  } while (!done && left != 0u);
+  return done;
+}
+#else
 __device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int count_bits, unsigned mask, int hshift, bool ident) {
   unsigned h = ident ? (key - 1u) : ((key * 0x9E3779B1u) >> hshift);
   const unsigned fresh = (key << count_bits) | 1u;
@@ -2099,6 +2139,7 @@ __device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int coun
   }
   return ok;
 }
+#endif
 
 // "This prefetched register is needed now": an empty asm that reads it makes the compiler place the wait for its load HERE -- ahead
 // of the stores that follow -- instead of at its first use in the next row, where the wait would also cover every store issued in
@@ -2107,6 +2148,23 @@ __device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int coun
 #define URCCO_SETTLE(x) ((void)(x))
 #else
 #define URCCO_SETTLE(x) asm volatile("" : "+v"(x) : : "memory")  // "memory": the stores that follow must not be scheduled above it
+#endif
+
+// "This kernel argument gets scalar registers of its own": the kernel arguments arrive as 16-dword tuples, the register allocator spills
+// and reloads a tuple as a whole, and a wave at eight waves per SIMD has 78 scalar registers for ~90 dwords of arguments -- so the pair
+// loop of the one-wave class reloaded SIXTEEN spilled scalars (v_readlane each) per cooccurrence pair to get at the ONE pointer it uses.
+// An empty asm that redefines the value cuts it out of its tuple: a pair of its own, spilled -- if at all -- as a pair.
+// (A pointer that went through the asm has lost its provenance -- the compiler would address it with FLAT instructions, which also tie up
+// the LDS counter --, so pointers make the trip as GLOBAL-address-space pointers: URCCO_OWN_GLOBAL_PTR.)
+#ifdef HIPSIM_HOST_BUILD
+#define URCCO_OWN_SGPRS(x) ((void)(x))
+#define URCCO_OWN_GLOBAL_PTR(T, name, src) T* name = (src)
+#else
+#define URCCO_OWN_SGPRS(x) asm volatile("" : "+s"(x))
+#define URCCO_OWN_GLOBAL_PTR(T, name, src)                                                    \
+  T __attribute__((address_space(1)))* name##_as1 = (T __attribute__((address_space(1)))*)(src); \
+  asm volatile("" : "+s"(name##_as1));                                                         \
+  T* name = (T*)name##_as1
 #endif
 
 // LDS hand-off inside ONE wave: DS operations of a wave execute in program order, so a compiler-level fence is all that
@@ -2236,6 +2294,17 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 template <int T, int E, int U, bool MP = false, bool DBG = false>
 __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T == 256 && E == 4096 ? 7 : 1))) void cco_rows_kernel(CcoArgs a, int bin) {
   const int dbg = DBG ? a.debug : 0;
+  // the arguments the row loop's inner loops use, each in scalar registers of its own (URCCO_OWN_SGPRS)
+  URCCO_OWN_GLOBAL_PTR(const int32_t, b_col_idx, a.b_col_idx);
+  URCCO_OWN_GLOBAL_PTR(const unsigned short, cnt_b16, a.cnt_b16);
+  URCCO_OWN_GLOBAL_PTR(const int32_t, cnt_b, a.cnt_b);
+  URCCO_OWN_GLOBAL_PTR(const double, xlx_tab, a.xlx_tab);
+  URCCO_OWN_GLOBAL_PTR(const double, xlx_hi, a.xlx_hi);
+  URCCO_OWN_GLOBAL_PTR(const double, col_ent, a.col_ent);
+  URCCO_OWN_GLOBAL_PTR(int32_t, out_idx, a.out_idx);
+  URCCO_OWN_GLOBAL_PTR(double, out_llr, a.out_llr);
+  long long n_users = a.n_users;
+  URCCO_OWN_SGPRS(n_users);
   constexpr int BLOCK = T < 256 ? 256 : T;
   constexpr int TEAMS = BLOCK / T;
   constexpr int SPT = E / T;
@@ -2243,6 +2312,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   constexpr int G = T == WAVE ? URCCO_G_WAVE : (T == 256 ? URCCO_G_BLOCK : URCCO_G_CU);  // column gathers in flight per lane
   constexpr int LOG2E = E == 1024 ? 10 : (E == 4096 ? 12 : (E == 8192 ? 13 : (E == 16384 ? 14 : 15)));
   static_assert((1 << LOG2E) == E, "table size");
+  constexpr int LOG2T = T == 64 ? 6 : (T == 256 ? 8 : (T == 512 ? 9 : 10));
+  static_assert((1 << LOG2T) == T, "team size");
   __shared__ unsigned s_tab[TEAMS * E];
   // One-wave teams and the small block class: the chunk operands (insert phase), the select histograms + survivor list (select
   // passes) and the ambiguous / staged survivors (after the passes; they overlay the histograms) are never live together and
@@ -2414,10 +2485,13 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
         const unsigned first = (unsigned)tl * per;
         if (first < total) {
           const unsigned last = first + per < total ? first + per : total;
-          int lo = 1, hi = T;  // first idx in [1, T] with uoff[idx] > first (uoff[T] = total > first)
-          while (lo < hi) {
+          int lo = 1, hi = T;  // first idx in [1, T] with uoff[idx] > first (uoff[T] = total > first).  T candidates, halved exactly log2(T) times:
+#pragma unroll             // a fixed trip count, selects instead of branches (the data-dependent loop cost four scalar instructions per step)
+          for (int step = 0; step < LOG2T; ++step) {
             const int mid = (lo + hi) >> 1;
-            if (uoff[mid] > first) hi = mid; else lo = mid + 1;
+            const bool gt = uoff[mid] > first;
+            hi = gt ? mid : hi;
+            lo = gt ? lo : mid + 1;
           }
           int o = lo - 1;
           int64_t pos = ustart[o] + (first - uoff[o]);
@@ -2438,7 +2512,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
                   pos = ustart[o];
                   uend = uoff[o + 1];
                 }
-                jj[q] = (unsigned)a.b_col_idx[pos++];
+                jj[q] = (unsigned)b_col_idx[pos++];
               }
             }
 #pragma unroll
@@ -2518,7 +2592,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
           cbj[x] = 0;
           if (vv[x] != 0u) {
             const int j = MP ? (int)((((vv[x] >> cb) - 1u) << mp_s) | mp_q) : (int)(vv[x] >> cb) - 1;
-            cbj[x] = (dbg & 512) ? 100 : (use16 ? (int)a.cnt_b16[j] : a.cnt_b[j]);  // the ONE scattered gather per candidate (ablation 512: none)
+            cbj[x] = (dbg & 512) ? 100 : (use16 ? (int)cnt_b16[j] : cnt_b[j]);  // the ONE scattered gather per candidate (ablation 512: none)
           }
         }
 #pragma unroll
@@ -2530,7 +2604,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             unsigned long long key = 0ull;
             if (!(a.exclude_self && j == i)) {
               const double llr = (dbg & 2) ? (double)k11
-                                               : llr_of<URCCO_LLR_FAST_ROWS != 0>(row_entropy, xlx_n, k11, ca, (long long)cbj[x], a.n_users, a.xlx_tab, a.xlx_hi, a.col_ent);
+                                               : llr_of<URCCO_LLR_FAST_ROWS != 0>(row_entropy, xlx_n, k11, ca, (long long)cbj[x], n_users, xlx_tab, xlx_hi, col_ent);
               if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
             }
             kk[t] = key;
@@ -2773,8 +2847,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
           const unsigned col = (unsigned)((int)(tab[t] >> cb) - 1);
           if (key > thr_key || (key == thr_key && ~col >= thr_ncol)) {
             const unsigned pos = atomicAdd(nsel, 1u);
-            a.out_idx[obase + pos] = (int)col;
-            a.out_llr[obase + pos] = __longlong_as_double((long long)key);
+            out_idx[obase + pos] = (int)col;
+            out_llr[obase + pos] = __longlong_as_double((long long)key);
           }
         }
         team_sync<T>();
@@ -2834,8 +2908,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
           amb_key[rank] = mk;
           amb_col[rank] = (unsigned)mc;
         } else {
-          a.out_idx[obase + rank] = mc;
-          a.out_llr[obase + rank] = __longlong_as_double((long long)mk);
+          out_idx[obase + rank] = mc;
+          out_llr[obase + rank] = __longlong_as_double((long long)mk);
         }
       }
       if (staged) {
@@ -2843,8 +2917,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
         for (unsigned base = 0; base < n; base += T) {
           const unsigned t = base + (unsigned)tl;
           if (t >= n) continue;
-          a.out_idx[obase + t] = (int)amb_col[t];
-          a.out_llr[obase + t] = __longlong_as_double((long long)amb_key[t]);
+          out_idx[obase + t] = (int)amb_col[t];
+          out_llr[obase + t] = __longlong_as_double((long long)amb_key[t]);
         }
       }
       if (tl == 0) a.out_count[i - a.item_lo] = (int)n;
@@ -2856,8 +2930,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
       const unsigned long long* rk = s_runk + run_cur * MP_KMAX;
       const unsigned* rc = s_runc + run_cur * MP_KMAX;
       for (unsigned t = (unsigned)tl; t < n_run; t += T) {
-        a.out_idx[obase + t] = (int)rc[t];
-        a.out_llr[obase + t] = __longlong_as_double((long long)rk[t]);
+        out_idx[obase + t] = (int)rc[t];
+        out_llr[obase + t] = __longlong_as_double((long long)rk[t]);
       }
       if (tl == 0) a.out_count[i - a.item_lo] = (int)n_run;
     }
@@ -2879,6 +2953,38 @@ constexpr int MICRO_WORDS = 448;
 template <bool DBG>
 __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
   const int dbg = DBG ? a.debug : 0;
+  // every argument the row loop touches in scalar registers of its own (URCCO_OWN_GLOBAL_PTR: the arguments arrive as 16-dword tuples that
+  // spill and reload whole; rounds 1-4 noted "the kernel argument block alone keeps ~60 SGPRs live")
+#if URCCO_OWN_PTRS_MICRO
+  URCCO_OWN_GLOBAL_PTR(const int32_t, bin_rows, a.bin_rows);
+  URCCO_OWN_GLOBAL_PTR(const int64_t, a_col_ptr, a.a_col_ptr);
+  URCCO_OWN_GLOBAL_PTR(const int64_t, pstart, a.pstart);
+  URCCO_OWN_GLOBAL_PTR(const int32_t, b_col_idx, a.b_col_idx);
+  URCCO_OWN_GLOBAL_PTR(const int32_t, cnt_a, a.cnt_a);
+  URCCO_OWN_GLOBAL_PTR(const double, ent_a, a.ent_a);
+  URCCO_OWN_GLOBAL_PTR(const double, xlx_tab, a.xlx_tab);
+  URCCO_OWN_GLOBAL_PTR(const double, xlx_hi, a.xlx_hi);
+  URCCO_OWN_GLOBAL_PTR(const double, col_ent, a.col_ent);
+  URCCO_OWN_GLOBAL_PTR(int32_t, out_idx, a.out_idx);
+  URCCO_OWN_GLOBAL_PTR(double, out_llr, a.out_llr);
+  URCCO_OWN_GLOBAL_PTR(int32_t, out_count, a.out_count);
+  long long n_users = a.n_users;
+  URCCO_OWN_SGPRS(n_users);
+#else
+  URCCO_PLAIN_PTR(const int32_t, bin_rows, a.bin_rows);
+  URCCO_PLAIN_PTR(const int64_t, a_col_ptr, a.a_col_ptr);
+  URCCO_PLAIN_PTR(const int64_t, pstart, a.pstart);
+  URCCO_PLAIN_PTR(const int32_t, b_col_idx, a.b_col_idx);
+  URCCO_PLAIN_PTR(const int32_t, cnt_a, a.cnt_a);
+  URCCO_PLAIN_PTR(const double, ent_a, a.ent_a);
+  URCCO_PLAIN_PTR(const double, xlx_tab, a.xlx_tab);
+  URCCO_PLAIN_PTR(const double, xlx_hi, a.xlx_hi);
+  URCCO_PLAIN_PTR(const double, col_ent, a.col_ent);
+  URCCO_PLAIN_PTR(int32_t, out_idx, a.out_idx);
+  URCCO_PLAIN_PTR(double, out_llr, a.out_llr);
+  URCCO_PLAIN_PTR(int32_t, out_count, a.out_count);
+  long long n_users = a.n_users;
+#endif
   constexpr int TEAMS = 256 / WAVE;
   __shared__ unsigned s_tab[TEAMS * MICRO_WORDS];
   __shared__ long long s_ustart[TEAMS * WAVE];
@@ -2915,13 +3021,13 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
   //    (URCCO_SETTLE) just before the row's output stores, so that the next row never waits behind those stores.
   // Round 4 found the rounds 1-3 form of this loop waiting three times per row for loads it had issued as "prefetches".
   const int stride = total_teams;
-  auto row_at = [&](int l) { return a.bin_rows[list_start + (l < list_n ? l : list_n - 1)]; };
+  auto row_at = [&](int l) { return bin_rows[list_start + (l < list_n ? l : list_n - 1)]; };
   const unsigned* wp32 = reinterpret_cast<const unsigned*>(a.wp);  // low words: a row only uses differences (<= 64) between its own entries
   const unsigned* cnt_words = use16 ? reinterpret_cast<const unsigned*>(a.cnt_b16) : reinterpret_cast<const unsigned*>(a.cnt_b);  // the column counts, read a word at a time
   int i_cur = row_at(li);              // this row
   int i_n1 = row_at(li + stride);      // the next one: id ...
   int i_n2 = row_at(li + 2 * stride);  // (two ahead: id only)
-  int64_t cs1 = a.a_col_ptr[i_n1], ce1 = a.a_col_ptr[i_n1 + 1];  // ... and CSC bounds
+  int64_t cs1 = a_col_ptr[i_n1], ce1 = a_col_ptr[i_n1 + 1];  // ... and CSC bounds
   // operands of the row about to be processed; wp[cs] is what lane 0 reads as its user's entry
   unsigned pf_w1, pf_wp;
   int64_t pf_start;
@@ -2929,14 +3035,14 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
   double pf_ent;
   int n_cur;  // users of the row about to be processed
   {
-    const int64_t cs0 = a.a_col_ptr[i_cur], ce0 = a.a_col_ptr[i_cur + 1];
+    const int64_t cs0 = a_col_ptr[i_cur], ce0 = a_col_ptr[i_cur + 1];
     n_cur = (int)(ce0 - cs0);
     const int64_t pl = lane < n_cur ? cs0 + lane : ce0 - 1;
     pf_w1 = wp32[2 * ce0];
     pf_wp = wp32[2 * pl];
-    pf_start = a.pstart[pl];
-    pf_ca = a.cnt_a[i_cur];
-    pf_ent = a.ent_a[i_cur];
+    pf_start = pstart[pl];
+    pf_ca = cnt_a[i_cur];
+    pf_ent = ent_a[i_cur];
   }
   // (collected here as at the end of every row: with a load still pending on ONE way into the loop header the compiler waits there
   // for everything in flight on every pass)
@@ -2954,15 +3060,15 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
     const unsigned my_off = owns_user ? pf_wp - w0 : total;
     // ... and the rows ahead take them: id of row + 3, bounds of row + 2, operands of row + 1
     int i_n3 = row_at(li + 3 * stride);
-    int64_t cs2 = a.a_col_ptr[i_n2], ce2 = a.a_col_ptr[i_n2 + 1];
+    int64_t cs2 = a_col_ptr[i_n2], ce2 = a_col_ptr[i_n2 + 1];
     n_cur = (int)(ce1 - cs1);
     {
       const int64_t pl = lane < n_cur ? cs1 + lane : ce1 - 1;
       pf_w1 = wp32[2 * ce1];
       pf_wp = wp32[2 * pl];
-      pf_start = a.pstart[pl];
-      pf_ca = a.cnt_a[i_n1];
-      pf_ent = a.ent_a[i_n1];
+      pf_start = pstart[pl];
+      pf_ca = cnt_a[i_n1];
+      pf_ent = ent_a[i_n1];
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) tab[lane + q * WAVE] = 0u;
@@ -2977,7 +3083,7 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
         if (uoff[mid] > (unsigned)lane) hi = mid; else lo = mid + 1;
       }
       const int o = lo - 1;
-      const unsigned jj = (unsigned)a.b_col_idx[ustart[o] + ((unsigned)lane - uoff[o])];
+      const unsigned jj = (unsigned)b_col_idx[ustart[o] + ((unsigned)lane - uoff[o])];
       if (!(dbg & 1) && !tab_insert(tab, jj + 1u, cb, 255u, 24, ident)) atomicAdd(a.err, 1ull);
     }
     wave_sync();
@@ -3007,7 +3113,7 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
       if (!(a.exclude_self && j == i)) {
         const long long cbj = (dbg & 512) ? 100ll : (long long)(use16 ? ((j & 1) ? cb_raw >> 16 : cb_raw & 0xffffu) : cb_raw);
         const double llr = (dbg & 2) ? (double)k11
-                                         : llr_of<URCCO_LLR_FAST_MICRO != 0>(row_entropy, xlx_n, k11, ca, cbj, a.n_users, a.xlx_tab, a.xlx_hi, a.col_ent);
+                                         : llr_of<URCCO_LLR_FAST_MICRO != 0>(row_entropy, xlx_n, k11, ca, cbj, n_users, xlx_tab, xlx_hi, col_ent);
         if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
           mk = (unsigned long long)__double_as_longlong(llr);
           mc = j;
@@ -3027,10 +3133,10 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
       settle_prefetch();
       if (mk != 0ull) {
         const int pos = __popcll(valid_mask & lt);
-        a.out_idx[obase + pos] = mc;
-        a.out_llr[obase + pos] = __longlong_as_double((long long)mk);
+        out_idx[obase + pos] = mc;
+        out_llr[obase + pos] = __longlong_as_double((long long)mk);
       }
-      if (lane == 0) a.out_count[i - a.item_lo] = n_valid;
+      if (lane == 0) out_count[i - a.item_lo] = n_valid;
     } else if (!(dbg & 4)) {
       const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
       const unsigned rank = mk == 0ull ? 0u : rank_by_counting(kkm, D, mk, mc, [&](unsigned u) { return (int)(cand[u] >> cb) - 1; });  // broadcast LDS reads
@@ -3046,10 +3152,10 @@ __global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
       wave_sync();
       settle_prefetch();
       if ((unsigned)lane < n_out) {
-        a.out_idx[obase + lane] = (int)srt_col[lane];
-        a.out_llr[obase + lane] = __longlong_as_double((long long)srt_key[lane]);
+        out_idx[obase + lane] = (int)srt_col[lane];
+        out_llr[obase + lane] = __longlong_as_double((long long)srt_key[lane]);
       }
-      if (lane == 0) a.out_count[i - a.item_lo] = (int)n_out;
+      if (lane == 0) out_count[i - a.item_lo] = (int)n_out;
     } else {
       settle_prefetch();
     }
