@@ -1464,7 +1464,6 @@ __global__ __launch_bounds__(TR_THREADS) void tr_place_kernel(const unsigned sho
   const int64_t col0 = (int64_t)b << bits;
   const int64_t bs = offsets[(int64_t)b * n_parts], be_all = offsets[(int64_t)(b + 1) * n_parts];
   if (n_blk > 1) {  // block-uniform: a chunk of a heavy bucket
-    if (blockIdx.y != 0) return;  // (the column slices below belong to the single-block buckets)
     const int64_t c0 = bs + (int64_t)(blk - blk_prefix[b]) * TR_CHUNK;
     const int64_t c1 = c0 + TR_CHUNK < be_all ? c0 + TR_CHUNK : be_all;
     for (int64_t e = c0 + threadIdx.x; e < c1; e += TR_THREADS) {
@@ -1473,28 +1472,25 @@ __global__ __launch_bounds__(TR_THREADS) void tr_place_kernel(const unsigned sho
     }
     return;
   }
-  // gridDim.y blocks share a bucket, each owning a slice of its columns (round 5): every block walks the bucket's entries (2 + 4 bytes each,
-  // out of the L2 / Infinity Cache after the first) and places those of its own columns -- a bucket was ONE block walking ~80K entries four at
-  // a time, 489 blocks for 256 CUs: a latency chain (load -> LDS atomic -> store) at two blocks' worth of parallelism per CU
-  const int sub_w = (width + (int)gridDim.y - 1) / (int)gridDim.y;
-  const unsigned c_lo = (unsigned)(sub_w * (int)blockIdx.y), c_hi = c_lo + (unsigned)sub_w < (unsigned)width ? c_lo + (unsigned)sub_w : (unsigned)width;
   const int64_t base = col_ptr[col0];  // where the bucket's CSC segment starts (a bucket holds < 2^32 entries)
-  for (unsigned c = c_lo + threadIdx.x; c < c_hi; c += TR_THREADS) s_cur[c] = col0 + c < n_cols ? (unsigned)(col_ptr[col0 + c] - base) : 0u;
+  for (int c = threadIdx.x; c < width; c += TR_THREADS) s_cur[c] = col0 + c < n_cols ? (unsigned)(col_ptr[col0 + c] - base) : 0u;
   __syncthreads();
   const int64_t be = be_all;
-  // four entries per thread and round: their loads are requested together (a round is a chain load -> LDS atomic -> store)
+  // four entries per thread and round: their loads are requested together (a round is a chain load -> LDS atomic -> store).
+  // (Round 5 measured column slices -- 2, 4, 8 blocks per bucket, each placing the entries of its own columns: +-0, profiles/r05_transpose_slices_ab.log:
+  // the pass is not bound by the parallelism of its latency chains.)
   for (int64_t e = bs + threadIdx.x; e < be; e += TR_THREADS * 4) {
     unsigned c[4];
     int r[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int64_t x = e + (int64_t)q * TR_THREADS;
-      c[q] = x < be ? (unsigned)bk_col[x] : 0xffffffffu;
+      c[q] = x < be ? (unsigned)bk_col[x] : 0u;
       r[q] = x < be ? bk_row[x] : 0;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      if (c[q] >= c_lo && c[q] < c_hi) out_rows[base + atomicAdd(&s_cur[c[q]], 1u)] = r[q];
+      if (e + (int64_t)q * TR_THREADS < be) out_rows[base + atomicAdd(&s_cur[c[q]], 1u)] = r[q];
   }
 }
 
@@ -1538,11 +1534,7 @@ hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const in
                      offsets, bk_col, bk_row);
   hipLaunchKernelGGL(tr_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, offsets, (int)n_buckets, n_parts, blk_prefix);
   const int64_t max_blocks = n_buckets + nnz / TR_CHUNK;
-  const char* se = getenv("URCCO_TR_PLACE_SLICES");  // A/B knob: blocks per bucket of the placement pass
-  int slices = se && *se ? atoi(se) : 4;
-  if (slices < 1) slices = 1;
-  if (slices > 16) slices = 16;
-  hipLaunchKernelGGL(tr_place_kernel, dim3((unsigned)max_blocks, (unsigned)slices), dim3(TR_THREADS), 0, st, bk_col, bk_row, offsets, bits, (int)n_buckets, n_parts, blk_prefix, col_ptr,
+  hipLaunchKernelGGL(tr_place_kernel, dim3((unsigned)max_blocks), dim3(TR_THREADS), 0, st, bk_col, bk_row, offsets, bits, (int)n_buckets, n_parts, blk_prefix, col_ptr,
                      n_cols, cursor, out_row_idx);
   return hipGetLastError();
 }
