@@ -2942,8 +2942,11 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
 // --------------------------------------------------------------------------------------------
 constexpr int MICRO_WORDS = 448;
 
+#ifndef URCCO_OCC_MICRO
+#define URCCO_OCC_MICRO 8  // blocks of four one-wave teams per CU the micro class is compiled for (A/B knob)
+#endif
 template <bool DBG>
-__global__ __launch_bounds__(256, 8) void cco_rows_micro_kernel(CcoArgs a) {
+__global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(CcoArgs a) {
   const int dbg = DBG ? a.debug : 0;
   // every argument the row loop touches in scalar registers of its own (URCCO_OWN_GLOBAL_PTR: the arguments arrive as 16-dword tuples that
   // spill and reload whole; rounds 1-4 noted "the kernel argument block alone keeps ~60 SGPRs live")
