@@ -49,11 +49,12 @@ PCIE_PEAK_GBS = 63.0   # same guide: PCIe gen5 x16, per direction
 LDS_ATOMIC_PEAK_GOPS = 16 * 256 * 2.4
 
 BIN_STAGES = ["cco_rows_micro", "cco_rows_wave", "cco_rows_block_small", "cco_rows_block", "cco_rows_cu_half", "cco_rows_cu", "cco_rows_global"]
-STAGE_TO_KERNEL = {"cco_rows_micro": "cco_rows_micro_kernel", "cco_rows_wave": "cco_rows_kernel<64, 1024, 2, false>",
-                   "cco_rows_block_small": "cco_rows_kernel<256, 4096, 2, false>", "cco_rows_block": "cco_rows_kernel<256, 8192, 2, false>",
-                   "cco_rows_cu_half": "cco_rows_kernel<512, 16384, 1, false>", "cco_rows_cu": "cco_rows_kernel<1024, 32768, 1, false>",
-                   "cco_rows_global": "cco_rows_kernel<1024, 32768, 1, true>",
-                   "downsample_flags": "downsample_flags_kernel<false>", "compact_indicators": "compact_indicators_kernel"}
+# (round 5: the row kernels' last template argument is DBG -- false in production; the flags kernel's second one is the 32-bit RNG)
+STAGE_TO_KERNEL = {"cco_rows_micro": "cco_rows_micro_kernel<false>", "cco_rows_wave": "cco_rows_kernel<64, 1024, 2, false, false>",
+                   "cco_rows_block_small": "cco_rows_kernel<256, 4096, 2, false, false>", "cco_rows_block": "cco_rows_kernel<256, 8192, 2, false, false>",
+                   "cco_rows_cu_half": "cco_rows_kernel<512, 16384, 1, false, false>", "cco_rows_cu": "cco_rows_kernel<1024, 32768, 1, false, false>",
+                   "cco_rows_global": "cco_rows_kernel<1024, 32768, 1, true, false>",
+                   "downsample_flags": "downsample_flags_kernel<false, false>", "compact_indicators": "compact_indicators_kernel"}
 NAMES = {"config3": "config3: synthetic 1M users x 200K items, Zipf-1.0, purchase/view/category-pref",
          "config4": "config4: synthetic 10M users x 2M items, Zipf-1.0, 5 event types (purchase/view/add-to-cart/search/category-pref)",
          "config5": "config5: synthetic 10M x 2M skewed (top 0.1 % of the items = 40 % of the interactions, 1 % heavy users x50), 5 event types, indicators form"}
@@ -61,7 +62,7 @@ NAMES = {"config3": "config3: synthetic 1M users x 200K items, Zipf-1.0, purchas
 
 def kernel_source_id() -> str:
     """Identity of the kernel sources the in-tree library is built from: sha256 over csrc/*, first 16 hex digits.  The PMC traffic file
-    under profiles/ records the id it was collected on (tools/r04_measure.sh); a file with another id is not quoted."""
+    under profiles/ records the id it was collected on (tools/r05_measure.sh); a file with another id is not quoted."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "universal-recommender_amd", "csrc")
@@ -615,7 +616,9 @@ def measure(job: Job, args, full: bool):
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot wrap the process it runs in).  The file must have
     # been collected on THESE kernel sources (kernel_source_id), else no traffic is quoted (round 3 quoted a stale one).
     traffic, traffic_src = None, None
-    for tpath in (os.path.join(ROOT, "profiles", f"r04_hbm_traffic_pmc_{job.workload}.json"),):
+    for tpath in (os.path.join(ROOT, "profiles", f"r05_hbm_traffic_pmc_{job.workload}.json"), os.path.join(ROOT, "profiles", f"r04_hbm_traffic_pmc_{job.workload}.json")):
+        if traffic is not None:
+            break
         if world == 1 and n_local == 1 and args.scale == 1.0 and os.path.exists(tpath) and dominant in STAGE_TO_KERNEL:
             tj = json.load(open(tpath))
             if tj.get("kernel_source_id") != kernel_source_id():

@@ -3115,6 +3115,8 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
         }
       }
       kkm[lane] = mk;
+      cand[lane] = (unsigned)j;  // the packed word has been consumed: the slot now holds the COLUMN, which is all the ranking loop reads of it (a shift and a
+                                 // subtraction per compared element and lane less: every lane was unpacking the same word)
     }
     wave_sync();
     const unsigned long long valid_mask = __ballot(mk != 0ull);
@@ -3134,7 +3136,7 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
       if (lane == 0) out_count[i - a.item_lo] = n_valid;
     } else if (!(dbg & 4)) {
       const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
-      const unsigned rank = mk == 0ull ? 0u : rank_by_counting(kkm, D, mk, mc, [&](unsigned u) { return (int)(cand[u] >> cb) - 1; });  // broadcast LDS reads
+      const unsigned rank = mk == 0ull ? 0u : rank_by_counting(kkm, D, mk, mc, [&](unsigned u) { return (int)cand[u]; });  // broadcast LDS reads
       // the row is put in order in LDS (the accumulator words are free again) and leaves as contiguous stores
       wave_sync();
       unsigned* srt_col = tab;                                                    // [64]
