@@ -794,6 +794,14 @@ __global__ __launch_bounds__(SCAN_THREADS) void pl_blockmap_kernel(const long lo
 static inline int pl_splits(int n_buckets, int64_t n_parts) {
   int64_t S = (2048 + n_buckets - 1) / n_buckets;
   if (S > n_parts / 4) S = n_parts / 4;
+  // ... and an average block should count a few ten thousand ids for the 64 KiB of LDS it clears and the 64 KiB of partial counters it
+  // publishes (a rank's user shard at 8 ranks: 2200 blocks of ~20K ids each; the weight split keeps the hot buckets' blocks average too)
+  const char* e = getenv("URCCO_PL_BLOCK_IDS");  // A/B knob: ids per average histogram block (0 = no such bound)
+  const int64_t ids = e && *e ? atoll(e) : 49152;
+  if (ids > 0) {
+    const int64_t by_work = n_parts * PL_PART / ((int64_t)n_buckets * ids);
+    if (S > by_work) S = by_work;
+  }
   if (S < 1) S = 1;
   return (int)S;
 }

@@ -557,6 +557,7 @@ int stage_rows(DevState& D, EvState& E, EvState& A, int d, const DsParams& pa, c
 struct InputGate {
   const HostTrace* trace = nullptr;
   std::function<int(int)> after_chain;  // called by the thread that has just enqueued event type d's chain (see PendingBuild::res)
+  std::vector<int> order;               // the order the event types are staged in (primary first): a single enqueueing thread follows it
   std::vector<std::promise<int>> staged;
   std::vector<std::shared_future<int>> fut;
   std::vector<char> released;
@@ -656,7 +657,8 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
     E.b_nnz_bound = sh[(size_t)d].nnz;
     URC(stage_rows(D, E, A, d, ps_[0], ps_[(size_t)d], n_users, sh[0].nnz, fuse));
     if (gate && gate->trace) gate->trace->mark("chain enqueued", d);
-    if (gate && gate->after_chain) URC(gate->after_chain(d));
+    // (one enqueueing thread for everything -- URCCO_FLAG_SINGLE_STREAM: the downloads wait until every chain is enqueued, see below)
+    if (threaded && gate && gate->after_chain) URC(gate->after_chain(d));
     return URCCO_OK;
   };
   // one enqueueing thread per secondary (see above); host-side hand-offs make sure an event has been RECORDED before a stream is
@@ -711,14 +713,28 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
     A.b_nnz_bound = sh[0].nnz;
     st = stage_rows(D, A, A, 0, ps_[0], ps_[0], n_users, sh[0].nnz);
     if (gate && gate->trace) gate->trace->mark("chain enqueued", 0);
-    if (st == URCCO_OK && gate && gate->after_chain) st = gate->after_chain(0);
+    if (st == URCCO_OK && threaded && gate && gate->after_chain) st = gate->after_chain(0);
   }
   for (std::thread& t : workers) t.join();
   if (st != URCCO_OK) return st;
   if (!threaded) {
-    for (int d = 1; d < n_ds; ++d) URC(sample_secondary(d));
+    // ONE thread enqueues everything: a download (two blocking stream waits) between two chains would turn the build into chain, D2H, chain, D2H ...
+    //  -- so every chain is enqueued first, the secondaries in the order their uploads were staged (largest first, gate->order), and the
+    // results are brought over afterwards, in the order the chains end
+    std::vector<int> order;
+    for (int d = 1; d < n_ds; ++d) order.push_back(d);
+    if (gate && !gate->order.empty()) {
+      order.clear();
+      for (int d : gate->order)
+        if (d >= 1 && d < n_ds) order.push_back(d);
+    }
+    for (int d : order) URC(sample_secondary(d));
     if (fuse) URC(fused_expand());
-    for (int d = 1; d < n_ds; ++d) URC(rows_secondary(d));
+    for (int d : order) URC(rows_secondary(d));
+    if (gate && gate->after_chain) {
+      URC(gate->after_chain(0));
+      for (int d : order) URC(gate->after_chain(d));
+    }
   }
   for (int d = 1; d < n_ds; ++d)
     if (status[(size_t)d] != URCCO_OK) return fail(status[(size_t)d], "%s", message[(size_t)d].c_str());
@@ -1647,6 +1663,12 @@ int urcco_context_stage(urcco_context* c, const urcco_dataset* datasets, int32_t
       if (!pb->stats_block) return fail(URCCO_OOM_HOST, "pinned statistics block");
       memset(pb->stats_block, 0, sizeof(int64_t) * (URCCO_STATS_LEN + 1) * (size_t)n_ds);
       pb->gate->after_chain = [c, pb](int d) { return download_event(c, pb, d); };
+      {  // (fixed before the builder starts: it reads gate->order)
+        std::vector<int> ord((size_t)n_ds);
+        for (int d = 0; d < n_ds; ++d) ord[(size_t)d] = d;
+        std::stable_sort(ord.begin() + 1, ord.end(), [&](int a, int b) { return pb->nnz_raw[(size_t)a] > pb->nnz_raw[(size_t)b]; });
+        pb->gate->order = ord;
+      }
       pb->builder = std::thread([c, pb] {
         pb->build_st = guarded([&] { return run_build(c, pb->sh, pb->ps, pb->n_users, pb->seed, nullptr, pb->gate.get()); });
         if (pb->build_st != URCCO_OK) pb->build_msg = err_buf();
@@ -1656,9 +1678,7 @@ int urcco_context_stage(urcco_context* c, const urcco_dataset* datasets, int32_t
       // upload order: the primary, then the secondaries from the largest down -- the heaviest A'B_d starts first and runs under the
       // remaining uploads, and what is still to come when the link goes quiet is the smallest chain and its few results (round 3
       // staged in index order: on config 4 the largest secondary's SpGEMM and 2.2 GB of finished results waited behind the uploads)
-      std::vector<int> order((size_t)n_ds);
-      for (int d = 0; d < n_ds; ++d) order[(size_t)d] = d;
-      std::stable_sort(order.begin() + 1, order.end(), [&](int a, int b) { return P->nnz_raw[(size_t)a] > P->nnz_raw[(size_t)b]; });
+      const std::vector<int>& order = P->gate->order;
       for (int d : order) {
         if (stage_st == URCCO_OK) {
           stage_st = guarded([&] { return stage_event(d); });
