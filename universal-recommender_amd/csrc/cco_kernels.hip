@@ -752,16 +752,17 @@ __global__ __launch_bounds__(256) void pl_reduce_kernel(const unsigned* __restri
   counts[j] = (int32_t)sum;
 }
 
-// weight[b] = ids of bucket b over all parts (one block per bucket sums its slice lengths) ...
-__global__ __launch_bounds__(256) void pl_weights_kernel(const unsigned short* __restrict__ loc_t, int64_t n_parts, long long* __restrict__ weight) {
+// weight[b] = ids of bucket b over all parts: gridDim.y blocks per bucket sum their share of its slice lengths (one block per bucket was a
+// 16 us latency chain ten times per build); weight[] is zero on entry ...
+__global__ __launch_bounds__(256) void pl_weights_kernel(const unsigned short* __restrict__ loc_t, int64_t n_parts, unsigned long long* __restrict__ weight) {
   __shared__ long long s_wave[256 / WAVE];
   const unsigned short* lo_t = loc_t + (int64_t)blockIdx.x * n_parts;
   const unsigned short* hi_t = lo_t + n_parts;
   long long sum = 0;
-  for (int64_t p = threadIdx.x; p < n_parts; p += 256) sum += (long long)hi_t[p] - (long long)lo_t[p];
+  for (int64_t p = (int64_t)blockIdx.y * 256 + threadIdx.x; p < n_parts; p += (int64_t)gridDim.y * 256) sum += (long long)hi_t[p] - (long long)lo_t[p];
   long long tot;
   block_exclusive_scan<256>(sum, s_wave, &tot);
-  if (threadIdx.x == 0) weight[blockIdx.x] = tot;
+  if (threadIdx.x == 0 && tot != 0) atomicAdd(&weight[blockIdx.x], (unsigned long long)tot);
 }
 // ... and (single block) blk_prefix[b] = first histogram block of bucket b: S blocks per average bucket weight, at least one, at most one per part
 __global__ __launch_bounds__(SCAN_THREADS) void pl_blockmap_kernel(const long long* __restrict__ weight, int n_buckets, int64_t n_parts, int S,
@@ -842,7 +843,10 @@ hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_i
     int32_t* blk_prefix = reinterpret_cast<int32_t*>(scratch); scratch += al(((int64_t)n_buckets + 1) * 4);
     unsigned* partial = reinterpret_cast<unsigned*>(scratch);
     hipLaunchKernelGGL(pl_partition_kernel, dim3((unsigned)n_parts), dim3(PL_THREADS), 0, st, col_idx, nnz, nnz_dev, n_buckets, n_parts, bucketed, loc_t, vec_ok);
-    hipLaunchKernelGGL(pl_weights_kernel, dim3((unsigned)n_buckets), dim3(256), 0, st, loc_t, n_parts, weight);
+    hipError_t we = hipMemsetAsync(weight, 0, sizeof(long long) * (size_t)n_buckets, st);
+    if (we != hipSuccess) return we;
+    const unsigned wsplit = (unsigned)(n_parts >= 8192 ? 8 : (n_parts >= 1024 ? 4 : 1));
+    hipLaunchKernelGGL(pl_weights_kernel, dim3((unsigned)n_buckets, wsplit), dim3(256), 0, st, loc_t, n_parts, reinterpret_cast<unsigned long long*>(weight));
     hipLaunchKernelGGL(pl_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, weight, n_buckets, n_parts, S, blk_prefix);
     const char* de = getenv("URCCO_PL_DEBUG");   // profiling only: 1 = no LDS atomics, 2 = no loads (the counts are then meaningless)
     const char* le = getenv("URCCO_PL_LANES");   // A/B: lanes per slice (16, 8 or 4)
@@ -1926,8 +1930,30 @@ __global__ __launch_bounds__(BS_THREADS) void bin_scan_kernel(int64_t* __restric
   __shared__ long long s_tot[BIN_COLS];
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
   for (int k = wave; k < BIN_COLS; k += BS_THREADS / WAVE) {  // wave-uniform
+    if (k >= NBINS) {
+      // pairs / users / total columns: only their TOTALS are used (statistics) -- a plain sum, every lane four loads deep, one reduction at the
+      // end (rounds 1-4 ran the same carried shuffle scan over all 22 columns and wrote 15 prefixes nobody read: 54 us per event type)
+      long long acc = 0;
+      for (int64_t base = 0; base < n_tiles; base += 4 * WAVE) {
+        long long v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int64_t i = base + q * WAVE + lane;
+          v[q] = i < n_tiles ? tile_counts[i * BIN_COLS + k] : 0;
+        }
+        acc += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+#pragma unroll
+      for (int d = 1; d < WAVE; d <<= 1) {
+        const long long o = shfl_up_i64(acc, d);
+        if (lane >= d) acc += o;
+      }
+      acc = shfl_i64(acc, WAVE - 1);
+      if (lane == 0) s_tot[k] = acc;
+      continue;
+    }
     long long carry = 0;
-    for (int64_t base = 0; base < n_tiles; base += WAVE) {
+    for (int64_t base = 0; base < n_tiles; base += WAVE) {  // rows-per-bin columns: exclusive prefix over the tiles = where a tile's rows go
       const int64_t i = base + lane;
       const long long v = i < n_tiles ? tile_counts[i * BIN_COLS + k] : 0;
       long long inc = v;
