@@ -8,3 +8,4 @@ tools/r05_measure.sh r05_final prof pmc_hbm pmc_sq > $O/measure.log 2>&1; tail -
 RANKS=8 tools/r05_emulate.sh > $O/emulate.log 2>&1; grep "rank_total" $O/emulate.log | cut -c1-200
 timeout 300 python bench.py --workload config5 --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_config5.log 2>/dev/null; python tools/bench_brief.py $O/bench_config5.log
 timeout 300 python bench.py --force-exchange --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $O/bench_force_exchange.log 2>/dev/null; python tools/bench_brief.py $O/bench_force_exchange.log
+timeout 120 python tools/ablate.py --config4 1.0 0,4,1 > $O/ablation_topk.log 2>&1; grep debug= $O/ablation_topk.log
