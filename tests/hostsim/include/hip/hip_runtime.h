@@ -228,6 +228,7 @@ static inline int hipsim_update_dpp(int line, int old, int src, int ctrl, int ro
 }
 #define __builtin_amdgcn_update_dpp(...) hipsim_update_dpp(__LINE__, __VA_ARGS__)
 #define __builtin_amdgcn_readlane(v, l) hipsim_shfl(__LINE__, (int)(v), (int)(l))
+#define __builtin_amdgcn_ds_bpermute(addr, v) hipsim_shfl(__LINE__, (int)(v), ((int)(addr) >> 2) & 63)  /* byte address of the source lane */
 #define __builtin_amdgcn_readfirstlane(v) (v)  /* only ever applied to wave-uniform values */
 static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned base) {
   const int lane = hipsim::lane_id();

@@ -32,6 +32,34 @@ def test_hash_tables_and_all_bins(sim_session):
     assert bins[1] > 0 and bins[2] + bins[3] > 0 and bins[4] + bins[5] > 0, bins
 
 
+def _micro_case(rng, n_items_a, users_per_item, b_cols, b_len_lo, b_len_hi, empty_frac=0.2):
+    """A: every item held by `users_per_item`-ish users who hold nothing else; B: rows of b_len_lo..b_len_hi columns (some empty), so an
+    item's cooccurrence pairs -- and, with many columns, its distinct candidates -- land anywhere in 1..64."""
+    upi = rng.integers(1, users_per_item + 1, n_items_a)
+    n_users = int(upi.sum()) + 5                       # a few users without a primary event
+    a_cols = np.repeat(np.arange(n_items_a, dtype=np.int32), upi)
+    a_rp = np.concatenate([np.arange(a_cols.size + 1, dtype=np.int64), np.full(5, a_cols.size, np.int64)])
+    a = O.Csr(n_users, n_items_a, a_rp, a_cols)
+    lens = rng.integers(b_len_lo, b_len_hi + 1, n_users)
+    lens[rng.random(n_users) < empty_frac] = 0
+    rows = [np.sort(rng.choice(b_cols, size=min(int(l), b_cols), replace=False)).astype(np.int32) for l in lens]
+    b_rp = np.zeros(n_users + 1, np.int64)
+    np.cumsum([r.size for r in rows], out=b_rp[1:])
+    return a, O.Csr(n_users, b_cols, b_rp, np.concatenate(rows) if rows else np.zeros(0, np.int32))
+
+
+def test_micro_class_every_ranking_form(sim_session):
+    """Rows of the micro class (<= 64 users and pairs) with 1..64 distinct candidates: the candidate's owner is the lane that claimed its
+    column, rows of <= 16 / <= 32 / <= 64 candidates are ranked by four / two / one replica(s), k cuts inside the row, columns repeat
+    (k11 > 1) and LLRs tie (few columns), empty B' rows sit before, between and behind the users of a row."""
+    rng = np.random.default_rng(77)
+    for b_cols, lo, hi, upi, k in [(5000, 1, 16, 4, 50), (5000, 8, 32, 2, 50), (5000, 20, 60, 1, 50), (5000, 1, 30, 3, 7), (40, 1, 12, 5, 50),
+                                   (40, 1, 12, 5, 3), (200, 0, 3, 20, 50), (300, 30, 64, 1, 64)]:
+        a, b = _micro_case(rng, 400, upi, b_cols, lo, hi)
+        _, _, stats = compare_with_oracle(sim_session, [a, b], [P(100000, k), P(100000, k)], 13)
+        assert stats[1][0][1] > 100, stats[1][0][1:8]   # rows of the micro class in A'B
+
+
 def test_global_accumulator_rows(sim_session):
     """Rows that cannot be bounded below an LDS table (w > 10240 with > 16384 columns) take the dense global path."""
     rng = np.random.default_rng(3)

@@ -2067,6 +2067,31 @@ __device__ __forceinline__ bool best_before(unsigned long long ka, int ca, unsig
 #ifndef URCCO_LLR_FAST_MICRO
 #define URCCO_LLR_FAST_MICRO 0
 #endif
+// The table-only evaluation of a candidate's LLR as a WAVE-level decision (round 5): llr_operands_in_tables is the single range test of
+// llr_candidate (cco_device.h); when it holds for every candidate of the wave, llr_from_tables issues the five table reads together --
+// the same five values in the same expression order as the general forms, bit for bit -- in straight-line code; otherwise the wave takes
+// the general form.  (The per-lane form of the single test was slower in round 5: its rolled logarithm shared the lanes' registers.)
+#ifndef URCCO_LLR_WAVE_FAST
+#define URCCO_LLR_WAVE_FAST 1  // micro class
+#endif
+#ifndef URCCO_LLR_WAVE_FAST_ROWS
+#define URCCO_LLR_WAVE_FAST_ROWS 1  // the LDS accumulator classes
+#endif
+__device__ __forceinline__ bool llr_operands_in_tables(unsigned k11, long long ca, unsigned cb, long long n_users, const double* col_ent) {
+  const long long k12 = ca - (long long)k11, d22 = ca + (long long)cb - (long long)k11;  // k22 = n_users - d22; k11 <= cb, k21 <= cb
+  return col_ent != nullptr && (unsigned long long)(k12 | (long long)cb | d22) < (unsigned long long)XLX_TABLE && d22 <= n_users;
+}
+__device__ __forceinline__ double llr_from_tables(double row_entropy, double xlx_n, unsigned k11, unsigned ca, unsigned cb, const double* __restrict__ xlx_tab,
+                                                  const double* __restrict__ xlx_hi, const double* __restrict__ col_ent) {
+  double t11 = xlx_tab[k11], t12 = xlx_tab[ca - k11], t21 = xlx_tab[cb - k11], t22 = xlx_hi[ca + cb - k11], tce = col_ent[cb];
+#ifndef HIPSIM_HOST_BUILD
+  asm volatile("" : "+v"(t11), "+v"(t12), "+v"(t21), "+v"(t22), "+v"(tce));  // all five in flight before the first is consumed
+#endif
+  const double matrix_entropy = (((xlx_n - t11) - t12) - t21) - t22;
+  const double s = row_entropy + tce;
+  if (s < matrix_entropy) return 0.0; /* round off error */
+  return 2.0 * (s - matrix_entropy);
+}
 template <bool FAST>
 __device__ __forceinline__ double llr_of(double row_entropy, double xlx_n, long long k11, long long ca, long long cb, long long n_users,
                                          const double* __restrict__ xlx_tab, const double* __restrict__ xlx_hi, const double* __restrict__ col_ent) {
@@ -2167,9 +2192,58 @@ __device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int coun
 }
 #endif
 
+// tab_insert for the micro class: the lane whose CAS finds the slot EMPTY owns the new column, and is told which slot that is
+// (0xffffffff: the column was known, or -- impossible while the binning rule holds -- no slot was found: *ok false).
+__device__ __forceinline__ unsigned tab_insert_claim(unsigned* tab, unsigned key, int count_bits, unsigned mask, int hshift, bool ident, bool* ok) {
+  unsigned h = ident ? (key - 1u) : ((key * 0x9E3779B1u) >> hshift);
+  const unsigned fresh = (key << count_bits) | 1u;
+  unsigned mine = 0xffffffffu;
+  bool done;
+  unsigned left = mask + 1u;
+#pragma unroll 1
+  do {
+    const unsigned v = atomicCAS(&tab[h], 0u, fresh);
+    const bool hit = (v >> count_bits) == key;
+    if (hit) atomicAdd(&tab[h], 1u);
+    mine = v == 0u ? h : mine;
+    done = hit || v == 0u;
+    h = (h + 1u) & mask;
+    --left;
+  } while (!done && left != 0u);
+  *ok = done;
+  return mine;
+}
+// rank_by_counting with the elements dealt out to R replicas of the candidates: this lane counts elements first, first + R, ... of
+// keys / cols [0, n_pad) -- n_pad a multiple of R (wave-uniform), the padding filled with (key 0, column 0xffffffff), which sorts before
+// nothing -- and the caller adds the replicas' counts.  R compile-time: the element offsets are immediates of the LDS reads.
+template <int R>
+__device__ __forceinline__ unsigned rank_by_counting_strided(const unsigned long long* keys, const unsigned* cols, unsigned first, unsigned n_pad_uniform,
+                                                             unsigned long long mk, unsigned mc) {
+  const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)n_pad_uniform);
+  const unsigned long long* kp = keys + first;
+  const unsigned* cp = cols + first;
+  unsigned r0 = 0, r1 = 0, r2 = 0, r3 = 0, u = 0;  // four chains
+  for (; u + 4 * R <= n; u += 4 * R) {
+    count_if_before(r0, kp[u], cp[u], mk, mc);
+    count_if_before(r1, kp[u + R], cp[u + R], mk, mc);
+    count_if_before(r2, kp[u + 2 * R], cp[u + 2 * R], mk, mc);
+    count_if_before(r3, kp[u + 3 * R], cp[u + 3 * R], mk, mc);
+  }
+  for (; u < n; u += R) count_if_before(r0, kp[u], cp[u], mk, mc);
+  return (r0 + r1) + (r2 + r3);
+}
+
 // "This prefetched register is needed now": an empty asm that reads it makes the compiler place the wait for its load HERE -- ahead
 // of the stores that follow -- instead of at its first use in the next row, where the wait would also cover every store issued in
 // between (the memory counter retires in order) and so expose the write latency of the row's output at the top of the next row.
+// "Recompute what derives from this where it is used": an empty asm that redefines a loop-invariant value inside the loop keeps the compiler
+// from hoisting everything computed from it (per-lane LDS addresses of paths only some rows take) into registers that then live -- or spill
+// to scratch, and a scratch reload is a memory load the in-order counter waits on -- across the whole row loop.
+#ifdef HIPSIM_HOST_BUILD
+#define URCCO_OPAQUE(x) ((void)(x))
+#else
+#define URCCO_OPAQUE(x) asm volatile("" : "+v"(x))
+#endif
 #ifdef HIPSIM_HOST_BUILD
 #define URCCO_SETTLE(x) ((void)(x))
 #else
@@ -2218,6 +2292,31 @@ __device__ __forceinline__ unsigned wave_inclusive_sum(unsigned v) {
   x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
   x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
   return (unsigned)x;
+}
+// Inclusive prefix MAXIMUM over the 64 lanes (same ladder as wave_inclusive_sum; identity 0).  Every lane must be active.
+__device__ __forceinline__ unsigned wave_inclusive_max(unsigned v) {
+  int x = (int)v;
+  int y;
+  y = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+  x = (unsigned)y > (unsigned)x ? y : x;
+  y = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+  x = (unsigned)y > (unsigned)x ? y : x;
+  y = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+  x = (unsigned)y > (unsigned)x ? y : x;
+  y = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+  x = (unsigned)y > (unsigned)x ? y : x;
+  y = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  x = (unsigned)y > (unsigned)x ? y : x;
+  y = __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  x = (unsigned)y > (unsigned)x ? y : x;
+  return (unsigned)x;
+}
+// value of lane src (per-lane src in [0, 64)): one ds_bpermute, no LDS memory.  Every lane must be active.
+__device__ __forceinline__ unsigned wave_gather(unsigned v, unsigned src) { return (unsigned)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)v); }
+__device__ __forceinline__ int64_t wave_gather64(int64_t v, unsigned src) {
+  const unsigned lo = wave_gather((unsigned)(unsigned long long)v, src);
+  const unsigned hi = wave_gather((unsigned)((unsigned long long)v >> 32), src);
+  return (int64_t)(((unsigned long long)hi << 32) | (unsigned long long)lo);
 }
 // A value every lane of the wave agrees on, moved to a scalar register.  The compiler cannot tell that threadIdx.x / T, or
 // anything loaded through it (the row id, its CSC bounds, the chunk's work bounds, counts read back from LDS), is uniform, and
@@ -2621,6 +2720,14 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             cbj[x] = (dbg & 512) ? 100 : (use16 ? (int)cnt_b16[j] : cnt_b[j]);  // the ONE scattered gather per candidate (ablation 512: none)
           }
         }
+        // every operand of these U candidates of every lane inside the tables: the wave takes the straight-line table form (see llr_from_tables)
+        bool in_tables = true;
+        if (URCCO_LLR_WAVE_FAST_ROWS) {
+#pragma unroll
+          for (int x = 0; x < U; ++x)
+            if (vv[x] != 0u) in_tables = in_tables && llr_operands_in_tables(vv[x] & cmask, ca, (unsigned)cbj[x], n_users, col_ent);
+        }
+        const bool all_in_tables = URCCO_LLR_WAVE_FAST_ROWS && !(dbg & 2) && __ballot(!in_tables) == 0ull;  // wave-uniform
 #pragma unroll
         for (int x = 0; x < U; ++x) {
           const unsigned t = t0 + (unsigned)x * T;
@@ -2629,8 +2736,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             const long long k11 = (long long)(vv[x] & cmask);
             unsigned long long key = 0ull;
             if (!(a.exclude_self && j == i)) {
-              const double llr = (dbg & 2) ? (double)k11
-                                               : llr_of<URCCO_LLR_FAST_ROWS != 0>(row_entropy, xlx_n, k11, ca, (long long)cbj[x], n_users, xlx_tab, xlx_hi, col_ent);
+              const double llr = all_in_tables ? llr_from_tables(row_entropy, xlx_n, (unsigned)k11, (unsigned)ca, (unsigned)cbj[x], xlx_tab, xlx_hi, col_ent)
+                                               : ((dbg & 2) ? (double)k11
+                                                            : llr_of<URCCO_LLR_FAST_ROWS != 0>(row_entropy, xlx_n, k11, ca, (long long)cbj[x], n_users, xlx_tab, xlx_hi, col_ent));
               if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
             }
             kk[t] = key;
@@ -2723,7 +2831,11 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
           p0 = kdiff == 0ull ? 8 : (__clzll((long long)kdiff) >> 3);
           thr_key = p0 == 0 ? 0ull : (kor & ~(p0 >= 8 ? 0ull : (~0ull >> (8 * p0))));
         }
-        for (int b = tl; b < NH * 128; b += T) hist[b] = 0u;
+        {
+          int tz = tl;
+          URCCO_OPAQUE(tz);  // (the address is formed here: hoisted out of the row loop it was the one register the one-wave class spilled to scratch)
+          for (int b = tz; b < NH * 128; b += T) hist[b] = 0u;
+        }
         if (tl == 0) { sel_res[0] = 0u; sel_res[1] = 0u; }  // list length, ambiguous-set length
         team_sync<T>();
         const int first_col_pass = 8 + (3 - (a.col_bytes - 1));  // column digits above the highest used byte are constant: skip
@@ -2975,6 +3087,20 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
 // Team LDS layout (words): [0,256) accumulator, [256,320) packed candidates, [320,448) their 64-bit keys.
 // --------------------------------------------------------------------------------------------
 constexpr int MICRO_WORDS = 448;
+constexpr int MICRO2_WORDS = 528;
+// Round 5, second form of the row body (URCCO_MICRO_V2): the class is bound by vector-instruction issue (~350 per row, 76 % of the issue
+// slots of config 4's launches), so the row body was rebuilt around instruction count:
+//  * a pair finds its user by a mark + prefix maximum (one LDS atomic, one LDS read, six DPP steps, two lane gathers) instead of a
+//    seven-step binary search over LDS;
+//  * the lane whose insert CLAIMS a column owns the candidate: it reads the finished count from its own slot, clears the slot (the
+//    accumulator is zero between rows without a zeroing pass) and scores it -- no compaction sweep over the 256 slots;
+//  * rows of <= 32 (<= 16) candidates are ranked by two (four) replicas of the candidates that each count every second (fourth) element.
+#ifndef URCCO_MICRO_V2
+#define URCCO_MICRO_V2 1
+#endif
+#ifndef URCCO_MICRO_REPLICAS
+#define URCCO_MICRO_REPLICAS 1  // 0: every row ranked by one replica (A/B knob)
+#endif
 
 #ifndef URCCO_OCC_MICRO
 #define URCCO_OCC_MICRO 8  // blocks of four one-wave teams per CU the micro class is compiled for (A/B knob)
@@ -3015,6 +3141,17 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
   long long n_users = a.n_users;
 #endif
   constexpr int TEAMS = 256 / WAVE;
+#if URCCO_MICRO_V2
+  // Team LDS layout (words): [0,256) accumulator (zero between rows), [256,324) candidate columns, [324,460) their 64-bit keys (both with
+  // room for three padding elements), [460,526) the pair -> user marks.
+  __shared__ __attribute__((aligned(16))) unsigned s_tab[TEAMS * MICRO2_WORDS];
+  const int team = threadIdx.x / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1);
+  unsigned* tab = s_tab + team * MICRO2_WORDS;
+  unsigned* cand = tab + 256;
+  unsigned long long* kkm = reinterpret_cast<unsigned long long*>(tab + 324);
+  unsigned* marks = tab + 460;
+#else
   __shared__ unsigned s_tab[TEAMS * MICRO_WORDS];
   __shared__ long long s_ustart[TEAMS * WAVE];
   __shared__ unsigned s_uoff[TEAMS * (WAVE + 1)];
@@ -3027,6 +3164,7 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
   unsigned long long* kkm = reinterpret_cast<unsigned long long*>(tab + 320);
   long long* ustart = s_ustart + team * WAVE;
   unsigned* uoff = s_uoff + team * (WAVE + 1);
+#endif
   const int list_start = a.bin_off[0];
   const int list_n = a.bin_off[1] - list_start;
   const int total_teams = gridDim.x * TEAMS;
@@ -3035,7 +3173,9 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
   const unsigned cmask = (1u << cb) - 1u;
   const double xlx_n = *a.xlx_n;
   const bool use16 = *a.cnt16_bad == 0;
+#if !URCCO_MICRO_V2
   const unsigned long long lt = (1ull << lane) - 1ull;
+#endif
   unsigned long long cand_acc = 0ull;  // candidates scored by this wave (statistics)
 
   int li = blockIdx.x * TEAMS + team;
@@ -3077,6 +3217,10 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
   // for everything in flight on every pass)
   URCCO_SETTLE(pf_w1); URCCO_SETTLE(pf_wp); URCCO_SETTLE(pf_start); URCCO_SETTLE(pf_ca); URCCO_SETTLE(pf_ent);
   URCCO_SETTLE(cs1); URCCO_SETTLE(ce1); URCCO_SETTLE(i_n2);
+#if URCCO_MICRO_V2
+#pragma unroll
+  for (int q = 0; q < 4; ++q) tab[lane + q * WAVE] = 0u;  // the accumulator: zero between rows (a candidate's owner clears its slot)
+#endif
   for (; li < list_n; li += stride) {  // each wave runs its own row loop: wave-level sync only
     const int i = i_cur;
     // this row's operands leave their registers ...
@@ -3099,6 +3243,127 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
       pf_ca = cnt_a[i_n1];
       pf_ent = ent_a[i_n1];
     }
+#if URCCO_MICRO_V2
+    // ---- pair -> user: user u marks the first pair of its B' row with u (the LAST user of an offset is the one whose row is not
+    // empty); a pair's user is the largest mark at or below it
+    marks[lane] = 0u;
+    wave_sync();
+    if (owns_user) atomicMax(&marks[my_off], (unsigned)lane);  // my_off <= total <= 64: marks has 66 words
+    wave_sync();
+    const unsigned o = wave_inclusive_max(marks[lane]);
+    const int64_t base_o = wave_gather64(my_start - (int64_t)my_off, o);  // B' position of pair p of user o: base + p
+    // ---- insert; the claiming lane owns the candidate
+    unsigned slot = 0xffffffffu;
+    if ((unsigned)lane < total) {
+      const unsigned jj = (unsigned)b_col_idx[base_o + lane];
+      if (!(dbg & 1)) {
+        bool ok;
+        slot = tab_insert_claim(tab, jj + 1u, cb, 255u, 24, ident, &ok);
+        if (!ok) atomicAdd(a.err, 1ull);
+      }
+    }
+    wave_sync();
+    const bool is_cand = slot != 0xffffffffu;
+    const unsigned long long cand_mask = __ballot(is_cand);
+    const unsigned D = (unsigned)__popcll(cand_mask);
+    cand_acc += D;
+    unsigned long long mk = 0ull;
+    unsigned vv = 0u, cb_raw = 0u;
+    if (is_cand) {  // the finished count leaves the accumulator, the slot is zero again, and the count gather is issued (ONE 4-byte load whichever
+                    // width the counts have; nothing reads it before the block below)
+      vv = tab[slot];
+      tab[slot] = 0u;
+      const int j = (int)(vv >> cb) - 1;
+      cb_raw = cnt_words[use16 ? j >> 1 : j];
+    }
+    if (lane < 3) {  // padding of the ranking loop's element list: sorts before nothing
+      kkm[D + (unsigned)lane] = 0ull;
+      cand[D + (unsigned)lane] = 0xffffffffu;
+    }
+    bool in_tables = true;
+    if (is_cand) {
+      const int j = (int)(vv >> cb) - 1;
+      const long long k11 = (long long)(vv & cmask);
+      const unsigned cbj = (dbg & 512) ? 100u : (use16 ? ((j & 1) ? cb_raw >> 16 : cb_raw & 0xffffu) : cb_raw);
+      in_tables = llr_operands_in_tables((unsigned)k11, ca, cbj, n_users, col_ent);
+    }
+    // Every operand of every candidate inside the tables (always, once the interaction cut has capped the counts): the wave takes the
+    // straight-line form -- five table reads in flight together, no logarithm behind a divergent branch.  Wave-uniform test.
+    const bool all_in_tables = URCCO_LLR_WAVE_FAST && !(dbg & 2) && __ballot(is_cand && !in_tables) == 0ull;
+    if (is_cand) {
+      const int j = (int)(vv >> cb) - 1;
+      const long long k11 = (long long)(vv & cmask);
+      if (!(a.exclude_self && j == i)) {
+        const unsigned cbj = (dbg & 512) ? 100u : (use16 ? ((j & 1) ? cb_raw >> 16 : cb_raw & 0xffffu) : cb_raw);
+        const double llr = all_in_tables ? llr_from_tables(row_entropy, xlx_n, (unsigned)k11, (unsigned)ca, cbj, xlx_tab, xlx_hi, col_ent)
+                                         : ((dbg & 2) ? (double)k11
+                                                      : llr_of<URCCO_LLR_FAST_MICRO != 0>(row_entropy, xlx_n, k11, ca, (long long)cbj, n_users, xlx_tab, xlx_hi, col_ent));
+        if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) mk = (unsigned long long)__double_as_longlong(llr);
+      }
+      const unsigned pos = lanes_below(cand_mask);
+      kkm[pos] = mk;
+      cand[pos] = (unsigned)j;
+    }
+    wave_sync();
+    const unsigned long long valid_mask = __ballot(mk != 0ull);
+    const int n_valid = __popcll(valid_mask);
+    auto settle_prefetch = [&]() {  // the next row's operands have had the score phase to arrive: collect them before the output stores
+      URCCO_SETTLE(pf_w1); URCCO_SETTLE(pf_wp); URCCO_SETTLE(pf_start); URCCO_SETTLE(pf_ca); URCCO_SETTLE(pf_ent);
+      URCCO_SETTLE(cs2); URCCO_SETTLE(ce2); URCCO_SETTLE(i_n3);
+    };
+    if (a.unordered && n_valid <= a.k && !(dbg & 4)) {  // every candidate is emitted: no ranking needed (wave-uniform)
+      const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
+      settle_prefetch();
+      if (mk != 0ull) {
+        const unsigned opos = lanes_below(valid_mask);
+        out_idx[obase + opos] = (int)(vv >> cb) - 1;
+        out_llr[obase + opos] = __longlong_as_double((long long)mk);
+      }
+      if (lane == 0) out_count[i - a.item_lo] = n_valid;
+    } else if (!(dbg & 4)) {
+      const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
+      // candidates dense by lane, replicated while they fit twice / four times into the wave: replica q counts elements q, q + R, ...
+      unsigned rank;
+      unsigned long long rk;
+      unsigned rc;
+      unsigned ln = (unsigned)lane;
+      URCCO_OPAQUE(ln);  // the per-lane LDS addresses of the three forms are computed here, not kept across the row loop
+      if (URCCO_MICRO_REPLICAS && D <= 16u) {  // wave-uniform
+        const unsigned c = ln & 15u;
+        rk = kkm[c];
+        rc = cand[c];
+        rank = rank_by_counting_strided<4>(kkm, cand, ln >> 4, (D + 3u) & ~3u, rk, rc);
+        rank += (unsigned)__shfl_xor((int)rank, 16);
+        rank += (unsigned)__shfl_xor((int)rank, 32);
+      } else if (URCCO_MICRO_REPLICAS && D <= 32u) {
+        const unsigned c = ln & 31u;
+        rk = kkm[c];
+        rc = cand[c];
+        rank = rank_by_counting_strided<2>(kkm, cand, ln >> 5, (D + 1u) & ~1u, rk, rc);
+        rank += (unsigned)__shfl_xor((int)rank, 32);
+      } else {
+        rk = kkm[ln];
+        rc = cand[ln];
+        rank = rank_by_counting_strided<1>(kkm, cand, 0u, D, rk, rc);
+      }
+      // the row is put in order in LDS (every lane has its element in registers: in place) and leaves as contiguous stores
+      wave_sync();
+      const unsigned n_out = (unsigned)(n_valid < a.k ? n_valid : a.k);
+      if ((unsigned)lane < D && rk != 0ull && rank < n_out) {
+        cand[rank] = rc;
+        kkm[rank] = rk;
+      }
+      wave_sync();
+      settle_prefetch();
+      if ((unsigned)lane < n_out) {
+        out_idx[obase + lane] = (int)cand[lane];
+        out_llr[obase + lane] = __longlong_as_double((long long)kkm[lane]);
+      }
+      if (lane == 0) out_count[i - a.item_lo] = (int)n_out;
+    } else {
+      settle_prefetch();
+    }
+#else
 #pragma unroll
     for (int q = 0; q < 4; ++q) tab[lane + q * WAVE] = 0u;
     ustart[lane] = my_start;
@@ -3190,6 +3455,7 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
     } else {
       settle_prefetch();
     }
+#endif
     i_cur = i_n1;
     i_n1 = i_n2;
     i_n2 = i_n3;
