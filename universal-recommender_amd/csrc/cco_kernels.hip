@@ -2318,6 +2318,27 @@ __device__ __forceinline__ int64_t wave_gather64(int64_t v, unsigned src) {
   const unsigned hi = wave_gather((unsigned)((unsigned long long)v >> 32), src);
   return (int64_t)(((unsigned long long)hi << 32) | (unsigned long long)lo);
 }
+// OR over the 64 lanes of a wave, in the VALU (the inclusive ladder of wave_inclusive_sum; lane 63 ends up with everything), returned as a
+// wave-uniform value.  Every lane must be active.  (The butterfly of __shfl_xor it replaces was 6 x 2 ds_bpermute per 64-bit word.)
+__device__ __forceinline__ unsigned wave_or(unsigned v) {
+  int x = (int)v;
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
+  return (unsigned)__builtin_amdgcn_readlane(x, WAVE - 1);
+}
+// AND / OR of a 64-bit value over the wave (AND as the complement of the OR of the complements), wave-uniform results
+__device__ __forceinline__ void wave_and_or_u64(unsigned long long& kand, unsigned long long& kor) {
+  const unsigned nal = wave_or(~(unsigned)kand);
+  const unsigned nah = wave_or(~(unsigned)(kand >> 32));
+  const unsigned orl = wave_or((unsigned)kor);
+  const unsigned orh = wave_or((unsigned)(kor >> 32));
+  kand = ~(((unsigned long long)nah << 32) | (unsigned long long)nal);
+  kor = ((unsigned long long)orh << 32) | (unsigned long long)orl;
+}
 // A value every lane of the wave agrees on, moved to a scalar register.  The compiler cannot tell that threadIdx.x / T, or
 // anything loaded through it (the row id, its CSC bounds, the chunk's work bounds, counts read back from LDS), is uniform, and
 // keeps all arithmetic, addressing and loop control that derives from it in the vector unit -- where every instruction costs a
@@ -2342,6 +2363,25 @@ __device__ __forceinline__ unsigned lanes_below(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 
+// List positions for the lanes that `want` one: the wave's lanes are numbered by a ballot and the wave takes its block of the team's list
+// with ONE LDS atomic (T > 64) or none at all (T == 64: the list is the wave's own and its length lives in `wave_count`).  Sixty-four
+// lanes each adding 1 to the same LDS word are sixty-four serialised atomics -- on the LDS pipe every wave of the CU shares.
+// Wave-uniform control flow only; the positions of one call are consecutive in lane order.
+template <int T>
+__device__ __forceinline__ unsigned claim_positions(bool want, unsigned* counter, unsigned& wave_count) {
+  const unsigned long long m = __ballot(want);
+  const unsigned c = (unsigned)__popcll(m);
+  unsigned base;
+  if (T == WAVE) {
+    base = wave_count;
+    wave_count += c;
+  } else {
+    unsigned b = 0u;
+    if ((threadIdx.x & (WAVE - 1)) == 0 && c != 0u) b = atomicAdd(counter, c);
+    base = wave_read_lane(b, 0);
+  }
+  return base + lanes_below(m);
+}
 // exclusive scan of one unsigned per thread across a team of T threads; *total = team sum.  Every thread must call.
 template <int T>
 __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_wsum /*[T / WAVE]*/, unsigned* total) {
@@ -2757,11 +2797,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
     URCCO_SETTLE(idv); URCCO_SETTLE(bnd_c);
     if (!MP) { URCCO_SETTLE(pf_w0); URCCO_SETTLE(pf_w1); URCCO_SETTLE(pf_wp); URCCO_SETTLE(pf_start); }
     if (SKIP_SHARED) {
-#pragma unroll
-      for (int msk = 1; msk < WAVE; msk <<= 1) {
-        kand &= shfl_xor_u64(kand, msk);
-        kor |= shfl_xor_u64(kor, msk);
-      }
+      wave_and_or_u64(kand, kor);
       if (lane == 0) {  // published by the barriers inside the scan below
         s_kbits[2 * (tl / WAVE)] = kand;
         s_kbits[2 * (tl / WAVE) + 1] = kor;
@@ -2806,11 +2842,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
               kor |= key;
             }
           }
-#pragma unroll
-          for (int msk = 1; msk < WAVE; msk <<= 1) {
-            kand &= shfl_xor_u64(kand, msk);
-            kor |= shfl_xor_u64(kor, msk);
-          }
+          wave_and_or_u64(kand, kor);
           if (T != WAVE) {
             if (lane == 0) {
               s_kbits[2 * (tl / WAVE)] = kand;
@@ -2852,25 +2884,29 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
           const bool build = SEL_CAP > 0 && !have_list && !first_pass && prev_cnt <= (unsigned)SEL_CAP;  // this sweep also records the survivors
           const unsigned n_scan = have_list ? list_n : D;
           const int shk = p < 8 ? 56 - 8 * p : 0, shc = p < 8 ? 0 : 24 - 8 * (p - 8);
-          for (unsigned base = 0; base < n_scan; base += T) {  // scalar loop control
+          unsigned lst_n = 0u;  // (unused: only teams of several waves build a list)
+          for (unsigned base = 0; base < n_scan; base += T) {  // scalar loop control, no divergent exits (claim_positions is a wave operation)
             const unsigned idx = base + (unsigned)tl;
-            if (idx >= n_scan) continue;
-            const unsigned t = have_list ? (unsigned)lst[idx] : idx;
-            const unsigned long long key = kk[t];
-            if (key == 0ull) continue;
-            bool match;
-            unsigned dig;
-            if (p < 8) {
-              match = first_pass || (key >> (shk + 8)) == (thr_key >> (shk + 8));
-              dig = (unsigned)(key >> shk) & 255u;
-            } else {
-              const unsigned ncol = ~(unsigned)((int)(tab[t] >> cb) - 1);
-              match = key == thr_key && (p == first_col_pass || (ncol >> (shc + 8)) == (thr_ncol >> (shc + 8)));
-              dig = (ncol >> shc) & 255u;
+            bool match = false;
+            unsigned dig = 0u, t = 0u;
+            if (idx < n_scan) {
+              t = have_list ? (unsigned)lst[idx] : idx;
+              const unsigned long long key = kk[t];
+              if (key != 0ull) {
+                if (p < 8) {
+                  match = first_pass || (key >> (shk + 8)) == (thr_key >> (shk + 8));
+                  dig = (unsigned)(key >> shk) & 255u;
+                } else {
+                  const unsigned ncol = ~(unsigned)((int)(tab[t] >> cb) - 1);
+                  match = key == thr_key && (p == first_col_pass || (ncol >> (shc + 8)) == (thr_ncol >> (shc + 8)));
+                  dig = (ncol >> shc) & 255u;
+                }
+              }
             }
-            if (match) {
-              atomicAdd(&H[dig >> 1], 1u << (16 * (dig & 1u)));  // counts < 2^16: D is bounded by the table size
-              if (build) lst[atomicAdd(&sel_res[0], 1u)] = (unsigned short)t;
+            if (match) atomicAdd(&H[dig >> 1], 1u << (16 * (dig & 1u)));  // counts < 2^16: D is bounded by the table size
+            if (build) {  // team-uniform
+              const unsigned pos = claim_positions<T>(match, &sel_res[0], lst_n);
+              if (match) lst[pos] = (unsigned short)t;
             }
           }
           team_sync<T>();
@@ -2934,23 +2970,27 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             // team-uniform, so every wave takes the barrier.  (debug 262144 skips it: the regression test's negative control.)
             if (SHARE && T != WAVE && !(dbg & 262144)) team_sync<T>();
             const unsigned n_scan2 = have_list ? list_n : D;
-            for (unsigned base = 0; base < n_scan2; base += T) {
+            unsigned amb_n = 0u;  // (one-wave teams: the length of the set)
+            for (unsigned base = 0; base < n_scan2; base += T) {  // scalar loop control, no divergent exits: claim_positions is a wave operation
               const unsigned idx = base + (unsigned)tl;
-              if (idx >= n_scan2) continue;
-              const unsigned t = have_list ? (unsigned)lst[idx] : idx;
-              const unsigned long long key = kk[t];
-              if (key == 0ull) continue;
-              const unsigned col = (unsigned)((int)(tab[t] >> cb) - 1);
-              const bool match = p < 8 ? (key >> shk) == (thr_key >> shk) : (key == thr_key && (~col >> shc) == (thr_ncol >> shc));
+              unsigned long long key = 0ull;
+              unsigned col = 0u;
+              bool match = false;
+              if (idx < n_scan2) {
+                const unsigned t = have_list ? (unsigned)lst[idx] : idx;
+                key = kk[t];
+                col = (unsigned)((int)(tab[t] >> cb) - 1);
+                match = key != 0ull && (p < 8 ? (key >> shk) == (thr_key >> shk) : (key == thr_key && (~col >> shc) == (thr_ncol >> shc)));
+              }
+              const unsigned pos = claim_positions<T>(match, &sel_res[1], amb_n);
               if (match) {
-                const unsigned pos = atomicAdd(&sel_res[1], 1u);
                 amb_key[pos] = key;
                 amb_col[pos] = col;
               }
             }
             team_sync<T>();
             // ... and rank them by counting; the need-th best composite is the exact threshold
-            const unsigned m = uni(sel_res[1]);
+            const unsigned m = T == WAVE ? amb_n : uni(sel_res[1]);
             for (unsigned base = 0; base < m; base += T) {
               const unsigned x = base + (unsigned)tl;
               if (x >= m) continue;
@@ -2977,37 +3017,45 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
         // URCCO_FLAG_UNORDERED_ROWS: the top-k SET of the row, in whatever order the lanes claim output slots -- what
         // Mahout's computeSimilarities returns (a sparse vector has no score order; the reference sorts later, in
         // toStringMapRDD, package.scala:102).  No ranking pass.
-        for (unsigned base = 0; base < D; base += T) {
+        unsigned out_n = 0u;  // (one-wave teams: entries written)
+        for (unsigned base = 0; base < D; base += T) {  // scalar loop control, no divergent exits
           const unsigned t = base + (unsigned)tl;
-          if (t >= D) continue;
-          const unsigned long long key = kk[t];
-          if (key == 0ull) continue;
-          const unsigned col = (unsigned)((int)(tab[t] >> cb) - 1);
-          if (key > thr_key || (key == thr_key && ~col >= thr_ncol)) {
-            const unsigned pos = atomicAdd(nsel, 1u);
+          unsigned long long key = 0ull;
+          unsigned col = 0u;
+          if (t < D) {
+            key = kk[t];
+            col = (unsigned)((int)(tab[t] >> cb) - 1);
+          }
+          const bool sel = key != 0ull && (key > thr_key || (key == thr_key && ~col >= thr_ncol));
+          const unsigned pos = claim_positions<T>(sel, nsel, out_n);
+          if (sel) {
             out_idx[obase + pos] = (int)col;
             out_llr[obase + pos] = __longlong_as_double((long long)key);
           }
         }
         team_sync<T>();
-        if (tl == 0) a.out_count[i - a.item_lo] = (int)*nsel;
+        if (tl == 0) a.out_count[i - a.item_lo] = (int)(T == WAVE ? out_n : *nsel);
         team_sync<T>();
         continue;
       }
-      for (unsigned base = 0; base < D; base += T) {
+      unsigned sel_n = 0u;  // (one-wave teams: survivors so far)
+      for (unsigned base = 0; base < D; base += T) {  // scalar loop control, no divergent exits
         const unsigned t = base + (unsigned)tl;
-        if (t >= D) continue;
-        const unsigned long long key = kk[t];
-        if (key == 0ull) continue;
-        const unsigned col = (unsigned)((int)(tab[t] >> cb) - 1);
-        if (key > thr_key || (key == thr_key && ~col >= thr_ncol)) {
-          const unsigned pos = atomicAdd(nsel, 1u);
+        unsigned long long key = 0ull;
+        unsigned col = 0u;
+        if (t < D) {
+          key = kk[t];
+          col = (unsigned)((int)(tab[t] >> cb) - 1);
+        }
+        const bool sel = key != 0ull && (key > thr_key || (key == thr_key && ~col >= thr_ncol));
+        const unsigned pos = claim_positions<T>(sel, nsel, sel_n);
+        if (sel) {
           selk[pos] = key;
           selc[pos] = MP ? ((col << mp_s) | mp_q) : col;  // MP: the pass cut by the column inside the pass, the merge cuts by the full column
         }
       }
       team_sync<T>();
-      const unsigned n = (dbg & 16) ? 0u : uni(*nsel);  // ablation 16: no ranking / output
+      const unsigned n = (dbg & 16) ? 0u : (T == WAVE ? sel_n : uni(*nsel));  // ablation 16: no ranking / output
       if (MP) {
         // merge the pass's <= k survivors into the running top k: every element of both lists is ranked over both (by counting),
         // the best k land in the other running buffer at their rank -- which is the output order
