@@ -2427,7 +2427,7 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 #define URCCO_OCC_WAVE 8  // blocks of four one-wave teams per CU the one-wave class is compiled for
 #endif
 #ifndef URCCO_G_WAVE
-#define URCCO_G_WAVE 1
+#define URCCO_G_WAVE 2
 #endif
 #ifndef URCCO_SEL_AMB_WAVE
 #define URCCO_SEL_AMB_WAVE 64
@@ -2437,6 +2437,9 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 #endif
 #ifndef URCCO_G_BLOCK
 #define URCCO_G_BLOCK 1
+#endif
+#ifndef URCCO_SKIP_SHARED_WAVE
+#define URCCO_SKIP_SHARED_WAVE 0  // 1: the one-wave class tracks the shared key bytes while it scores (A/B knob)
 #endif
 #ifndef URCCO_SWEEP_SHARED
 #define URCCO_SWEEP_SHARED 1  // classes other than the 256-thread ones find the key bytes all candidates share with a sweep before the select
@@ -2511,7 +2514,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   // exponent bits: typically the whole first pass).  Measured on config 3: -7..9 % for the 256-thread classes, but the
   // extra live registers cost the one-wave class +4 % (spills at its 80-VGPR cap) and the 512/1024-thread classes
   // +0..4 %, so only T == 256 tracks the shared bytes.
-  constexpr bool SKIP_SHARED = T == 256;
+  constexpr bool SKIP_SHARED = T == 256 || (T == WAVE && URCCO_SKIP_SHARED_WAVE != 0);
   __shared__ unsigned long long s_kbits[2 * NW];  // per wave: AND / OR over its valid keys
   __shared__ unsigned s_mpflag;                    // MP: a pass overflowed its table
   __shared__ unsigned long long s_runk[MP ? 2 * MP_KMAX : 1];  // MP: the row's running top k (two buffers: a merge reads one, writes the other)
