@@ -2438,6 +2438,9 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 #ifndef URCCO_G_BLOCK
 #define URCCO_G_BLOCK 1
 #endif
+#ifndef URCCO_MERGED_RANK
+#define URCCO_MERGED_RANK 1  // the cut bin and everything above it ranked ONCE (see the select's finish); 0: ambiguous set, then survivors
+#endif
 #ifndef URCCO_SKIP_SHARED_WAVE
 #define URCCO_SKIP_SHARED_WAVE 0  // 1: the one-wave class tracks the shared key bytes while it scores (A/B knob)
 #endif
@@ -2592,8 +2595,11 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
     const unsigned my_wp = pf_wp;
     const int64_t my_start = pf_start;
     // ... and the rows ahead take them
-    idv = a.bin_rows[pos_of(li + (1 + lane3) * S)];
-    bnd_c = a.a_col_ptr[id2 + (lane & 1)];
+    int lz = lane;
+    URCCO_OPAQUE(lz);  // (what derives from the lane here is recomputed per row: kept across the row loop it was spilled at 64 registers, and a scratch reload at
+                       // the top of a row is a wait for the prefetches just issued)
+    idv = a.bin_rows[pos_of(li + (1 + (lz < 3 ? lz : 2)) * S)];
+    bnd_c = a.a_col_ptr[id2 + (lz & 1)];
     if (!MP) {  // (the multi-pass rows re-read every chunk once per pass: no prefetched first chunk)
       const int64_t c1 = cs_n + T < ce_n ? cs_n + T : ce_n;
       const int64_t pl = cs_n + tl < c1 ? cs_n + tl : c1 - 1;
@@ -2817,6 +2823,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
     const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
     unsigned long long thr_key = 0ull;
     unsigned thr_ncol = 0u;
+    bool row_done = false;  // team-uniform: the select's finish has already written the row
     if (!(dbg & 4)) {
       if (dbg & 8) {  // ablation: no select (nothing passes)
         if (C > (unsigned)a.k) thr_key = ~0ull;
@@ -2972,7 +2979,12 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             // fault of profiles/r03_rocprofv3_stats_failure.txt; found by tools/race_hunt.py, profiles/r04_race_hunt.log).  prev_cnt is
             // team-uniform, so every wave takes the barrier.  (debug 262144 skips it: the regression test's negative control.)
             if (SHARE && T != WAVE && !(dbg & 262144)) team_sync<T>();
-            const unsigned n_scan2 = have_list ? list_n : D;
+            // Round 5: when the cut bin AND everything above it (k - need composites) fit the set, they are copied out together and ranked ONCE --
+            // the best k of that ranking ARE the row, in output order.  (Before: the bin's members ranked among themselves for the exact threshold,
+            // a sweep for the survivors, the survivors ranked again: two sweeps and two rankings, at four vector instructions per compared element,
+            // in classes that are bound by vector issue.)  The sweep then covers every candidate: what lies above the bin is not in the index list.
+            const bool merged = URCCO_MERGED_RANK != 0 && !MP && !a.unordered && !(dbg & 16) && ((unsigned)a.k - need) + prev_cnt <= (unsigned)SEL_M;  // team-uniform
+            const unsigned n_scan2 = (have_list && !merged) ? list_n : D;
             unsigned amb_n = 0u;  // (one-wave teams: the length of the set)
             for (unsigned base = 0; base < n_scan2; base += T) {  // scalar loop control, no divergent exits: claim_positions is a wave operation
               const unsigned idx = base + (unsigned)tl;
@@ -2980,10 +2992,11 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
               unsigned col = 0u;
               bool match = false;
               if (idx < n_scan2) {
-                const unsigned t = have_list ? (unsigned)lst[idx] : idx;
+                const unsigned t = (have_list && !merged) ? (unsigned)lst[idx] : idx;
                 key = kk[t];
                 col = (unsigned)((int)(tab[t] >> cb) - 1);
-                match = key != 0ull && (p < 8 ? (key >> shk) == (thr_key >> shk) : (key == thr_key && (~col >> shc) == (thr_ncol >> shc)));
+                if (merged) match = key != 0ull && (p < 8 ? (key >> shk) >= (thr_key >> shk) : (key > thr_key || (key == thr_key && (~col >> shc) >= (thr_ncol >> shc))));
+                else match = key != 0ull && (p < 8 ? (key >> shk) == (thr_key >> shk) : (key == thr_key && (~col >> shc) == (thr_ncol >> shc)));
               }
               const unsigned pos = claim_positions<T>(match, &sel_res[1], amb_n);
               if (match) {
@@ -2994,6 +3007,33 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             team_sync<T>();
             // ... and rank them by counting; the need-th best composite is the exact threshold
             const unsigned m = T == WAVE ? amb_n : uni(sel_res[1]);
+            if (merged) {  // m = (k - need) + the bin's members >= k: ranks 0 .. k - 1 are the row
+              unsigned long long* selk = kk + D;                          // [k]: the row in output order (the survivors' arrays of the general path)
+              unsigned* selc = reinterpret_cast<unsigned*>(selk + a.k);  // [k]
+              for (unsigned base = 0; base < m; base += T) {
+                const unsigned x = base + (unsigned)tl;
+                if (x >= m) continue;
+                const unsigned long long mk = amb_key[x];
+                const int mc = (int)amb_col[x];
+                const unsigned rank = rank_by_counting(amb_key, m, mk, mc, [&](unsigned u) { return (int)amb_col[u]; });
+                if (rank < (unsigned)a.k) {
+                  selk[rank] = mk;
+                  selc[rank] = (unsigned)mc;
+                }
+              }
+              team_sync<T>();
+              unsigned tz = (unsigned)tl;
+              URCCO_OPAQUE(tz);  // (the stores' per-lane addresses are formed here, not kept -- spilled -- across the row loop)
+              for (unsigned t = tz; t < (unsigned)a.k; t += T) {
+                out_idx[obase + t] = (int)selc[t];
+                out_llr[obase + t] = __longlong_as_double((long long)selk[t]);
+              }
+              int kout = a.k;
+              URCCO_OPAQUE(kout);  // (likewise: the hoisted vector copy of k was spilled, and reloaded behind the row's stores)
+              if (tl == 0) a.out_count[i - a.item_lo] = kout;
+              row_done = true;
+              break;
+            }
             for (unsigned base = 0; base < m; base += T) {
               const unsigned x = base + (unsigned)tl;
               if (x >= m) continue;
@@ -3011,6 +3051,10 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             break;
           }
         }
+      }
+      if (row_done) {  // team-uniform
+        team_sync<T>();  // the table is re-zeroed by the next row
+        continue;
       }
       if (tl == 0) *nsel = 0u;
       team_sync<T>();
