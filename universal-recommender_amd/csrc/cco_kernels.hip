@@ -2438,6 +2438,12 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 #ifndef URCCO_G_BLOCK
 #define URCCO_G_BLOCK 1
 #endif
+#ifndef URCCO_SEL_M_BLOCK
+#define URCCO_SEL_M_BLOCK 128  // capacity of the ambiguous set of the teams of several waves (>= URCCO_SEL_AMB_BLOCK)
+#endif
+#ifndef URCCO_MERGE_WAITS
+#define URCCO_MERGE_WAITS 0  // 1: the select goes on until the cut bin and what lies above it fit the set together (A/B knob)
+#endif
 #ifndef URCCO_MERGED_RANK
 #define URCCO_MERGED_RANK 1  // the cut bin and everything above it ranked ONCE (see the select's finish); 0: ambiguous set, then survivors
 #endif
@@ -2495,7 +2501,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   // two words it has just read.
   constexpr int NH = T == WAVE ? 1 : 3;
   constexpr int SEL_CAP = T == WAVE ? 0 : (T == 256 ? 512 : 2048);  // explicit survivor list (16-bit indices); a wave sweeps its <= 341 candidates directly
-  constexpr int SEL_M = T == WAVE ? 64 : 128;                        // capacity of the ambiguous-set / staged-output arrays
+  constexpr int SEL_M = T == WAVE ? 64 : URCCO_SEL_M_BLOCK;          // capacity of the ambiguous-set / staged-output arrays
   constexpr int SEL_AMB = T == WAVE ? URCCO_SEL_AMB_WAVE : URCCO_SEL_AMB_BLOCK;  // the cut bin is ranked directly once it holds this many or fewer
   static_assert(SEL_AMB <= SEL_M, "ambiguous set capacity");
   constexpr bool SHARE = T == WAVE || (T == 256 && E == 4096);
@@ -2969,7 +2975,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             if (NH == 1) team_sync<T>();  // the histogram just cleared is the next pass's target
             ++q;
           }
-          if (prev_cnt <= (unsigned)SEL_AMB) {
+          if (prev_cnt <= (unsigned)SEL_AMB &&
+              (!URCCO_MERGE_WAITS || MP || a.unordered || (dbg & 16) || ((unsigned)a.k - need) + prev_cnt <= (unsigned)SEL_M || p == 11)) {  // team-uniform
             // finish: copy out the members of the cut bin (they match the prefix through digit p) ...
             // In the SHARE layout amb_key / amb_col OVERLAY the three rotating histograms.  Every wave has run the digit search above for
             // itself, at its own pace: a wave that arrives here first must not write the ambiguous set over histogram words a sibling has
