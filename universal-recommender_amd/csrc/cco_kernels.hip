@@ -1729,6 +1729,8 @@ hipError_t launch_expand_prepare(hipStream_t st, int n_cu, const int64_t* a_col_
 // a 40 MB table, fabric-bound).  The secondaries' row pointers are first interleaved per user (32 bits each) so that a CSC entry's single
 // gather -- 32 consecutive bytes for four secondaries -- serves every event type.
 // --------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) Words4 { unsigned a, b, c, d; };
+struct __attribute__((packed, aligned(4))) Words2 { unsigned a, b; };
 struct ExpandMultiArgs {
   const int64_t* b_rp[EXPAND_MULTI_MAX];
   int64_t* pstart[EXPAND_MULTI_MAX];
@@ -1766,9 +1768,18 @@ __global__ __launch_bounds__(256) void expand_prepare_multi_kernel(const int64_t
           const uint4 x = *reinterpret_cast<const uint4*>(t), y = *reinterpret_cast<const uint4*>(t + 4);
           v[q][0] = x.x; v[q][1] = x.y; v[q][2] = x.z; v[q][3] = x.w;
           v[q][4 % (2 * N)] = y.x; v[q][5 % (2 * N)] = y.y; v[q][6 % (2 * N)] = y.z; v[q][7 % (2 * N)] = y.w;
-        } else {
+        } else {  // 2 N consecutive words, 4-byte aligned: 16-byte loads while they last (global loads only need dword alignment), then 8, then 4
+          constexpr int W = 2 * N;
 #pragma unroll
-          for (int d = 0; d < 2 * N; ++d) v[q][d] = t[d];
+          for (int d = 0; d + 4 <= W; d += 4) {
+            const Words4 x = *reinterpret_cast<const Words4*>(t + d);
+            v[q][d] = x.a; v[q][(d + 1) % W] = x.b; v[q][(d + 2) % W] = x.c; v[q][(d + 3) % W] = x.d;
+          }
+          if (W % 4 >= 2) {
+            const Words2 x = *reinterpret_cast<const Words2*>(t + (W / 4) * 4);
+            v[q][(W / 4) * 4 % W] = x.a; v[q][((W / 4) * 4 + 1) % W] = x.b;
+          }
+          if (W % 2 == 1) v[q][W - 1] = t[W - 1];
         }
       } else {
 #pragma unroll

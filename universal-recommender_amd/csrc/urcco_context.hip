@@ -613,6 +613,12 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
   // landed at 63 ms, its chain was enqueued at 102 ms -- the fused pass saves 2 ms of GPU time and cost 40 ms of wall time).
   bool fuse = n_ds >= 3 && n_ds - 1 <= urcco::EXPAND_MULTI_MAX && !(c->debug & 4096) && gate == nullptr;
   for (int d = 1; d < n_ds; ++d) fuse = fuse && sh[(size_t)d].nnz < ((int64_t)1 << 32);
+  // Round 5: the PRIMARY's expand preparation rides on the same pass (A'A reads the down-sampled A as its B): its own pass was a second
+  // scattered gather per CSC entry of A' -- 0.95 ms on config 4 against 1.1 ms for the four secondaries together -- and the price is that
+  // A'A starts once every secondary has been sampled instead of right behind the transposition (URCCO_FOLD_PRIMARY=0: as before).
+  static const bool fold_env = [] { const char* e = getenv("URCCO_FOLD_PRIMARY"); return !(e && e[0] == '0'); }();
+  const bool fold = fuse && fold_env && n_ds <= urcco::EXPAND_MULTI_MAX && sh[0].nnz < ((int64_t)1 << 32);
+  const int f0 = fold ? 0 : 1;  // first event type of the fused pass
   std::vector<std::promise<int>> sampled((size_t)n_ds);
   std::vector<std::shared_future<int>> sampled_f((size_t)n_ds);
   for (int d = 0; d < n_ds; ++d) sampled_f[(size_t)d] = sampled[(size_t)d].get_future().share();
@@ -622,19 +628,19 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
   auto fused_expand = [&]() -> int {  // on the first secondary's stream; every secondary's ev_sampled and a_ready have been recorded
     EvState& L = D.ev[1];
     if (L.s != A.s) HIPC(hipStreamWaitEvent(L.s->stream, D.a_ready, 0));
-    std::vector<const int64_t*> rp((size_t)n_ds - 1);
-    std::vector<int64_t*> ps((size_t)n_ds - 1);
-    std::vector<int32_t*> pl((size_t)n_ds - 1);
-    for (int d = 1; d < n_ds; ++d) {
+    std::vector<const int64_t*> rp((size_t)(n_ds - f0));
+    std::vector<int64_t*> ps((size_t)(n_ds - f0));
+    std::vector<int32_t*> pl((size_t)(n_ds - f0));
+    for (int d = f0; d < n_ds; ++d) {
       EvState& E = D.ev[(size_t)d];
-      if (E.s != L.s) HIPC(hipStreamWaitEvent(L.s->stream, E.ev_sampled, 0));
+      if (d > 0 && E.s != L.s) HIPC(hipStreamWaitEvent(L.s->stream, E.ev_sampled, 0));  // (the primary: a_ready, above)
       URC(E.pre_pstart.ensure((size_t)a_cap + 1));
       URC(E.pre_plen.ensure((size_t)a_cap + 1));
-      rp[(size_t)d - 1] = E.s_rp.p;
-      ps[(size_t)d - 1] = E.pre_pstart.p;
-      pl[(size_t)d - 1] = E.pre_plen.p;
+      rp[(size_t)(d - f0)] = E.s_rp.p;
+      ps[(size_t)(d - f0)] = E.pre_pstart.p;
+      pl[(size_t)(d - f0)] = E.pre_plen.p;
     }
-    URC(expand_multi(L.s, n_ds - 1, D.a_cp[D.par].p, (int32_t)ps_[0].n_cols, D.a_ri[D.par].p, a_cap, rp.data(), n_users, ps.data(), pl.data()));
+    URC(expand_multi(L.s, n_ds - f0, D.a_cp[D.par].p, (int32_t)ps_[0].n_cols, D.a_ri[D.par].p, a_cap, rp.data(), n_users, ps.data(), pl.data()));
     HIPC(hipEventRecord(D.b_expanded, L.s->stream));
     return URCCO_OK;
   };
@@ -706,13 +712,19 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
   }();
   a_ok = st == URCCO_OK;
   a_recorded.set_value();  // also on failure: the workers must not wait forever
-  if (st == URCCO_OK) {
+  auto rows_primary = [&]() -> int {
     A.b_rp = A.s_rp.p;
     A.b_ci = A.s_ci.p;
     A.b_rows = sh[0].n_rows;
     A.b_nnz_bound = sh[0].nnz;
-    st = stage_rows(D, A, A, 0, ps_[0], ps_[0], n_users, sh[0].nnz);
+    if (fold && A.s != D.ev[1].s) HIPC(hipStreamWaitEvent(A.s->stream, D.b_expanded, 0));
+    URC(stage_rows(D, A, A, 0, ps_[0], ps_[0], n_users, sh[0].nnz, fold));
     if (gate && gate->trace) gate->trace->mark("chain enqueued", 0);
+    return URCCO_OK;
+  };
+  if (st == URCCO_OK && !(fold && !threaded)) {  // (folded and one enqueueing thread: behind the fused pass, below)
+    if (fold) st = expanded_f.get();  // the fused pass has been enqueued (its event recorded) by the first secondary's thread
+    if (st == URCCO_OK) st = rows_primary();
     if (st == URCCO_OK && threaded && gate && gate->after_chain) st = gate->after_chain(0);
   }
   for (std::thread& t : workers) t.join();
@@ -730,6 +742,7 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
     }
     for (int d : order) URC(sample_secondary(d));
     if (fuse) URC(fused_expand());
+    if (fold) URC(rows_primary());
     for (int d : order) URC(rows_secondary(d));
     if (gate && gate->after_chain) {
       URC(gate->after_chain(0));
