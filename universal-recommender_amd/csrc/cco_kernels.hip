@@ -2447,7 +2447,7 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 #define URCCO_SEL_AMB_BLOCK 128
 #endif
 #ifndef URCCO_G_BLOCK
-#define URCCO_G_BLOCK 1
+#define URCCO_G_BLOCK 2
 #endif
 #ifndef URCCO_SEL_M_BLOCK
 #define URCCO_SEL_M_BLOCK 128  // capacity of the ambiguous set of the teams of several waves (>= URCCO_SEL_AMB_BLOCK)
@@ -2465,7 +2465,7 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 #define URCCO_SWEEP_SHARED 1  // classes other than the 256-thread ones find the key bytes all candidates share with a sweep before the select
 #endif
 #ifndef URCCO_G_CU
-#define URCCO_G_CU 1
+#define URCCO_G_CU 2
 #endif
 // MP ("multi-pass", bin 6): rows no single LDS table can hold -- a hot item of a skewed catalogue pairs with tens of thousands
 // of distinct columns -- or whose counts overflow the packed field.  Such a row is accumulated in P = 2^s passes over its
