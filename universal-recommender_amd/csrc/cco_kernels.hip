@@ -2437,6 +2437,9 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 #ifndef URCCO_OCC_WAVE
 #define URCCO_OCC_WAVE 8  // blocks of four one-wave teams per CU the one-wave class is compiled for
 #endif
+#ifndef URCCO_OCC_BS
+#define URCCO_OCC_BS 7  // blocks per CU the 256-thread / 4Ki class is compiled for (8 = 64 registers: seven of them spill)
+#endif
 #ifndef URCCO_G_WAVE
 #define URCCO_G_WAVE 2
 #endif
@@ -2480,7 +2483,7 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 // per SIMD a wave has 78 scalar registers and the one-wave class spilled 128 of them to vector lanes (round 5: 69 after this and the
 // single-check LLR).
 template <int T, int E, int U, bool MP = false, bool DBG = false>
-__global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T == 256 && E == 4096 ? 7 : 1))) void cco_rows_kernel(CcoArgs a, int bin) {
+__global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T == 256 && E == 4096 ? URCCO_OCC_BS : 1))) void cco_rows_kernel(CcoArgs a, int bin) {
   const int dbg = DBG ? a.debug : 0;
   // the arguments the row loop's inner loops use, each in scalar registers of its own (URCCO_OWN_SGPRS)
   URCCO_OWN_GLOBAL_PTR(const int32_t, b_col_idx, a.b_col_idx);
