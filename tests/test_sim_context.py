@@ -312,14 +312,16 @@ def fused_expand_case(lib, device):
     from universal_recommender_amd import _lib
     from universal_recommender_amd.device import Context, DeviceSession, cross_occurrence_context, cross_occurrence_device
     rng = np.random.default_rng(47)
-    n_users = 1500
-    empty = O.Csr(n_users, 9, np.zeros(n_users + 1, np.int64), np.zeros(0, np.int32))
     sess = DeviceSession(device, lib)
     try:
-        for n_sec in (2, 5, 8, 9):
-            mats = [rand_csr(rng, n_users, 300, 5, zipf_s=1.1)] + [rand_csr(rng, n_users, 40 + 37 * d, 3 + d, empty_frac=0.1 * (d % 3)) for d in range(n_sec)]
+        # (the last shape: > 32768 CSC entries of A' -- the tiled scans, whose tile sums the fused pass leaves behind, over a partial last tile)
+        for n_users, n_sec in ((1500, 2), (1500, 5), (1500, 8), (1500, 9), (9000, 3)):
+            empty = O.Csr(n_users, 9, np.zeros(n_users + 1, np.int64), np.zeros(0, np.int32))
+            mats = [rand_csr(rng, n_users, 300, 5 if n_users < 9000 else 7, zipf_s=1.1)] + [rand_csr(rng, n_users, 40 + 37 * d, 3 + d, empty_frac=0.1 * (d % 3)) for d in range(n_sec)]
             if n_sec == 5:
                 mats[3] = empty
+            if n_users >= 9000:
+                assert mats[0].row_ptr[-1] > 40000
             ps = [P(30, 10)] + [P(25 + d, 6 + d, 0.1 if d == 1 else None) for d in range(n_sec)]
             ref = [r.to_host() for r in cross_occurrence_device(sess, [to_dev(m, device) for m in mats], to_params(ps), 5)]
             sess.synchronize()

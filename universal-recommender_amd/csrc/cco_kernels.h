@@ -158,8 +158,10 @@ hipError_t launch_expand_prepare(hipStream_t st, int n_cu, const int64_t* a_col_
 // the same for up to EXPAND_MULTI_MAX event types with ONE gather per CSC entry: T = scratch of n_rows_b * n * 8 bytes
 constexpr int EXPAND_MULTI_MAX = 8;
 hipError_t launch_expand_prepare_multi(hipStream_t st, int n_cu, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx, int n,
-                                       const int64_t* const* b_row_ptr, int64_t n_rows_b, int64_t cap, int64_t* const* pstart, int32_t* const* plen, void* T);
-hipError_t launch_expand_scan(hipStream_t st, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* plen, int64_t cap, int64_t* wp, int64_t* tile_sums);
+                                       const int64_t* const* b_row_ptr, int64_t n_rows_b, int64_t cap, int64_t* const* pstart, int32_t* const* plen, void* T,
+                                       int64_t* const* tsum /* nullable; tsum[d]: ceil(cap / 2048) + 2 words: the scan-tile sums of plen[d] */);
+hipError_t launch_expand_scan(hipStream_t st, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* plen, int64_t cap, int64_t* wp, int64_t* tile_sums,
+                              bool tile_sums_ready = false);
 hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr, const int64_t* wp, int64_t* work);
 
 // binning: tile_counts scratch [(ceil(n/BIN_TILE)+1) * BIN_COLS_HOST] int64;

@@ -346,14 +346,14 @@ __global__ __launch_bounds__(SB_THREADS) void scan_block_kernel(Load ld, int64_t
 }
 
 template <typename Load>
-static hipError_t launch_scan(hipStream_t st, Load ld, int64_t n, int64_t* out, int64_t* tile_sums, const int64_t* n_live = nullptr) {
+static hipError_t launch_scan(hipStream_t st, Load ld, int64_t n, int64_t* out, int64_t* tile_sums, const int64_t* n_live = nullptr, bool tile_sums_ready = false) {
   if (n <= 0) return hipMemsetAsync(out, 0, sizeof(int64_t), st);
   if (n <= SB_MAX) {
     hipLaunchKernelGGL((scan_block_kernel<Load>), dim3(1), dim3(SB_THREADS), 0, st, ld, n, out);
     return hipGetLastError();
   }
   const int64_t n_tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-  hipLaunchKernelGGL((scan_reduce_kernel<Load>), dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, st, ld, n, tile_sums, n_live);
+  if (!tile_sums_ready) hipLaunchKernelGGL((scan_reduce_kernel<Load>), dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, st, ld, n, tile_sums, n_live);
   hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(ST_THREADS), 0, st, tile_sums, n_tiles, n_live);
   hipLaunchKernelGGL((scan_downsweep_kernel<Load>), dim3((unsigned)n_tiles), dim3(SCAN_THREADS), 0, st, ld, n, tile_sums, n_tiles, out, n_live);
   return hipGetLastError();
@@ -1735,6 +1735,7 @@ struct ExpandMultiArgs {
   const int64_t* b_rp[EXPAND_MULTI_MAX];
   int64_t* pstart[EXPAND_MULTI_MAX];
   int32_t* plen[EXPAND_MULTI_MAX];
+  int64_t* tsum[EXPAND_MULTI_MAX];  // nullable: the scan-tile sums of plen[d] (launch_expand_scan(..., tile_sums_ready = true))
   int n;
 };
 // Round 4: the table holds only the STARTS -- T[u][d] = row_ptr_d[u] as 32 bits, u = 0 .. n_rows (the interleaved, narrowed row pointers
@@ -1748,60 +1749,89 @@ __global__ __launch_bounds__(256) void expand_pack_kernel(ExpandMultiArgs a, int
 template <int N>
 __global__ __launch_bounds__(256) void expand_prepare_multi_kernel(const int64_t* __restrict__ a_cp, int32_t n_items_a, const int32_t* __restrict__ a_ri,
                                                                    const unsigned* __restrict__ T, int64_t cap, ExpandMultiArgs a) {
+  // A block owns whole SCAN TILES of the CSC entries (round 5): besides pstart / plen it leaves every event type's tile sums of plen
+  // (a.tsum[d], when given) -- the first of the three passes of the scans that turn the lengths into the work prefix, which then do
+  // not read the lengths a second time.
+  __shared__ long long s_part[256 / WAVE][N];
   const int64_t nnz = a_cp[n_items_a];
   int64_t lim = (nnz / SCAN_TILE + 1) * SCAN_TILE;  // the scans skip tiles that start at or beyond nnz
   if (lim > cap) lim = cap;
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  for (int64_t p0 = (int64_t)blockIdx.x * 256 + threadIdx.x; p0 < lim; p0 += stride * 2) {  // two entries per thread and round: both gathers in flight
-    int u[2];
-    unsigned v[2][2 * N];  // starts of user u, then of user u + 1: 2 N consecutive words
+  const int64_t n_tiles = (lim + SCAN_TILE - 1) / SCAN_TILE;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // block-uniform
+    const int64_t base = tile * SCAN_TILE;
+    long long sum[N];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int64_t p = p0 + q * stride;
-      u[q] = p < nnz ? a_ri[p] : -1;
-    }
+    for (int d = 0; d < N; ++d) sum[d] = 0;
+    for (int r = 0; r < SCAN_ITEMS; r += 2) {  // two entries per thread and round: both gathers in flight
+      int u[2];
+      unsigned v[2][2 * N];  // starts of user u, then of user u + 1: 2 N consecutive words
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (u[q] >= 0) {
-        const unsigned* t = T + (int64_t)u[q] * N;
-        if (N == 4) {  // 16-byte aligned: two 16-byte loads
-          const uint4 x = *reinterpret_cast<const uint4*>(t), y = *reinterpret_cast<const uint4*>(t + 4);
-          v[q][0] = x.x; v[q][1] = x.y; v[q][2] = x.z; v[q][3] = x.w;
-          v[q][4 % (2 * N)] = y.x; v[q][5 % (2 * N)] = y.y; v[q][6 % (2 * N)] = y.z; v[q][7 % (2 * N)] = y.w;
-        } else {  // 2 N consecutive words, 4-byte aligned: 16-byte loads while they last (global loads only need dword alignment), then 8, then 4
-          constexpr int W = 2 * N;
-#pragma unroll
-          for (int d = 0; d + 4 <= W; d += 4) {
-            const Words4 x = *reinterpret_cast<const Words4*>(t + d);
-            v[q][d] = x.a; v[q][(d + 1) % W] = x.b; v[q][(d + 2) % W] = x.c; v[q][(d + 3) % W] = x.d;
-          }
-          if (W % 4 >= 2) {
-            const Words2 x = *reinterpret_cast<const Words2*>(t + (W / 4) * 4);
-            v[q][(W / 4) * 4 % W] = x.a; v[q][((W / 4) * 4 + 1) % W] = x.b;
-          }
-          if (W % 2 == 1) v[q][W - 1] = t[W - 1];
-        }
-      } else {
-#pragma unroll
-        for (int d = 0; d < 2 * N; ++d) v[q][d] = 0u;
+      for (int q = 0; q < 2; ++q) {
+        const int64_t p = base + (int64_t)(r + q) * 256 + threadIdx.x;
+        u[q] = p < nnz ? a_ri[p] : -1;
       }
-    }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int64_t p = p0 + q * stride;
-      if (p < lim) {
+      for (int q = 0; q < 2; ++q) {
+        if (u[q] >= 0) {
+          const unsigned* t = T + (int64_t)u[q] * N;
+          if (N == 4) {  // 16-byte aligned: two 16-byte loads
+            const uint4 x = *reinterpret_cast<const uint4*>(t), y = *reinterpret_cast<const uint4*>(t + 4);
+            v[q][0] = x.x; v[q][1] = x.y; v[q][2] = x.z; v[q][3] = x.w;
+            v[q][4 % (2 * N)] = y.x; v[q][5 % (2 * N)] = y.y; v[q][6 % (2 * N)] = y.z; v[q][7 % (2 * N)] = y.w;
+          } else {  // 2 N consecutive words, 4-byte aligned: 16-byte loads while they last (global loads only need dword alignment), then 8, then 4
+            constexpr int W = 2 * N;
 #pragma unroll
-        for (int d = 0; d < N; ++d) {
-          a.pstart[d][p] = (int64_t)v[q][d];
-          a.plen[d][p] = (int32_t)(v[q][N + d] - v[q][d]);
+            for (int d = 0; d + 4 <= W; d += 4) {
+              const Words4 x = *reinterpret_cast<const Words4*>(t + d);
+              v[q][d] = x.a; v[q][(d + 1) % W] = x.b; v[q][(d + 2) % W] = x.c; v[q][(d + 3) % W] = x.d;
+            }
+            if (W % 4 >= 2) {
+              const Words2 x = *reinterpret_cast<const Words2*>(t + (W / 4) * 4);
+              v[q][(W / 4) * 4 % W] = x.a; v[q][((W / 4) * 4 + 1) % W] = x.b;
+            }
+            if (W % 2 == 1) v[q][W - 1] = t[W - 1];
+          }
+        } else {
+#pragma unroll
+          for (int d = 0; d < 2 * N; ++d) v[q][d] = 0u;
         }
       }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int64_t p = base + (int64_t)(r + q) * 256 + threadIdx.x;
+        if (p < lim) {
+#pragma unroll
+          for (int d = 0; d < N; ++d) {
+            const int32_t len = (int32_t)(v[q][N + d] - v[q][d]);
+            a.pstart[d][p] = (int64_t)v[q][d];
+            a.plen[d][p] = len;
+            sum[d] += (long long)len;
+          }
+        }
+      }
     }
+    // the tile's sums: waves by shuffles, the block's four waves through LDS
+#pragma unroll
+    for (int d = 0; d < N; ++d) {
+      unsigned long long x = (unsigned long long)sum[d];
+#pragma unroll
+      for (int m = 1; m < WAVE; m <<= 1) x += shfl_xor_u64(x, m);
+      if ((threadIdx.x & (WAVE - 1)) == 0) s_part[threadIdx.x / WAVE][d] = (long long)x;
+    }
+    __syncthreads();
+    if (threadIdx.x < N && a.tsum[threadIdx.x]) {
+      long long tot = 0;
+#pragma unroll
+      for (int w = 0; w < 256 / WAVE; ++w) tot += s_part[w][threadIdx.x];
+      a.tsum[threadIdx.x][tile] = tot;
+    }
+    __syncthreads();  // s_part is the next tile's
   }
 }
 // pstart[d][cap], plen[d][cap] for n <= EXPAND_MULTI_MAX event types (every B must hold fewer than 2^32 entries); T: (n_rows_b + 1) * n words of 32 bits
 hipError_t launch_expand_prepare_multi(hipStream_t st, int n_cu, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx, int n,
-                                       const int64_t* const* b_row_ptr, int64_t n_rows_b, int64_t cap, int64_t* const* pstart, int32_t* const* plen, void* T) {
+                                       const int64_t* const* b_row_ptr, int64_t n_rows_b, int64_t cap, int64_t* const* pstart, int32_t* const* plen, void* T,
+                                       int64_t* const* tsum) {
   if (n < 1 || n > EXPAND_MULTI_MAX) return hipErrorInvalidValue;
   if (cap <= 0) return hipSuccess;
   ExpandMultiArgs a;
@@ -1810,12 +1840,13 @@ hipError_t launch_expand_prepare_multi(hipStream_t st, int n_cu, const int64_t* 
     a.b_rp[d] = d < n ? b_row_ptr[d] : nullptr;
     a.pstart[d] = d < n ? pstart[d] : nullptr;
     a.plen[d] = d < n ? plen[d] : nullptr;
+    a.tsum[d] = (d < n && tsum) ? tsum[d] : nullptr;
   }
   int64_t nb = (n_rows_b + 255) / 256;
   if (nb > (int64_t)n_cu * 8) nb = (int64_t)n_cu * 8;
   if (nb < 1) nb = 1;
   hipLaunchKernelGGL(expand_pack_kernel, dim3((unsigned)nb), dim3(256), 0, st, a, n_rows_b, static_cast<unsigned*>(T));
-  int64_t blocks = (cap + 511) / 512;
+  int64_t blocks = (cap + SCAN_TILE - 1) / SCAN_TILE;  // a block owns whole scan tiles
   const int64_t lim = (int64_t)n_cu * 16;
   if (blocks > lim) blocks = lim;
   const unsigned* Tc = static_cast<const unsigned*>(T);
@@ -1832,8 +1863,10 @@ hipError_t launch_expand_prepare_multi(hipStream_t st, int n_cu, const int64_t* 
   return hipGetLastError();
 }
 // wp = exclusive prefix of plen over cap entries (the second half of launch_expand_prepare, for lengths produced by the multi form)
-hipError_t launch_expand_scan(hipStream_t st, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* plen, int64_t cap, int64_t* wp, int64_t* tile_sums) {
-  return launch_scan(st, LoadI32{plen}, cap, wp, tile_sums, a_col_ptr + n_items_a);
+// tile_sums_ready: tile_sums already holds the sums of plen's scan tiles (expand_prepare_multi left them): the reduce pass is skipped
+hipError_t launch_expand_scan(hipStream_t st, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* plen, int64_t cap, int64_t* wp, int64_t* tile_sums,
+                              bool tile_sums_ready) {
+  return launch_scan(st, LoadI32{plen}, cap, wp, tile_sums, a_col_ptr + n_items_a, tile_sums_ready);
 }
 
 __global__ __launch_bounds__(256) void row_work_kernel(int32_t item_lo, int32_t item_hi, const int64_t* __restrict__ a_cp,

@@ -400,7 +400,7 @@ int partition_dev(urcco_session* s, int32_t n_items, const int64_t* work, int32_
 int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a, const int64_t* a_col_ptr, const int32_t* a_row_idx, int64_t nnz_a_bound,
                   const int64_t* b_row_ptr, const int32_t* b_col_idx, int32_t n_cols_b, const int32_t* counts_a, const int32_t* counts_b, int64_t n_users,
                   int32_t exclude_self, int32_t k, int32_t has_min_llr, double min_llr, int32_t* out_count, int32_t* out_idx, double* out_llr, int64_t* stats_dev,
-                  const int64_t* pre_pstart, const int32_t* pre_plen) {
+                  const int64_t* pre_pstart, const int32_t* pre_plen, int64_t* pre_tile_sums) {
   if (!s || item_lo < 0 || item_hi < item_lo || item_hi > n_items_a || n_cols_b < 0 || n_users < 0 || nnz_a_bound < 0 || !a_col_ptr || !b_row_ptr)
     return fail(URCCO_BAD_ARG, "urcco_dev_cco_rows: bad argument");
   if (k <= 0) return fail(URCCO_BAD_ARG, "maxInterestingElements must be positive, got %d", k);
@@ -461,7 +461,7 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
 
   s->begin(URCCO_STAGE_ROW_WORK);
   if (pre_pstart && pre_plen)
-    HIPC(urcco::launch_expand_scan(s->stream, a_col_ptr, n_items_a, pre_plen, cap, wp, p_tile_sums));
+    HIPC(urcco::launch_expand_scan(s->stream, a_col_ptr, n_items_a, pre_plen, cap, wp, pre_tile_sums ? pre_tile_sums : p_tile_sums, pre_tile_sums != nullptr));
   else
     HIPC(urcco::launch_expand_prepare(s->stream, s->n_cu, a_col_ptr, n_items_a, a_row_idx, b_row_ptr, b_rp32, n_users, cap, own_pstart, own_plen, wp, p_tile_sums));
   HIPC(urcco::launch_row_work(s->stream, s->n_cu, item_lo, item_hi, a_col_ptr, wp, work));
@@ -505,12 +505,12 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
 // Expand preparation of n secondaries in one pass over the CSC of A' (cco_kernels.hip, expand_prepare_multi): pstart[d] / plen[d] hold
 // cap entries each.  The interleaved (start, length) table lives in the session's arena for the duration of the launch.
 int expand_multi(urcco_session* s, int n, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx, int64_t cap, const int64_t* const* b_row_ptr,
-                 int64_t n_users, int64_t* const* pstart, int32_t* const* plen) {
+                 int64_t n_users, int64_t* const* pstart, int32_t* const* plen, int64_t* const* tile_sums) {
   if (!s || n < 1 || n > urcco::EXPAND_MULTI_MAX || !a_col_ptr || cap < 0) return fail(URCCO_BAD_ARG, "expand_multi: bad argument");
   URC(s->reserve(urcco_session::need(((size_t)n_users + 2) * (size_t)n, 4) + 256));
   void* T = s->take<unsigned>(((size_t)n_users + 2) * (size_t)n);  // n_users + 1 records of n starts (+ one record of slack: the last user's 2 n-word read)
   s->begin(URCCO_STAGE_ROW_WORK);
-  HIPC(urcco::launch_expand_prepare_multi(s->stream, s->n_cu, a_col_ptr, n_items_a, a_row_idx, n, b_row_ptr, n_users, cap, pstart, plen, T));
+  HIPC(urcco::launch_expand_prepare_multi(s->stream, s->n_cu, a_col_ptr, n_items_a, a_row_idx, n, b_row_ptr, n_users, cap, pstart, plen, T, tile_sums));
   s->end();
   return URCCO_OK;
 }

@@ -187,6 +187,7 @@ struct EvState {
   DBuf<unsigned long long> verr;
   DBuf<int64_t> pre_pstart;     // this event type's share of the fused expand preparation (builds with >= 2 secondaries)
   DBuf<int32_t> pre_plen;
+  DBuf<int64_t> pre_tsum;       // ... and the scan-tile sums of pre_plen the fused pass leaves (the expand scan then skips its reduce pass)
   // row-filtered exchange: the shard's row lengths masked per destination [W][rows] (int32 / as they travel when 16 bits do), their
   // exclusive scan (where every sent row starts in `pack`), the rows packed per destination, and to_nnz[p * W + q] = column indices
   // rank p sends to rank q (own row computed here, the others gathered)
@@ -205,7 +206,7 @@ struct EvState {
     in_rp.release(); in_ci.release(); raw.release(); post.release(); s_rp.release(); s_ci.release(); deg.release(); f_deg.release();
     deg16.release(); f_deg16.release();
     f_rp.release(); f_ci.release(); sizes.release(); scan_tmp.release(); o_count.release(); o_idx.release(); o_llr.release(); c_rp.release();
-    c_idx.release(); c_llr.release(); stats.release(); verr.release(); pre_pstart.release(); pre_plen.release();
+    c_idx.release(); c_llr.release(); stats.release(); verr.release(); pre_pstart.release(); pre_plen.release(); pre_tsum.release();
     mlen.release(); pack.release(); mlen16.release(); mlen_bad.release(); moff.release(); mtmp.release(); to_nnz.release();
     if (ev_sampled) (void)hipEventDestroy(ev_sampled);
     if (ev_done) (void)hipEventDestroy(ev_done);
@@ -542,7 +543,7 @@ int stage_rows(DevState& D, EvState& E, EvState& A, int d, const DsParams& pa, c
   URC(E.stats.ensure(URCCO_STATS_LEN));
   URC(cco_rows_impl(E.s, D.item_lo, D.item_hi, (int32_t)pa.n_cols, D.a_cp[D.par].p, D.a_ri[D.par].p, a_nnz_bound, E.b_rp, E.b_ci, (int32_t)p.n_cols,
                     post_of(D, 0).p, post_of(D, d).p, n_users, d == 0 ? 1 : 0, p.k, p.has_min_llr, p.min_llr, E.o_count.p, E.o_idx.p, E.o_llr.p, E.stats.p,
-                    pre_expanded ? E.pre_pstart.p : nullptr, pre_expanded ? E.pre_plen.p : nullptr));
+                    pre_expanded ? E.pre_pstart.p : nullptr, pre_expanded ? E.pre_plen.p : nullptr, pre_expanded ? E.pre_tsum.p : nullptr));
   URC(urcco_dev_compact_indicators(E.s, n, p.k, E.o_count.p, E.o_idx.p, E.o_llr.p, E.c_rp.p, E.c_idx.p, E.c_llr.p));
   HIPC(hipEventRecord(E.ev_done, E.s->stream));
   HIPC(hipEventRecord(E.ev_cons[D.par], E.s->stream));
@@ -631,16 +632,19 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
     std::vector<const int64_t*> rp((size_t)(n_ds - f0));
     std::vector<int64_t*> ps((size_t)(n_ds - f0));
     std::vector<int32_t*> pl((size_t)(n_ds - f0));
+    std::vector<int64_t*> ts((size_t)(n_ds - f0));
     for (int d = f0; d < n_ds; ++d) {
       EvState& E = D.ev[(size_t)d];
       if (d > 0 && E.s != L.s) HIPC(hipStreamWaitEvent(L.s->stream, E.ev_sampled, 0));  // (the primary: a_ready, above)
       URC(E.pre_pstart.ensure((size_t)a_cap + 1));
       URC(E.pre_plen.ensure((size_t)a_cap + 1));
+      URC(E.pre_tsum.ensure(expand_tile_words(a_cap)));
+      ts[(size_t)(d - f0)] = E.pre_tsum.p;
       rp[(size_t)(d - f0)] = E.s_rp.p;
       ps[(size_t)(d - f0)] = E.pre_pstart.p;
       pl[(size_t)(d - f0)] = E.pre_plen.p;
     }
-    URC(expand_multi(L.s, n_ds - f0, D.a_cp[D.par].p, (int32_t)ps_[0].n_cols, D.a_ri[D.par].p, a_cap, rp.data(), n_users, ps.data(), pl.data()));
+    URC(expand_multi(L.s, n_ds - f0, D.a_cp[D.par].p, (int32_t)ps_[0].n_cols, D.a_ri[D.par].p, a_cap, rp.data(), n_users, ps.data(), pl.data(), ts.data()));
     HIPC(hipEventRecord(D.b_expanded, L.s->stream));
     return URCCO_OK;
   };
@@ -1184,17 +1188,20 @@ int build_sharded(urcco_context* c, const std::vector<std::vector<Shard>>& sh, c
       std::vector<const int64_t*> rp((size_t)n_ds - 1);
       std::vector<int64_t*> pst((size_t)n_ds - 1);
       std::vector<int32_t*> pl((size_t)n_ds - 1);
+      std::vector<int64_t*> ts((size_t)n_ds - 1);
       for (int d = 1; d < n_ds; ++d) {
         EvState& E = D.ev[(size_t)d];
         HIPC(hipEventRecord(E.ev_sampled, E.s->stream));  // behind the scan that rebuilt the whole matrix's row_ptr
         if (E.s != L.s) HIPC(hipStreamWaitEvent(L.s->stream, E.ev_sampled, 0));
         URC(E.pre_pstart.ensure((size_t)D.a_ents + 1));
         URC(E.pre_plen.ensure((size_t)D.a_ents + 1));
+        URC(E.pre_tsum.ensure(expand_tile_words(D.a_ents)));
+        ts[(size_t)d - 1] = E.pre_tsum.p;
         rp[(size_t)d - 1] = E.b_rp;
         pst[(size_t)d - 1] = E.pre_pstart.p;
         pl[(size_t)d - 1] = E.pre_plen.p;
       }
-      URC(expand_multi(L.s, n_ds - 1, D.a_cp[D.par].p, n_items_a, D.a_ri[D.par].p, D.a_ents, rp.data(), n_users, pst.data(), pl.data()));
+      URC(expand_multi(L.s, n_ds - 1, D.a_cp[D.par].p, n_items_a, D.a_ri[D.par].p, D.a_ents, rp.data(), n_users, pst.data(), pl.data(), ts.data()));
       HIPC(hipEventRecord(D.b_expanded, L.s->stream));
     }
     for (int d = 1; d < n_ds; ++d) {
