@@ -3825,16 +3825,20 @@ static int blocks_per_cu(int bin) {
   return cache[bin].load(std::memory_order_relaxed);
 }
 
-hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, int bin) {
+hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, int bin, int32_t n_rows) {
   // Persistent grids sized to the chip; each kernel reads its own row list length from bin_off on the device,
   // so no host synchronisation sits between binning and the SpGEMM.
-  // Twice as many blocks as fit the chip (tunable per class through URCCO_GRID_FACTORS="f0,f1,..,f5" for measurements):
-  // the second half starts as blocks of the first retire, which evens out the classes' ragged ends and lets short kernels
-  // of the other event types' streams in -- a grid that exactly fills the chip locks them out until it ends (measured:
-  // single-block kernels of another stream waited 0.2 ms).  3.5-3.7 -> 3.2-3.3 ms per build of config 3; 3x, 4x and 8x
-  // measured no better than 1x (profiles/r02_grid_factor_sweep.log).
+  // Several times as many blocks as fit the chip (tunable per class through URCCO_GRID_FACTORS="f0,f1,..,f5" for measurements):
+  // the later ones start as blocks of the first wave retire, which evens out the classes' ragged ends -- rows are dealt out by a
+  // static stride, so a block's share of heavy rows is luck -- and lets short kernels of the other event types' streams in: a grid
+  // that exactly fills the chip locks them out until it ends (measured: single-block kernels of another stream waited 0.2 ms).
+  // Round 2 (config 3): 2x, and 3x / 4x / 8x measured no better.  Round 5 (config 4 / 5, after the row kernels had lost a third of
+  // their time): 8x for the four big classes and 4x for the 512/1024-thread classes = -0.55 / -0.8 ms per build, every class's own
+  // time included (profiles/r05_grid_factors_ab.log); bounded by one row loop per 32 item rows of the build (small builds and the ranks of a sharded
+  // build keep the 2x: a row loop's start-up -- three rows of prefetches -- is not free; at an eighth of config 4's rows 4x measured 0.12 ms
+  // per rank slower than 2x).
   struct Factors {  // initialised once, thread-safely: every event type's enqueueing thread comes through here in the first build
-    int f[7] = {2, 2, 2, 2, 2, 2, 2};
+    int f[7] = {8, 8, 8, 8, 4, 4, 2};
     Factors() {
       if (const char* e = getenv("URCCO_GRID_FACTORS")) {
         int v[6];
@@ -3846,7 +3850,15 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
   };
   static const Factors factors;
   const int* factor = factors.f;
-  auto grid = [&](int b) { return dim3((unsigned)(n_cu * blocks_per_cu(b)) * (unsigned)factor[b]); };
+  auto grid = [&](int b) {
+    const long long fill = (long long)n_cu * blocks_per_cu(b);  // blocks resident at once
+    const long long teams = b <= 1 ? 4 : 1;                       // row loops per block (micro / one-wave classes: four one-wave teams)
+    long long cap = ((long long)n_rows + teams * 32 - 1) / (teams * 32);
+    if (cap < 2 * fill) cap = 2 * fill;  // (as rounds 2-4)
+    long long blocks = fill * factor[b];
+    if (blocks > cap) blocks = cap;
+    return dim3((unsigned)blocks);
+  };
   const bool dbgk = (args.debug & (1 | 2 | 4 | 8 | 16 | 512 | 131072 | 262144)) != 0;  // the ablation / test switches live in the DBG instantiations only
   switch (bin) {
     case 0:

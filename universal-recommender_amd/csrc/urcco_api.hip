@@ -495,7 +495,7 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
   for (int step = 0; step < urcco::NBINS; ++step) {
     const int bin = (s->debug & 65536) ? step : urcco::NBINS - 1 - step;
     s->begin(URCCO_STAGE_CCO_BIN0 + bin);
-    HIPC(urcco::launch_cco_rows_bin(s->stream, s->n_cu, a, bin));
+    HIPC(urcco::launch_cco_rows_bin(s->stream, s->n_cu, a, bin, n));
     s->end();
   }
   if (s->timing) HIPC(urcco::launch_bin_out_stats(s->stream, bin_rows, bin_off, item_lo, out_count, cand, stats));
