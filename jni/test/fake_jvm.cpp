@@ -1,9 +1,15 @@
 // TEST-ONLY fake JVM: implements the JNIEnv of jni/stub/jni.h on plain heap objects and drives the shim's native method
-// the way the Scala host does (Native.crossOccurrenceDownsampled).  tests/test_jni_shim.py loads this through ctypes,
+// the way the Scala host does (Native.crossOccurrenceDownsampled).  Like a JVM it LINKS the native methods by name: the
+// caller declares the holder class and the method (fake_jvm_bind), the name is mangled as the JNI specification prescribes
+// ('.' -> '_', '_' -> "_1", ';' -> "_2", '[' -> "_3", anything else outside [A-Za-z0-9] -> "_0xxxx": '$' of a Scala module
+// class becomes "_00024") and resolved with dlsym in this very library -- an unresolved name is the UnsatisfiedLinkError a
+// real JVM throws at the first call (round 5's `object Native` would have been caught here).  tests/test_jni_shim.py loads this through ctypes,
 // hands it numpy CSR matrices and compares what comes back with the oracle -- so the marshalling of jni/urcco_jni.cpp is
 // executed, not only type-checked, although this image has no JDK.  It also enforces the JNI critical-section rule: no
 // JNI call may be made while a primitive array is held critically.
 #include <jni.h>
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -12,12 +18,43 @@
 #include <string>
 #include <vector>
 
-extern "C" jobjectArray Java_com_actionml_urcco_Native_crossOccurrenceDownsampled(JNIEnv*, jclass, jobjectArray, jobjectArray, jlongArray, jintArray,
-                                                                                jintArray, jdoubleArray, jint, jint, jint);
-extern "C" jint Java_com_actionml_urcco_Native_deviceCount(JNIEnv*, jclass);
-extern "C" void Java_com_actionml_urcco_Native_shutdown(JNIEnv*, jclass);
-
 namespace {
+
+using CrossFn = jobjectArray (*)(JNIEnv*, jclass, jobjectArray, jobjectArray, jlongArray, jintArray, jintArray, jdoubleArray, jint, jint, jint);
+using CountFn = jint (*)(JNIEnv*, jclass);
+using ShutFn = void (*)(JNIEnv*, jclass);
+CrossFn g_cross = nullptr;  // bound by fake_jvm_bind, as a JVM binds a native method at its first call
+CountFn g_count = nullptr;
+ShutFn g_shut = nullptr;
+
+// JNI specification, "Resolving Native Method Names": Java_ + mangled fully-qualified class name + _ + mangled method name
+std::string jni_mangle(const std::string& s) {
+  std::string out;
+  for (unsigned char c : s) {
+    if (c == '.' || c == '/') out += '_';
+    else if (c == '_') out += "_1";
+    else if (c == ';') out += "_2";
+    else if (c == '[') out += "_3";
+    else if ((c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z')) out += (char)c;
+    else {
+      char buf[8];
+      snprintf(buf, sizeof buf, "_0%04x", (unsigned)c);
+      out += buf;
+    }
+  }
+  return out;
+}
+
+void* resolve_native(const char* cls, const char* method, std::string* symbol) {
+  *symbol = "Java_" + jni_mangle(cls) + "_" + jni_mangle(method);
+  Dl_info info;
+  if (!dladdr((void*)&jni_mangle, &info) || !info.dli_fname) return nullptr;
+  void* self = dlopen(info.dli_fname, RTLD_NOW | RTLD_NOLOAD);  // the library System.loadLibrary would have loaded: the shim is linked into it
+  if (!self) return nullptr;
+  void* f = dlsym(self, symbol->c_str());
+  dlclose(self);
+  return f;
+}
 
 struct IntArr : _jintArray { std::vector<jint> v; };
 struct LongArr : _jlongArray { std::vector<jlong> v; };
@@ -119,7 +156,11 @@ int fake_jvm_cross_occurrence(int n, const int64_t* n_rows, const int64_t* n_col
     mi->v.push_back(max_int[d]);
     ml->v.push_back(min_llr[d]);
   }
-  jobjectArray res = Java_com_actionml_urcco_Native_crossOccurrenceDownsampled(&env, nullptr, rps, cis, nc, mr, mi, ml, seed, device, n_gpus);
+  if (!g_cross) {
+    snprintf(err, (size_t)err_cap, "java.lang.UnsatisfiedLinkError: crossOccurrenceDownsampled is not bound (call fake_jvm_bind first)");
+    return 3;
+  }
+  jobjectArray res = g_cross(&env, nullptr, rps, cis, nc, mr, mi, ml, seed, device, n_gpus);
   if (env.violations > 0 || env.critical != 0 || env.pending_violations > 0) {
     snprintf(err, (size_t)err_cap, "JNI rule violated: %d call(s) inside a critical section, %d array(s) still held, %d throwing call(s) with an exception pending",
              env.violations, env.critical, env.pending_violations);
@@ -147,7 +188,28 @@ int fake_jvm_cross_occurrence(int n, const int64_t* n_rows, const int64_t* n_col
 }
 
 void fake_jvm_free(void* p) { free(p); }
-int fake_jvm_device_count(void) { return Java_com_actionml_urcco_Native_deviceCount(nullptr, nullptr); }
-void fake_jvm_shutdown(void) { Java_com_actionml_urcco_Native_shutdown(nullptr, nullptr); }
+int fake_jvm_device_count(void) { return g_count ? g_count(nullptr, nullptr) : -1; }
+void fake_jvm_shutdown(void) { if (g_shut) g_shut(nullptr, nullptr); }
+
+// 1 when `cls`.`method` (cls = the JVM's binary class name, e.g. "com.actionml.urcco.Native" or "...Native$") links against
+// the shim by the JNI short name; the mangled symbol that was looked up is written to `symbol`.
+int fake_jvm_resolves(const char* cls, const char* method, char* symbol, int symbol_cap) {
+  std::string sym;
+  void* f = resolve_native(cls, method, &sym);
+  if (symbol && symbol_cap > 0) snprintf(symbol, (size_t)symbol_cap, "%s", sym.c_str());
+  return f ? 1 : 0;
+}
+
+// Links the three native methods of the holder class `cls`; 0, or 3 with "java.lang.UnsatisfiedLinkError: <symbol>" in err.
+int fake_jvm_bind(const char* cls, char* err, int err_cap) {
+  std::string sym;
+  g_cross = (CrossFn)resolve_native(cls, "crossOccurrenceDownsampled", &sym);
+  if (g_cross) g_count = (CountFn)resolve_native(cls, "deviceCount", &sym);
+  if (g_cross && g_count) g_shut = (ShutFn)resolve_native(cls, "shutdown", &sym);
+  if (g_cross && g_count && g_shut) return 0;
+  g_cross = nullptr, g_count = nullptr, g_shut = nullptr;
+  snprintf(err, (size_t)err_cap, "java.lang.UnsatisfiedLinkError: %s", sym.c_str());
+  return 3;
+}
 
 }  // extern "C"

@@ -3,6 +3,8 @@
 // Pure marshalling: it binds exactly the host-level entry points that replace the two Mahout calls of
 // URAlgorithm.calcAll (reference src/main/scala/URAlgorithm.scala:323-329 `SimilarityAnalysis.cooccurrencesIDSs` and
 // :343-346 `SimilarityAnalysis.crossOccurrenceDownsampled`); scala/HipSimilarityAnalysis.scala is the Scala side.
+// The exported names are the JNI short names of the STATIC native methods of the JAVA class com.actionml.urcco.Native
+// (java/com/actionml/urcco/Native.java) -- not of a Scala `object`, whose methods live on `Native$` (..._Native_00024_...).
 //
 // Build (on a box with a JDK):  make -C jni JAVA_HOME=/path/to/jdk      -> jni/liburcco_jni.so
 // Checked here (no JDK in this image): `make -C jni check` compiles it against jni/stub/jni.h, and tests/test_jni_shim.py

@@ -4,7 +4,9 @@ the product library on the GPU box -- so that the marshalling (critical sections
 call -- the fake JVM overwrites a released array, so a library that read it later would fail --, NaN = None, Object[3n]
 result, RuntimeException on failure) is executed and its output compared with the oracle."""
 import ctypes as C
+import glob
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -21,9 +23,70 @@ def test_shim_type_checks_against_the_stub_header():
     subprocess.check_call(["make", "-s", "-C", JNI, "check"])
 
 
+def declared_native_methods():
+    """(JVM binary class name, method) of every native method the host sources declare -- read from the sources a maintainer
+    copies into the reference tree, not from the shim.  A Java `class X` holds them on X; a Scala `object X` holds them on
+    the module class X$ (round 5's defect: the shim exported ..._Native_... while the JVM looked for ..._Native_00024_...)."""
+    out = []
+    for path in glob.glob(os.path.join(ROOT, "java", "**", "*.java"), recursive=True):
+        src = re.sub(r"/\*.*?\*/|//[^\n]*", "", open(path).read(), flags=re.S)
+        pkg = re.search(r"\bpackage\s+([\w.]+)\s*;", src).group(1)
+        cls = re.search(r"\bclass\s+(\w+)", src).group(1)
+        for m in re.finditer(r"\b(static\s+)?native\b[^;(]*?\b(\w+)\s*\(", src):
+            assert m.group(1), f"{m.group(2)}: the shim's functions take a jclass, i.e. bind STATIC native methods"
+            out.append((f"{pkg}.{cls}", m.group(2)))
+    for path in glob.glob(os.path.join(ROOT, "scala", "*.scala")):
+        src = re.sub(r"/\*.*?\*/|//[^\n]*", "", open(path).read(), flags=re.S)
+        pkg = re.search(r"\bpackage\s+([\w.]+)", src).group(1)
+        for m in re.finditer(r"@native\s+def\s+(\w+)", src):
+            holders = list(re.finditer(r"\b(object|class)\s+(\w+)", src[:m.start()]))
+            kind, name = holders[-1].group(1), holders[-1].group(2)
+            out.append((f"{pkg}.{name}" + ("$" if kind == "object" else ""), m.group(1)))
+    return out
+
+
 def _fake_jvm(lib_path: str, tag: str):
     subprocess.check_call(["make", "-s", "-C", JNI, "fake", f"URCCO_SO={lib_path}", f"TAG={tag}"])
-    return C.CDLL(os.path.join(JNI, "_build", f"libfake_jvm_{tag}.so"))
+    jvm = C.CDLL(os.path.join(JNI, "_build", f"libfake_jvm_{tag}.so"))
+    # link like a JVM: by the mangled name of the class that DECLARES the native methods
+    holders = sorted({c for c, _ in declared_native_methods()})
+    assert len(holders) == 1, holders
+    err = C.create_string_buffer(600)
+    assert jvm.fake_jvm_bind(holders[0].encode(), err, 600) == 0, err.value.decode()
+    return jvm
+
+
+def test_native_methods_resolve_by_jni_name(sim_lib):
+    """Every native method the host sources declare links against the shim under the name a JVM computes for it; the same
+    methods on a Scala module class (`object Native` -> Native$ -> ..._Native_00024_...) do not: the negative control."""
+    from hostsim import build_sim
+    jvm = _fake_jvm(build_sim.OUT, "sim")
+    decl = declared_native_methods()
+    assert sorted(m for _, m in decl) == ["crossOccurrenceDownsampled", "deviceCount", "shutdown"], decl
+    sym = C.create_string_buffer(300)
+    for cls, method in decl:
+        assert not cls.endswith("$"), f"{cls}: native methods of a Scala object bind to the module class; keep them on the Java holder"
+        assert jvm.fake_jvm_resolves(cls.encode(), method.encode(), sym, 300) == 1, f"UnsatisfiedLinkError: {sym.value.decode()}"
+        assert sym.value.decode() == "Java_" + cls.replace(".", "_") + "_" + method
+        assert jvm.fake_jvm_resolves((cls + "$").encode(), method.encode(), sym, 300) == 0
+        assert "_00024_" in sym.value.decode()
+    err = C.create_string_buffer(600)
+    assert jvm.fake_jvm_bind(b"com.actionml.urcco.Native$", err, 600) == 3 and b"UnsatisfiedLinkError" in err.value
+    assert jvm.fake_jvm_device_count() == -1                       # nothing is bound after a failed link
+    assert jvm.fake_jvm_bind(decl[0][0].encode(), err, 600) == 0
+
+
+def test_scala_host_keeps_mahouts_signatures():
+    """the two entry points keep Mahout 0.13.0's parameter lists (names matter: URAlgorithm.scala:323-329 calls
+    with named arguments), incl. the ignored `parOpts`."""
+    src = open(os.path.join(ROOT, "scala", "HipSimilarityAnalysis.scala")).read()
+    sig = re.search(r"def cooccurrencesIDSs\((.*?)\)\s*:\s*List\[IndexedDataset\]", src, flags=re.S).group(1)
+    names = re.findall(r"(\w+)\s*:", sig)
+    assert names == ["indexedDatasets", "randomSeed", "maxInterestingItemsPerThing", "maxNumInteractions", "parOpts"], names
+    assert "parOpts: ParOpts = defaultParOpts" in sig
+    sig = re.search(r"def crossOccurrenceDownsampled\((.*?)\)\s*:\s*List\[IndexedDataset\]", src, flags=re.S).group(1)
+    assert re.findall(r"(\w+)\s*:", sig) == ["datasets", "randomSeed"]
+    assert "rp(nrow).toInt" not in src.replace("new Array[Int](rp(nrow).toInt)", "") and "Int.MaxValue" in src  # the 2^31 guard precedes the cast
 
 
 def run_shim(jvm, mats, params, seed, n_gpus=1):
