@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define URCCO_VERSION 303 /* 0.3.3: urcco_dev_result.sampled_nnz_total */
+#define URCCO_VERSION 304 /* 0.3.4: URCCO_BUSY, urcco_cross_occurrence_cancel_any; _cancel only discards the caller's own staged build */
 
 typedef enum urcco_status {
   URCCO_OK = 0,
@@ -39,7 +39,8 @@ typedef enum urcco_status {
   URCCO_HIP_ERROR = 4,
   URCCO_INTERNAL = 5,
   URCCO_NO_DEVICE = 6,
-  URCCO_RCCL_ERROR = 7   /* a collective failed, or more than one GPU was asked for and librccl could not be loaded */
+  URCCO_RCCL_ERROR = 7,  /* a collective failed, or more than one GPU was asked for and librccl could not be loaded */
+  URCCO_BUSY = 8         /* the process-wide context holds ANOTHER thread's staged build (stage: not finished within the wait; cancel: not the caller's to discard) */
 } urcco_status;
 
 /* D9: how sampleDownAndBinarize's perRowSampleRate is evaluated */
@@ -49,7 +50,11 @@ typedef enum urcco_status {
  * into row_rate_mode wherever that travels (urcco_options.row_rate_mode, urcco_dev_downsample): a stateless uniform keyed by
  * (seed, global row, column), identical in oracle/cco_oracle.{py,c} and on the device. */
 #define URCCO_RNG_SPLITMIX53 0         /* 64-bit splitmix finaliser, 53-bit uniform (default) */
-#define URCCO_RNG_MIX32 0x100          /* 32-bit: column xor (row, seed) key, two-round multiply-xorshift; ~10 instead of ~25 instructions per interaction */
+#define URCCO_RNG_MIX32 0x100          /* 32-bit: column xor (row, seed) key, two-round multiply-xorshift; ~10 instead of ~25 instructions per interaction.
+                                        * Known structure: the seed and the row enter the key LINEARLY (key = row * C1 + seed * C2 + C3), so two seeds give the
+                                        * same stream up to a constant shift of the row index, and hash(row1, col) == hash(row2, col ^ key1 ^ key2): different seeds are
+                                        * relabelings of ONE sample family, not independent samples of the whole matrix.  Per-entry uniformity and the per-column keep
+                                        * rates are unaffected (tests/test_oracle.py); a caller that needs independent re-samples across seeds uses the default. */
 
 /* One IndexedDataset.matrix (user x item, binary), rows = the shared user dictionary
  * (Preparator.scala:44-87).  row_ptr has n_rows + 1 entries; col_idx is sorted and unique inside a row. */
@@ -149,10 +154,15 @@ void urcco_free_indicators(urcco_indicators* indicators, int32_t n);
 int urcco_cross_occurrence_stage(const urcco_dataset* datasets, int32_t n_datasets, int32_t random_seed, const urcco_options* options);
 int urcco_cross_occurrence_finish(urcco_indicators* out, int32_t n_datasets, urcco_dataset_stats* stats);
 /* The process-wide context behind these calls holds ONE build at a time: a second thread's _stage waits until the first thread's
- * _finish (at most URCCO_STAGE_WAIT_S seconds, default 600, then URCCO_INTERNAL), the same thread staging twice is URCCO_BAD_ARG.
- * A _finish whose n_datasets differs from the staged count DISCARDS the staged build (URCCO_BAD_ARG; the context is free again), and
- * _cancel discards a staged build nobody will finish -- a caller that gave up between the halves calls it so that others do not wait. */
+ * _finish (at most URCCO_STAGE_WAIT_S seconds, default 600, then URCCO_BUSY -- a status of its own, so that a caller can tell "occupied"
+ * from a real internal fault), the same thread staging twice is URCCO_BAD_ARG.
+ * A _finish whose n_datasets differs from the staged count DISCARDS the staged build (URCCO_BAD_ARG; the context is free again).
+ * _cancel discards the CALLING thread's own staged build (a caller that gave up between the halves calls it so that others do not wait);
+ * nothing staged is a no-op, another thread's build is left alone (URCCO_BUSY): a thread that merely timed out in _stage must not be able
+ * to throw away the owner's legitimately staged build.  _cancel_any discards whatever is staged, whoever staged it -- for a supervisor
+ * that KNOWS the owner is gone (a thread that staged and died); the owner's _finish then reports "nothing staged". */
 int urcco_cross_occurrence_cancel(void);
+int urcco_cross_occurrence_cancel_any(void);
 
 /* ---- CONTEXT level: the persistent form of the host level, and the multi-GPU build ------------------------------
  * A context owns, per GPU, one HIP stream + scratch arena per event type, every intermediate and output buffer (grown

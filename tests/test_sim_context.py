@@ -387,7 +387,13 @@ def test_stage_finish_protocol(sim_lib):
         t.join(30)
     finally:
         del os.environ["URCCO_STAGE_WAIT_S"]
-    assert got == [_lib.INTERNAL], got
+    assert got == [_lib.BUSY], got                                                     # a status of its own, not INTERNAL
+    # ... and that thread cannot discard the owner's build: _cancel from a non-owner is BUSY and leaves it staged (the owner's _finish works)
+    got = []
+    t = threading.Thread(target=lambda: got.append(lib.urcco_cross_occurrence_cancel()))
+    t.start()
+    t.join(30)
+    assert got == [_lib.BUSY], got
     assert lib.urcco_cross_occurrence_finish(out, n, None) == _lib.OK
     ref = O.cross_occurrence_downsampled(mats, [P()] * n, 3)
     for d, r in enumerate(ref):
@@ -396,6 +402,14 @@ def test_stage_finish_protocol(sim_lib):
         check_indicators((np.ctypeslib.as_array(o.row_ptr, shape=(o.n_rows + 1,)).copy(), np.ctypeslib.as_array(o.col_idx, shape=(max(nnz, 1),))[:nnz].copy(),
                           np.ctypeslib.as_array(o.llr, shape=(max(nnz, 1),))[:nnz].copy()), r)
     lib.urcco_free_indicators(out, n)
+    # an owner that is gone: only _cancel_any frees the context for the others; the owner's late _finish then finds nothing staged
+    t = threading.Thread(target=lambda: got.append(lib.urcco_cross_occurrence_stage(arr, n, 3, C.byref(opts))))
+    t.start()
+    t.join(30)
+    assert got[-1] == _lib.OK
+    assert lib.urcco_cross_occurrence_cancel() == _lib.BUSY
+    assert lib.urcco_cross_occurrence_cancel_any() == _lib.OK
+    assert lib.urcco_cross_occurrence_finish(out, n, None) == _lib.BAD_ARG
     assert lib.urcco_cross_occurrence_stage(arr, n, 3, C.byref(opts)) == _lib.OK
     assert lib.urcco_shutdown() == 0                                                  # abandons the staged build
     assert lib.urcco_cross_occurrence_finish(out, n, None) == _lib.BAD_ARG

@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_PATH = os.path.join(_HERE, "lib", "liburcco.so")
 
-OK, BAD_ARG, OOM_HOST, OOM_DEVICE, HIP_ERROR, INTERNAL, NO_DEVICE, RCCL_ERROR = range(8)
+OK, BAD_ARG, OOM_HOST, OOM_DEVICE, HIP_ERROR, INTERNAL, NO_DEVICE, RCCL_ERROR, BUSY = range(9)
 FLAG_SINGLE_STREAM = 1
 FLAG_FORCE_EXCHANGE = 2
 FLAG_UNORDERED_ROWS = 4
@@ -111,6 +111,7 @@ SYMBOLS = {
     "urcco_cross_occurrence_stage": (C.c_int, [C.POINTER(Dataset), C.c_int32, C.c_int32, C.POINTER(Options)]),
     "urcco_cross_occurrence_finish": (C.c_int, [C.POINTER(Indicators), C.c_int32, C.POINTER(DatasetStats)]),
     "urcco_cross_occurrence_cancel": (C.c_int, []),
+    "urcco_cross_occurrence_cancel_any": (C.c_int, []),
     "urcco_context_stage": (C.c_int, [_p, C.POINTER(Dataset), C.c_int32, C.c_int32]),
     "urcco_context_finish": (C.c_int, [_p, C.POINTER(Indicators), C.POINTER(DatasetStats)]),
     "urcco_shutdown": (C.c_int, []),

@@ -27,6 +27,9 @@ __device__ __forceinline__ double u01_hash(uint32_t seed, uint32_t row, uint32_t
 // once per tile plus one multiply per entry --, the column by xor, and the two-round multiply-xorshift finaliser ("lowbias32", bias
 // measured by its author at the level of the murmur3 finaliser) mixes the sum: 2 + 8 vector instructions per interaction where the
 // 64-bit splitmix finaliser above costs ~25 on a machine without a 64-bit integer multiplier.  u01 = h * 2^-32.
+// Limitation (documented in include/urcco.h): seed and row enter the key linearly, so another seed is the same stream with the rows
+// shifted by a constant -- a relabeling, not an independent sample.  A non-linear row key would cost a multiply-xorshift round per ENTRY (the
+// scan forms key0 + t * MIX32_ROW incrementally inside a tile), which is the saving this mode exists for; the default RNG has no such structure.
 constexpr uint32_t MIX32_ROW = 0x9E3779B1u, MIX32_SEED = 0x85EBCA77u, MIX32_ADD = 0xC2B2AE3Du;
 __device__ __forceinline__ uint32_t mix32_row_key(uint32_t seed, uint32_t row) { return row * MIX32_ROW + (seed * MIX32_SEED + MIX32_ADD); }
 __device__ __forceinline__ uint32_t mix32_finish(uint32_t x) {
@@ -117,42 +120,6 @@ __device__ __forceinline__ double llr_from_entropies_tab(double row_entropy, dou
   const double s = row_entropy + column_entropy;
   if (s < matrix_entropy) return 0.0; /* round off error */
   return 2.0 * (s - matrix_entropy);
-}
-
-// ---- one check, then five table reads -------------------------------------------------------------------------------------------
-// After the interaction cut every operand of a candidate's LLR is small: k11, k12 = cA - k11, k21 = cB - k11, the column count cB and
-// N - k22 = cA + cB - k11 all sit below the table size, so columnEntropy and the four xLogX terms of matrixEntropy are five table reads.
-// The general forms above test every operand on its own and carry an inlined logarithm behind every test: eleven copies of it made
-// up half of the instructions of a row kernel (and a divergent branch each) for a path that a build of config 4 never takes.  Here ONE
-// test guards the table-only evaluation; whatever fails it goes through llr_candidate_slow, which evaluates the same expressions in the
-// same order with ONE copy of the logarithm (the table entries were produced by that very function: the value is bit-identical).
-__device__ __forceinline__ double llr_candidate_slow(double row_entropy, double xlx_n, long long k11, long long k12, long long k21, long long k22, long long cb, long long n_users) {
-  // columnEntropy = (xLogX(N) - xLogX(cB)) - xLogX(N - cB), matrixEntropy = (((xLogX(N) - xLogX(k11)) - xLogX(k12)) - xLogX(k21)) - xLogX(k22): two
-  // left-to-right chains from xLogX(N), walked by ONE rolled loop (one copy of the logarithm)
-  double acc = xlx_n, column_entropy = 0.0;
-#pragma unroll 1
-  for (int t = 0; t < 6; ++t) {
-    if (t == 2) {
-      column_entropy = acc;
-      acc = xlx_n;
-    }
-    const long long x = t == 0 ? cb : (t == 1 ? n_users - cb : (t == 2 ? k11 : (t == 3 ? k12 : (t == 4 ? k21 : k22))));
-    acc = acc - x_log_x(x);
-  }
-  const double s = row_entropy + column_entropy;
-  if (s < acc) return 0.0; /* round off error */
-  return 2.0 * (s - acc);
-}
-__device__ __forceinline__ double llr_candidate(double row_entropy, double xlx_n, long long k11, long long ca, long long cb, long long n_users,
-                                                const double* __restrict__ xlx_tab, const double* __restrict__ xlx_hi, const double* __restrict__ col_ent) {
-  const long long k12 = ca - k11, k21 = cb - k11, d22 = ca + cb - k11;  // k22 = n_users - d22
-  if (col_ent != nullptr && (unsigned long long)(k12 | cb | d22) < (unsigned long long)XLX_TABLE && d22 <= n_users) {  // (k11 <= cb, k21 <= cb)
-    const double matrix_entropy = (((xlx_n - xlx_tab[k11]) - xlx_tab[k12]) - xlx_tab[k21]) - xlx_hi[d22];
-    const double s = row_entropy + col_ent[cb];
-    if (s < matrix_entropy) return 0.0; /* round off error */
-    return 2.0 * (s - matrix_entropy);
-  }
-  return llr_candidate_slow(row_entropy, xlx_n, k11, k12, k21, n_users - d22, cb, n_users);
 }
 
 // LogLikelihood.logLikelihoodRatio with the row / column entropies supplied (they are per-item constants:

@@ -791,15 +791,32 @@ __global__ __launch_bounds__(SCAN_THREADS) void pl_blockmap_kernel(const long lo
   if (b == 0) blk_prefix[n_buckets] = (int32_t)tot;
 }
 
-// histogram blocks per AVERAGE bucket: a few thousand blocks in all, each with at least a handful of parts
-static inline int pl_splits(int n_buckets, int64_t n_parts) {
+// Environment knobs of the column counts.  The profiling-only ones are read ONCE per process (every launch called getenv
+// from several enqueueing threads); the two the test-suite toggles at run time -- URCCO_COLCOUNT_GLOBAL_LAYOUT and URCCO_PH_CHUNK_BIG_NNZ
+// -- stay per call, and column_counts_scratch_bytes sizes for whichever value the launch may later see (see there).
+struct PlKnobs {
+  long long block_ids = 49152;  // URCCO_PL_BLOCK_IDS: ids per average histogram block (0 = no such bound)
+  int debug = 0;                // URCCO_PL_DEBUG (profiling only): 1 = no LDS atomics, 2 = no loads (the counts are then meaningless)
+  int lanes = 8;                // URCCO_PL_LANES: lanes per slice (16, 8 or 4)
+  PlKnobs() {
+    if (const char* e = getenv("URCCO_PL_BLOCK_IDS")) if (*e) block_ids = atoll(e);
+    if (const char* e = getenv("URCCO_PL_DEBUG")) if (*e) debug = atoi(e);
+    if (const char* e = getenv("URCCO_PL_LANES")) if (*e) lanes = atoi(e);
+  }
+};
+static const PlKnobs& pl_knobs() {
+  static const PlKnobs k;
+  return k;
+}
+// histogram blocks per AVERAGE bucket: a few thousand blocks in all, each with at least a handful of parts; bounded = false: without the
+// bound by work (an upper bound of the split for any knob value: what the scratch is sized for)
+static inline int pl_splits(int n_buckets, int64_t n_parts, bool bounded = true) {
   int64_t S = (2048 + n_buckets - 1) / n_buckets;
   if (S > n_parts / 4) S = n_parts / 4;
   // ... and an average block should count a few ten thousand ids for the 64 KiB of LDS it clears and the 64 KiB of partial counters it
   // publishes (a rank's user shard at 8 ranks: 2200 blocks of ~20K ids each; the weight split keeps the hot buckets' blocks average too)
-  const char* e = getenv("URCCO_PL_BLOCK_IDS");  // A/B knob: ids per average histogram block (0 = no such bound)
-  const int64_t ids = e && *e ? atoll(e) : 49152;
-  if (ids > 0) {
+  const int64_t ids = pl_knobs().block_ids;
+  if (bounded && ids > 0) {
     const int64_t by_work = n_parts * PL_PART / ((int64_t)n_buckets * ids);
     if (S > by_work) S = by_work;
   }
@@ -807,26 +824,34 @@ static inline int pl_splits(int n_buckets, int64_t n_parts) {
   return (int)S;
 }
 static inline int64_t pl_max_blocks(int n_buckets, int S) { return ((int64_t)S + 1) * n_buckets; }
+static inline bool pl_fits(int32_t n_cols) { return (((int64_t)n_cols + PL_BUCKET - 1) >> PL_BITS) <= PL_MAX_BUCKETS; }
 static inline bool pl_applies(int32_t n_cols) {
-  const char* e = getenv("URCCO_COLCOUNT_GLOBAL_LAYOUT");  // A/B and test knob: the bucket-contiguous form above
+  const char* e = getenv("URCCO_COLCOUNT_GLOBAL_LAYOUT");  // A/B and test knob (per call): the bucket-contiguous form above
   if (e && *e == '1') return false;
-  return (((int64_t)n_cols + PL_BUCKET - 1) >> PL_BITS) <= PL_MAX_BUCKETS;
+  return pl_fits(n_cols);
 }
 
+// The larger of what the two layouts need (0 when neither applies): the layout and the chunk size are chosen per call from the environment,
+// and a value that changed between this call and the launch must not leave the launch with a buffer sized for the other form.
 int64_t column_counts_scratch_bytes(int64_t nnz, int32_t n_cols) {
   auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
-  if (nnz >= PH_MIN_NNZ && pl_applies(n_cols)) {
+  if (nnz < PH_MIN_NNZ) return 0;
+  int64_t need = 0;
+  if (pl_fits(n_cols)) {
     const int64_t n_buckets = ((int64_t)n_cols + PL_BUCKET - 1) >> PL_BITS;
     const int64_t n_parts = (nnz + PL_PART - 1) / PL_PART;
-    return al(n_parts * PL_PART * 2 + 64) + al((n_buckets + 1) * n_parts * 2) + al(n_buckets * 8) + al((n_buckets + 1) * 4) +
-           al(pl_max_blocks((int)n_buckets, pl_splits((int)n_buckets, n_parts)) * (int64_t)PL_BUCKET * 4);
+    need = al(n_parts * PL_PART * 2 + 64) + al((n_buckets + 1) * n_parts * 2) + al(n_buckets * 8) + al((n_buckets + 1) * 4) +
+           al(pl_max_blocks((int)n_buckets, pl_splits((int)n_buckets, n_parts, false)) * (int64_t)PL_BUCKET * 4);
   }
-  if (nnz < PH_MIN_NNZ || (((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS) > PH_MAX_BUCKETS) return 0;
-  const int64_t n_buckets = ((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS;
-  const int64_t n_parts = (nnz + PH_PART - 1) / PH_PART;
-  const int64_t m = n_buckets * n_parts;
-  const int64_t max_blocks = n_buckets + (nnz + ph_chunk(nnz) - 1) / ph_chunk(nnz);
-  return al(m * 4) + al((m + 1) * 8) + al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8) + al(nnz * 2 + 16) + al((n_buckets + 1) * 4) + al(max_blocks * PH_BUCKET * 2);
+  if ((((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS) <= PH_MAX_BUCKETS) {
+    const int64_t n_buckets = ((int64_t)n_cols + PH_BUCKET - 1) >> PH_BITS;
+    const int64_t n_parts = (nnz + PH_PART - 1) / PH_PART;
+    const int64_t m = n_buckets * n_parts;
+    const int64_t max_blocks = n_buckets + (nnz + PH_CHUNK_SMALL - 1) / PH_CHUNK_SMALL;  // (the smaller chunk: the larger block count)
+    const int64_t ph = al(m * 4) + al((m + 1) * 8) + al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8) + al(nnz * 2 + 16) + al((n_buckets + 1) * 4) + al(max_blocks * PH_BUCKET * 2);
+    if (ph > need) need = ph;
+  }
+  return need;
 }
 
 hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_idx, int64_t nnz, const int64_t* nnz_dev, int32_t n_cols,
@@ -848,9 +873,7 @@ hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_i
     const unsigned wsplit = (unsigned)(n_parts >= 8192 ? 8 : (n_parts >= 1024 ? 4 : 1));
     hipLaunchKernelGGL(pl_weights_kernel, dim3((unsigned)n_buckets, wsplit), dim3(256), 0, st, loc_t, n_parts, reinterpret_cast<unsigned long long*>(weight));
     hipLaunchKernelGGL(pl_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, weight, n_buckets, n_parts, S, blk_prefix);
-    const char* de = getenv("URCCO_PL_DEBUG");   // profiling only: 1 = no LDS atomics, 2 = no loads (the counts are then meaningless)
-    const char* le = getenv("URCCO_PL_LANES");   // A/B: lanes per slice (16, 8 or 4)
-    const int dbg = de && *de ? atoi(de) : 0, lps = le && *le ? atoi(le) : 8;
+    const int dbg = pl_knobs().debug, lps = pl_knobs().lanes;
     const dim3 hg((unsigned)pl_max_blocks(n_buckets, S)), hb(PLH_THREADS);
     if (lps == 4) hipLaunchKernelGGL((pl_hist_kernel<4>), hg, hb, 0, st, bucketed, loc_t, n_buckets, n_parts, blk_prefix, n_cols, partial, dbg);
     else if (lps == 8) hipLaunchKernelGGL((pl_hist_kernel<8>), hg, hb, 0, st, bucketed, loc_t, n_buckets, n_parts, blk_prefix, n_cols, partial, dbg);
@@ -941,9 +964,7 @@ __global__ __launch_bounds__(256) void tile_rows_kernel(int64_t n_rows, const in
 // `debug` (profiling only, results meaningless): 32 = cheap hash, 64 = no threshold gather, 128 = no row lookup
 constexpr int DS_RUN = 8;
 constexpr int DS_RUNS = DS_TILE / (DS_THREADS * DS_RUN);  // 2
-#ifndef URCCO_DS_WAVES
-#define URCCO_DS_WAVES 1  // minimum waves per SIMD the flags kernel is compiled for (A/B knob: 8 caps it at 64 VGPRs)
-#endif
+constexpr int URCCO_DS_WAVES = 1;  // minimum waves per SIMD the flags kernel is compiled for (A/B knob: 8 caps it at 64 VGPRs)
 template <bool DEBUG, bool RNG32>
 __global__ __launch_bounds__(DS_THREADS, URCCO_DS_WAVES) void downsample_flags_kernel(int64_t n_rows, const int64_t* __restrict__ rp,
                                                                       const int32_t* __restrict__ ci, int64_t nnz,
@@ -1900,12 +1921,8 @@ hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t it
 constexpr int E0 = 1024, E1S = 4096, E1 = 8192, E2S = 16384, E2 = 32768;  // LDS table words: wave / small block / block / half CU / CU
 constexpr int MP_KMAX = 256;  // largest k the multi-pass class keeps its running lists for (MP_KMAX_HOST in cco_kernels.h)
 
-#ifndef URCCO_WB1
-#define URCCO_WB1 512
-#endif
-#ifndef URCCO_WB2
-#define URCCO_WB2 8192
-#endif
+constexpr int URCCO_WB1 = 512;
+constexpr int URCCO_WB2 = 8192;
 __device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_cols_b, int32_t count_bits, int32_t k) {
   if (ca <= 0 || w <= 0) return -1;  // no users or no pairs: empty indicator row
   if (count_bits < 31 && ca > ((1ll << count_bits) - 1)) return NBINS - 1;
@@ -2100,30 +2117,17 @@ __device__ __forceinline__ bool best_before(unsigned long long ka, int ca, unsig
 // ~45 % of the VALU instructions of a typical one-wave row.  Equal keys are COMMON (an LLR is a function of four small integer
 // counts), so the column comparison cannot be left to a rare path (measured: a key-only loop with a second pass for lanes that
 // saw their key twice was 8 % slower than the plain loop).
-// The single-check LLR (llr_candidate, cco_device.h) per kernel family: A/B knobs, both OFF.  Negative result of round 5
-// (profiles/r05_llr_rank_variants_ab.log): it halves the static code of every row kernel (eleven inlined logarithms become one) and removes
-// four divergent branches per candidate, and it is SLOWER -- micro class 4.73 -> 4.88 ms, one-wave class 5.98 -> 6.30 ms on config 4: the
-// rolled general form behind the one check costs the 64-VGPR classes three to six vector registers spilled to scratch in the row loop,
-// and the branches it removes were never taken (skipping cold code is free; the instruction cache was not the limit).
-#ifndef URCCO_LLR_FAST_ROWS
-#define URCCO_LLR_FAST_ROWS 0
-#endif
-#ifndef URCCO_LLR_FAST_MICRO
-#define URCCO_LLR_FAST_MICRO 0
-#endif
-// The table-only evaluation of a candidate's LLR as a WAVE-level decision (round 5): llr_operands_in_tables is the single range test of
-// llr_candidate (cco_device.h); when it holds for every candidate of the wave, llr_from_tables issues the five table reads together --
-// the same five values in the same expression order as the general forms, bit for bit -- in straight-line code; otherwise the wave takes
-// the general form.  (The per-lane form of the single test was slower in round 5: its rolled logarithm shared the lanes' registers.)
-#ifndef URCCO_LLR_WAVE_FAST
-#define URCCO_LLR_WAVE_FAST 1  // micro class
-#endif
-#ifndef URCCO_LLR_WAVE_FAST_ROWS
-#define URCCO_LLR_WAVE_FAST_ROWS 1  // the LDS accumulator classes
-#endif
+// The table-only evaluation of a candidate's LLR as a WAVE-level decision (round 5).  After the interaction cut every operand of a
+// candidate's LLR is small -- k11, k12 = cA - k11, k21 = cB - k11, cB and N - k22 = cA + cB - k11 all sit below the table size -- so
+// columnEntropy and the four xLogX terms of matrixEntropy are five table reads.  llr_operands_in_tables is ONE range test over all of
+// them; when it holds for every candidate of the wave, llr_from_tables issues the five reads together -- the same five values in the
+// same expression order as the general form (llr_of), bit for bit -- in straight-line code; otherwise the wave takes the general form.
+// (A per-lane single-check form with one rolled logarithm behind it was slower: profiles/r05_llr_rank_variants_ab.log.)
+// k21 is part of the test: the context level guarantees k11 <= cB (post-sampling counts of the same B'), a caller of
+// urcco_dev_cco_rows with inconsistent counts_b does not -- cB - k11 would wrap and index ~32 GiB past the table.
 __device__ __forceinline__ bool llr_operands_in_tables(unsigned k11, long long ca, unsigned cb, long long n_users, const double* col_ent) {
-  const long long k12 = ca - (long long)k11, d22 = ca + (long long)cb - (long long)k11;  // k22 = n_users - d22; k11 <= cb, k21 <= cb
-  return col_ent != nullptr && (unsigned long long)(k12 | (long long)cb | d22) < (unsigned long long)XLX_TABLE && d22 <= n_users;
+  const long long k12 = ca - (long long)k11, k21 = (long long)cb - (long long)k11, d22 = ca + k21;  // k22 = n_users - d22
+  return col_ent != nullptr && (unsigned long long)(k12 | k21 | (long long)cb | d22) < (unsigned long long)XLX_TABLE && d22 <= n_users;
 }
 __device__ __forceinline__ double llr_from_tables(double row_entropy, double xlx_n, unsigned k11, unsigned ca, unsigned cb, const double* __restrict__ xlx_tab,
                                                   const double* __restrict__ xlx_hi, const double* __restrict__ col_ent) {
@@ -2136,10 +2140,9 @@ __device__ __forceinline__ double llr_from_tables(double row_entropy, double xlx
   if (s < matrix_entropy) return 0.0; /* round off error */
   return 2.0 * (s - matrix_entropy);
 }
-template <bool FAST>
+// the general form: every operand tested on its own, a logarithm behind every table miss (taken by the waves that hold a candidate outside the tables)
 __device__ __forceinline__ double llr_of(double row_entropy, double xlx_n, long long k11, long long ca, long long cb, long long n_users,
                                          const double* __restrict__ xlx_tab, const double* __restrict__ xlx_hi, const double* __restrict__ col_ent) {
-  if (FAST) return llr_candidate(row_entropy, xlx_n, k11, ca, cb, n_users, xlx_tab, xlx_hi, col_ent);
   return llr_from_entropies_tab(row_entropy, column_entropy_of(cb, xlx_n, n_users, xlx_tab, xlx_hi, col_ent), xlx_n, k11, ca - k11, cb - k11, n_users - ca - cb + k11, xlx_tab,
                                 n_users, xlx_hi);
 }
@@ -2150,11 +2153,8 @@ __device__ __forceinline__ double llr_of(double row_entropy, double xlx_n, long 
 // an s_and and an s_or per element, then the add-with-carry -- kept the CU's one scalar unit as busy as its four vector units: ~950 scalar
 // against ~1180 vector instructions per row of the one-wave class (profiles/r04_sq_counters_pmc_config4.json), half of them in these loops.
 // (__builtin_subc chains are taken apart into the same compares by the compiler: inline assembly it is.)
-#ifndef URCCO_RANK_ASM
-#define URCCO_RANK_ASM 1
-#endif
 __device__ __forceinline__ void count_if_before(unsigned& r, unsigned long long ka, unsigned ca, unsigned long long mk, unsigned mc) {
-#if defined(HIPSIM_HOST_BUILD) || !URCCO_RANK_ASM
+#ifdef HIPSIM_HOST_BUILD
   r += best_before(ka, (int)ca, mk, (int)mc) ? 1u : 0u;
 #else
   unsigned t;
@@ -2187,16 +2187,6 @@ __device__ __forceinline__ unsigned rank_by_counting(const unsigned long long* k
 // without finding the key or a free slot -- impossible while the binning rule holds (the table always has room for the
 // row's distinct columns); the bound keeps a broken invariant from turning into a hung GPU and is reported through
 // stats[1 + 4 * NBINS].
-// (the micro class keeps plain argument pointers: with pointers of their own it spilled five VECTOR registers to scratch and ran 3 % slower,
-// profiles/r05_sgpr_diet_variants_ab.log)
-#ifndef URCCO_OWN_PTRS_MICRO
-#define URCCO_OWN_PTRS_MICRO 0
-#endif
-#define URCCO_PLAIN_PTR(T, name, src) T* name = (src)
-#ifndef URCCO_TAB_INSERT_V2
-#define URCCO_TAB_INSERT_V2 1
-#endif
-#if URCCO_TAB_INSERT_V2
 __device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int count_bits, unsigned mask, int hshift, bool ident) {
   unsigned h = ident ? (key - 1u) : ((key * 0x9E3779B1u) >> hshift);
   const unsigned fresh = (key << count_bits) | 1u;
@@ -2216,25 +2206,6 @@ __device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int coun
   } while (!done && left != 0u);
   return done;
 }
-#else
-__device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int count_bits, unsigned mask, int hshift, bool ident) {
-  unsigned h = ident ? (key - 1u) : ((key * 0x9E3779B1u) >> hshift);
-  const unsigned fresh = (key << count_bits) | 1u;
-  bool ok = false;
-#pragma unroll 1
-  for (unsigned probe = 0; probe <= mask; ++probe) {
-    const unsigned v = atomicCAS(&tab[h], 0u, fresh);
-    if (v == 0u) { ok = true; break; }
-    if ((v >> count_bits) == key) {
-      atomicAdd(&tab[h], 1u);
-      ok = true;
-      break;
-    }
-    h = (h + 1u) & mask;
-  }
-  return ok;
-}
-#endif
 
 // tab_insert for the micro class: the lane whose CAS finds the slot EMPTY owns the new column, and is told which slot that is
 // (0xffffffff: the column was known, or -- impossible while the binning rule holds -- no slot was found: *ok false).
@@ -2452,57 +2423,19 @@ __device__ __forceinline__ unsigned team_exclusive_scan(unsigned v, unsigned* s_
 
 // candidates scored together per lane (their count gathers travel together), per class.  Round 3, config 4 (the count table no
 // longer fits an L2): two per lane -5 % on the one-wave and both 256-thread classes, +11 % on the half-CU class, +-0 on the CU class
-#ifndef URCCO_U_WAVE
-#define URCCO_U_WAVE 2
-#endif
-#ifndef URCCO_U_BS
-#define URCCO_U_BS 2
-#endif
-#ifndef URCCO_U_B
-#define URCCO_U_B 2
-#endif
-#ifndef URCCO_U_H
-#define URCCO_U_H 1
-#endif
-#ifndef URCCO_U_C
-#define URCCO_U_C 1
-#endif
-#ifndef URCCO_OCC_WAVE
-#define URCCO_OCC_WAVE 8  // blocks of four one-wave teams per CU the one-wave class is compiled for
-#endif
-#ifndef URCCO_OCC_BS
-#define URCCO_OCC_BS 7  // blocks per CU the 256-thread / 4Ki class is compiled for (8 = 64 registers: seven of them spill)
-#endif
-#ifndef URCCO_G_WAVE
-#define URCCO_G_WAVE 2
-#endif
-#ifndef URCCO_SEL_AMB_WAVE
-#define URCCO_SEL_AMB_WAVE 64
-#endif
-#ifndef URCCO_SEL_AMB_BLOCK
-#define URCCO_SEL_AMB_BLOCK 128
-#endif
-#ifndef URCCO_G_BLOCK
-#define URCCO_G_BLOCK 2
-#endif
-#ifndef URCCO_SEL_M_BLOCK
-#define URCCO_SEL_M_BLOCK 128  // capacity of the ambiguous set of the teams of several waves (>= URCCO_SEL_AMB_BLOCK)
-#endif
-#ifndef URCCO_MERGE_WAITS
-#define URCCO_MERGE_WAITS 0  // 1: the select goes on until the cut bin and what lies above it fit the set together (A/B knob)
-#endif
-#ifndef URCCO_MERGED_RANK
-#define URCCO_MERGED_RANK 1  // the cut bin and everything above it ranked ONCE (see the select's finish); 0: ambiguous set, then survivors
-#endif
-#ifndef URCCO_SKIP_SHARED_WAVE
-#define URCCO_SKIP_SHARED_WAVE 0  // 1: the one-wave class tracks the shared key bytes while it scores (A/B knob)
-#endif
-#ifndef URCCO_SWEEP_SHARED
-#define URCCO_SWEEP_SHARED 1  // classes other than the 256-thread ones find the key bytes all candidates share with a sweep before the select
-#endif
-#ifndef URCCO_G_CU
-#define URCCO_G_CU 2
-#endif
+constexpr int URCCO_U_WAVE = 2;
+constexpr int URCCO_U_BS = 2;
+constexpr int URCCO_U_B = 2;
+constexpr int URCCO_U_H = 1;
+constexpr int URCCO_U_C = 1;
+constexpr int URCCO_OCC_WAVE = 8;  // blocks of four one-wave teams per CU the one-wave class is compiled for
+constexpr int URCCO_OCC_BS = 7;  // blocks per CU the 256-thread / 4Ki class is compiled for (8 = 64 registers: seven of them spill)
+constexpr int URCCO_G_WAVE = 2;
+constexpr int URCCO_SEL_AMB_WAVE = 64;
+constexpr int URCCO_SEL_AMB_BLOCK = 128;
+constexpr int URCCO_G_BLOCK = 2;
+constexpr int URCCO_SEL_M_BLOCK = 128;  // capacity of the ambiguous set of the teams of several waves (>= URCCO_SEL_AMB_BLOCK)
+constexpr int URCCO_G_CU = 2;
 // MP ("multi-pass", bin 6): rows no single LDS table can hold -- a hot item of a skewed catalogue pairs with tens of thousands
 // of distinct columns -- or whose counts overflow the packed field.  Such a row is accumulated in P = 2^s passes over its
 // cooccurrence pairs: pass q keeps the columns with (col mod P) == q, keyed by col div P (so the key narrows by s bits and the
@@ -2570,7 +2503,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   // exponent bits: typically the whole first pass).  Measured on config 3: -7..9 % for the 256-thread classes, but the
   // extra live registers cost the one-wave class +4 % (spills at its 80-VGPR cap) and the 512/1024-thread classes
   // +0..4 %, so only T == 256 tracks the shared bytes.
-  constexpr bool SKIP_SHARED = T == 256 || (T == WAVE && URCCO_SKIP_SHARED_WAVE != 0);
+  constexpr bool SKIP_SHARED = T == 256;
   __shared__ unsigned long long s_kbits[2 * NW];  // per wave: AND / OR over its valid keys
   __shared__ unsigned s_mpflag;                    // MP: a pass overflowed its table
   __shared__ unsigned long long s_runk[MP ? 2 * MP_KMAX : 1];  // MP: the row's running top k (two buffers: a merge reads one, writes the other)
@@ -2824,12 +2757,10 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
         }
         // every operand of these U candidates of every lane inside the tables: the wave takes the straight-line table form (see llr_from_tables)
         bool in_tables = true;
-        if (URCCO_LLR_WAVE_FAST_ROWS) {
 #pragma unroll
-          for (int x = 0; x < U; ++x)
-            if (vv[x] != 0u) in_tables = in_tables && llr_operands_in_tables(vv[x] & cmask, ca, (unsigned)cbj[x], n_users, col_ent);
-        }
-        const bool all_in_tables = URCCO_LLR_WAVE_FAST_ROWS && !(dbg & 2) && __ballot(!in_tables) == 0ull;  // wave-uniform
+        for (int x = 0; x < U; ++x)
+          if (vv[x] != 0u) in_tables = in_tables && llr_operands_in_tables(vv[x] & cmask, ca, (unsigned)cbj[x], n_users, col_ent);
+        const bool all_in_tables = !(dbg & 2) && __ballot(!in_tables) == 0ull;  // wave-uniform
 #pragma unroll
         for (int x = 0; x < U; ++x) {
           const unsigned t = t0 + (unsigned)x * T;
@@ -2840,7 +2771,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             if (!(a.exclude_self && j == i)) {
               const double llr = all_in_tables ? llr_from_tables(row_entropy, xlx_n, (unsigned)k11, (unsigned)ca, (unsigned)cbj[x], xlx_tab, xlx_hi, col_ent)
                                                : ((dbg & 2) ? (double)k11
-                                                            : llr_of<URCCO_LLR_FAST_ROWS != 0>(row_entropy, xlx_n, k11, ca, (long long)cbj[x], n_users, xlx_tab, xlx_hi, col_ent));
+                                                            : llr_of(row_entropy, xlx_n, k11, ca, (long long)cbj[x], n_users, xlx_tab, xlx_hi, col_ent));
               if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) key = (unsigned long long)__double_as_longlong(llr);
             }
             kk[t] = key;
@@ -2891,7 +2822,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
         unsigned need = (unsigned)a.k;
         if (a.col_bytes < 4) thr_ncol = 0xffffffffu << (8 * a.col_bytes);  // digits of ~col above the highest used byte are all ones
         int p0 = 0;  // first key byte that differs between candidates
-        if (!SKIP_SHARED && URCCO_SWEEP_SHARED) {
+        if (!SKIP_SHARED) {
           // The classes that do not track the shared key bytes while they score (registers) find them here, with one cheap sweep over
           // the keys (an AND and an OR per key, no histogram, no atomics): the LLRs of a row share their sign / exponent byte, so the
           // select's first pass -- a full histogram sweep plus a digit search -- found one bin holding everything and was wasted.
@@ -2914,7 +2845,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             team_sync<T>();
           }
         }
-        if (SKIP_SHARED || URCCO_SWEEP_SHARED) {
+        {
           if (T != WAVE) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) {
@@ -3022,8 +2953,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             if (NH == 1) team_sync<T>();  // the histogram just cleared is the next pass's target
             ++q;
           }
-          if (prev_cnt <= (unsigned)SEL_AMB &&
-              (!URCCO_MERGE_WAITS || MP || a.unordered || (dbg & 16) || ((unsigned)a.k - need) + prev_cnt <= (unsigned)SEL_M || p == 11)) {  // team-uniform
+          if (prev_cnt <= (unsigned)SEL_AMB) {  // team-uniform
             // finish: copy out the members of the cut bin (they match the prefix through digit p) ...
             // In the SHARE layout amb_key / amb_col OVERLAY the three rotating histograms.  Every wave has run the digit search above for
             // itself, at its own pace: a wave that arrives here first must not write the ambiguous set over histogram words a sibling has
@@ -3037,7 +2967,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             // the best k of that ranking ARE the row, in output order.  (Before: the bin's members ranked among themselves for the exact threshold,
             // a sweep for the survivors, the survivors ranked again: two sweeps and two rankings, at four vector instructions per compared element,
             // in classes that are bound by vector issue.)  The sweep then covers every candidate: what lies above the bin is not in the index list.
-            const bool merged = URCCO_MERGED_RANK != 0 && !MP && !a.unordered && !(dbg & 16) && ((unsigned)a.k - need) + prev_cnt <= (unsigned)SEL_M;  // team-uniform
+            const bool merged = !MP && !a.unordered && !(dbg & 16) && ((unsigned)a.k - need) + prev_cnt <= (unsigned)SEL_M;  // team-uniform
             const unsigned n_scan2 = (have_list && !merged) ? list_n : D;
             unsigned amb_n = 0u;  // (one-wave teams: the length of the set)
             for (unsigned base = 0; base < n_scan2; base += T) {  // scalar loop control, no divergent exits: claim_positions is a wave operation
@@ -3233,64 +3163,37 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
 // Micro rows (bin 0): <= 64 users and <= 64 cooccurrence pairs -- more than half of all item rows under a Zipf
 // catalogue.  One wave per row, one pair per lane, a 256-word accumulator, compaction by ballots, at most one
 // candidate per lane ranked by counting: no scans, no chunk loop, no selection passes, few registers (8 waves/SIMD).
-// Team LDS layout (words): [0,256) accumulator, [256,320) packed candidates, [320,448) their 64-bit keys.
 // --------------------------------------------------------------------------------------------
-constexpr int MICRO_WORDS = 448;
 constexpr int MICRO2_WORDS = 528;
-// Round 5, second form of the row body (URCCO_MICRO_V2): the class is bound by vector-instruction issue (~350 per row, 76 % of the issue
+// The row body (round 5; the rounds 1-4 form -- binary search per pair, compaction sweep, one ranking replica -- is
+// profiles/r05_micro_v2_wave_llr_ab.log's "v1"): the class is bound by vector-instruction issue (~350 per row, 76 % of the issue
 // slots of config 4's launches), so the row body was rebuilt around instruction count:
 //  * a pair finds its user by a mark + prefix maximum (one LDS atomic, one LDS read, six DPP steps, two lane gathers) instead of a
 //    seven-step binary search over LDS;
 //  * the lane whose insert CLAIMS a column owns the candidate: it reads the finished count from its own slot, clears the slot (the
 //    accumulator is zero between rows without a zeroing pass) and scores it -- no compaction sweep over the 256 slots;
 //  * rows of <= 32 (<= 16) candidates are ranked by two (four) replicas of the candidates that each count every second (fourth) element.
-#ifndef URCCO_MICRO_V2
-#define URCCO_MICRO_V2 1
-#endif
-#ifndef URCCO_MICRO_REPLICAS
-#define URCCO_MICRO_REPLICAS 1  // 0: every row ranked by one replica (A/B knob)
-#endif
 
-#ifndef URCCO_OCC_MICRO
-#define URCCO_OCC_MICRO 8  // blocks of four one-wave teams per CU the micro class is compiled for (A/B knob)
-#endif
+constexpr int URCCO_OCC_MICRO = 8;  // blocks of four one-wave teams per CU the micro class is compiled for (A/B knob)
 template <bool DBG>
 __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(CcoArgs a) {
   const int dbg = DBG ? a.debug : 0;
-  // every argument the row loop touches in scalar registers of its own (URCCO_OWN_GLOBAL_PTR: the arguments arrive as 16-dword tuples that
-  // spill and reload whole; rounds 1-4 noted "the kernel argument block alone keeps ~60 SGPRs live")
-#if URCCO_OWN_PTRS_MICRO
-  URCCO_OWN_GLOBAL_PTR(const int32_t, bin_rows, a.bin_rows);
-  URCCO_OWN_GLOBAL_PTR(const int64_t, a_col_ptr, a.a_col_ptr);
-  URCCO_OWN_GLOBAL_PTR(const int64_t, pstart, a.pstart);
-  URCCO_OWN_GLOBAL_PTR(const int32_t, b_col_idx, a.b_col_idx);
-  URCCO_OWN_GLOBAL_PTR(const int32_t, cnt_a, a.cnt_a);
-  URCCO_OWN_GLOBAL_PTR(const double, ent_a, a.ent_a);
-  URCCO_OWN_GLOBAL_PTR(const double, xlx_tab, a.xlx_tab);
-  URCCO_OWN_GLOBAL_PTR(const double, xlx_hi, a.xlx_hi);
-  URCCO_OWN_GLOBAL_PTR(const double, col_ent, a.col_ent);
-  URCCO_OWN_GLOBAL_PTR(int32_t, out_idx, a.out_idx);
-  URCCO_OWN_GLOBAL_PTR(double, out_llr, a.out_llr);
-  URCCO_OWN_GLOBAL_PTR(int32_t, out_count, a.out_count);
+  // (plain argument pointers here: with scalar registers of their own -- URCCO_OWN_GLOBAL_PTR, as in cco_rows_kernel -- this class spilled five
+  // VECTOR registers to scratch and ran 3 % slower, profiles/r05_sgpr_diet_variants_ab.log)
+  const int32_t* bin_rows = a.bin_rows;
+  const int64_t* a_col_ptr = a.a_col_ptr;
+  const int64_t* pstart = a.pstart;
+  const int32_t* b_col_idx = a.b_col_idx;
+  const int32_t* cnt_a = a.cnt_a;
+  const double* ent_a = a.ent_a;
+  const double* xlx_tab = a.xlx_tab;
+  const double* xlx_hi = a.xlx_hi;
+  const double* col_ent = a.col_ent;
+  int32_t* out_idx = a.out_idx;
+  double* out_llr = a.out_llr;
+  int32_t* out_count = a.out_count;
   long long n_users = a.n_users;
-  URCCO_OWN_SGPRS(n_users);
-#else
-  URCCO_PLAIN_PTR(const int32_t, bin_rows, a.bin_rows);
-  URCCO_PLAIN_PTR(const int64_t, a_col_ptr, a.a_col_ptr);
-  URCCO_PLAIN_PTR(const int64_t, pstart, a.pstart);
-  URCCO_PLAIN_PTR(const int32_t, b_col_idx, a.b_col_idx);
-  URCCO_PLAIN_PTR(const int32_t, cnt_a, a.cnt_a);
-  URCCO_PLAIN_PTR(const double, ent_a, a.ent_a);
-  URCCO_PLAIN_PTR(const double, xlx_tab, a.xlx_tab);
-  URCCO_PLAIN_PTR(const double, xlx_hi, a.xlx_hi);
-  URCCO_PLAIN_PTR(const double, col_ent, a.col_ent);
-  URCCO_PLAIN_PTR(int32_t, out_idx, a.out_idx);
-  URCCO_PLAIN_PTR(double, out_llr, a.out_llr);
-  URCCO_PLAIN_PTR(int32_t, out_count, a.out_count);
-  long long n_users = a.n_users;
-#endif
   constexpr int TEAMS = 256 / WAVE;
-#if URCCO_MICRO_V2
   // Team LDS layout (words): [0,256) accumulator (zero between rows), [256,324) candidate columns, [324,460) their 64-bit keys (both with
   // room for three padding elements), [460,526) the pair -> user marks.
   __shared__ __attribute__((aligned(16))) unsigned s_tab[TEAMS * MICRO2_WORDS];
@@ -3300,20 +3203,6 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
   unsigned* cand = tab + 256;
   unsigned long long* kkm = reinterpret_cast<unsigned long long*>(tab + 324);
   unsigned* marks = tab + 460;
-#else
-  __shared__ unsigned s_tab[TEAMS * MICRO_WORDS];
-  __shared__ long long s_ustart[TEAMS * WAVE];
-  __shared__ unsigned s_uoff[TEAMS * (WAVE + 1)];
-  // (moving the row id, bounds and counts to scalar registers as in cco_rows_kernel was measured 12 % SLOWER here: the kernel
-  // argument block alone keeps ~60 SGPRs live and the extra scalars spill to VGPR lanes)
-  const int team = threadIdx.x / WAVE;
-  const int lane = threadIdx.x & (WAVE - 1);
-  unsigned* tab = s_tab + team * MICRO_WORDS;
-  unsigned* cand = tab + 256;
-  unsigned long long* kkm = reinterpret_cast<unsigned long long*>(tab + 320);
-  long long* ustart = s_ustart + team * WAVE;
-  unsigned* uoff = s_uoff + team * (WAVE + 1);
-#endif
   const int list_start = a.bin_off[0];
   const int list_n = a.bin_off[1] - list_start;
   const int total_teams = gridDim.x * TEAMS;
@@ -3322,9 +3211,6 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
   const unsigned cmask = (1u << cb) - 1u;
   const double xlx_n = *a.xlx_n;
   const bool use16 = *a.cnt16_bad == 0;
-#if !URCCO_MICRO_V2
-  const unsigned long long lt = (1ull << lane) - 1ull;
-#endif
   unsigned long long cand_acc = 0ull;  // candidates scored by this wave (statistics)
 
   int li = blockIdx.x * TEAMS + team;
@@ -3366,10 +3252,8 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
   // for everything in flight on every pass)
   URCCO_SETTLE(pf_w1); URCCO_SETTLE(pf_wp); URCCO_SETTLE(pf_start); URCCO_SETTLE(pf_ca); URCCO_SETTLE(pf_ent);
   URCCO_SETTLE(cs1); URCCO_SETTLE(ce1); URCCO_SETTLE(i_n2);
-#if URCCO_MICRO_V2
 #pragma unroll
   for (int q = 0; q < 4; ++q) tab[lane + q * WAVE] = 0u;  // the accumulator: zero between rows (a candidate's owner clears its slot)
-#endif
   for (; li < list_n; li += stride) {  // each wave runs its own row loop: wave-level sync only
     const int i = i_cur;
     // this row's operands leave their registers ...
@@ -3392,7 +3276,6 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
       pf_ca = cnt_a[i_n1];
       pf_ent = ent_a[i_n1];
     }
-#if URCCO_MICRO_V2
     // ---- pair -> user: user u marks the first pair of its B' row with u (the LAST user of an offset is the one whose row is not
     // empty); a pair's user is the largest mark at or below it
     marks[lane] = 0u;
@@ -3438,7 +3321,7 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
     }
     // Every operand of every candidate inside the tables (always, once the interaction cut has capped the counts): the wave takes the
     // straight-line form -- five table reads in flight together, no logarithm behind a divergent branch.  Wave-uniform test.
-    const bool all_in_tables = URCCO_LLR_WAVE_FAST && !(dbg & 2) && __ballot(is_cand && !in_tables) == 0ull;
+    const bool all_in_tables = !(dbg & 2) && __ballot(is_cand && !in_tables) == 0ull;
     if (is_cand) {
       const int j = (int)(vv >> cb) - 1;
       const long long k11 = (long long)(vv & cmask);
@@ -3446,7 +3329,7 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
         const unsigned cbj = (dbg & 512) ? 100u : (use16 ? ((j & 1) ? cb_raw >> 16 : cb_raw & 0xffffu) : cb_raw);
         const double llr = all_in_tables ? llr_from_tables(row_entropy, xlx_n, (unsigned)k11, (unsigned)ca, cbj, xlx_tab, xlx_hi, col_ent)
                                          : ((dbg & 2) ? (double)k11
-                                                      : llr_of<URCCO_LLR_FAST_MICRO != 0>(row_entropy, xlx_n, k11, ca, (long long)cbj, n_users, xlx_tab, xlx_hi, col_ent));
+                                                      : llr_of(row_entropy, xlx_n, k11, ca, (long long)cbj, n_users, xlx_tab, xlx_hi, col_ent));
         if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) mk = (unsigned long long)__double_as_longlong(llr);
       }
       const unsigned pos = lanes_below(cand_mask);
@@ -3477,14 +3360,14 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
       unsigned rc;
       unsigned ln = (unsigned)lane;
       URCCO_OPAQUE(ln);  // the per-lane LDS addresses of the three forms are computed here, not kept across the row loop
-      if (URCCO_MICRO_REPLICAS && D <= 16u) {  // wave-uniform
+      if (D <= 16u) {  // wave-uniform
         const unsigned c = ln & 15u;
         rk = kkm[c];
         rc = cand[c];
         rank = rank_by_counting_strided<4>(kkm, cand, ln >> 4, (D + 3u) & ~3u, rk, rc);
         rank += (unsigned)__shfl_xor((int)rank, 16);
         rank += (unsigned)__shfl_xor((int)rank, 32);
-      } else if (URCCO_MICRO_REPLICAS && D <= 32u) {
+      } else if (D <= 32u) {
         const unsigned c = ln & 31u;
         rk = kkm[c];
         rc = cand[c];
@@ -3512,99 +3395,6 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
     } else {
       settle_prefetch();
     }
-#else
-#pragma unroll
-    for (int q = 0; q < 4; ++q) tab[lane + q * WAVE] = 0u;
-    ustart[lane] = my_start;
-    uoff[lane] = my_off;
-    if (lane == 0) uoff[WAVE] = total;
-    wave_sync();
-    if ((unsigned)lane < total) {
-      int lo = 1, hi = WAVE;  // first idx in [1, 64] with uoff[idx] > lane
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (uoff[mid] > (unsigned)lane) hi = mid; else lo = mid + 1;
-      }
-      const int o = lo - 1;
-      const unsigned jj = (unsigned)b_col_idx[ustart[o] + ((unsigned)lane - uoff[o])];
-      if (!(dbg & 1) && !tab_insert(tab, jj + 1u, cb, 255u, 24, ident)) atomicAdd(a.err, 1ull);
-    }
-    wave_sync();
-    unsigned D = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const unsigned v = tab[lane + q * WAVE];
-      const unsigned long long m = __ballot(v != 0u);
-      if (v != 0u) cand[D + lanes_below(m)] = v;
-      D += (unsigned)__popcll(m);
-    }
-    cand_acc += D;
-    wave_sync();
-    unsigned long long mk = 0ull;
-    int mc = 0x7fffffff;
-    const bool is_cand = (unsigned)lane < D;
-    unsigned vv = 0u, cb_raw = 0u;
-    if (is_cand) {  // the count gather is issued -- ONE 4-byte load whichever width the counts have (two alternative loads meet in a
-                    // copy, and a copy next to a load is a wait) -- and nothing reads it before the block below
-      vv = cand[lane];
-      const int j = (int)(vv >> cb) - 1;
-      cb_raw = cnt_words[use16 ? j >> 1 : j];
-    }
-    if (is_cand) {
-      const int j = (int)(vv >> cb) - 1;
-      const long long k11 = (long long)(vv & cmask);
-      if (!(a.exclude_self && j == i)) {
-        const long long cbj = (dbg & 512) ? 100ll : (long long)(use16 ? ((j & 1) ? cb_raw >> 16 : cb_raw & 0xffffu) : cb_raw);
-        const double llr = (dbg & 2) ? (double)k11
-                                         : llr_of<URCCO_LLR_FAST_MICRO != 0>(row_entropy, xlx_n, k11, ca, cbj, n_users, xlx_tab, xlx_hi, col_ent);
-        if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) {
-          mk = (unsigned long long)__double_as_longlong(llr);
-          mc = j;
-        }
-      }
-      kkm[lane] = mk;
-      cand[lane] = (unsigned)j;  // the packed word has been consumed: the slot now holds the COLUMN, which is all the ranking loop reads of it (a shift and a
-                                 // subtraction per compared element and lane less: every lane was unpacking the same word)
-    }
-    wave_sync();
-    const unsigned long long valid_mask = __ballot(mk != 0ull);
-    const int n_valid = __popcll(valid_mask);
-    auto settle_prefetch = [&]() {  // the next row's operands have had the score phase to arrive: collect them before the output stores
-      URCCO_SETTLE(pf_w1); URCCO_SETTLE(pf_wp); URCCO_SETTLE(pf_start); URCCO_SETTLE(pf_ca); URCCO_SETTLE(pf_ent);
-      URCCO_SETTLE(cs2); URCCO_SETTLE(ce2); URCCO_SETTLE(i_n3);
-    };
-    if (a.unordered && n_valid <= a.k && !(dbg & 4)) {  // every candidate is emitted: no ranking needed (wave-uniform)
-      const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
-      settle_prefetch();
-      if (mk != 0ull) {
-        const int pos = __popcll(valid_mask & lt);
-        out_idx[obase + pos] = mc;
-        out_llr[obase + pos] = __longlong_as_double((long long)mk);
-      }
-      if (lane == 0) out_count[i - a.item_lo] = n_valid;
-    } else if (!(dbg & 4)) {
-      const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
-      const unsigned rank = mk == 0ull ? 0u : rank_by_counting(kkm, D, mk, mc, [&](unsigned u) { return (int)cand[u]; });  // broadcast LDS reads
-      // the row is put in order in LDS (the accumulator words are free again) and leaves as contiguous stores
-      wave_sync();
-      unsigned* srt_col = tab;                                                    // [64]
-      unsigned long long* srt_key = reinterpret_cast<unsigned long long*>(tab + 64);  // [64]
-      const unsigned n_out = (unsigned)(n_valid < a.k ? n_valid : a.k);
-      if (mk != 0ull && rank < n_out) {
-        srt_col[rank] = (unsigned)mc;
-        srt_key[rank] = mk;
-      }
-      wave_sync();
-      settle_prefetch();
-      if ((unsigned)lane < n_out) {
-        out_idx[obase + lane] = (int)srt_col[lane];
-        out_llr[obase + lane] = __longlong_as_double((long long)srt_key[lane]);
-      }
-      if (lane == 0) out_count[i - a.item_lo] = (int)n_out;
-    } else {
-      settle_prefetch();
-    }
-#endif
     i_cur = i_n1;
     i_n1 = i_n2;
     i_n2 = i_n3;

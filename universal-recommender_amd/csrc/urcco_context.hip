@@ -732,6 +732,11 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
     if (st == URCCO_OK && threaded && gate && gate->after_chain) st = gate->after_chain(0);
   }
   for (std::thread& t : workers) t.join();
+  // A worker's failure first, with the WORKER's message (it lives in that thread's error buffer): with the folded expand pass the main thread
+  // takes its status from expanded_f -- a secondary's sampling error arrives here as a bare code, and returning it at once left
+  // urcco_last_error() empty or stale for the real failure.
+  for (int d = 1; d < n_ds; ++d)
+    if (status[(size_t)d] != URCCO_OK && !message[(size_t)d].empty()) return fail(status[(size_t)d], "%s", message[(size_t)d].c_str());
   if (st != URCCO_OK) return st;
   if (!threaded) {
     // ONE thread enqueues everything: a download (two blocking stream waits) between two chains would turn the build into chain, D2H, chain, D2H ...
@@ -1949,7 +1954,7 @@ int urcco_cross_occurrence_stage(const urcco_dataset* datasets, int32_t n_datase
     const char* we = getenv("URCCO_STAGE_WAIT_S");
     const long wait_s = we && *we ? atol(we) : 600;
     if (!g_default_cv.wait_for(g, std::chrono::seconds(wait_s > 0 ? wait_s : 1), [] { return !g_default_busy; }))
-      return fail(URCCO_INTERNAL, "urcco_cross_occurrence_stage: another thread's staged build was not finished within %ld s (urcco_cross_occurrence_cancel discards it)", wait_s);
+      return fail(URCCO_BUSY, "urcco_cross_occurrence_stage: another thread's staged build was not finished within %ld s (its owner finishes or cancels it; urcco_cross_occurrence_cancel_any discards it for an owner that is gone)", wait_s);
     urcco_context* c = nullptr;
     URC(default_context(options, &c));
     const int st = urcco_context_stage(c, datasets, n_datasets, random_seed);
@@ -1985,16 +1990,22 @@ int urcco_cross_occurrence_finish(urcco_indicators* out, int32_t n_datasets, urc
   });
 }
 
-int urcco_cross_occurrence_cancel(void) {
+static int cancel_staged(bool any) {
   return guarded([&]() -> int {
     err_buf()[0] = 0;
     std::lock_guard<std::mutex> g(g_default_mu);
+    // ownership: only the thread that staged may discard with _cancel -- e.g. a thread whose own _stage just timed out would
+    // otherwise throw away the owner's build, and the owner's _finish would fail with "nothing staged"
+    if (!any && g_default_busy && g_default_owner != std::this_thread::get_id())
+      return fail(URCCO_BUSY, "urcco_cross_occurrence_cancel: the staged build belongs to another thread (urcco_cross_occurrence_cancel_any discards it regardless)");
     if (g_default_ctx && g_default_ctx->pending) discard_pending(g_default_ctx);
     g_default_busy = false;
     g_default_cv.notify_all();
     return URCCO_OK;
   });
 }
+int urcco_cross_occurrence_cancel(void) { return cancel_staged(false); }
+int urcco_cross_occurrence_cancel_any(void) { return cancel_staged(true); }
 
 int urcco_cross_occurrence_downsampled(const urcco_dataset* datasets, int32_t n_datasets, int32_t random_seed, const urcco_options* options,
                                        urcco_indicators* out, urcco_dataset_stats* stats) {

@@ -89,7 +89,7 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
 int partition_dev(urcco_session* s, int32_t n_items, const int64_t* work, int32_t n_parts, int32_t* bounds_dev, int32_t** bounds_out);
 int expand_multi(urcco_session* s, int n, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx, int64_t cap, const int64_t* const* b_row_ptr,
                  int64_t n_users, int64_t* const* pstart, int32_t* const* plen, int64_t* const* tile_sums = nullptr /* [d]: expand_tile_words(cap) words */);
-inline size_t expand_tile_words(int64_t cap) { return (size_t)((cap + 2047) / 2048 + 2); }  // (2048 = cco_kernels.hip's SCAN_TILE)
+inline size_t expand_tile_words(int64_t cap) { return (size_t)((cap + urcco::SCAN_TILE - 1) / urcco::SCAN_TILE + 2); }
 }  // namespace urcco_detail
 
 using namespace urcco_detail;
