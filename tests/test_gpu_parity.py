@@ -35,6 +35,15 @@ def test_logic_case_on_gpu(case, gpu_session):
     case(gpu_session)
 
 
+@pytest.mark.parametrize("case", [logic.test_large_transpose_long_rows_and_empty_parts, logic.test_large_transpose_skewed_ids_heavy_bucket], ids=lambda f: f.__name__)
+def test_transposition_edge_case_on_gpu(case, gpu_session):
+    case(gpu_session)
+
+
+def test_transposition_empty_row_runs_on_gpu(gpu_session):
+    logic.test_large_transpose_long_runs_of_empty_rows(gpu_session)
+
+
 @pytest.mark.parametrize("wire", ["u16", "i32"])
 def test_merge_of_csc_fragments_on_gpu(gpu_session, wire):
     logic.test_merge_of_csc_fragments(gpu_session, wire)

@@ -298,13 +298,13 @@ def test_large_transpose_with_item_range(sim_session):
 
 
 def test_large_transpose_long_rows_and_empty_parts(sim_session):
-    """The two-level transposition's part table: rows longer than a part's quota (parts behind them are empty), a row beyond
-    the LDS staging capacity (that part scatters unstaged), runs of empty rows, a ragged last part; every column compared."""
+    """The two-level transposition's parts (flat runs of 16384 entries since round 6): rows longer than a part (several parts inside one row),
+    runs of empty rows, a ragged last part; every column compared."""
     rng = np.random.default_rng(14)
     lengths = rng.poisson(19, 70000)
     lengths[rng.random(70000) < 0.2] = 0
-    lengths[100] = 25_000          # > TR_CAP: unstaged scatter
-    lengths[101] = 17_000          # > TR_PART but staged
+    lengths[100] = 25_000          # a row over more than one part
+    lengths[101] = 17_000
     lengths[40_000:40_300] = 0
     lengths[69_999] = 20_000       # the last part ends in a long row
     m = _csr_from_lengths(rng, lengths, 50_000)
@@ -314,6 +314,33 @@ def test_large_transpose_long_rows_and_empty_parts(sim_session):
     counts = guarded(torch.from_numpy(O.column_counts(m)).to(dev))
     cp_ref, ri_ref = O.transpose(m)
     for lo, hi in [(0, m.n_cols), (123, 45_678)]:
+        cp, ri = sim_session.transpose(d, counts, lo, hi)
+        sim_session.synchronize()
+        cp, ri = cp.cpu().numpy(), ri.cpu().numpy()
+        expect = np.diff(cp_ref).copy()
+        expect[:lo] = 0
+        expect[hi:] = 0
+        assert np.array_equal(np.diff(cp), expect)
+        for j in range(lo, hi):
+            assert np.array_equal(np.sort(ri[cp[j]:cp[j + 1]]), ri_ref[cp_ref[j]:cp_ref[j + 1]]), j
+
+
+def test_large_transpose_long_runs_of_empty_rows(sim_session):
+    """Round 6's part-local transposition finds an entry's row from 16-bit marks of the part's row starts; a part whose row slice holds more
+    than 65536 rows (a long run of users without a single kept interaction) takes the binary-search form instead.  Every column compared."""
+    rng = np.random.default_rng(16)
+    lengths = rng.poisson(11, 200_000)
+    lengths[50_000:120_100] = 0          # 70 100 empty rows inside one part
+    lengths[120_100] = 3
+    lengths[0] = 0
+    lengths[199_990:] = 0                # empty rows behind the last entry
+    m = _csr_from_lengths(rng, lengths, 40_000)
+    assert m.nnz >= (1 << 20)
+    dev = sim_session.device
+    d = to_dev(m, dev)
+    counts = guarded(torch.from_numpy(O.column_counts(m)).to(dev))
+    cp_ref, ri_ref = O.transpose(m)
+    for lo, hi in [(0, m.n_cols), (1000, 39_000)]:
         cp, ri = sim_session.transpose(d, counts, lo, hi)
         sim_session.synchronize()
         cp, ri = cp.cpu().numpy(), ri.cpu().numpy()

@@ -91,11 +91,10 @@ hipError_t launch_downsample_compact(hipStream_t st, int64_t n_rows, const int64
 hipError_t launch_scan_i32_range(hipStream_t st, const int32_t* in, int64_t n, int32_t lo, int32_t hi, int64_t* out, int64_t* tile_sums);
 hipError_t launch_transpose(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int g_log2,
                             const int64_t* col_ptr, int32_t* cursor, int32_t* out_row_idx, int32_t col_lo, int32_t col_hi);
-// counting-sort variant for large matrices: returns 0 scratch bytes when the cursor-atomic kernel should be used
+// two-level counting sort for large matrices (part-local partition + placement): returns 0 scratch bytes when the cursor-atomic kernel should be used
 int64_t transpose_scratch_bytes(int64_t n_rows, int64_t nnz, int32_t n_cols);
-hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int g_log2,
-                                        int32_t n_cols, const int64_t* col_ptr, int32_t* cursor /* [n_cols] zero */, int32_t* out_row_idx, int32_t col_lo, int32_t col_hi,
-                                        char* scratch);
+hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
+                                        const int64_t* col_ptr, int32_t* cursor /* [n_cols] zero */, int32_t* out_row_idx, int32_t col_lo, int32_t col_hi, char* scratch);
 hipError_t launch_row_work_csr(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* a_row_ptr, const int32_t* a_col_idx,
                                const int64_t* b_row_ptr, int g_log2, int32_t n_items_a, int64_t* work);
 

@@ -1333,31 +1333,10 @@ hipError_t launch_transpose(hipStream_t st, int n_cu, int64_t n_rows, const int6
   return hipGetLastError();
 }
 
-// --------------------------------------------------------------------------------------------
-// K3b  CSR -> CSC as a two-level counting sort by column (matrices large enough to repay the launches).
-// The cursor-atomic kernel above takes one RETURNING L2 atomic per entry (~25 G/s on this part).  Here:
-//   parts    row-aligned runs of ~TR_PART consecutive entries (part p starts at the first row at or behind entry p * TR_PART)
-//   count    per part: entries per column bucket (LDS atomics, lane-private copies)        scan   bucket-major offsets
-//   scatter  per part: (column in bucket, row) pairs grouped by bucket IN LDS, then written as whole runs -- with 245 buckets
-//            and 512-row parts the round-2 kernel scattered ~8-entry runs of 2- and 4-byte stores: 140 GB/s on config 4
-//   place    ONE block per bucket: the bucket's column cursors live in LDS (<= 8192 columns), its entries stream through once;
-//            the scattered 4-byte stores stay inside the bucket's CSC segment (a few hundred KB written by one CU: the L2 merges
-//            them) -- no per-chunk histograms, no prefix pass (round 2: blockmap + hist + prefix + place, 2 x 48 MB of partials)
-// The bucket width adapts to the catalogue so that there are ~256+ buckets (one per CU and more) whenever n_cols allows.
-// Only columns in [col_lo, col_hi) are kept (multi-GPU item range).  Order inside a column is arbitrary, as above.
-// --------------------------------------------------------------------------------------------
-constexpr int TR_PART = 16384;
-constexpr int TR_CAP = TR_PART + 2048;  // staged entries per part; a part whose last row overshoots this scatters unstaged
-constexpr int TR_THREADS = 1024;
-constexpr int TR_COPIES = 8;
+constexpr int TR_PART = 16384;        // entries per part
+constexpr int64_t TR_CHUNK = 1 << 18;  // a bucket heavier than this is placed by several blocks
 
-static int tr_bucket_bits(int32_t n_cols) {
-  int bits = 6;
-  while (bits < PH_BITS && (((int64_t)n_cols + ((int64_t)1 << bits) - 1) >> bits) > 512) ++bits;
-  return bits;
-}
-
-// R[p] = first row r with rp[r] >= p * TR_PART (p < n_parts), R[n_parts] = n_rows: part p = rows [R[p], R[p + 1])
+// R[p] = first row r with rp[r] >= p * TR_PART (p < n_parts), R[n_parts] = n_rows
 __global__ __launch_bounds__(256) void tr_parts_kernel(int64_t n_rows, const int64_t* __restrict__ rp, int64_t n_parts, int64_t* __restrict__ R) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p > n_parts) return;
@@ -1371,102 +1350,206 @@ __global__ __launch_bounds__(256) void tr_parts_kernel(int64_t n_rows, const int
   R[p] = lo;
 }
 
-__global__ __launch_bounds__(TR_THREADS) void tr_count_kernel(const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, const int64_t* __restrict__ R,
-                                                              int bits, int n_buckets, int64_t n_parts, int32_t col_lo, int32_t col_hi,
-                                                              int32_t* __restrict__ part_counts) {
-  __shared__ int s_cnt[TR_COPIES * PH_MAX_BUCKETS];
-  for (int b = threadIdx.x; b < TR_COPIES * n_buckets; b += TR_THREADS) s_cnt[b] = 0;
-  __syncthreads();
-  int* mine = s_cnt + (threadIdx.x & (TR_COPIES - 1)) * n_buckets;
-  const int64_t e0 = rp[R[blockIdx.x]], e1 = rp[R[blockIdx.x + 1]];
-  for (int64_t e = e0 + threadIdx.x; e < e1; e += TR_THREADS) {
-    const int j = ci[e];
-    if (j >= col_lo && j < col_hi) atomicAdd(&mine[j >> bits], 1);
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < n_buckets; b += TR_THREADS) {
-    int tot = 0;
-#pragma unroll
-    for (int c = 0; c < TR_COPIES; ++c) tot += s_cnt[c * n_buckets + b];
-    part_counts[(int64_t)b * n_parts + blockIdx.x] = tot;
-  }
+// --------------------------------------------------------------------------------------------
+// K3b  CSR -> CSC as a two-level counting sort by column, part-local form (round 6; the column counts' round-5 layout applied to the
+// transposition; matrices large enough to repay the launches -- the cursor-atomic kernel above takes one RETURNING L2 atomic per entry).
+// Rounds 2-5 (git 5263357, profiles/r06_transpose_rowscan_ab.log "URCCO_TRANSPOSE_V1=1") read the column indices twice (count, scatter),
+// scanned a (bucket x part) table in between, walked a part ROW BY ROW (2^g lanes per row behind a dependent row_ptr read: sixteen
+// short latency chains per thread) and wrote each bucket's run where the bucket lies: ~33-entry runs of 2- and 4-byte stores
+// (scatter 747 us + place 507 us for config 4's 40 M entries: 1.41 ms, 4 % of HBM; this form: 0.88 ms on the same box).  Here:
+//   partition  one block per FLAT part of TP_PART consecutive entries: column indices in 16-byte loads (32 per thread, all in flight
+//              before anything else), entry -> row from the part's row starts (bit mask + slice index per start + prefix maximum: the
+//              CSR row scan's lookup, no search), rank inside (bucket, lane copy) by one returning LDS atomic, the 16-bit in-bucket
+//              columns grouped by bucket in LDS and written as the part lies (whole lines), the rows scattered INSIDE the part's own
+//              64 KB (partial stores of one block into one region: the L2 merges them), loc_t[b][p] = start of bucket b in part p
+//   place      one block per bucket (several per heavy bucket, sharing cursors in global memory): the bucket's column cursors in LDS,
+//              four lanes per slice, eight entries (one 16-byte column load, two 16-byte row loads) per lane and step
+// No count pass, no scan, no block-level row walk.  Only columns in [col_lo, col_hi) are kept; order inside a column is arbitrary.
+// --------------------------------------------------------------------------------------------
+constexpr int TP_PART = TR_PART;  // 16384 (tr_parts_kernel's quota)
+constexpr int TP_THREADS = 512;
+constexpr int TP_PER_THREAD = TP_PART / TP_THREADS;  // 32 entries in registers: eight runs of four
+constexpr int TP_COPIES = 4;                         // lane-private copies of the bucket counters
+constexpr int TP_MAX_BUCKETS = 512;
+constexpr int TP_MAX_BITS = 14;                      // <= 16384 columns per bucket: 16-bit in-bucket columns, 64 KB of LDS cursors
+constexpr int TP_WORDS = TP_PART / 64;
+static_assert(TP_PER_THREAD % 4 == 0 && TP_MAX_BUCKETS <= TP_THREADS && TP_WORDS <= TP_THREADS, "one scan round; one thread per mask word");
+
+static int tp_bucket_bits(int32_t n_cols) {
+  int bits = 6;
+  while (bits < TP_MAX_BITS && (((int64_t)n_cols + ((int64_t)1 << bits) - 1) >> bits) > TP_MAX_BUCKETS) ++bits;
+  return bits;
 }
 
-__global__ __launch_bounds__(TR_THREADS) void tr_scatter_kernel(const int64_t* __restrict__ rp, const int32_t* __restrict__ ci, const int64_t* __restrict__ R,
-                                                                int g_log2, int bits, int n_buckets, int64_t n_parts, int32_t col_lo, int32_t col_hi,
-                                                                const int64_t* __restrict__ offsets, unsigned short* __restrict__ bk_col,
-                                                                int32_t* __restrict__ bk_row) {
-  __shared__ long long s_base[PH_MAX_BUCKETS];
-  __shared__ int s_loc[PH_MAX_BUCKETS + 1];  // where the bucket's run starts inside the staging arrays
-  __shared__ int s_cur[PH_MAX_BUCKETS];
-  __shared__ unsigned short s_col[TR_CAP];
-  __shared__ int s_row[TR_CAP];
-  __shared__ long long s_wave[TR_THREADS / WAVE];
-  long long carry = 0;
-  for (int base = 0; base < n_buckets; base += TR_THREADS) {  // block-uniform: exclusive prefix of this part's slice lengths
-    const int b = base + threadIdx.x;
-    long long len = 0;
-    if (b < n_buckets) {
-      const int64_t idx = (int64_t)b * n_parts + blockIdx.x;
-      const long long o = offsets[idx];
-      s_base[b] = o;
-      len = offsets[idx + 1] - o;
-      s_cur[b] = 0;
-    }
-    long long tot;
-    const long long ex = block_exclusive_scan<TR_THREADS>(len, s_wave, &tot);
-    if (b < n_buckets) s_loc[b] = (int)(carry + ex < (long long)TR_CAP ? carry + ex : (long long)TR_CAP);  // only read when the part is staged
-    carry += tot;
+__global__ __launch_bounds__(TP_THREADS, 2) void tp_partition_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                                  const int64_t* __restrict__ R, int bits, int n_buckets, int64_t n_parts, int32_t col_lo,
+                                                                  int32_t col_hi, unsigned short* __restrict__ bk_col, int32_t* __restrict__ bk_row,
+                                                                  unsigned short* __restrict__ loc_t, int vec_ok) {
+  __shared__ int s_cnt[TP_COPIES * TP_MAX_BUCKETS];  // counts, then the start of every (copy, bucket) run inside the part
+  __shared__ uint4 s_stage4[TP_PART / 8];            // the part's in-bucket columns grouped by bucket (leaves in 16-byte stores)
+  __shared__ unsigned long long s_mask[TP_WORDS];    // bit e: a non-empty row starts at entry e of the part
+  __shared__ __attribute__((aligned(16))) unsigned short s_row_at[TP_PART];  // [e] (only where the bit is set): slice index of that row
+  __shared__ int s_tbefore[TP_WORDS];                // slice index of the last row starting before word w (0: the row covering the part's start)
+  __shared__ long long s_wave[TP_THREADS / WAVE];
+  __shared__ int s_wmax[TP_WORDS / WAVE];
+  unsigned short* s_stage = reinterpret_cast<unsigned short*>(s_stage4);
+  const int64_t part = blockIdx.x;
+  const int64_t nnz = rp[n_rows];
+  const int64_t e0 = part * TP_PART;
+  if (e0 >= nnz) {  // a part beyond the device-side length (the launch is sized for the host's bound): every slice is empty (block-uniform)
+    for (int b = threadIdx.x; b <= n_buckets; b += TP_THREADS) loc_t[(int64_t)b * n_parts + part] = 0;
+    return;
   }
-  if (threadIdx.x == 0) s_loc[n_buckets] = (int)(carry < (long long)TR_CAP ? carry : (long long)TR_CAP);
+  const int n = (int)(e0 + TP_PART < nnz ? TP_PART : nnz - e0);
+  // all column loads of the thread are requested first: register 4 r + q holds entry r * (4 * TP_THREADS) + 4 * tid + q of the part
+  int cols[TP_PER_THREAD];
+#pragma unroll
+  for (int r = 0; r < TP_PER_THREAD / 4; ++r) {
+    const int el0 = r * (TP_THREADS * 4) + (int)threadIdx.x * 4;
+    const int64_t e = e0 + el0;
+    int4 x = make_int4(-1, -1, -1, -1);
+    if (vec_ok && el0 + 3 < n) {
+      x = *reinterpret_cast<const int4*>(ci + e);
+    } else {
+      if (el0 < n) x.x = ci[e];
+      if (el0 + 1 < n) x.y = ci[e + 1];
+      if (el0 + 2 < n) x.z = ci[e + 2];
+      if (el0 + 3 < n) x.w = ci[e + 3];
+    }
+    cols[4 * r] = x.x; cols[4 * r + 1] = x.y; cols[4 * r + 2] = x.z; cols[4 * r + 3] = x.w;
+  }
+  for (int b = threadIdx.x; b < TP_COPIES * n_buckets; b += TP_THREADS) s_cnt[b] = 0;
+  if (threadIdx.x < TP_WORDS) s_mask[threadIdx.x] = 0ull;
+  // rows r_s .. r_e - 1 own the part's entries: r_s covers (or starts at) e0, r_e is the first row that starts at or behind the part's end
+  const int64_t g0 = R[part];
+  const int64_t r_s = (g0 < n_rows && rp[g0] == e0) ? g0 : g0 - 1;  // (rp[n_rows] = nnz > e0: g0 == n_rows means row n_rows - 1 covers e0)
+  const int64_t g1 = R[part + 1];
+  const int64_t r_e = g1 < n_rows ? g1 : n_rows;
+  const int64_t n_slice = r_e - r_s + 1;
+  const bool by_marks = n_slice <= 65536;  // block-uniform: slice indices fit the 16-bit marks (else: one binary search per run, rare)
   __syncthreads();
-  const bool staged = carry <= TR_CAP;  // block-uniform: the part's kept entries fit the staging arrays
-  const unsigned cmask = (1u << bits) - 1u;
-  const int G = 1 << g_log2;
-  const int gl = threadIdx.x & (G - 1);
-  const int64_t r0 = R[blockIdx.x], r1 = R[blockIdx.x + 1];
-  for (int64_t r = r0 + (threadIdx.x >> g_log2); r < r1; r += TR_THREADS >> g_log2) {
-    const int64_t s = rp[r], e = rp[r + 1];
-    for (int64_t p = s + gl; p < e; p += G) {
-      const int j = ci[p];
-      if (j < col_lo || j >= col_hi) continue;
-      const int b = j >> bits;
-      const int k = atomicAdd(&s_cur[b], 1);
-      if (staged) {
-        s_col[s_loc[b] + k] = (unsigned short)((unsigned)j & cmask);
-        s_row[s_loc[b] + k] = (int32_t)r;
-      } else {
-        bk_col[s_base[b] + k] = (unsigned short)((unsigned)j & cmask);
-        bk_row[s_base[b] + k] = (int32_t)r;
+  if (by_marks) {
+    for (int64_t t = threadIdx.x; t + 1 < n_slice; t += TP_THREADS) {
+      const int64_t a = rp[r_s + t] - e0, b = rp[r_s + t + 1] - e0;
+      if (b > a && a >= 0) {  // non-empty and starting inside the part (a < TP_PART: only r_e may start at or behind its end)
+        s_row_at[a] = (unsigned short)t;
+        atomicOr(&s_mask[a >> 6], 1ull << (a & 63));
       }
     }
   }
-  if (!staged) return;
   __syncthreads();
-  // one wave per bucket run, lanes on consecutive entries
-  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-  for (int b = wave; b < n_buckets; b += TR_THREADS / WAVE) {
-    const int l0 = s_loc[b], len = s_loc[b + 1] - l0;
-    const long long dst = s_base[b];
-    for (int t = lane; t < len; t += WAVE) {
-      bk_col[dst + t] = s_col[l0 + t];
-      bk_row[dst + t] = s_row[l0 + t];
+  if (by_marks) {  // exclusive prefix maximum over the words: slice indices grow with the position
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    int inc = 0;
+    if (threadIdx.x < TP_WORDS) {
+      const unsigned long long m = s_mask[threadIdx.x];
+      inc = m ? (int)s_row_at[threadIdx.x * 64 + 63 - __clzll((long long)m)] : 0;
+#pragma unroll
+      for (int d = 1; d < WAVE; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc = o > inc ? o : inc;
+      }
+      if (lane == WAVE - 1) s_wmax[wave] = inc;
+    }
+    __syncthreads();
+    if (threadIdx.x < TP_WORDS) {
+      int before = 0;
+#pragma unroll
+      for (int w = 0; w < TP_WORDS / WAVE; ++w)
+        if (w < wave) before = s_wmax[w] > before ? s_wmax[w] : before;
+      const int ex = __shfl_up(inc, 1);
+      const int mine = lane == 0 ? 0 : ex;
+      s_tbefore[threadIdx.x] = mine > before ? mine : before;
+    }
+    __syncthreads();
+  }
+  // rank inside (bucket, copy): one returning LDS atomic per kept entry (two 16-bit ranks per register)
+  int* mine = s_cnt + (threadIdx.x & (TP_COPIES - 1)) * n_buckets;
+  unsigned rank2[TP_PER_THREAD / 2];
+#pragma unroll
+  for (int q = 0; q < TP_PER_THREAD; ++q) {
+    const int j = cols[q];  // (-1 behind the matrix's end)
+    const bool keep = j >= col_lo && j < col_hi;
+    unsigned rk = 0u;
+    if (keep) rk = (unsigned)atomicAdd(&mine[j >> bits], 1);
+    else cols[q] = -1;
+    rank2[q >> 1] = (q & 1) ? (rank2[q >> 1] | (rk << 16)) : rk;
+  }
+  __syncthreads();
+  {  // exclusive prefix over (bucket, copy), bucket-major: where every run starts; the bucket starts go out as loc_t[b][part]
+    const int b = threadIdx.x;  // n_buckets <= TP_MAX_BUCKETS <= TP_THREADS: one round
+    long long tot = 0;
+    if (b < n_buckets) {
+#pragma unroll
+      for (int k = 0; k < TP_COPIES; ++k) tot += s_cnt[k * n_buckets + b];
+    }
+    long long all;
+    const long long ex = block_exclusive_scan<TP_THREADS>(tot, s_wave, &all);
+    if (b < n_buckets) {
+      int run = (int)ex;
+      loc_t[(int64_t)b * n_parts + part] = (unsigned short)run;
+#pragma unroll
+      for (int k = 0; k < TP_COPIES; ++k) {
+        const int c = s_cnt[k * n_buckets + b];
+        s_cnt[k * n_buckets + b] = run;
+        run += c;
+      }
+    }
+    if (b == n_buckets % TP_THREADS) loc_t[(int64_t)n_buckets * n_parts + part] = (unsigned short)all;  // <= TP_PART = 16384
+  }
+  __syncthreads();
+  // entry -> row (a run of four at a time: nothing of it is held across the phases above), then the entry goes to its place in the part
+  const unsigned cmask = (1u << bits) - 1u;
+  int32_t* row_dst = bk_row + e0;
+#pragma unroll
+  for (int r = 0; r < TP_PER_THREAD / 4; ++r) {
+    const int el0 = r * (TP_THREADS * 4) + (int)threadIdx.x * 4;
+    int rows[4];
+    if (by_marks) {
+      const int w = el0 >> 6, sh = el0 & 63;
+      const unsigned long long m = s_mask[w];
+      const unsigned starts = (unsigned)(m >> sh) & 0xfu;       // rows starting inside the run
+      const unsigned long long low = m & ((1ull << sh) - 1ull);  // ... and before it, in the same word
+      int t_cur = s_tbefore[w];
+      if (low) t_cur = (int)s_row_at[w * 64 + 63 - __clzll((long long)low)];
+      const uint2 at2 = *reinterpret_cast<const uint2*>(&s_row_at[el0]);
+      const int at[4] = {(int)(at2.x & 0xffffu), (int)(at2.x >> 16), (int)(at2.y & 0xffffu), (int)(at2.y >> 16)};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        t_cur = (starts >> q) & 1u ? at[q] : t_cur;
+        rows[q] = (int)(r_s + t_cur);
+      }
+    } else {
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) rows[q] = el0 + q < n ? (int)(upper_bound_i64(rp, r_s, r_e, e0 + el0 + q) - 1) : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = cols[4 * r + q];
+      if (j >= 0) {
+        const unsigned rk = (q & 1) ? rank2[(4 * r + q) >> 1] >> 16 : rank2[(4 * r + q) >> 1] & 0xffffu;
+        const int pos = mine[j >> bits] + (int)rk;
+        s_stage[pos] = (unsigned short)((unsigned)j & cmask);
+        row_dst[pos] = rows[q];
+      }
     }
   }
+  __syncthreads();
+  // the columns leave as the part lies: 16-byte stores (bk_col + e0 is 32 KiB-aligned relative to the array's 256-byte-aligned base)
+  uint4* dst = reinterpret_cast<uint4*>(bk_col + e0);
+  for (int v = threadIdx.x; v * 8 < n; v += TP_THREADS) dst[v] = s_stage4[v];  // entries behind the kept ones are stale: inside the part's own 32 KiB, never read
 }
 
-// blk_prefix[b] = first placement block of bucket b: a bucket gets one block per TR_CHUNK entries (at least one)
-constexpr int64_t TR_CHUNK = 1 << 18;
-__global__ __launch_bounds__(SCAN_THREADS) void tr_blockmap_kernel(const int64_t* __restrict__ offsets, int n_buckets, int64_t n_parts,
-                                                                  int32_t* __restrict__ blk_prefix) {
+// weight -> placement blocks: a bucket of up to TR_CHUNK entries is placed by ONE block (cursors in LDS), a heavier one by one block per TR_CHUNK entries
+__global__ __launch_bounds__(SCAN_THREADS) void tp_blockmap_kernel(const long long* __restrict__ weight, int n_buckets, int64_t n_parts, int32_t* __restrict__ blk_prefix) {
   __shared__ long long s_wave[SCAN_THREADS / WAVE];
   long long carry = 0;
   for (int base = 0; base < n_buckets; base += SCAN_THREADS) {  // block-uniform
     const int b = base + threadIdx.x;
     long long v = 0;
     if (b < n_buckets) {
-      const long long size = offsets[(int64_t)(b + 1) * n_parts] - offsets[(int64_t)b * n_parts];
-      v = size > 0 ? (size + TR_CHUNK - 1) / TR_CHUNK : 1;
+      v = weight[b] > 0 ? (weight[b] + TR_CHUNK - 1) / TR_CHUNK : 1;
+      if (v > n_parts) v = n_parts;
     }
     long long tot;
     const long long ex = block_exclusive_scan(v, s_wave, &tot);
@@ -1476,99 +1559,116 @@ __global__ __launch_bounds__(SCAN_THREADS) void tr_blockmap_kernel(const int64_t
   if (threadIdx.x == 0) blk_prefix[n_buckets] = (int32_t)carry;
 }
 
-// A bucket of up to TR_CHUNK entries is placed by ONE block with its column cursors in LDS.  A heavier bucket -- a catalogue whose
-// ids follow popularity (ids by first appearance do) concentrates the interactions in the first buckets -- is split over several
-// blocks that share cursors in global memory (returning L2 atomics, the price of the cursor-atomic kernel, paid by those buckets only).
-__global__ __launch_bounds__(TR_THREADS) void tr_place_kernel(const unsigned short* __restrict__ bk_col, const int32_t* __restrict__ bk_row,
-                                                              const int64_t* __restrict__ offsets, int bits, int n_buckets, int64_t n_parts,
-                                                              const int32_t* __restrict__ blk_prefix, const int64_t* __restrict__ col_ptr, int32_t n_cols,
-                                                              int32_t* __restrict__ g_cursor /* [n_cols] zero */, int32_t* __restrict__ out_rows) {
-  __shared__ unsigned s_cur[PH_BUCKET];
+constexpr int TPP_THREADS = 1024;
+constexpr int TPP_LPS = 4;  // lanes per slice: a slice of a 2M-column catalogue holds ~33 entries, a step of four lanes covers 32
+__global__ __launch_bounds__(TPP_THREADS) void tp_place_kernel(const unsigned short* __restrict__ bk_col, const int32_t* __restrict__ bk_row,
+                                                               const unsigned short* __restrict__ loc_t, int bits, int n_buckets, int64_t n_parts,
+                                                               const int32_t* __restrict__ blk_prefix, const int64_t* __restrict__ col_ptr, int32_t n_cols,
+                                                               int32_t* __restrict__ g_cursor /* [n_cols] zero */, int32_t* __restrict__ out_rows) {
+  __shared__ unsigned s_cur[1 << TP_MAX_BITS];
   const int blk = blockIdx.x;
   if (blk >= blk_prefix[n_buckets]) return;  // block-uniform
-  int lo = 0, hi = n_buckets;  // last b with blk_prefix[b] <= blk
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (blk_prefix[mid] <= blk) lo = mid; else hi = mid;
+  int blo = 0, bhi = n_buckets;  // last b with blk_prefix[b] <= blk
+  while (bhi - blo > 1) {
+    const int mid = (blo + bhi) >> 1;
+    if (blk_prefix[mid] <= blk) blo = mid; else bhi = mid;
   }
-  const int b = lo;
-  const int n_blk = blk_prefix[b + 1] - blk_prefix[b];
+  const int b = blo, s = blk - blk_prefix[b], S = blk_prefix[b + 1] - blk_prefix[b];
   const int width = 1 << bits;
   const int64_t col0 = (int64_t)b << bits;
-  const int64_t bs = offsets[(int64_t)b * n_parts], be_all = offsets[(int64_t)(b + 1) * n_parts];
-  if (n_blk > 1) {  // block-uniform: a chunk of a heavy bucket
-    const int64_t c0 = bs + (int64_t)(blk - blk_prefix[b]) * TR_CHUNK;
-    const int64_t c1 = c0 + TR_CHUNK < be_all ? c0 + TR_CHUNK : be_all;
-    for (int64_t e = c0 + threadIdx.x; e < c1; e += TR_THREADS) {
-      const int64_t j = col0 + bk_col[e];
-      out_rows[col_ptr[j] + atomicAdd(&g_cursor[j], 1)] = bk_row[e];
-    }
-    return;
-  }
+  const bool shared_cursors = S > 1;  // block-uniform: a heavy bucket's blocks share cursors in global memory (returning L2 atomics)
   const int64_t base = col_ptr[col0];  // where the bucket's CSC segment starts (a bucket holds < 2^32 entries)
-  for (int c = threadIdx.x; c < width; c += TR_THREADS) s_cur[c] = col0 + c < n_cols ? (unsigned)(col_ptr[col0 + c] - base) : 0u;
+  if (!shared_cursors) {
+    for (int c = threadIdx.x; c < width; c += TPP_THREADS) s_cur[c] = col0 + c < n_cols ? (unsigned)(col_ptr[col0 + c] - base) : 0u;
+  }
   __syncthreads();
-  const int64_t be = be_all;
-  // four entries per thread and round: their loads are requested together (a round is a chain load -> LDS atomic -> store).
-  // (Round 5 measured column slices -- 2, 4, 8 blocks per bucket, each placing the entries of its own columns: +-0, profiles/r05_transpose_slices_ab.log:
-  // the pass is not bound by the parallelism of its latency chains.)
-  for (int64_t e = bs + threadIdx.x; e < be; e += TR_THREADS * 4) {
-    unsigned c[4];
-    int r[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int64_t x = e + (int64_t)q * TR_THREADS;
-      c[q] = x < be ? (unsigned)bk_col[x] : 0u;
-      r[q] = x < be ? bk_row[x] : 0;
+  const int64_t pp = (n_parts + S - 1) / S;
+  const int64_t p0 = (int64_t)s * pp < n_parts ? (int64_t)s * pp : n_parts, p1 = p0 + pp < n_parts ? p0 + pp : n_parts;
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+  const unsigned short* lo_t = loc_t + (int64_t)b * n_parts;
+  const unsigned short* hi_t = loc_t + (int64_t)(b + 1) * n_parts;
+  constexpr int GP = WAVE / TPP_LPS;  // parts per group = slices per wave and round (lane l < GP holds the bounds of part g + l)
+  const int sub = lane / TPP_LPS, sl = lane % TPP_LPS;
+  const int64_t gstep = (int64_t)(TPP_THREADS / WAVE) * GP;
+  int64_t g = p0 + (int64_t)wave * GP;
+  unsigned lo_n = 0u, hi_n = 0u;  // the NEXT group's bounds travel while this group's slices are placed
+  if (g < p1 && lane < GP && g + lane < p1) {
+    lo_n = lo_t[g + lane];
+    hi_n = hi_t[g + lane];
+  }
+  for (; g < p1; g += gstep) {  // wave-uniform
+    const unsigned lo = lo_n, hi = hi_n;
+    lo_n = 0u;
+    hi_n = 0u;
+    if (g + gstep < p1 && lane < GP && g + gstep + lane < p1) {
+      lo_n = lo_t[g + gstep + lane];
+      hi_n = hi_t[g + gstep + lane];
     }
+    const unsigned lo_j = (unsigned)__shfl((int)lo, sub);  // (parts past the range carry lo == hi == 0)
+    const unsigned hi_j = (unsigned)__shfl((int)hi, sub);
+    const unsigned short* csrc = bk_col + (g + sub) * TP_PART;
+    const int32_t* rsrc = bk_row + (g + sub) * TP_PART;
+    for (unsigned at = (lo_j & ~7u) + 8u * (unsigned)sl; at < hi_j; at += 8u * TPP_LPS) {
+      const uint4 c4 = *reinterpret_cast<const uint4*>(csrc + at);
+      const int4 r0 = *reinterpret_cast<const int4*>(rsrc + at), r1 = *reinterpret_cast<const int4*>(rsrc + at + 4);
+      const unsigned cw[4] = {c4.x, c4.y, c4.z, c4.w};
+      const int rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (e + (int64_t)q * TR_THREADS < be) out_rows[base + atomicAdd(&s_cur[c[q]], 1u)] = r[q];
+      for (int k = 0; k < 8; ++k) {
+        const unsigned t = at + (unsigned)k;
+        if (t >= lo_j && t < hi_j) {
+          const unsigned c = (k & 1) ? cw[k >> 1] >> 16 : cw[k >> 1] & 0xffffu;
+          if (shared_cursors) out_rows[col_ptr[col0 + c] + atomicAdd(&g_cursor[col0 + c], 1)] = rr[k];
+          else out_rows[base + atomicAdd(&s_cur[c], 1u)] = rr[k];
+        }
+      }
+    }
   }
 }
 
-static void tr_geometry(int64_t nnz, int32_t n_cols, int* bits, int64_t* n_buckets, int64_t* n_parts) {
-  *bits = tr_bucket_bits(n_cols);
+static void tp_geometry(int64_t nnz, int32_t n_cols, int* bits, int64_t* n_buckets, int64_t* n_parts) {
+  *bits = tp_bucket_bits(n_cols);
   *n_buckets = ((int64_t)n_cols + ((int64_t)1 << *bits) - 1) >> *bits;
-  *n_parts = (nnz + TR_PART - 1) / TR_PART;
+  *n_parts = (nnz + TP_PART - 1) / TP_PART;
 }
 
+// 0: the cursor-atomic kernel serves the matrix (small, or more than TP_MAX_BUCKETS buckets of 2^TP_MAX_BITS columns: beyond 8M columns)
 int64_t transpose_scratch_bytes(int64_t n_rows, int64_t nnz, int32_t n_cols) {
+  (void)n_rows;
+  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  if (nnz < PH_MIN_NNZ) return 0;
   int bits;
   int64_t n_buckets, n_parts;
-  tr_geometry(nnz, n_cols, &bits, &n_buckets, &n_parts);
-  if (nnz < PH_MIN_NNZ || n_buckets > PH_MAX_BUCKETS || n_buckets < 1) return 0;
-  const int64_t m = n_buckets * n_parts;
-  auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
-  return al((n_parts + 1) * 8) + al(m * 4) + al((m + 1) * 8) + al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8) + al(nnz * 2 + 16) + al(nnz * 4 + 16) +
-         al((n_buckets + 1) * 4);
+  tp_geometry(nnz, n_cols, &bits, &n_buckets, &n_parts);
+  if (n_buckets < 1 || n_buckets > TP_MAX_BUCKETS) return 0;
+  return al((n_parts + 1) * 8) + al(n_parts * TP_PART * 2 + 64) + al(n_parts * TP_PART * 4 + 64) + al((n_buckets + 1) * n_parts * 2) + al(n_buckets * 8) + al((n_buckets + 1) * 4);
 }
 
-hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int g_log2,
-                                        int32_t n_cols, const int64_t* col_ptr, int32_t* cursor, int32_t* out_row_idx, int32_t col_lo, int32_t col_hi,
-                                        char* scratch) {
+hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
+                                        const int64_t* col_ptr, int32_t* cursor, int32_t* out_row_idx, int32_t col_lo, int32_t col_hi, char* scratch) {
   int bits;
   int64_t n_buckets, n_parts;
-  tr_geometry(nnz, n_cols, &bits, &n_buckets, &n_parts);
-  const int64_t m = n_buckets * n_parts;
   auto al = [](int64_t v) { return (v + 255) / 256 * 256; };
+  tp_geometry(nnz, n_cols, &bits, &n_buckets, &n_parts);
+  if (n_buckets < 1 || n_buckets > TP_MAX_BUCKETS) return hipErrorInvalidValue;
   int64_t* R = reinterpret_cast<int64_t*>(scratch); scratch += al((n_parts + 1) * 8);
-  int32_t* part_counts = reinterpret_cast<int32_t*>(scratch); scratch += al(m * 4);
-  int64_t* offsets = reinterpret_cast<int64_t*>(scratch); scratch += al((m + 1) * 8);
-  int64_t* tile_sums = reinterpret_cast<int64_t*>(scratch); scratch += al(((m + SCAN_TILE - 1) / SCAN_TILE + 2) * 8);
-  unsigned short* bk_col = reinterpret_cast<unsigned short*>(scratch); scratch += al(nnz * 2 + 16);
-  int32_t* bk_row = reinterpret_cast<int32_t*>(scratch); scratch += al(nnz * 4 + 16);
+  unsigned short* bk_col = reinterpret_cast<unsigned short*>(scratch); scratch += al(n_parts * TP_PART * 2 + 64);
+  int32_t* bk_row = reinterpret_cast<int32_t*>(scratch); scratch += al(n_parts * TP_PART * 4 + 64);
+  unsigned short* loc_t = reinterpret_cast<unsigned short*>(scratch); scratch += al((n_buckets + 1) * n_parts * 2);
+  long long* weight = reinterpret_cast<long long*>(scratch); scratch += al(n_buckets * 8);
   int32_t* blk_prefix = reinterpret_cast<int32_t*>(scratch);
+  const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
   hipLaunchKernelGGL(tr_parts_kernel, dim3((unsigned)((n_parts + 256) / 256)), dim3(256), 0, st, n_rows, row_ptr, n_parts, R);
-  hipLaunchKernelGGL(tr_count_kernel, dim3((unsigned)n_parts), dim3(TR_THREADS), 0, st, row_ptr, col_idx, R, bits, (int)n_buckets, n_parts, col_lo, col_hi, part_counts);
-  hipError_t e = launch_scan_i32(st, part_counts, m, offsets, tile_sums);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(tr_scatter_kernel, dim3((unsigned)n_parts), dim3(TR_THREADS), 0, st, row_ptr, col_idx, R, g_log2, bits, (int)n_buckets, n_parts, col_lo, col_hi,
-                     offsets, bk_col, bk_row);
-  hipLaunchKernelGGL(tr_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, offsets, (int)n_buckets, n_parts, blk_prefix);
+  hipLaunchKernelGGL(tp_partition_kernel, dim3((unsigned)n_parts), dim3(TP_THREADS), 0, st, n_rows, row_ptr, col_idx, R, bits, (int)n_buckets, n_parts, col_lo, col_hi, bk_col,
+                     bk_row, loc_t, vec_ok);
+  hipError_t we = hipMemsetAsync(weight, 0, sizeof(long long) * (size_t)n_buckets, st);
+  if (we != hipSuccess) return we;
+  const unsigned wsplit = (unsigned)(n_parts >= 8192 ? 8 : (n_parts >= 1024 ? 4 : 1));
+  hipLaunchKernelGGL(pl_weights_kernel, dim3((unsigned)n_buckets, wsplit), dim3(256), 0, st, loc_t, n_parts, reinterpret_cast<unsigned long long*>(weight));
+  hipLaunchKernelGGL(tp_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, weight, (int)n_buckets, n_parts, blk_prefix);
   const int64_t max_blocks = n_buckets + nnz / TR_CHUNK;
-  hipLaunchKernelGGL(tr_place_kernel, dim3((unsigned)max_blocks), dim3(TR_THREADS), 0, st, bk_col, bk_row, offsets, bits, (int)n_buckets, n_parts, blk_prefix, col_ptr,
-                     n_cols, cursor, out_row_idx);
+  hipLaunchKernelGGL(tp_place_kernel, dim3((unsigned)max_blocks), dim3(TPP_THREADS), 0, st, bk_col, bk_row, loc_t, bits, (int)n_buckets, n_parts, blk_prefix, col_ptr, n_cols, cursor,
+                     out_row_idx);
   return hipGetLastError();
 }
 

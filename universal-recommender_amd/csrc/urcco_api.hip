@@ -296,7 +296,7 @@ int urcco_dev_transpose(urcco_session* s, int64_t n_rows, const int64_t* row_ptr
     if (g > 6) g = 6;
     HIPC(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (size_t)n_cols, s->stream));
     if (tr_bytes > 0) {
-      HIPC(urcco::launch_transpose_partitioned(s->stream, n_rows, row_ptr, col_idx, nnz, g, n_cols, out_col_ptr, cursor, out_row_idx, col_lo, col_hi,
+      HIPC(urcco::launch_transpose_partitioned(s->stream, n_rows, row_ptr, col_idx, nnz, n_cols, out_col_ptr, cursor, out_row_idx, col_lo, col_hi,
                                                s->take<char>((size_t)tr_bytes)));
     } else {
       HIPC(urcco::launch_transpose(s->stream, s->n_cu, n_rows, row_ptr, col_idx, g, out_col_ptr, cursor, out_row_idx, col_lo, col_hi));
