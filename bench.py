@@ -450,6 +450,8 @@ class Job:
             os.close(saved_fd)
         if args.gathered_primary:
             self.ctx.set_debug(8192)
+        if os.environ.get("URCCO_BENCH_DEBUG"):   # A/B aid: debug switches of the context (include/urcco.h, urcco_context_set_debug)
+            self.ctx.set_debug(int(os.environ["URCCO_BENCH_DEBUG"]))
 
     def host_copy(self):
         """(name, n_cols, row_ptr, col_idx) numpy, whole matrices (single-GPU jobs)."""

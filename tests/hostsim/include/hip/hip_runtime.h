@@ -246,7 +246,8 @@ static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = hipsim::guard_on() ? hipsim::guard_alloc(n ? n : 1) : malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
 static inline hipError_t hipFree(void* p) { if (!p || !hipsim::guard_free(p)) free(p); return hipSuccess; }
-enum { hipHostMallocDefault = 0, hipHostMallocPortable = 1 };
+enum { hipHostMallocDefault = 0, hipHostMallocPortable = 1, hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000 };
+static inline hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) { *dev = host; return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void* p) { return hipFree(p); }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) memcpy(d, s, n); return hipSuccess; }

@@ -139,6 +139,8 @@ hipError_t launch_frag_place(hipStream_t st, int n_cu, int32_t world, int32_t lo
 hipError_t launch_validate_csr(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
                                int g_log2, int64_t rp0, unsigned long long* err);
 hipError_t launch_rebase_i64(hipStream_t st, int n_cu, int64_t* p, int64_t n, int64_t delta);
+// *dst_mapped = *src, dst_mapped = the device address of host-mapped pinned memory (no copy engine involved)
+hipError_t launch_publish_word(hipStream_t st, const unsigned long long* src, unsigned long long* dst_mapped);
 
 // PopModel interval histograms: counts[b * n_items + i] = events of item i with bounds[b] <= t < bounds[b + 1], b < n_buckets <= 3
 hipError_t launch_pop_counts(hipStream_t st, int n_cu, int64_t n, const int32_t* item, const int64_t* t_ms, int32_t n_items, int n_buckets,

@@ -4134,6 +4134,13 @@ hipError_t launch_validate_csr(hipStream_t st, int n_cu, int64_t n_rows, const i
 __global__ __launch_bounds__(256) void rebase_kernel(int64_t* __restrict__ p, int64_t n, int64_t delta) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] -= delta;
 }
+// One device word -> host-mapped pinned memory by a STORE of the GPU, not by a copy: a D2H copy of eight bytes queues on the copy engine behind
+// whatever results another event type is bringing over (round 6, host level: config 4's last event type waited 39 ms for its boundary check).
+__global__ void publish_word_kernel(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst_mapped) { *dst_mapped = *src; }
+hipError_t launch_publish_word(hipStream_t st, const unsigned long long* src, unsigned long long* dst_mapped) {
+  hipLaunchKernelGGL(publish_word_kernel, dim3(1), dim3(1), 0, st, src, dst_mapped);
+  return hipGetLastError();
+}
 hipError_t launch_rebase_i64(hipStream_t st, int n_cu, int64_t* p, int64_t n, int64_t delta) {
   if (n <= 0 || delta == 0) return hipSuccess;
   int64_t blocks = (n + 255) / 256;

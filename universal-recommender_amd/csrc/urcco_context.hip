@@ -185,6 +185,14 @@ struct EvState {
   DBuf<double> c_llr;
   DBuf<int64_t> stats;
   DBuf<unsigned long long> verr;
+  unsigned long long* h_verr = nullptr;  // host-mapped pinned word the boundary check's result is STORED to by the GPU (host level, one GPU) ...
+  unsigned long long* h_verr_dev = nullptr;  // ... and its device address
+  int ensure_h_verr() {
+    if (h_verr) return URCCO_OK;
+    HIPC(hipHostMalloc((void**)&h_verr, sizeof(unsigned long long), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPC(hipHostGetDevicePointer((void**)&h_verr_dev, h_verr, 0));
+    return URCCO_OK;
+  }
   DBuf<int64_t> pre_pstart;     // this event type's share of the fused expand preparation (builds with >= 2 secondaries)
   DBuf<int32_t> pre_plen;
   DBuf<int64_t> pre_tsum;       // ... and the scan-tile sums of pre_plen the fused pass leaves (the expand scan then skips its reduce pass)
@@ -208,6 +216,9 @@ struct EvState {
     f_rp.release(); f_ci.release(); sizes.release(); scan_tmp.release(); o_count.release(); o_idx.release(); o_llr.release(); c_rp.release();
     c_idx.release(); c_llr.release(); stats.release(); verr.release(); pre_pstart.release(); pre_plen.release(); pre_tsum.release();
     mlen.release(); pack.release(); mlen16.release(); mlen_bad.release(); moff.release(); mtmp.release(); to_nnz.release();
+    if (h_verr) (void)hipHostFree(h_verr);
+    h_verr = nullptr;
+    h_verr_dev = nullptr;
     if (ev_sampled) (void)hipEventDestroy(ev_sampled);
     if (ev_done) (void)hipEventDestroy(ev_done);
     if (ev_rp) (void)hipEventDestroy(ev_rp);
@@ -573,9 +584,10 @@ struct InputGate {
     const int st = fut[(size_t)d].get();
     if (st != URCCO_OK) return fail(st, "dataset %d: staging failed", d);
     EvState& E = D.ev[(size_t)d];
-    unsigned long long bad = 0;
-    HIPC(hipMemcpyAsync(&bad, E.verr.p, sizeof(bad), hipMemcpyDeviceToHost, E.s->stream));
+    // the check's result was STORED to host-mapped memory by the last kernel of the staging chain (stage_event): waiting for the stream is all
+    // it takes -- an 8-byte D2H copy here queued on the copy engine behind the other event types' results (round 6: 39 ms on config 4)
     HIPC(hipStreamSynchronize(E.s->stream));
+    const unsigned long long bad = E.h_verr ? *(volatile unsigned long long*)E.h_verr : 0ull;
     if (bad)
       return fail(URCCO_BAD_ARG, "dataset %d: %llu invalid entries (row_ptr not monotone, or col_idx out of [0, n_cols) / not strictly increasing inside a row)", d, bad);
     if (trace) trace->mark("matrices landed and checked", d);
@@ -1287,6 +1299,10 @@ int download_event(urcco_context* c, PendingBuild* pb, int d) {
   o.llr = (double*)pinned_pool().get(sizeof(double) * (size_t)(o.nnz ? o.nnz : 1));
   if (!o.col_idx || !o.llr) return fail(URCCO_OOM_HOST, "pinned indicator arrays");
   if (o.nnz > 0) {
+    // (round 6 A/B, profiles/r06_host_level_ab.log: the same bytes moved by the GPU's own stores into the mapped block instead of the copy engine
+    // slowed the concurrent uploads down -- 158-172 ms per call against 129-131)
+    // (also measured and not kept: the two arrays in 32 MB / 8 MB pieces so that upload chunks could slip in between -- 139-142 ms per call against 123-126:
+    // uploads and downloads slow each other down whatever the granularity -- 7 GB cross the link in ~125 ms, ~56 GB/s in BOTH directions together)
     HIPC(hipMemcpyAsync(o.col_idx, E.c_idx.p, sizeof(int32_t) * (size_t)o.nnz, hipMemcpyDeviceToHost, E.s->stream));
     HIPC(hipMemcpyAsync(o.llr, E.c_llr.p, sizeof(double) * (size_t)o.nnz, hipMemcpyDeviceToHost, E.s->stream));
     HIPC(hipStreamSynchronize(E.s->stream));
@@ -1655,6 +1671,7 @@ int urcco_context_stage(urcco_context* c, const urcco_dataset* datasets, int32_t
         URC(E.in_rp.ensure((size_t)rows + 1));
         URC(E.in_ci.ensure((size_t)nnz + 4));
         URC(E.verr.ensure(1));
+        URC(E.ensure_h_verr());
         sh[(size_t)d][g] = Shard{rows, u0, nnz, E.in_rp.p, E.in_ci.p};
       }
     }
@@ -1673,6 +1690,7 @@ int urcco_context_stage(urcco_context* c, const urcco_dataset* datasets, int32_t
         gl = gl < 1 ? 1 : (gl > 6 ? 6 : gl);
         HIPC(urcco::launch_validate_csr(E.s->stream, D.n_cu, x.n_rows, E.in_rp.p, E.in_ci.p, x.nnz, (int32_t)m.n_cols, gl, e0, E.verr.p));
         HIPC(urcco::launch_rebase_i64(E.s->stream, D.n_cu, E.in_rp.p, x.n_rows + 1, e0));
+        HIPC(urcco::launch_publish_word(E.s->stream, E.verr.p, E.h_verr_dev));
         return URCCO_OK;
       });
     };
