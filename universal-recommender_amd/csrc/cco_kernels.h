@@ -18,14 +18,15 @@ constexpr int DS_TILE = 4096;            // entries per down-sample tile (256 th
 constexpr int GLOBAL_BIN_BLOCKS = 128;    // persistent blocks of the global-accumulator kernel (upper bound)
 constexpr int BIN_TILE = 1024;           // items per binning tile
 constexpr int XLX_TABLE_HOST = 4096;     // entries of the small-integer xLogX table (== XLX_TABLE in cco_device.h)
-constexpr int BIN_COLS_HOST = 3 * NBINS + 1;  // int64 per binning tile
+constexpr int BIN_COLS_HOST = 3 * NBINS + 3;  // int64 per binning tile (rows per internal bin -- the micro class has three sub-lists --, pairs and users per bin, total)
+constexpr int BIN_OFF_LEN = NBINS + 3;        // bin_off: [0 .. NBINS] list offsets of the classes, then the starts of the micro class's second and third sub-list
 constexpr int CAND_SLOTS = 64;           // words the row kernels spread their candidate counts over (see CcoArgs::cand)
 constexpr int STATS_LEN = 32;            // [0] pairs, then NBINS each of rows / pairs / users / out entries per bin, [1 + 4 NBINS] table overflows
 
 struct CcoArgs {
   // row lists per bin
   const int32_t* bin_rows;   // item ids grouped by bin
-  const int32_t* bin_off;    // [NBINS+1] offsets into bin_rows
+  const int32_t* bin_off;    // [BIN_OFF_LEN] offsets into bin_rows
   // matrices
   const int64_t* a_col_ptr;  // CSC of A': users of item i are entries [a_col_ptr[i], a_col_ptr[i+1])
   const int64_t* pstart;     // per CSC entry: start of that user's B' row in b_col_idx
@@ -166,7 +167,7 @@ hipError_t launch_expand_scan(hipStream_t st, const int64_t* a_col_ptr, int32_t 
 hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t item_hi, const int64_t* a_col_ptr, const int64_t* wp, int64_t* work);
 
 // binning: tile_counts scratch [(ceil(n/BIN_TILE)+1) * BIN_COLS_HOST] int64;
-// bin_off[NBINS+1] int32, bin_rows[n] int32, stats[STATS_LEN] int64.
+// bin_off[BIN_OFF_LEN] int32, bin_rows[n] int32, stats[STATS_LEN] int64.
 hipError_t launch_binning(hipStream_t st, int32_t item_lo, int32_t n, const int64_t* work, const int32_t* cnt_a, int32_t n_cols_b,
                           int32_t count_bits, int32_t k, int64_t* tile_counts, int32_t* bin_off, int32_t* bin_rows, int64_t* stats);
 

@@ -2040,9 +2040,20 @@ __device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_c
   return cap_bin > work_bin ? cap_bin : work_bin;
 }
 
+// Round 6: the micro class in three sub-lists by row size -- rows of <= 16 pairs and users share a wave four at a time, rows of <= 32 two
+// at a time (see cco_rows_micro_kernel).  The binning works on INTERNAL bins (0, 1, 2 = the sub-lists, 3 .. = the other classes); towards
+// everything else the micro class stays one bin: bin_off[0 .. NBINS] as before, the sub-lists' starts behind it (bin_off[NBINS + 1], [NBINS + 2]).
+constexpr int MICRO_SUBS = 3;
+constexpr int IBINS = NBINS - 1 + MICRO_SUBS;
+__device__ __forceinline__ int micro_sub(long long w, long long ca) { return (w <= 16 && ca <= 16) ? 0 : ((w <= 32 && ca <= 32) ? 1 : 2); }
+__device__ __forceinline__ int internal_bin(int b, long long w, long long ca) { return b < 0 ? -1 : (b == 0 ? micro_sub(w, ca) : b + MICRO_SUBS - 1); }
+__device__ __forceinline__ int internal_start(const int32_t* __restrict__ bin_off, int ib) {
+  return ib == 0 ? bin_off[0] : (ib < MICRO_SUBS ? bin_off[NBINS + ib] : bin_off[ib - (MICRO_SUBS - 1)]);
+}
 constexpr int BIN_THREADS = 256;
 constexpr int BIN_ITEMS = BIN_TILE / BIN_THREADS;  // 4
-constexpr int BIN_COLS = 3 * NBINS + 1;            // per tile: rows per bin, pairs per bin, users per bin, total pairs
+constexpr int BIN_COLS = IBINS + 2 * NBINS + 1;    // per tile: rows per INTERNAL bin, pairs per bin, users per bin, total pairs
+static_assert(BIN_COLS == BIN_COLS_HOST && BIN_OFF_LEN == NBINS + MICRO_SUBS, "scratch sizes of the callers");
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo, int32_t n, const int64_t* __restrict__ work,
                                                                 const int32_t* __restrict__ cnt_a, int32_t n_cols_b, int32_t count_bits, int32_t k,
@@ -2050,10 +2061,12 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo,
   __shared__ long long s_acc[BIN_COLS];
   if (threadIdx.x < BIN_COLS) s_acc[threadIdx.x] = 0;
   __syncthreads();
-  int c[NBINS];
+  int c[IBINS];
   long long pw[NBINS], pu[NBINS];
 #pragma unroll
-  for (int k = 0; k < NBINS; ++k) { c[k] = 0; pw[k] = 0; pu[k] = 0; }
+  for (int k = 0; k < IBINS; ++k) c[k] = 0;
+#pragma unroll
+  for (int k = 0; k < NBINS; ++k) { pw[k] = 0; pu[k] = 0; }
   long long pairs = 0;
 #pragma unroll
   for (int q = 0; q < BIN_ITEMS; ++q) {
@@ -2063,35 +2076,39 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo,
       const long long ca = cnt_a[item_lo + t];
       pairs += w;
       const int b = choose_bin(w, ca, n_cols_b, count_bits, k);
+      const int ib = internal_bin(b, w, ca);
+#pragma unroll
+      for (int k = 0; k < IBINS; ++k) c[k] += (ib == k);
 #pragma unroll
       for (int k = 0; k < NBINS; ++k) {
-        c[k] += (b == k);
         pw[k] += (b == k) ? w : 0;
         pu[k] += (b == k) ? ca : 0;
       }
     }
   }
 #pragma unroll
+  for (int k = 0; k < IBINS; ++k)
+    if (c[k]) atomicAdd((unsigned long long*)&s_acc[k], (unsigned long long)c[k]);
+#pragma unroll
   for (int k = 0; k < NBINS; ++k)
-    if (c[k]) {
-      atomicAdd((unsigned long long*)&s_acc[k], (unsigned long long)c[k]);
-      atomicAdd((unsigned long long*)&s_acc[NBINS + k], (unsigned long long)pw[k]);
-      atomicAdd((unsigned long long*)&s_acc[2 * NBINS + k], (unsigned long long)pu[k]);
+    if (pu[k]) {
+      atomicAdd((unsigned long long*)&s_acc[IBINS + k], (unsigned long long)pw[k]);
+      atomicAdd((unsigned long long*)&s_acc[IBINS + NBINS + k], (unsigned long long)pu[k]);
     }
-  if (pairs) atomicAdd((unsigned long long*)&s_acc[3 * NBINS], (unsigned long long)pairs);
+  if (pairs) atomicAdd((unsigned long long*)&s_acc[IBINS + 2 * NBINS], (unsigned long long)pairs);
   __syncthreads();
   if (threadIdx.x < BIN_COLS) tile_counts[(int64_t)blockIdx.x * BIN_COLS + threadIdx.x] = s_acc[threadIdx.x];
 }
 
 // single block: per-column exclusive scan over the tiles (in place), totals -> bin_off / stats.  One wave per column of
-// the tile table (rows / pairs / users per bin, total pairs), 16 columns at a time.
+// the tile table (rows per internal bin, pairs / users per bin, total pairs), 16 columns at a time.
 constexpr int BS_THREADS = 1024;
 __global__ __launch_bounds__(BS_THREADS) void bin_scan_kernel(int64_t* __restrict__ tile_counts, int64_t n_tiles, int32_t* __restrict__ bin_off,
                                                               int64_t* __restrict__ stats) {
   __shared__ long long s_tot[BIN_COLS];
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
   for (int k = wave; k < BIN_COLS; k += BS_THREADS / WAVE) {  // wave-uniform
-    if (k >= NBINS) {
+    if (k >= IBINS) {
       // pairs / users / total columns: only their TOTALS are used (statistics) -- a plain sum, every lane four loads deep, one reduction at the
       // end (rounds 1-4 ran the same carried shuffle scan over all 22 columns and wrote 15 prefixes nobody read: 54 us per event type)
       long long acc = 0;
@@ -2131,17 +2148,24 @@ __global__ __launch_bounds__(BS_THREADS) void bin_scan_kernel(int64_t* __restric
   __syncthreads();
   if (threadIdx.x == 0) {
     int32_t off = 0;
-    for (int k = 0; k < NBINS; ++k) {
-      bin_off[k] = off;
-      off += (int32_t)s_tot[k];
-      if (stats) {
-        stats[1 + k] = s_tot[k];                          // rows
-        stats[1 + NBINS + k] = s_tot[NBINS + k];          // pairs
-        stats[1 + 2 * NBINS + k] = s_tot[2 * NBINS + k];  // users (sum of cA over the bin's rows)
-      }
+    for (int ib = 0; ib < IBINS; ++ib) {  // list order = internal bin order: the micro sub-lists, then the other classes
+      if (ib == 0) bin_off[0] = off;
+      else if (ib < MICRO_SUBS) bin_off[NBINS + ib] = off;
+      else bin_off[ib - (MICRO_SUBS - 1)] = off;
+      off += (int32_t)s_tot[ib];
     }
     bin_off[NBINS] = off;
-    if (stats) stats[0] = s_tot[3 * NBINS];
+    if (stats) {
+      for (int k = 0; k < NBINS; ++k) {
+        long long rows = 0;
+        if (k == 0) for (int q = 0; q < MICRO_SUBS; ++q) rows += s_tot[q];
+        else rows = s_tot[k + MICRO_SUBS - 1];
+        stats[1 + k] = rows;                                      // rows
+        stats[1 + NBINS + k] = s_tot[IBINS + k];                  // pairs
+        stats[1 + 2 * NBINS + k] = s_tot[IBINS + NBINS + k];      // users (sum of cA over the bin's rows)
+      }
+      stats[0] = s_tot[IBINS + 2 * NBINS];
+    }
   }
 }
 
@@ -2154,14 +2178,18 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int32_t item_l
 #pragma unroll
   for (int q = 0; q < BIN_ITEMS; ++q) {
     const int64_t t = (int64_t)blockIdx.x * BIN_TILE + (int64_t)threadIdx.x * BIN_ITEMS + q;
-    b[q] = t < n ? choose_bin(work[t], cnt_a[item_lo + t], n_cols_b, count_bits, k) : -1;
+    b[q] = -1;
+    if (t < n) {
+      const long long w = work[t], ca = cnt_a[item_lo + t];
+      b[q] = internal_bin(choose_bin(w, ca, n_cols_b, count_bits, k), w, ca);
+    }
   }
-  for (int k = 0; k < NBINS; ++k) {  // block-uniform: one block scan per bin
+  for (int k = 0; k < IBINS; ++k) {  // block-uniform: one block scan per internal bin
     int c = 0;
 #pragma unroll
     for (int q = 0; q < BIN_ITEMS; ++q) c += (b[q] == k);
     long long tot;
-    long long pos = block_exclusive_scan(c, s_wave, &tot) + tile_counts[(int64_t)blockIdx.x * BIN_COLS + k] + bin_off[k];
+    long long pos = block_exclusive_scan(c, s_wave, &tot) + tile_counts[(int64_t)blockIdx.x * BIN_COLS + k] + internal_start(bin_off, k);
 #pragma unroll
     for (int q = 0; q < BIN_ITEMS; ++q)
       if (b[q] == k) bin_rows[pos++] = item_lo + (int32_t)((int64_t)blockIdx.x * BIN_TILE + (int64_t)threadIdx.x * BIN_ITEMS + q);
@@ -2171,7 +2199,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int32_t item_l
 hipError_t launch_binning(hipStream_t st, int32_t item_lo, int32_t n, const int64_t* work, const int32_t* cnt_a, int32_t n_cols_b,
                           int32_t count_bits, int32_t k, int64_t* tile_counts, int32_t* bin_off, int32_t* bin_rows, int64_t* stats) {
   if (n <= 0) {
-    hipError_t e = hipMemsetAsync(bin_off, 0, sizeof(int32_t) * (NBINS + 1), st);
+    hipError_t e = hipMemsetAsync(bin_off, 0, sizeof(int32_t) * BIN_OFF_LEN, st);
     if (e == hipSuccess && stats) e = hipMemsetAsync(stats, 0, sizeof(int64_t) * STATS_LEN, st);
     return e;
   }
@@ -3261,22 +3289,71 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
 
 // --------------------------------------------------------------------------------------------
 // Micro rows (bin 0): <= 64 users and <= 64 cooccurrence pairs -- more than half of all item rows under a Zipf
-// catalogue.  One wave per row, one pair per lane, a 256-word accumulator, compaction by ballots, at most one
-// candidate per lane ranked by counting: no scans, no chunk loop, no selection passes, few registers (8 waves/SIMD).
-// --------------------------------------------------------------------------------------------
-constexpr int MICRO2_WORDS = 528;
+// catalogue.  One pair per lane, an accumulator of four words per lane, at most one candidate per lane ranked by counting:
+// no scans, no chunk loop, no selection passes, few registers (8 waves/SIMD).
 // The row body (round 5; the rounds 1-4 form -- binary search per pair, compaction sweep, one ranking replica -- is
-// profiles/r05_micro_v2_wave_llr_ab.log's "v1"): the class is bound by vector-instruction issue (~350 per row, 76 % of the issue
-// slots of config 4's launches), so the row body was rebuilt around instruction count:
-//  * a pair finds its user by a mark + prefix maximum (one LDS atomic, one LDS read, six DPP steps, two lane gathers) instead of a
+// profiles/r05_micro_v2_wave_llr_ab.log's "v1"): the class is bound by vector-instruction issue (~310 per row, 76 % of the issue
+// slots of config 4's launches), so the row body is built around instruction count:
+//  * a pair finds its user by a mark + prefix maximum (one LDS atomic, one LDS read, DPP steps, two lane gathers) instead of a
 //    seven-step binary search over LDS;
 //  * the lane whose insert CLAIMS a column owns the candidate: it reads the finished count from its own slot, clears the slot (the
-//    accumulator is zero between rows without a zeroing pass) and scores it -- no compaction sweep over the 256 slots;
-//  * rows of <= 32 (<= 16) candidates are ranked by two (four) replicas of the candidates that each count every second (fourth) element.
+//    accumulator is zero between rows without a zeroing pass) and scores it -- no compaction sweep over the slots;
+//  * few candidates are ranked by two or four replicas of the candidates that each count every second (fourth) element.
+// Round 6: S ROWS PER WAVE.  The average micro row of config 4 holds 33 pairs -- half of the wave's lanes idled through ~310 vector
+// instructions --, 61 % of the class's rows hold <= 32 pairs and users and 33 % <= 16.  The binning pass sorts the class into three
+// sub-lists (bin_off[NBINS + 1], [NBINS + 2]); rows of the first share a wave four at a time (S = 4, 16 lanes and 64 accumulator words
+// each), rows of the second two at a time, the rest keep a wave to themselves.  A sub-row is a SEGMENT of L = 64 / S lanes: everything
+// per row (ids, bounds, operands, counts, entropy, output base) is a per-lane value that is uniform inside a segment; prefix maxima
+// stop at segment boundaries (the DPP row broadcasts that would cross them are left out), ballots are masked to the segment, lane
+// gathers address inside it, and the ranking loops run to the LARGEST candidate count of the wave's rows over sentinel-padded lists.
+// --------------------------------------------------------------------------------------------
+constexpr int URCCO_OCC_MICRO = 8;  // blocks of four waves per CU the micro class is compiled for
+template <int L> struct MicroGeom {
+  static constexpr int S = WAVE / L;
+  static constexpr int TW = 256 / S;                 // accumulator words per row
+  static constexpr int LOG2TW = S == 1 ? 8 : (S == 2 ? 7 : 6);
+  static constexpr int LIST = L + 4;                 // candidate columns / keys per row (with room for the padding of the ranking loops)
+  static constexpr int MARKS = L + 2;                // pair -> user marks per row (offsets 0 .. L)
+  static constexpr int ROW_WORDS = LIST + 2 * LIST + MARKS;  // (LIST even: the 64-bit keys behind the columns stay 8-byte aligned)
+  static constexpr int WORDS = (256 + S * ROW_WORDS + 3) / 4 * 4;
+};
+// inclusive prefix maximum inside segments of L lanes (wave_inclusive_max without the row broadcasts that cross a segment boundary)
+template <int L>
+__device__ __forceinline__ unsigned seg_inclusive_max(unsigned v) {
+  if (L == WAVE) return wave_inclusive_max(v);
+  int x = (int)v;
+  int y;
+  y = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+  x = (unsigned)y > (unsigned)x ? y : x;
+  y = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+  x = (unsigned)y > (unsigned)x ? y : x;
+  y = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+  x = (unsigned)y > (unsigned)x ? y : x;
+  y = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+  x = (unsigned)y > (unsigned)x ? y : x;
+  if (L == 32) {
+    y = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3: the upper half of either 32-lane segment
+    x = (unsigned)y > (unsigned)x ? y : x;
+  }
+  return (unsigned)x;
+}
+// the largest number of set bits of m inside one segment of L lanes (wave-uniform m: scalar arithmetic)
+template <int L>
+__device__ __forceinline__ unsigned seg_max_popc(unsigned long long m) {
+  if (L == WAVE) return (unsigned)__popcll(m);
+  unsigned best = 0;
+#pragma unroll
+  for (int q = 0; q < WAVE / L; ++q) {
+    const unsigned c = (unsigned)__popcll((m >> (q * L)) & ((1ull << L) - 1ull));
+    best = c > best ? c : best;
+  }
+  return best;
+}
 
-constexpr int URCCO_OCC_MICRO = 8;  // blocks of four one-wave teams per CU the micro class is compiled for (A/B knob)
-template <bool DBG>
-__global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(CcoArgs a) {
+template <int L, bool DBG>
+__global__ __launch_bounds__(256, (L == WAVE ? URCCO_OCC_MICRO : URCCO_OCC_MICRO - 2)) void cco_rows_micro_kernel(CcoArgs a) {
+  using G = MicroGeom<L>;
+  constexpr int S = G::S;
   const int dbg = DBG ? a.debug : 0;
   // (plain argument pointers here: with scalar registers of their own -- URCCO_OWN_GLOBAL_PTR, as in cco_rows_kernel -- this class spilled five
   // VECTOR registers to scratch and ran 3 % slower, profiles/r05_sgpr_diet_variants_ab.log)
@@ -3294,19 +3371,24 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
   int32_t* out_count = a.out_count;
   long long n_users = a.n_users;
   constexpr int TEAMS = 256 / WAVE;
-  // Team LDS layout (words): [0,256) accumulator (zero between rows), [256,324) candidate columns, [324,460) their 64-bit keys (both with
-  // room for three padding elements), [460,526) the pair -> user marks.
-  __shared__ __attribute__((aligned(16))) unsigned s_tab[TEAMS * MICRO2_WORDS];
+  // Wave LDS layout (words): [0,256) the S accumulators (zero between rows), then per row: candidate columns [LIST], their 64-bit keys [LIST],
+  // the pair -> user marks [MARKS]
+  __shared__ __attribute__((aligned(16))) unsigned s_tab[TEAMS * G::WORDS];
   const int team = threadIdx.x / WAVE;
   const int lane = threadIdx.x & (WAVE - 1);
-  unsigned* tab = s_tab + team * MICRO2_WORDS;
-  unsigned* cand = tab + 256;
-  unsigned long long* kkm = reinterpret_cast<unsigned long long*>(tab + 324);
-  unsigned* marks = tab + 460;
-  const int list_start = a.bin_off[0];
-  const int list_n = a.bin_off[1] - list_start;
+  const int seg = lane / L, sl = lane % L;  // this lane's row of the wave's S rows, and its position in the row's segment
+  const unsigned long long seg_mask = L == WAVE ? ~0ull : (((1ull << (L % WAVE)) - 1ull) << (seg * L));
+  unsigned* tab_w = s_tab + team * G::WORDS;
+  unsigned* tab = tab_w + seg * G::TW;
+  unsigned* cand = tab_w + 256 + seg * G::ROW_WORDS;
+  unsigned long long* kkm = reinterpret_cast<unsigned long long*>(cand + G::LIST);
+  unsigned* marks = cand + 3 * G::LIST;
+  // this instantiation's sub-list of the class: rows of <= 16 / <= 32 / <= 64 pairs and users (bin_off, see the binning pass)
+  const int list_start = L == 16 ? a.bin_off[0] : a.bin_off[NBINS + (L == 32 ? 1 : 2)];
+  const int list_n = (L == 16 ? a.bin_off[NBINS + 1] : (L == 32 ? a.bin_off[NBINS + 2] : a.bin_off[1])) - list_start;
+  const int n_groups = (list_n + S - 1) / S;  // a wave takes S consecutive rows of the list at a time
   const int total_teams = gridDim.x * TEAMS;
-  const bool ident = a.n_cols_b <= 256;
+  const bool ident = a.n_cols_b <= G::TW;
   const int cb = a.count_bits;
   const unsigned cmask = (1u << cb) - 1u;
   const double xlx_n = *a.xlx_n;
@@ -3314,25 +3396,25 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
   unsigned long long cand_acc = 0ull;  // candidates scored by this wave (statistics)
 
   int li = blockIdx.x * TEAMS + team;
-  if (li >= list_n) return;  // (wave-level synchronisation only: a wave without rows may leave)
+  if (li >= n_groups) return;  // (wave-level synchronisation only: a wave without rows may leave)
   // The row loop is a chain of dependent gathers (row id -> CSC bounds -> per-user operands -> B' columns -> column counts), and
   // the memory counter retires IN ORDER: a wave that waits for any load waits for every older one, and for every older store.  So
   //  * every link of the chain is issued at the TOP of a row, for the rows ahead -- the row id three rows ahead, the CSC bounds two,
   //    the operands one -- where the wait for this row's B' columns (the one unavoidable long wait) covers them all;
   //  * they are issued unconditionally (a branch with loads in it makes the compiler wait for everything where the paths join): list
-  //    positions past the end re-read the last row, lanes beyond a row's users its last user;
+  //    positions past the end re-read the last row (and are marked dead), lanes beyond a row's users its last user;
   //  * nothing is touched where it is loaded (a conversion next to a load is a wait for it), and everything is collected
   //    (URCCO_SETTLE) just before the row's output stores, so that the next row never waits behind those stores.
   // Round 4 found the rounds 1-3 form of this loop waiting three times per row for loads it had issued as "prefetches".
   const int stride = total_teams;
-  auto row_at = [&](int l) { return bin_rows[list_start + (l < list_n ? l : list_n - 1)]; };
+  auto row_at = [&](int g) { const int l = g * S + seg; return bin_rows[list_start + (l < list_n ? l : list_n - 1)]; };
   const unsigned* wp32 = reinterpret_cast<const unsigned*>(a.wp);  // low words: a row only uses differences (<= 64) between its own entries
   const unsigned* cnt_words = use16 ? reinterpret_cast<const unsigned*>(a.cnt_b16) : reinterpret_cast<const unsigned*>(a.cnt_b);  // the column counts, read a word at a time
   int i_cur = row_at(li);              // this row
   int i_n1 = row_at(li + stride);      // the next one: id ...
   int i_n2 = row_at(li + 2 * stride);  // (two ahead: id only)
   int64_t cs1 = a_col_ptr[i_n1], ce1 = a_col_ptr[i_n1 + 1];  // ... and CSC bounds
-  // operands of the row about to be processed; wp[cs] is what lane 0 reads as its user's entry
+  // operands of the row about to be processed; wp[cs] is what the segment's first lane reads as its user's entry
   unsigned pf_w1, pf_wp;
   int64_t pf_start;
   int pf_ca;  // as loaded: widened where it is used
@@ -3341,7 +3423,7 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
   {
     const int64_t cs0 = a_col_ptr[i_cur], ce0 = a_col_ptr[i_cur + 1];
     n_cur = (int)(ce0 - cs0);
-    const int64_t pl = lane < n_cur ? cs0 + lane : ce0 - 1;
+    const int64_t pl = sl < n_cur ? cs0 + sl : ce0 - 1;
     pf_w1 = wp32[2 * ce0];
     pf_wp = wp32[2 * pl];
     pf_start = pstart[pl];
@@ -3353,13 +3435,14 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
   URCCO_SETTLE(pf_w1); URCCO_SETTLE(pf_wp); URCCO_SETTLE(pf_start); URCCO_SETTLE(pf_ca); URCCO_SETTLE(pf_ent);
   URCCO_SETTLE(cs1); URCCO_SETTLE(ce1); URCCO_SETTLE(i_n2);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) tab[lane + q * WAVE] = 0u;  // the accumulator: zero between rows (a candidate's owner clears its slot)
-  for (; li < list_n; li += stride) {  // each wave runs its own row loop: wave-level sync only
+  for (int q = 0; q < 4; ++q) tab_w[lane + q * WAVE] = 0u;  // the accumulators: zero between rows (a candidate's owner clears its slot)
+  for (; li < n_groups; li += stride) {  // each wave runs its own row loop: wave-level sync only
     const int i = i_cur;
+    const bool live = S == 1 || li * S + seg < list_n;  // (the last group of a sub-list may be short: its dead segments hold no user and no pair)
     // this row's operands leave their registers ...
-    const unsigned w0 = wave_read_lane(pf_wp, 0);  // wp[cs]
-    const unsigned total = pf_w1 - w0;  // <= 64 by the binning rule
-    const bool owns_user = lane < n_cur;
+    const unsigned w0 = S == 1 ? wave_read_lane(pf_wp, 0) : wave_gather(pf_wp, (unsigned)(lane & ~(L - 1)));  // wp[cs]
+    const unsigned total = live ? pf_w1 - w0 : 0u;  // <= L by the binning rule
+    const bool owns_user = live && sl < n_cur;
     const long long ca = (long long)pf_ca;
     const double row_entropy = pf_ent;
     const int64_t my_start = owns_user ? pf_start : 0;
@@ -3369,7 +3452,7 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
     int64_t cs2 = a_col_ptr[i_n2], ce2 = a_col_ptr[i_n2 + 1];
     n_cur = (int)(ce1 - cs1);
     {
-      const int64_t pl = lane < n_cur ? cs1 + lane : ce1 - 1;
+      const int64_t pl = sl < n_cur ? cs1 + sl : ce1 - 1;
       pf_w1 = wp32[2 * ce1];
       pf_wp = wp32[2 * pl];
       pf_start = pstart[pl];
@@ -3378,27 +3461,28 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
     }
     // ---- pair -> user: user u marks the first pair of its B' row with u (the LAST user of an offset is the one whose row is not
     // empty); a pair's user is the largest mark at or below it
-    marks[lane] = 0u;
+    marks[sl] = 0u;
     wave_sync();
-    if (owns_user) atomicMax(&marks[my_off], (unsigned)lane);  // my_off <= total <= 64: marks has 66 words
+    if (owns_user) atomicMax(&marks[my_off], (unsigned)sl);  // my_off <= total <= L: marks has L + 2 words
     wave_sync();
-    const unsigned o = wave_inclusive_max(marks[lane]);
-    const int64_t base_o = wave_gather64(my_start - (int64_t)my_off, o);  // B' position of pair p of user o: base + p
+    const unsigned o = seg_inclusive_max<L>(marks[sl]);
+    const int64_t base_o = wave_gather64(my_start - (int64_t)my_off, (unsigned)(seg * L) + o);  // B' position of pair p of user o: base + p
     // ---- insert; the claiming lane owns the candidate
     unsigned slot = 0xffffffffu;
-    if ((unsigned)lane < total) {
-      const unsigned jj = (unsigned)b_col_idx[base_o + lane];
+    if ((unsigned)sl < total) {
+      const unsigned jj = (unsigned)b_col_idx[base_o + sl];
       if (!(dbg & 1)) {
         bool ok;
-        slot = tab_insert_claim(tab, jj + 1u, cb, 255u, 24, ident, &ok);
+        slot = tab_insert_claim(tab, jj + 1u, cb, (unsigned)(G::TW - 1), 32 - G::LOG2TW, ident, &ok);
         if (!ok) atomicAdd(a.err, 1ull);
       }
     }
     wave_sync();
     const bool is_cand = slot != 0xffffffffu;
     const unsigned long long cand_mask = __ballot(is_cand);
-    const unsigned D = (unsigned)__popcll(cand_mask);
-    cand_acc += D;
+    const unsigned D = (unsigned)__popcll(cand_mask & seg_mask);  // this row's candidates
+    const unsigned D_max = seg_max_popc<L>(cand_mask);            // the wave's largest row (wave-uniform: loop bounds)
+    cand_acc += (unsigned)__popcll(cand_mask);
     unsigned long long mk = 0ull;
     unsigned vv = 0u, cb_raw = 0u;
     if (is_cand) {  // the finished count leaves the accumulator, the slot is zero again, and the count gather is issued (ONE 4-byte load whichever
@@ -3408,9 +3492,9 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
       const int j = (int)(vv >> cb) - 1;
       cb_raw = cnt_words[use16 ? j >> 1 : j];
     }
-    if (lane < 3) {  // padding of the ranking loop's element list: sorts before nothing
-      kkm[D + (unsigned)lane] = 0ull;
-      cand[D + (unsigned)lane] = 0xffffffffu;
+    if (D + (unsigned)sl < (unsigned)G::LIST) {  // padding of the ranking loop's element list behind the row's candidates: sorts before nothing
+      kkm[D + (unsigned)sl] = 0ull;
+      cand[D + (unsigned)sl] = 0xffffffffu;
     }
     bool in_tables = true;
     if (is_cand) {
@@ -3432,66 +3516,67 @@ __global__ __launch_bounds__(256, URCCO_OCC_MICRO) void cco_rows_micro_kernel(Cc
                                                       : llr_of(row_entropy, xlx_n, k11, ca, (long long)cbj, n_users, xlx_tab, xlx_hi, col_ent));
         if (llr > 0.0 && (!a.has_min_llr || llr >= a.min_llr)) mk = (unsigned long long)__double_as_longlong(llr);
       }
-      const unsigned pos = lanes_below(cand_mask);
+      const unsigned pos = lanes_below(cand_mask & seg_mask);
       kkm[pos] = mk;
       cand[pos] = (unsigned)j;
     }
     wave_sync();
     const unsigned long long valid_mask = __ballot(mk != 0ull);
-    const int n_valid = __popcll(valid_mask);
+    const int n_valid = __popcll(valid_mask & seg_mask);
+    const bool all_fit_k = (int)seg_max_popc<L>(valid_mask) <= a.k;  // wave-uniform
     auto settle_prefetch = [&]() {  // the next row's operands have had the score phase to arrive: collect them before the output stores
       URCCO_SETTLE(pf_w1); URCCO_SETTLE(pf_wp); URCCO_SETTLE(pf_start); URCCO_SETTLE(pf_ca); URCCO_SETTLE(pf_ent);
       URCCO_SETTLE(cs2); URCCO_SETTLE(ce2); URCCO_SETTLE(i_n3);
     };
-    if (a.unordered && n_valid <= a.k && !(dbg & 4)) {  // every candidate is emitted: no ranking needed (wave-uniform)
+    if (a.unordered && all_fit_k && !(dbg & 4)) {  // every candidate is emitted: no ranking needed (wave-uniform)
       const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
       settle_prefetch();
       if (mk != 0ull) {
-        const unsigned opos = lanes_below(valid_mask);
+        const unsigned opos = lanes_below(valid_mask & seg_mask);
         out_idx[obase + opos] = (int)(vv >> cb) - 1;
         out_llr[obase + opos] = __longlong_as_double((long long)mk);
       }
-      if (lane == 0) out_count[i - a.item_lo] = n_valid;
+      if (sl == 0 && live) out_count[i - a.item_lo] = n_valid;
     } else if (!(dbg & 4)) {
       const int64_t obase = ((int64_t)(i - a.item_lo)) * a.k;
-      // candidates dense by lane, replicated while they fit twice / four times into the wave: replica q counts elements q, q + R, ...
+      // candidates dense by lane, replicated while they fit twice / four times into the row's segment: replica q counts elements q, q + R, ...
       unsigned rank;
       unsigned long long rk;
       unsigned rc;
-      unsigned ln = (unsigned)lane;
+      unsigned ln = (unsigned)sl;
       URCCO_OPAQUE(ln);  // the per-lane LDS addresses of the three forms are computed here, not kept across the row loop
-      if (D <= 16u) {  // wave-uniform
-        const unsigned c = ln & 15u;
+      if (D_max <= (unsigned)(L / 4)) {  // wave-uniform
+        const unsigned c = ln & (unsigned)(L / 4 - 1);
         rk = kkm[c];
         rc = cand[c];
-        rank = rank_by_counting_strided<4>(kkm, cand, ln >> 4, (D + 3u) & ~3u, rk, rc);
-        rank += (unsigned)__shfl_xor((int)rank, 16);
-        rank += (unsigned)__shfl_xor((int)rank, 32);
-      } else if (D <= 32u) {
-        const unsigned c = ln & 31u;
+        rank = rank_by_counting_strided<4>(kkm, cand, ln / (unsigned)(L / 4), (D_max + 3u) & ~3u, rk, rc);
+        rank += (unsigned)__shfl_xor((int)rank, L / 4);
+        rank += (unsigned)__shfl_xor((int)rank, L / 2);
+      } else if (D_max <= (unsigned)(L / 2)) {
+        const unsigned c = ln & (unsigned)(L / 2 - 1);
         rk = kkm[c];
         rc = cand[c];
-        rank = rank_by_counting_strided<2>(kkm, cand, ln >> 5, (D + 1u) & ~1u, rk, rc);
-        rank += (unsigned)__shfl_xor((int)rank, 32);
+        rank = rank_by_counting_strided<2>(kkm, cand, ln / (unsigned)(L / 2), (D_max + 1u) & ~1u, rk, rc);
+        rank += (unsigned)__shfl_xor((int)rank, L / 2);
       } else {
         rk = kkm[ln];
         rc = cand[ln];
-        rank = rank_by_counting_strided<1>(kkm, cand, 0u, D, rk, rc);
+        rank = rank_by_counting_strided<1>(kkm, cand, 0u, D_max, rk, rc);
       }
       // the row is put in order in LDS (every lane has its element in registers: in place) and leaves as contiguous stores
       wave_sync();
       const unsigned n_out = (unsigned)(n_valid < a.k ? n_valid : a.k);
-      if ((unsigned)lane < D && rk != 0ull && rank < n_out) {
+      if ((unsigned)sl < D && rk != 0ull && rank < n_out) {
         cand[rank] = rc;
         kkm[rank] = rk;
       }
       wave_sync();
       settle_prefetch();
-      if ((unsigned)lane < n_out) {
-        out_idx[obase + lane] = (int)cand[lane];
-        out_llr[obase + lane] = __longlong_as_double((long long)kkm[lane]);
+      if ((unsigned)sl < n_out) {
+        out_idx[obase + sl] = (int)cand[sl];
+        out_llr[obase + sl] = __longlong_as_double((long long)kkm[sl]);
       }
-      if (lane == 0) out_count[i - a.item_lo] = (int)n_out;
+      if (sl == 0 && live) out_count[i - a.item_lo] = (int)n_out;
     } else {
       settle_prefetch();
     }
@@ -3703,7 +3788,7 @@ static int blocks_per_cu(int bin) {
   if (cache[bin].load(std::memory_order_relaxed) == 0) {
     int n = 0;
     hipError_t e = hipErrorUnknown;
-    if (bin == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_micro_kernel<false>, 256, 0);
+    if (bin == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_micro_kernel<WAVE, false>, 256, 0);
     if (bin == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<64, E0, URCCO_U_WAVE>, 256, 0);
     if (bin == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1S, URCCO_U_BS>, 256, 0);
     if (bin == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1, URCCO_U_B>, 256, 0);
@@ -3740,20 +3825,39 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
   };
   static const Factors factors;
   const int* factor = factors.f;
-  auto grid = [&](int b) {
+  // the micro class's sub-lists of shared waves (two / four rows per wave and pass) hold a third of the class's passes each at most: smaller grids,
+  // so that a wave still runs several passes behind its start-up (three rows of prefetches).  URCCO_MICRO_GRID="f32,f16" for measurements.
+  struct MicroFactors {
+    int f32 = 3, f16 = 2;
+    MicroFactors() {
+      if (const char* e = getenv("URCCO_MICRO_GRID")) {
+        int a = 0, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && a <= 64 && b >= 1 && b <= 64) { f32 = a; f16 = b; }
+      }
+    }
+  };
+  static const MicroFactors micro_factors;
+  auto grid = [&](int b, int f = 0) {
     const long long fill = (long long)n_cu * blocks_per_cu(b);  // blocks resident at once
     const long long teams = b <= 1 ? 4 : 1;                       // row loops per block (micro / one-wave classes: four one-wave teams)
     long long cap = ((long long)n_rows + teams * 32 - 1) / (teams * 32);
     if (cap < 2 * fill) cap = 2 * fill;  // (as rounds 2-4)
-    long long blocks = fill * factor[b];
+    long long blocks = fill * (f > 0 ? f : factor[b]);
     if (blocks > cap) blocks = cap;
     return dim3((unsigned)blocks);
   };
   const bool dbgk = (args.debug & (1 | 2 | 4 | 8 | 16 | 512 | 131072 | 262144)) != 0;  // the ablation / test switches live in the DBG instantiations only
   switch (bin) {
-    case 0:
-      if (dbgk) hipLaunchKernelGGL(cco_rows_micro_kernel<true>, grid(0), dim3(256), 0, st, args);
-      else hipLaunchKernelGGL(cco_rows_micro_kernel<false>, grid(0), dim3(256), 0, st, args);
+    case 0:  // the class's three sub-lists, the rows that keep a wave to themselves first (each kernel reads its own list bounds on the device)
+      if (dbgk) {
+        hipLaunchKernelGGL((cco_rows_micro_kernel<64, true>), grid(0), dim3(256), 0, st, args);
+        hipLaunchKernelGGL((cco_rows_micro_kernel<32, true>), grid(0, micro_factors.f32), dim3(256), 0, st, args);
+        hipLaunchKernelGGL((cco_rows_micro_kernel<16, true>), grid(0, micro_factors.f16), dim3(256), 0, st, args);
+      } else {
+        hipLaunchKernelGGL((cco_rows_micro_kernel<64, false>), grid(0), dim3(256), 0, st, args);
+        hipLaunchKernelGGL((cco_rows_micro_kernel<32, false>), grid(0, micro_factors.f32), dim3(256), 0, st, args);
+        hipLaunchKernelGGL((cco_rows_micro_kernel<16, false>), grid(0, micro_factors.f16), dim3(256), 0, st, args);
+      }
       break;
     case 1:
       if (dbgk) hipLaunchKernelGGL((cco_rows_kernel<64, E0, URCCO_U_WAVE, false, true>), grid(1), dim3(256), 0, st, args, 1);

@@ -439,7 +439,7 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
   URC(s->reserve(urcco_session::need((size_t)cap, 8) + urcco_session::need((size_t)cap, 4) + urcco_session::need((size_t)cap + 1, 8) +
                  urcco_session::need((size_t)p_tiles + 2, 8) +
                  urcco_session::need((size_t)n, 8) + urcco_session::need((size_t)(n_tiles + 1) * urcco::BIN_COLS_HOST, 8) +
-                 urcco_session::need(urcco::NBINS + 1, 4) + urcco_session::need((size_t)n, 4) + urcco_session::need((size_t)n_items_a, 8) +
+                 urcco_session::need(urcco::BIN_OFF_LEN, 4) + urcco_session::need((size_t)n, 4) + urcco_session::need((size_t)n_items_a, 8) +
                  urcco_session::need((size_t)n_cols_b, 2) + urcco_session::need(1, 4) + urcco_session::need(urcco::CAND_SLOTS, 8) + urcco_session::need(1, 8) + urcco_session::need(URCCO_STATS_LEN, 8) +
                  urcco_session::need((size_t)n_users + 1, 4)));
   int64_t* own_pstart = s->take<int64_t>((size_t)cap);
@@ -449,7 +449,7 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
   int64_t* p_tile_sums = s->take<int64_t>((size_t)p_tiles + 2);
   int64_t* work = s->take<int64_t>((size_t)n);
   int64_t* tile_counts = s->take<int64_t>((size_t)(n_tiles + 1) * urcco::BIN_COLS_HOST);
-  int32_t* bin_off = s->take<int32_t>(urcco::NBINS + 1);
+  int32_t* bin_off = s->take<int32_t>(urcco::BIN_OFF_LEN);
   int32_t* bin_rows = s->take<int32_t>((size_t)n);
   double* ent_a = s->take<double>((size_t)n_items_a);
   unsigned short* cnt_b16 = s->take<unsigned short>((size_t)n_cols_b);
