@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define URCCO_VERSION 304 /* 0.3.4: URCCO_BUSY, urcco_cross_occurrence_cancel_any; _cancel only discards the caller's own staged build */
+#define URCCO_VERSION 305 /* 0.3.5: urcco_dev_pack_counts, urcco_dev_cco_rows_packed (304: URCCO_BUSY, urcco_cross_occurrence_cancel_any) */
 
 typedef enum urcco_status {
   URCCO_OK = 0,
@@ -391,6 +391,21 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
                        const int32_t* counts_b, int64_t n_users, int32_t exclude_self, int32_t k,
                        int32_t has_min_llr, double min_llr, int32_t* out_count, int32_t* out_idx,
                        double* out_llr, int64_t* stats_dev);
+
+/* B' with the columns' counts aboard (round 6): out_packed[e] = b_col_idx[e] | counts_b[b_col_idx[e]] << key_bits for the entries of B' (b_row_ptr[n_rows_b] of
+ * them, read on the device; nnz_b_bound >= that sizes the launch; out_packed holds nnz_b_bound words), key_bits = the bits of the value n_cols_b.
+ * out_bad[0] = number of entries whose count does not fit the word's 32 - key_bits spare bits or 16 bits.  urcco_dev_cco_rows_packed is
+ * urcco_dev_cco_rows for a B' that comes with such a copy: while out_bad[0] == 0 the row kernels read a candidate's cB off the word that claims its
+ * accumulator slot instead of gathering counts_b[col] once per candidate -- more than half of the SpGEMM's cache-line fills; otherwise,
+ * or with b_packed == pack_bad == NULL, it IS urcco_dev_cco_rows.  The context level packs every B' itself.  Results are identical either way. */
+int urcco_dev_pack_counts(urcco_session* s, int64_t n_rows_b, const int64_t* b_row_ptr, const int32_t* b_col_idx, int64_t nnz_b_bound, const int32_t* counts_b,
+                          int32_t n_cols_b, int32_t* out_packed, int32_t* out_bad);
+int urcco_dev_cco_rows_packed(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a,
+                              const int64_t* a_col_ptr, const int32_t* a_row_idx, int64_t nnz_a_bound,
+                              const int64_t* b_row_ptr, const int32_t* b_col_idx, int32_t n_cols_b, const int32_t* counts_a,
+                              const int32_t* counts_b, int64_t n_users, int32_t exclude_self, int32_t k,
+                              int32_t has_min_llr, double min_llr, int32_t* out_count, int32_t* out_idx,
+                              double* out_llr, int64_t* stats_dev, const int32_t* b_packed, const int32_t* pack_bad);
 
 /* Strided top-k rows -> CSR.  out_row_ptr[n_rows+1]; out_col_idx/out_llr capacity n_rows*k. */
 int urcco_dev_compact_indicators(urcco_session* s, int32_t n_rows, int32_t k, const int32_t* count,

@@ -26,7 +26,7 @@ def test_header_binding_and_library_agree():
     exported = set(re.findall(r" T (urcco_[a-z0-9_]+)", out))
     assert set(declared) <= exported, sorted(set(declared) - exported)
     lib = _lib.load(lib_path)                      # dlopen + symbol resolution of every declared entry point
-    assert lib.urcco_version() == 304
+    assert lib.urcco_version() == 305
     # the device code object really targets gfx950
     note = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", lib_path], capture_output=True, text=True).stdout
     blob = open(lib_path, "rb").read()

@@ -29,7 +29,8 @@ def P(max_rows=500, k=50, min_llr=None):
     logic.test_partition_balances_work, logic.test_partitioned_column_counts_large_matrix, logic.test_llr_operands_beyond_the_tables,
     logic.test_downsampling_under_the_32_bit_rng, logic.test_large_matrix_full_pipeline,
     logic.test_large_transpose_with_item_range, logic.test_all_equal_llr_ties_cut_by_column,
-    logic.test_many_ties_at_the_cut_after_skipped_column_passes, logic.test_row_scan_threshold_table_forms, logic.test_global_class_ties_at_the_cut, logic.test_micro_class_every_ranking_form],
+    logic.test_many_ties_at_the_cut_after_skipped_column_passes, logic.test_row_scan_threshold_table_forms, logic.test_global_class_ties_at_the_cut, logic.test_micro_class_every_ranking_form,
+    logic.test_counts_aboard_and_the_count_gather_agree],
     ids=lambda f: f.__name__)
 def test_logic_case_on_gpu(case, gpu_session):
     case(gpu_session)

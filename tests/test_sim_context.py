@@ -80,8 +80,9 @@ def context_reuse_case(lib, device):
     sess = DeviceSession(device, lib)
     ctx = Context(device, lib)
     try:
-        for flags in (0, _lib.FLAG_SINGLE_STREAM):
+        for flags, dbg in ((0, 0), (_lib.FLAG_SINGLE_STREAM, 0), (0, 1048576)):   # debug 1048576: B' without the counts aboard (one count gather per candidate)
             ctx.set_flags(flags)
+            ctx.set_debug(dbg)
             for mats, ps in cases:
                 ref = cross_occurrence_device(sess, [to_dev(m, device) for m in mats], to_params(ps), 17)
                 sess.synchronize()

@@ -190,6 +190,34 @@ def test_llr_operands_beyond_the_tables(sim_session):
     _, _, stats = compare_with_oracle(sim_session, [a, b], [P(100000, 50), P(100000, 50)], 9)       # ... and as the secondary
 
 
+def test_counts_aboard_and_the_count_gather_agree(sim_session):
+    """Round 6: B' words carry their column's post-sampling count (urcco_dev_pack_counts) and the row kernels read a candidate's cB off the word
+    that claims its accumulator slot -- what every other test of this file runs.  Here (a) the form of rounds 1-5 -- plain column indices, one
+    count gather per candidate -- on matrices that fill every accumulator class, and (b) a catalogue of 2^20 columns (11 spare bits in a word)
+    with a column held by 3000 users and no interaction cut: that count does not fit, the pack pass says so and the build falls back to the
+    gather.  Every row against the oracle in both cases."""
+    rng = np.random.default_rng(61)
+    a = rand_csr(rng, 3000, 900, 10, zipf_s=1.1)
+    b = rand_csr(rng, 3000, 2500, 25, zipf_s=1.0)
+    c = rand_csr(rng, 3000, 40, 3)
+    sim_session.pack_counts = False
+    try:
+        compare_with_oracle(sim_session, [a, b, c], [P(200, 20), P(200, 20), P(500, 50)], 17)
+    finally:
+        sim_session.pack_counts = True
+    n_users, n_cols = 4000, 1 << 20
+    base = rand_csr(rng, n_users, n_cols, 5)
+    hot = np.zeros(n_users, bool)
+    hot[rng.choice(n_users, 3000, replace=False)] = True
+    rows = [np.unique(np.concatenate([base.col_idx[base.row_ptr[u]:base.row_ptr[u + 1]], [12345] if hot[u] else []]).astype(np.int32)) for u in range(n_users)]
+    rp = np.zeros(n_users + 1, np.int64)
+    np.cumsum([len(r) for r in rows], out=rp[1:])
+    wide = O.Csr(n_users, n_cols, rp, np.concatenate(rows))
+    assert O.column_counts(wide)[12345] >= 2048          # beyond the 11 spare bits of a word of a 2^20-column catalogue
+    prim = rand_csr(rng, n_users, 300, 6, zipf_s=0.8)
+    compare_with_oracle(sim_session, [prim, wide], [P(100000, 50), P(100000, 50)], 23)
+
+
 def test_partition_balances_work(sim_session):
     rng = np.random.default_rng(9)
     work = guarded(torch.from_numpy(rng.zipf(1.5, 5000).astype(np.int64)).to(sim_session.device))

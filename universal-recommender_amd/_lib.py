@@ -146,6 +146,9 @@ SYMBOLS = {
     "urcco_dev_merge_fragments": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p, C.c_int32, _p, C.c_int64, _p, _p, _p, _p]),
     "urcco_dev_cco_rows": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, C.c_int64, _p, _p, C.c_int32, _p, _p, C.c_int64, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_double, _p, _p, _p, _p]),
+    "urcco_dev_pack_counts": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int64, _p, C.c_int32, _p, _p]),
+    "urcco_dev_cco_rows_packed": (C.c_int, [_p, C.c_int32, C.c_int32, C.c_int32, _p, _p, C.c_int64, _p, _p, C.c_int32, _p, _p, C.c_int64, C.c_int32,
+                                            C.c_int32, C.c_int32, C.c_double, _p, _p, _p, _p, _p, _p]),
     "urcco_dev_compact_indicators": (C.c_int, [_p, C.c_int32, C.c_int32, _p, _p, _p, _p, _p, _p]),
     "urcco_dev_pop_counts": (C.c_int, [_p, C.c_int64, _p, _p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), _p]),
     "urcco_dev_llr": (C.c_int, [_p, C.c_int64, _p, _p, _p, _p, _p]),

@@ -32,6 +32,11 @@ struct CcoArgs {
   const int64_t* pstart;     // per CSC entry: start of that user's B' row in b_col_idx
   const int64_t* wp;         // per CSC entry (+1): exclusive prefix of B' row lengths over the CSC
   const int32_t* b_col_idx;
+  // Round 6: B' with the column's post-sampling count riding in the spare bits of the column word -- word = col | cB << (32 - count_bits) -- so that a
+  // candidate's cB arrives with the pair that claims its accumulator slot instead of through one scattered 2-byte gather per candidate (more than half
+  // of the SpGEMM classes' line fills: profiles/r06_fetch_by_phase.txt).  Nullable; used while *pack_bad == 0 (every count fits its 32 - key bits).
+  const int32_t* b_packed;
+  const int32_t* pack_bad;   // [1] counts that do not fit the spare bits (then b_col_idx + the count gather serve the build)
   const int32_t* cnt_a;
   const int32_t* cnt_b;
   const double* ent_a;       // rowEntropy per item of A
@@ -147,6 +152,10 @@ hipError_t launch_publish_word(hipStream_t st, const unsigned long long* src, un
 hipError_t launch_pop_counts(hipStream_t st, int n_cu, int64_t n, const int32_t* item, const int64_t* t_ms, int32_t n_items, int n_buckets,
                              const int64_t* bounds, int32_t* counts);
 
+// out[e] = col_idx[e] | counts16[col_idx[e]] << (32 - count_bits) for e < *nnz_dev (<= nnz_bound); counts16 / bad16 as launch_narrow_counts leaves them;
+// bad[0] (zeroed here) = counts that do not fit (or 1 when *bad16 != 0: nothing packed)
+hipError_t launch_pack_counts(hipStream_t st, int n_cu, const int32_t* col_idx, const int64_t* nnz_dev, int64_t nnz_bound, const unsigned short* counts16,
+                              const int32_t* bad16, int32_t count_bits, int32_t* out, int32_t* bad);
 hipError_t launch_xlx_table(hipStream_t st, double* tab);
 hipError_t launch_xlx_hi_table(hipStream_t st, double* tab /*[2 * XLX_TABLE_HOST]: xlx_hi, then col_ent*/, const double* xlx_tab, long long n_users);
 hipError_t launch_item_entropy(hipStream_t st, const int32_t* counts, int32_t n, long long n_users, double* ent, double* xlx_n);

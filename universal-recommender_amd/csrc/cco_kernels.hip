@@ -1381,7 +1381,7 @@ static int tp_bucket_bits(int32_t n_cols) {
   return bits;
 }
 
-__global__ __launch_bounds__(TP_THREADS, 2) void tp_partition_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
+__global__ __launch_bounds__(TP_THREADS, 4) void tp_partition_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
                                                                   const int64_t* __restrict__ R, int bits, int n_buckets, int64_t n_parts, int32_t col_lo,
                                                                   int32_t col_hi, unsigned short* __restrict__ bk_col, int32_t* __restrict__ bk_row,
                                                                   unsigned short* __restrict__ loc_t, int vec_ok) {
@@ -1743,6 +1743,82 @@ hipError_t launch_narrow_counts(hipStream_t st, int n_cu, const int32_t* counts,
   return hipGetLastError();
 }
 
+// B' with counts aboard (CcoArgs::b_packed): one streaming pass, four entries per thread and step (one 16-byte load, four count gathers in
+// flight, one 16-byte store).  The gathers it makes -- one per ENTRY of B' -- replace one per CANDIDATE of every A'B row: an entry of B' is
+// expanded once per item its user holds in A' (~4x on config 4), and here nothing waits on the gather but the store.
+// 16-byte non-temporal accesses (the builtins take native vector types, not HIP's int4 class)
+typedef int urcco_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 nt_load4(const int32_t* p) {
+#ifdef HIPSIM_HOST_BUILD
+  return *reinterpret_cast<const int4*>(p);
+#else
+  const urcco_v4i v = __builtin_nontemporal_load(reinterpret_cast<const urcco_v4i*>(p));
+  return make_int4(v.x, v.y, v.z, v.w);
+#endif
+}
+__device__ __forceinline__ void nt_store4(int32_t* p, int4 y) {
+#ifdef HIPSIM_HOST_BUILD
+  *reinterpret_cast<int4*>(p) = y;
+#else
+  urcco_v4i v;
+  v.x = y.x; v.y = y.y; v.z = y.z; v.w = y.w;
+  __builtin_nontemporal_store(v, reinterpret_cast<urcco_v4i*>(p));
+#endif
+}
+// cnt: the 16-bit copy of the counts (narrow_counts_kernel: half the table behind the gathers); *bad16 != 0: a count beyond 16 bits -- nothing is packed
+__global__ __launch_bounds__(256) void pack_counts_kernel(const int32_t* __restrict__ ci, const int64_t* __restrict__ nnz_dev, int64_t nnz_bound,
+                                                          const unsigned short* __restrict__ cnt, const int32_t* __restrict__ bad16, int shift,
+                                                          int32_t* __restrict__ out, int32_t* __restrict__ bad, int vec_ok) {
+  if (*bad16 != 0) {  // grid-uniform
+    if (blockIdx.x == 0 && threadIdx.x == 0) *bad = 1;
+    return;
+  }
+  int64_t nnz = *nnz_dev;
+  if (nnz > nnz_bound) nnz = nnz_bound;
+  const unsigned limit = 32 - shift >= 16 ? 65536u : (1u << (32 - shift));  // counts must fit the word's spare bits AND the accumulators' 16-bit side arrays
+  int n_bad = 0;
+  const int64_t nvec = vec_ok ? nnz >> 2 : 0;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  // two vectors per thread and step: eight count gathers in flight; the streamed words bypass the caches' retention (non-temporal), the count table is
+  // what should stay in them
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += 2 * stride) {
+    const bool two = v + stride < nvec;
+    const int4 x = nt_load4(ci + 4 * v);
+    const int4 z = two ? nt_load4(ci + 4 * (v + stride)) : make_int4(0, 0, 0, 0);
+    const unsigned c0 = (unsigned)cnt[x.x], c1 = (unsigned)cnt[x.y], c2 = (unsigned)cnt[x.z], c3 = (unsigned)cnt[x.w];
+    const unsigned d0 = two ? (unsigned)cnt[z.x] : 0u, d1 = two ? (unsigned)cnt[z.y] : 0u, d2 = two ? (unsigned)cnt[z.z] : 0u, d3 = two ? (unsigned)cnt[z.w] : 0u;
+    n_bad += (c0 >= limit) + (c1 >= limit) + (c2 >= limit) + (c3 >= limit) + (d0 >= limit) + (d1 >= limit) + (d2 >= limit) + (d3 >= limit);
+    int4 y;
+    y.x = (int)((unsigned)x.x | (c0 << shift)); y.y = (int)((unsigned)x.y | (c1 << shift));
+    y.z = (int)((unsigned)x.z | (c2 << shift)); y.w = (int)((unsigned)x.w | (c3 << shift));
+    nt_store4(out + 4 * v, y);
+    if (two) {
+      y.x = (int)((unsigned)z.x | (d0 << shift)); y.y = (int)((unsigned)z.y | (d1 << shift));
+      y.z = (int)((unsigned)z.z | (d2 << shift)); y.w = (int)((unsigned)z.w | (d3 << shift));
+      nt_store4(out + 4 * (v + stride), y);
+    }
+  }
+  for (int64_t e = (nvec << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += stride) {
+    const unsigned j = (unsigned)ci[e], c = (unsigned)cnt[j];
+    n_bad += c >= limit;
+    out[e] = (int)(j | (c << shift));
+  }
+  if (n_bad) atomicAdd(bad, n_bad);
+}
+hipError_t launch_pack_counts(hipStream_t st, int n_cu, const int32_t* col_idx, const int64_t* nnz_dev, int64_t nnz_bound, const unsigned short* counts16,
+                              const int32_t* bad16, int32_t count_bits, int32_t* out, int32_t* bad) {
+  hipError_t e = hipMemsetAsync(bad, 0, sizeof(int32_t), st);
+  if (e != hipSuccess || nnz_bound <= 0) return e;
+  const int shift = 32 - count_bits;  // the column's bits (count_bits >= 1: shift <= 31)
+  int64_t blocks = (nnz_bound / 4 + 255) / 256;
+  const int64_t cap = (int64_t)n_cu * 16;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  const int vec_ok = ((reinterpret_cast<uintptr_t>(col_idx) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  hipLaunchKernelGGL(pack_counts_kernel, dim3((unsigned)blocks), dim3(256), 0, st, col_idx, nnz_dev, nnz_bound, counts16, bad16, shift, out, bad, vec_ok);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void xlx_table_kernel(double* __restrict__ tab) {
   const int x = blockIdx.x * 256 + threadIdx.x;
   if (x < XLX_TABLE) tab[x] = x_log_x((long long)x);
@@ -2021,6 +2097,11 @@ hipError_t launch_row_work(hipStream_t st, int n_cu, int32_t item_lo, int32_t it
 constexpr int E0 = 1024, E1S = 4096, E1 = 8192, E2S = 16384, E2 = 32768;  // LDS table words: wave / small block / block / half CU / CU
 constexpr int MP_KMAX = 256;  // largest k the multi-pass class keeps its running lists for (MP_KMAX_HOST in cco_kernels.h)
 
+// Round 6 layout of an accumulator table of E words (team of T threads).  Insert phase: table_slots(E, T) slots -- two thirds of the table, a multiple of
+// T -- of packed (column + 1, count) in words [0, SH), the slots' 16-bit column counts cB (left by the claiming lane: they rode in on the B' words) in the
+// SH / 2 words behind them (a pair of slots is one 8-byte access for the zeroing and the compaction sweep, its two counts one word).  Compaction: the D packed words to [0, D) and every candidate's cB into its slot of the KEY array behind them, which the score
+// phase reads and then overwrites with the candidate's key: no word more than rounds 1-5 needed (3 D + 3 k + 2 <= E), a third fewer slots.
+__host__ __device__ constexpr int table_slots(int E, int T) { return (2 * E / 3) / (2 * T) * (2 * T); }  // (a thread sweeps PAIRS of slots: 8-byte LDS accesses)
 constexpr int URCCO_WB1 = 512;
 constexpr int URCCO_WB2 = 8192;
 __device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_cols_b, int32_t count_bits, int32_t k) {
@@ -2315,21 +2396,27 @@ __device__ __forceinline__ unsigned rank_by_counting(const unsigned long long* k
 // without finding the key or a free slot -- impossible while the binning rule holds (the table always has room for the
 // row's distinct columns); the bound keeps a broken invariant from turning into a hung GPU and is reported through
 // stats[1 + 4 * NBINS].
-__device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int count_bits, unsigned mask, int hshift, bool ident) {
-  unsigned h = ident ? (key - 1u) : ((key * 0x9E3779B1u) >> hshift);
+// Round 6: NS slots, not a power of two (two thirds of the table: see table_slots) -- the multiplicative hash is reduced to [0, NS) by a
+// multiply-high, the probe sequence wraps by a compare -- and the lane that CLAIMS a slot leaves the column's count (it rode in on the B' word) in the
+// slot's entry of the 16-bit side array cbv.
+template <int NS>
+__device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int count_bits, bool ident, unsigned short* cbv, unsigned c_b) {
+  unsigned h = ident ? (key - 1u) : __umulhi(key * 0x9E3779B1u, (unsigned)NS);
   const unsigned fresh = (key << count_bits) | 1u;
   // ONE loop condition and no break: with two exits and a result flag the compiler spent ~25 scalar instructions per probe on execution
   // masks (round 5, ISA of the pair loop: the CU's single scalar unit was as loaded as its four vector units).  `left` bounds the probes
   // (a broken binning invariant must not hang the GPU); the add for a known column is predicated, not branched around.
   bool done;
-  unsigned left = mask + 1u;
+  unsigned left = (unsigned)NS;
 #pragma unroll 1
   do {
     const unsigned v = atomicCAS(&tab[h], 0u, fresh);
     const bool hit = (v >> count_bits) == key;
     if (hit) atomicAdd(&tab[h], 1u);
+    if (v == 0u) cbv[h] = (unsigned short)c_b;
     done = hit || v == 0u;
-    h = (h + 1u) & mask;
+    ++h;
+    h = h == (unsigned)NS ? 0u : h;
     --left;
   } while (!done && left != 0u);
   return done;
@@ -2576,11 +2663,20 @@ constexpr int URCCO_G_CU = 2;
 // launch it); the production instantiation carries neither their branches nor the scalar register a.debug would occupy -- at eight waves
 // per SIMD a wave has 78 scalar registers and the one-wave class spilled 128 of them to vector lanes (round 5: 69 after this and the
 // single-check LLR).
-template <int T, int E, int U, bool MP = false, bool DBG = false>
-__global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T == 256 && E == 4096 ? URCCO_OCC_BS : 1))) void cco_rows_kernel(CcoArgs a, int bin) {
+// PK: the instantiation for a B' with the columns' counts aboard (CcoArgs::b_packed).  Whether the counts fit is known on the DEVICE only (*pack_bad), so
+// the launcher enqueues both instantiations and the one whose turn it is not returns at once -- the price of keeping the other form's registers (the count
+// gather's pointers, the word masks as run-time values) out of each: as one kernel with a run-time switch the 256-thread class spilled and the 512-thread
+// class lost a wave per SIMD.
+template <int T, int E, int U, bool MP = false, bool DBG = false, bool PK = false>
+__global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T == 256 && E == 4096 ? URCCO_OCC_BS : (T == 512 ? 4 : 1)))) void cco_rows_kernel(CcoArgs a, int bin) {
+  if ((a.b_packed != nullptr && *a.pack_bad == 0) != PK) return;  // grid-uniform
   const int dbg = DBG ? a.debug : 0;
   // the arguments the row loop's inner loops use, each in scalar registers of its own (URCCO_OWN_SGPRS)
-  URCCO_OWN_GLOBAL_PTR(const int32_t, b_col_idx, a.b_col_idx);
+  // B' with the columns' counts aboard while every count fits (CcoArgs::b_packed), else the plain column indices and the count gather (wave-uniform)
+  constexpr bool packed = PK;
+  URCCO_OWN_GLOBAL_PTR(const int32_t, b_col_idx, PK ? a.b_packed : a.b_col_idx);
+  const int cshift = 32 - a.count_bits;                              // a B' word: column in the low cshift bits, count above
+  const unsigned colmask = PK ? (1u << cshift) - 1u : 0xffffffffu;  // (cshift <= 31: count_bits >= 1)
   URCCO_OWN_GLOBAL_PTR(const unsigned short, cnt_b16, a.cnt_b16);
   URCCO_OWN_GLOBAL_PTR(const int32_t, cnt_b, a.cnt_b);
   URCCO_OWN_GLOBAL_PTR(const double, xlx_tab, a.xlx_tab);
@@ -2592,14 +2688,16 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   URCCO_OWN_SGPRS(n_users);
   constexpr int BLOCK = T < 256 ? 256 : T;
   constexpr int TEAMS = BLOCK / T;
-  constexpr int SPT = E / T;
+  constexpr int SH = table_slots(E, T);  // accumulator slots
+  constexpr int SPT = SH / T;
+  static_assert(SH % (2 * T) == 0 && SH + SH / 2 <= E, "slots and their 16-bit column counts share the table");
   constexpr int NW = T / WAVE;  // waves per team
   constexpr int G = T == WAVE ? URCCO_G_WAVE : (T == 256 ? URCCO_G_BLOCK : URCCO_G_CU);  // column gathers in flight per lane
   constexpr int LOG2E = E == 1024 ? 10 : (E == 4096 ? 12 : (E == 8192 ? 13 : (E == 16384 ? 14 : 15)));
   static_assert((1 << LOG2E) == E, "table size");
   constexpr int LOG2T = T == 64 ? 6 : (T == 256 ? 8 : (T == 512 ? 9 : 10));
   static_assert((1 << LOG2T) == T, "team size");
-  __shared__ unsigned s_tab[TEAMS * E];
+  __shared__ __attribute__((aligned(16))) unsigned s_tab[TEAMS * E];
   // One-wave teams and the small block class: the chunk operands (insert phase), the select histograms + survivor list (select
   // passes) and the ambiguous / staged survivors (after the passes; they overlay the histograms) are never live together and
   // share ONE region per team.  One-wave class: 19.6 KB of LDS per block instead of 26.8, which with <= 64 VGPRs lets eight
@@ -2641,6 +2739,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   const int tl = threadIdx.x % T;
   const int lane = threadIdx.x & (WAVE - 1);
   unsigned* tab = s_tab + team * E;
+  unsigned short* cbv = reinterpret_cast<unsigned short*>(tab + SH);   // insert phase: the slots' column counts
   unsigned long long* share = s_share + (SHARE ? team * SHARE_WORDS : 0);
   long long* ustart = SHARE ? reinterpret_cast<long long*>(share) : s_ustart + team * T;
   unsigned* uoff = SHARE ? reinterpret_cast<unsigned*>(share + T) : s_uoff + team * (T + 1);
@@ -2654,7 +2753,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   const int list_start = a.bin_off[bin];
   const int list_n = a.bin_off[bin + 1] - list_start;
   const int total_teams = gridDim.x * TEAMS;
-  bool ident = (long long)a.n_cols_b * 3 + (long long)a.k * 3 + 2 <= E;  // the table spans every column of B: slots addressed by column
+  bool ident = (long long)a.n_cols_b * 3 + (long long)a.k * 3 + 2 <= E && a.n_cols_b <= SH;  // the table spans every column of B: slots addressed by column
   int cb = a.count_bits;                                                   // (MP: both follow the row's pass count)
   unsigned cmask = (1u << cb) - 1u;
   unsigned long long cand_acc = 0ull;  // distinct (row, column) candidates scored by this team (statistics)
@@ -2746,12 +2845,12 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
       while ((1ll << kb) <= cols_pp) ++kb;
       cb = 32 - kb;
       cmask = cb >= 32 ? 0xffffffffu : (1u << cb) - 1u;
-      ident = cols_pp * 3 + 3ll * a.k + 2ll <= (long long)E;
+      ident = cols_pp * 3 + 3ll * a.k + 2ll <= (long long)E && cols_pp <= (long long)SH;
       if (tl == 0) s_mpflag = 0u;
     }
     const unsigned mp_mask = MP ? (1u << mp_s) - 1u : 0u;
 #pragma unroll
-    for (int q = 0; q < SPT; ++q) tab[tl + q * T] = 0u;
+    for (int q = 0; q < SPT / 2; ++q) *reinterpret_cast<uint2*>(&tab[2 * (tl + q * T)]) = make_uint2(0u, 0u);
     team_sync<T>();
     // ---- 2. expand + accumulate
     for (int64_t c0 = cs; c0 < ce; c0 += T) {  // team-uniform
@@ -2806,11 +2905,12 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
 #pragma unroll
             for (int q = 0; q < G; ++q) {
               if (on[q]) {
+                const unsigned col = jj[q] & colmask, c_b = packed ? jj[q] >> cshift : 0u;
                 if (dbg & 1) {  // ablation: gather only
                   if (jj[q] == 0xffffffffu) tab[0] = 1u;
                 } else if (MP) {
-                  if ((jj[q] & mp_mask) == mp_q && !tab_insert(tab, (jj[q] >> mp_s) + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) s_mpflag = 1u;
-                } else if (!tab_insert(tab, jj[q] + 1u, cb, (unsigned)(E - 1), 32 - LOG2E, ident)) {
+                  if ((col & mp_mask) == mp_q && !tab_insert<SH>(tab, (col >> mp_s) + 1u, cb, ident, cbv, c_b)) s_mpflag = 1u;
+                } else if (!tab_insert<SH>(tab, col + 1u, cb, ident, cbv, c_b)) {
                   atomicAdd(a.err, 1ull);
                 }
               }
@@ -2823,31 +2923,56 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
     // ---- 3. compact the occupied slots to tab[0 .. D); candidate keys will live behind them in the same LDS:
     //         words [kb, kb + 2 D) with kb = D rounded up to even.  The binning rule keeps 3 D + 1 <= E.
     unsigned D;
-    if (T == WAVE) {  // one wave: positions from ballots (no scan); all SPT reads are issued before the first write
+    //         ... and every candidate's column count goes into its slot of that key array (the score phase reads it, then puts the key there)
+    // A thread sweeps PAIRS of neighbouring slots: one 8-byte read for the two packed words, one word for their two counts.
+    if (T == WAVE) {  // one wave: positions from ballots (no scan); all reads are issued before the first write
       unsigned v[SPT];
+      unsigned cw2[SPT / 2];  // the slots' counts, two per register
 #pragma unroll
-      for (int q = 0; q < SPT; ++q) v[q] = tab[tl + q * T];
+      for (int q = 0; q < SPT / 2; ++q) {
+        const uint2 x = *reinterpret_cast<const uint2*>(&tab[2 * (tl + q * T)]);
+        v[2 * q] = x.x;
+        v[2 * q + 1] = x.y;
+        cw2[q] = *reinterpret_cast<const unsigned*>(&cbv[2 * (tl + q * T)]);
+      }
       D = 0;
+#pragma unroll
+      for (int q = 0; q < SPT; ++q) D += (unsigned)__popcll(__ballot(v[q] != 0u));  // (the keys' base depends on D: counted first, positions below)
+      unsigned long long* kk0 = reinterpret_cast<unsigned long long*>(tab + ((D + 1u) & ~1u));
+      unsigned at0 = 0;
 #pragma unroll
       for (int q = 0; q < SPT; ++q) {
         const unsigned long long m = __ballot(v[q] != 0u);
-        if (v[q] != 0u) tab[D + lanes_below(m)] = v[q];
-        D += (unsigned)__popcll(m);
+        if (v[q] != 0u) {
+          const unsigned at = at0 + lanes_below(m);
+          tab[at] = v[q];
+          kk0[at] = (unsigned long long)((q & 1) ? cw2[q >> 1] >> 16 : cw2[q >> 1] & 0xffffu);
+        }
+        at0 += (unsigned)__popcll(m);
       }
     } else {
       unsigned v[SPT];
+      unsigned cw2[SPT / 2];
       unsigned occ = 0;
 #pragma unroll
-      for (int q = 0; q < SPT; ++q) {
-        v[q] = tab[tl + q * T];
-        occ += v[q] != 0u;
+      for (int q = 0; q < SPT / 2; ++q) {
+        const uint2 x = *reinterpret_cast<const uint2*>(&tab[2 * (tl + q * T)]);
+        v[2 * q] = x.x;
+        v[2 * q + 1] = x.y;
+        cw2[q] = *reinterpret_cast<const unsigned*>(&cbv[2 * (tl + q * T)]);
+        occ += (x.x != 0u) + (x.y != 0u);
       }
       unsigned wpos = team_exclusive_scan<T>(occ, s_wsum, &D);
       D = uni(D);
       team_sync<T>();  // every read of the table precedes every write below
+      unsigned long long* kk0 = reinterpret_cast<unsigned long long*>(tab + ((D + 1u) & ~1u));
 #pragma unroll
       for (int q = 0; q < SPT; ++q)
-        if (v[q] != 0u) tab[wpos++] = v[q];
+        if (v[q] != 0u) {
+          tab[wpos] = v[q];
+          kk0[wpos] = (unsigned long long)((q & 1) ? cw2[q >> 1] >> 16 : cw2[q >> 1] & 0xffffu);
+          ++wpos;
+        }
     }
     team_sync<T>();
     if (MP) {
@@ -2880,7 +3005,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
           cbj[x] = 0;
           if (vv[x] != 0u) {
             const int j = MP ? (int)((((vv[x] >> cb) - 1u) << mp_s) | mp_q) : (int)(vv[x] >> cb) - 1;
-            cbj[x] = (dbg & 512) ? 100 : (use16 ? (int)cnt_b16[j] : cnt_b[j]);  // the ONE scattered gather per candidate (ablation 512: none)
+            // the candidate's cB: out of its slot of the key array, where the compaction left it (it came with the B' word) -- or, for a B' without counts aboard, the ONE scattered
+            // gather per candidate of rounds 1-5 (ablation 512: a made-up count, no gather)
+            cbj[x] = packed ? (int)(unsigned)kk[t] : ((dbg & 512) ? (int)(vv[x] & cmask) + 100 : (use16 ? (int)cnt_b16[j] : cnt_b[j]));
           }
         }
         // every operand of these U candidates of every lane inside the tables: the wave takes the straight-line table form (see llr_from_tables)
@@ -3350,8 +3477,9 @@ __device__ __forceinline__ unsigned seg_max_popc(unsigned long long m) {
   return best;
 }
 
-template <int L, bool DBG>
+template <int L, bool DBG, bool PK = false>
 __global__ __launch_bounds__(256, (L == WAVE ? URCCO_OCC_MICRO : URCCO_OCC_MICRO - 2)) void cco_rows_micro_kernel(CcoArgs a) {
+  if ((a.b_packed != nullptr && *a.pack_bad == 0) != PK) return;  // grid-uniform: the other instantiation's turn (see cco_rows_kernel)
   using G = MicroGeom<L>;
   constexpr int S = G::S;
   const int dbg = DBG ? a.debug : 0;
@@ -3360,7 +3488,12 @@ __global__ __launch_bounds__(256, (L == WAVE ? URCCO_OCC_MICRO : URCCO_OCC_MICRO
   const int32_t* bin_rows = a.bin_rows;
   const int64_t* a_col_ptr = a.a_col_ptr;
   const int64_t* pstart = a.pstart;
-  const int32_t* b_col_idx = a.b_col_idx;
+  // B' with the columns' counts aboard while every count fits (CcoArgs::b_packed): the lane that claims a column has the column's count in the
+  // very word it inserted -- no gather; else the plain column indices and one scattered count gather per candidate (wave-uniform)
+  constexpr bool packed = PK;
+  const int32_t* b_col_idx = PK ? a.b_packed : a.b_col_idx;
+  const int cshift = 32 - a.count_bits;
+  const unsigned colmask = PK ? (1u << cshift) - 1u : 0xffffffffu;
   const int32_t* cnt_a = a.cnt_a;
   const double* ent_a = a.ent_a;
   const double* xlx_tab = a.xlx_tab;
@@ -3469,11 +3602,12 @@ __global__ __launch_bounds__(256, (L == WAVE ? URCCO_OCC_MICRO : URCCO_OCC_MICRO
     const int64_t base_o = wave_gather64(my_start - (int64_t)my_off, (unsigned)(seg * L) + o);  // B' position of pair p of user o: base + p
     // ---- insert; the claiming lane owns the candidate
     unsigned slot = 0xffffffffu;
+    unsigned jj = 0u;  // this lane's B' word: the column, and (packed) the column's count
     if ((unsigned)sl < total) {
-      const unsigned jj = (unsigned)b_col_idx[base_o + sl];
+      jj = (unsigned)b_col_idx[base_o + sl];
       if (!(dbg & 1)) {
         bool ok;
-        slot = tab_insert_claim(tab, jj + 1u, cb, (unsigned)(G::TW - 1), 32 - G::LOG2TW, ident, &ok);
+        slot = tab_insert_claim(tab, (jj & colmask) + 1u, cb, (unsigned)(G::TW - 1), 32 - G::LOG2TW, ident, &ok);
         if (!ok) atomicAdd(a.err, 1ull);
       }
     }
@@ -3490,7 +3624,7 @@ __global__ __launch_bounds__(256, (L == WAVE ? URCCO_OCC_MICRO : URCCO_OCC_MICRO
       vv = tab[slot];
       tab[slot] = 0u;
       const int j = (int)(vv >> cb) - 1;
-      cb_raw = cnt_words[use16 ? j >> 1 : j];
+      if (!packed) cb_raw = cnt_words[use16 ? j >> 1 : j];
     }
     if (D + (unsigned)sl < (unsigned)G::LIST) {  // padding of the ranking loop's element list behind the row's candidates: sorts before nothing
       kkm[D + (unsigned)sl] = 0ull;
@@ -3500,7 +3634,7 @@ __global__ __launch_bounds__(256, (L == WAVE ? URCCO_OCC_MICRO : URCCO_OCC_MICRO
     if (is_cand) {
       const int j = (int)(vv >> cb) - 1;
       const long long k11 = (long long)(vv & cmask);
-      const unsigned cbj = (dbg & 512) ? 100u : (use16 ? ((j & 1) ? cb_raw >> 16 : cb_raw & 0xffffu) : cb_raw);
+      const unsigned cbj = packed ? jj >> cshift : ((dbg & 512) ? (unsigned)k11 + 100u : (use16 ? ((j & 1) ? cb_raw >> 16 : cb_raw & 0xffffu) : cb_raw));
       in_tables = llr_operands_in_tables((unsigned)k11, ca, cbj, n_users, col_ent);
     }
     // Every operand of every candidate inside the tables (always, once the interaction cut has capped the counts): the wave takes the
@@ -3510,7 +3644,7 @@ __global__ __launch_bounds__(256, (L == WAVE ? URCCO_OCC_MICRO : URCCO_OCC_MICRO
       const int j = (int)(vv >> cb) - 1;
       const long long k11 = (long long)(vv & cmask);
       if (!(a.exclude_self && j == i)) {
-        const unsigned cbj = (dbg & 512) ? 100u : (use16 ? ((j & 1) ? cb_raw >> 16 : cb_raw & 0xffffu) : cb_raw);
+        const unsigned cbj = packed ? jj >> cshift : ((dbg & 512) ? (unsigned)k11 + 100u : (use16 ? ((j & 1) ? cb_raw >> 16 : cb_raw & 0xffffu) : cb_raw));
         const double llr = all_in_tables ? llr_from_tables(row_entropy, xlx_n, (unsigned)k11, (unsigned)ca, cbj, xlx_tab, xlx_hi, col_ent)
                                          : ((dbg & 2) ? (double)k11
                                                       : llr_of(row_entropy, xlx_n, k11, ca, (long long)cbj, n_users, xlx_tab, xlx_hi, col_ent));
@@ -3788,7 +3922,7 @@ static int blocks_per_cu(int bin) {
   if (cache[bin].load(std::memory_order_relaxed) == 0) {
     int n = 0;
     hipError_t e = hipErrorUnknown;
-    if (bin == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_micro_kernel<WAVE, false>, 256, 0);
+    if (bin == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (cco_rows_micro_kernel<WAVE, false, false>), 256, 0);
     if (bin == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<64, E0, URCCO_U_WAVE>, 256, 0);
     if (bin == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1S, URCCO_U_BS>, 256, 0);
     if (bin == 3) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cco_rows_kernel<256, E1, URCCO_U_B>, 256, 0);
@@ -3847,44 +3981,45 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
     return dim3((unsigned)blocks);
   };
   const bool dbgk = (args.debug & (1 | 2 | 4 | 8 | 16 | 512 | 131072 | 262144)) != 0;  // the ablation / test switches live in the DBG instantiations only
+  // A B' with counts aboard: BOTH instantiations are enqueued -- whether the counts fit is a device-side fact, the one whose turn it is not returns at
+  // once.  The DBG instantiations exist for the plain form only (the ablation switches price the count gather among other things).
+  CcoArgs plain = args;
+  plain.b_packed = nullptr;
+  const bool both = args.b_packed != nullptr && !dbgk;
+#define URCCO_LAUNCH_ROWS(TT, EE, UU, MPF, GRID, BLK, BINARG)                                                                      \
+  do {                                                                                                                           \
+    if (dbgk) hipLaunchKernelGGL((cco_rows_kernel<TT, EE, UU, MPF, true, false>), GRID, dim3(BLK), 0, st, plain, BINARG);          \
+    else {                                                                                                                       \
+      if (both) hipLaunchKernelGGL((cco_rows_kernel<TT, EE, UU, MPF, false, true>), GRID, dim3(BLK), 0, st, args, BINARG);         \
+      hipLaunchKernelGGL((cco_rows_kernel<TT, EE, UU, MPF, false, false>), GRID, dim3(BLK), 0, st, args, BINARG);                  \
+    }                                                                                                                            \
+  } while (0)
+#define URCCO_LAUNCH_MICRO(LL, GRID)                                                                                  \
+  do {                                                                                                                \
+    if (dbgk) hipLaunchKernelGGL((cco_rows_micro_kernel<LL, true, false>), GRID, dim3(256), 0, st, plain);              \
+    else {                                                                                                            \
+      if (both) hipLaunchKernelGGL((cco_rows_micro_kernel<LL, false, true>), GRID, dim3(256), 0, st, args);             \
+      hipLaunchKernelGGL((cco_rows_micro_kernel<LL, false, false>), GRID, dim3(256), 0, st, args);                      \
+    }                                                                                                                 \
+  } while (0)
   switch (bin) {
     case 0:  // the class's three sub-lists, the rows that keep a wave to themselves first (each kernel reads its own list bounds on the device)
-      if (dbgk) {
-        hipLaunchKernelGGL((cco_rows_micro_kernel<64, true>), grid(0), dim3(256), 0, st, args);
-        hipLaunchKernelGGL((cco_rows_micro_kernel<32, true>), grid(0, micro_factors.f32), dim3(256), 0, st, args);
-        hipLaunchKernelGGL((cco_rows_micro_kernel<16, true>), grid(0, micro_factors.f16), dim3(256), 0, st, args);
-      } else {
-        hipLaunchKernelGGL((cco_rows_micro_kernel<64, false>), grid(0), dim3(256), 0, st, args);
-        hipLaunchKernelGGL((cco_rows_micro_kernel<32, false>), grid(0, micro_factors.f32), dim3(256), 0, st, args);
-        hipLaunchKernelGGL((cco_rows_micro_kernel<16, false>), grid(0, micro_factors.f16), dim3(256), 0, st, args);
-      }
+      URCCO_LAUNCH_MICRO(64, grid(0));
+      URCCO_LAUNCH_MICRO(32, grid(0, micro_factors.f32));
+      URCCO_LAUNCH_MICRO(16, grid(0, micro_factors.f16));
       break;
-    case 1:
-      if (dbgk) hipLaunchKernelGGL((cco_rows_kernel<64, E0, URCCO_U_WAVE, false, true>), grid(1), dim3(256), 0, st, args, 1);
-      else hipLaunchKernelGGL((cco_rows_kernel<64, E0, URCCO_U_WAVE>), grid(1), dim3(256), 0, st, args, 1);
-      break;
-    case 2:
-      if (dbgk) hipLaunchKernelGGL((cco_rows_kernel<256, E1S, URCCO_U_BS, false, true>), grid(2), dim3(256), 0, st, args, 2);
-      else hipLaunchKernelGGL((cco_rows_kernel<256, E1S, URCCO_U_BS>), grid(2), dim3(256), 0, st, args, 2);
-      break;
-    case 3:
-      if (dbgk) hipLaunchKernelGGL((cco_rows_kernel<256, E1, URCCO_U_B, false, true>), grid(3), dim3(256), 0, st, args, 3);
-      else hipLaunchKernelGGL((cco_rows_kernel<256, E1, URCCO_U_B>), grid(3), dim3(256), 0, st, args, 3);
-      break;
-    case 4:
-      if (dbgk) hipLaunchKernelGGL((cco_rows_kernel<512, E2S, URCCO_U_H, false, true>), grid(4), dim3(512), 0, st, args, 4);
-      else hipLaunchKernelGGL((cco_rows_kernel<512, E2S, URCCO_U_H>), grid(4), dim3(512), 0, st, args, 4);
-      break;
-    case 5:
-      if (dbgk) hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C, false, true>), grid(5), dim3(1024), 0, st, args, 5);
-      else hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C>), grid(5), dim3(1024), 0, st, args, 5);
-      break;
+    case 1: URCCO_LAUNCH_ROWS(64, E0, URCCO_U_WAVE, false, grid(1), 256, 1); break;
+    case 2: URCCO_LAUNCH_ROWS(256, E1S, URCCO_U_BS, false, grid(2), 256, 2); break;
+    case 3: URCCO_LAUNCH_ROWS(256, E1, URCCO_U_B, false, grid(3), 256, 3); break;
+    case 4: URCCO_LAUNCH_ROWS(512, E2S, URCCO_U_H, false, grid(4), 512, 4); break;
+    case 5: URCCO_LAUNCH_ROWS(1024, E2, URCCO_U_C, false, grid(5), 1024, 5); break;
     default:
-      if (args.g_blocks > 0) hipLaunchKernelGGL(cco_rows_global_kernel, dim3((unsigned)args.g_blocks), dim3(GB_THREADS), 0, st, args);
-      else if (dbgk) hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C, true, true>), grid(6), dim3(1024), 0, st, args, 6);
-      else hipLaunchKernelGGL((cco_rows_kernel<1024, E2, URCCO_U_C, true>), grid(6), dim3(1024), 0, st, args, 6);
+      if (args.g_blocks > 0) hipLaunchKernelGGL(cco_rows_global_kernel, dim3((unsigned)args.g_blocks), dim3(GB_THREADS), 0, st, plain);
+      else URCCO_LAUNCH_ROWS(1024, E2, URCCO_U_C, true, grid(6), 1024, 6);
       break;
   }
+#undef URCCO_LAUNCH_ROWS
+#undef URCCO_LAUNCH_MICRO
   return hipGetLastError();
 }
 

@@ -379,6 +379,21 @@ int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32
                                      exclude_self, k, has_min_llr, min_llr, out_count, out_idx, out_llr, stats_dev, nullptr, nullptr);
 }
 
+int urcco_dev_pack_counts(urcco_session* s, int64_t n_rows_b, const int64_t* b_row_ptr, const int32_t* b_col_idx, int64_t nnz_b_bound, const int32_t* counts_b,
+                          int32_t n_cols_b, int32_t* out_packed, int32_t* out_bad) {
+  return urcco_detail::pack_counts(s, b_row_ptr, n_rows_b, b_col_idx, nnz_b_bound, counts_b, n_cols_b, out_packed, out_bad);
+}
+
+int urcco_dev_cco_rows_packed(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a, const int64_t* a_col_ptr,
+                              const int32_t* a_row_idx, int64_t nnz_a_bound, const int64_t* b_row_ptr, const int32_t* b_col_idx, int32_t n_cols_b,
+                              const int32_t* counts_a, const int32_t* counts_b, int64_t n_users, int32_t exclude_self, int32_t k,
+                              int32_t has_min_llr, double min_llr, int32_t* out_count, int32_t* out_idx, double* out_llr, int64_t* stats_dev,
+                              const int32_t* b_packed, const int32_t* pack_bad) {
+  if ((b_packed == nullptr) != (pack_bad == nullptr)) return fail(URCCO_BAD_ARG, "urcco_dev_cco_rows_packed: b_packed and pack_bad come together");
+  return urcco_detail::cco_rows_impl(s, item_lo, item_hi, n_items_a, a_col_ptr, a_row_idx, nnz_a_bound, b_row_ptr, b_col_idx, n_cols_b, counts_a, counts_b, n_users,
+                                     exclude_self, k, has_min_llr, min_llr, out_count, out_idx, out_llr, stats_dev, nullptr, nullptr, nullptr, b_packed, pack_bad);
+}
+
 }  // extern "C"
 
 namespace urcco_detail {
@@ -400,7 +415,7 @@ int partition_dev(urcco_session* s, int32_t n_items, const int64_t* work, int32_
 int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a, const int64_t* a_col_ptr, const int32_t* a_row_idx, int64_t nnz_a_bound,
                   const int64_t* b_row_ptr, const int32_t* b_col_idx, int32_t n_cols_b, const int32_t* counts_a, const int32_t* counts_b, int64_t n_users,
                   int32_t exclude_self, int32_t k, int32_t has_min_llr, double min_llr, int32_t* out_count, int32_t* out_idx, double* out_llr, int64_t* stats_dev,
-                  const int64_t* pre_pstart, const int32_t* pre_plen, int64_t* pre_tile_sums) {
+                  const int64_t* pre_pstart, const int32_t* pre_plen, int64_t* pre_tile_sums, const int32_t* b_packed, const int32_t* pack_bad) {
   if (!s || item_lo < 0 || item_hi < item_lo || item_hi > n_items_a || n_cols_b < 0 || n_users < 0 || nnz_a_bound < 0 || !a_col_ptr || !b_row_ptr)
     return fail(URCCO_BAD_ARG, "urcco_dev_cco_rows: bad argument");
   if (k <= 0) return fail(URCCO_BAD_ARG, "maxInterestingElements must be positive, got %d", k);
@@ -478,6 +493,8 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
   urcco::CcoArgs a;
   a.bin_rows = bin_rows; a.bin_off = bin_off;
   a.a_col_ptr = a_col_ptr; a.pstart = pstart; a.wp = wp; a.b_col_idx = b_col_idx;
+  a.b_packed = (b_packed && pack_bad && !(s->debug & 1048576)) ? b_packed : nullptr;  // debug 1048576: the count gather of rounds 1-5 (A/B, tests)
+  a.pack_bad = pack_bad;
   a.cnt_a = counts_a; a.cnt_b = counts_b; a.ent_a = ent_a; a.cnt_b16 = cnt_b16; a.cnt16_bad = cnt16_bad; a.xlx_n = xlx_n; a.xlx_tab = s->xlx_tab; a.xlx_hi = s->xlx_hi; a.col_ent = s->xlx_hi + urcco::XLX_TABLE_HOST; a.debug = s->debug;
   a.n_users = n_users; a.n_cols_b = n_cols_b; a.item_lo = item_lo; a.exclude_self = exclude_self ? 1 : 0; a.k = k;
   a.has_min_llr = has_min_llr ? 1 : 0; a.min_llr = min_llr; a.count_bits = count_bits;
@@ -499,6 +516,24 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
     s->end();
   }
   if (s->timing) HIPC(urcco::launch_bin_out_stats(s->stream, bin_rows, bin_off, item_lo, out_count, cand, stats));
+  return URCCO_OK;
+}
+
+int pack_counts(urcco_session* s, const int64_t* b_row_ptr, int64_t n_rows_b, const int32_t* b_col_idx, int64_t nnz_bound, const int32_t* counts_b, int32_t n_cols_b,
+                int32_t* out, int32_t* bad) {
+  if (!s || !b_row_ptr || n_rows_b < 0 || nnz_bound < 0 || !out || !bad || (nnz_bound > 0 && (!b_col_idx || !counts_b))) return fail(URCCO_BAD_ARG, "pack_counts: bad argument");
+  int key_bits = 1;  // as cco_rows_impl: the bits of a (column + 1) key; the column itself fits them too
+  while (((int64_t)1 << key_bits) <= (int64_t)n_cols_b) ++key_bits;
+  const int count_bits = 32 - key_bits;
+  if (count_bits < 1) return fail(URCCO_BAD_ARG, "n_cols_b %d too large for the packed accumulator", n_cols_b);
+  // the gathers read the 16-bit copy of the counts (half the table: 4 MB for a 2M-item catalogue) -- arena scratch, needed until the pack kernel has run
+  URC(s->reserve(urcco_session::need((size_t)n_cols_b + 8, 2) + urcco_session::need(1, 4) + 256));
+  unsigned short* c16 = s->take<unsigned short>((size_t)n_cols_b + 8);
+  int32_t* bad16 = s->take<int32_t>(1);
+  s->begin(URCCO_STAGE_ENTROPY);
+  HIPC(urcco::launch_narrow_counts(s->stream, s->n_cu, counts_b, n_cols_b, c16, bad16));
+  HIPC(urcco::launch_pack_counts(s->stream, s->n_cu, b_col_idx, b_row_ptr + n_rows_b, nnz_bound, c16, bad16, count_bits, out, bad));
+  s->end();
   return URCCO_OK;
 }
 

@@ -185,6 +185,8 @@ struct EvState {
   DBuf<double> c_llr;
   DBuf<int64_t> stats;
   DBuf<unsigned long long> verr;
+  DBuf<int32_t> b_pk;           // B' with the columns' counts aboard (CcoArgs::b_packed): rebuilt per build from b_ci + the post-sampling counts ...
+  DBuf<int32_t> pk_bad;         // ... and [1] counts that did not fit
   unsigned long long* h_verr = nullptr;  // host-mapped pinned word the boundary check's result is STORED to by the GPU (host level, one GPU) ...
   unsigned long long* h_verr_dev = nullptr;  // ... and its device address
   int ensure_h_verr() {
@@ -214,7 +216,7 @@ struct EvState {
     in_rp.release(); in_ci.release(); raw.release(); post.release(); s_rp.release(); s_ci.release(); deg.release(); f_deg.release();
     deg16.release(); f_deg16.release();
     f_rp.release(); f_ci.release(); sizes.release(); scan_tmp.release(); o_count.release(); o_idx.release(); o_llr.release(); c_rp.release();
-    c_idx.release(); c_llr.release(); stats.release(); verr.release(); pre_pstart.release(); pre_plen.release(); pre_tsum.release();
+    c_idx.release(); c_llr.release(); stats.release(); verr.release(); b_pk.release(); pk_bad.release(); pre_pstart.release(); pre_plen.release(); pre_tsum.release();
     mlen.release(); pack.release(); mlen16.release(); mlen_bad.release(); moff.release(); mtmp.release(); to_nnz.release();
     if (h_verr) (void)hipHostFree(h_verr);
     h_verr = nullptr;
@@ -552,9 +554,14 @@ int stage_rows(DevState& D, EvState& E, EvState& A, int d, const DsParams& pa, c
   URC(E.c_idx.ensure(strided));
   URC(E.c_llr.ensure(strided));
   URC(E.stats.ensure(URCCO_STATS_LEN));
+  // B' with the columns' counts aboard (round 6): one pass over the matrix this GPU multiplies with, with the FINAL post-sampling counts (all-reduced in a
+  // sharded build) -- the row kernels then read a candidate's cB off the word that claims its slot instead of gathering it
+  URC(E.b_pk.ensure((size_t)E.b_nnz_bound + 4));
+  URC(E.pk_bad.ensure(1));
+  URC(pack_counts(E.s, E.b_rp, E.b_rows, E.b_ci, E.b_nnz_bound, post_of(D, d).p, (int32_t)p.n_cols, E.b_pk.p, E.pk_bad.p));
   URC(cco_rows_impl(E.s, D.item_lo, D.item_hi, (int32_t)pa.n_cols, D.a_cp[D.par].p, D.a_ri[D.par].p, a_nnz_bound, E.b_rp, E.b_ci, (int32_t)p.n_cols,
                     post_of(D, 0).p, post_of(D, d).p, n_users, d == 0 ? 1 : 0, p.k, p.has_min_llr, p.min_llr, E.o_count.p, E.o_idx.p, E.o_llr.p, E.stats.p,
-                    pre_expanded ? E.pre_pstart.p : nullptr, pre_expanded ? E.pre_plen.p : nullptr, pre_expanded ? E.pre_tsum.p : nullptr));
+                    pre_expanded ? E.pre_pstart.p : nullptr, pre_expanded ? E.pre_plen.p : nullptr, pre_expanded ? E.pre_tsum.p : nullptr, E.b_pk.p, E.pk_bad.p));
   URC(urcco_dev_compact_indicators(E.s, n, p.k, E.o_count.p, E.o_idx.p, E.o_llr.p, E.c_rp.p, E.c_idx.p, E.c_llr.p));
   HIPC(hipEventRecord(E.ev_done, E.s->stream));
   HIPC(hipEventRecord(E.ev_cons[D.par], E.s->stream));

@@ -76,6 +76,7 @@ class DeviceSession:
     def __init__(self, device: torch.device, library=None, stream: Optional["torch.cuda.Stream"] = None):
         self.device = torch.device(device)
         self.lib = library if library is not None else _lib.lib()
+        self.pack_counts = True   # cco_rows: B' with the columns' counts aboard (False: one count gather per candidate, the form of rounds 1-5)
         self.torch_stream = None
         handle = C.c_void_p()
         if self.device.type == "cuda":
@@ -183,10 +184,22 @@ class DeviceSession:
         o_idx = self.empty(max(n * k, 1), torch.int32)
         o_llr = self.empty(max(n * k, 1), torch.float64)
         stats = self.empty(_lib.STATS_LEN, torch.int64)
-        self._check(self.lib.urcco_dev_cco_rows(self.handle, item_lo, item_hi, n_items_a, _ptr(a_col_ptr), _ptr(a_row_idx), nnz_a_bound, _ptr(b.row_ptr),
-                                               _ptr(b.col_idx), b.n_cols, _ptr(counts_a), _ptr(counts_b), n_users, int(exclude_self), k,
-                                               int(p.min_llr is not None), float(p.min_llr) if p.min_llr is not None else 0.0,
-                                               _ptr(o_count), _ptr(o_idx), _ptr(o_llr), _ptr(stats)))
+        # B' with the columns' counts aboard (round 6; what the context level does for every build): the row kernels read a candidate's cB off the
+        # word that claims its accumulator slot.  pack_counts=False: the plain entry point with one count gather per candidate (rounds 1-5)
+        if self.pack_counts and b.n_cols > 0:
+            packed = self.empty(max(b.nnz_bound, 1), torch.int32)
+            bad = self.empty(1, torch.int32)
+            self._check(self.lib.urcco_dev_pack_counts(self.handle, b.n_rows, _ptr(b.row_ptr), _ptr(b.col_idx), b.nnz_bound, _ptr(counts_b), b.n_cols,
+                                                      _ptr(packed), _ptr(bad)))
+            self._check(self.lib.urcco_dev_cco_rows_packed(self.handle, item_lo, item_hi, n_items_a, _ptr(a_col_ptr), _ptr(a_row_idx), nnz_a_bound, _ptr(b.row_ptr),
+                                                          _ptr(b.col_idx), b.n_cols, _ptr(counts_a), _ptr(counts_b), n_users, int(exclude_self), k,
+                                                          int(p.min_llr is not None), float(p.min_llr) if p.min_llr is not None else 0.0,
+                                                          _ptr(o_count), _ptr(o_idx), _ptr(o_llr), _ptr(stats), _ptr(packed), _ptr(bad)))
+        else:
+            self._check(self.lib.urcco_dev_cco_rows(self.handle, item_lo, item_hi, n_items_a, _ptr(a_col_ptr), _ptr(a_row_idx), nnz_a_bound, _ptr(b.row_ptr),
+                                                   _ptr(b.col_idx), b.n_cols, _ptr(counts_a), _ptr(counts_b), n_users, int(exclude_self), k,
+                                                   int(p.min_llr is not None), float(p.min_llr) if p.min_llr is not None else 0.0,
+                                                   _ptr(o_count), _ptr(o_idx), _ptr(o_llr), _ptr(stats)))
         c_rp = self.empty(n + 1, torch.int64)
         c_idx = self.empty(max(n * k, 1), torch.int32)
         c_llr = self.empty(max(n * k, 1), torch.float64)
