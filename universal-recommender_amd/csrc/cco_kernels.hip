@@ -2966,11 +2966,14 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
       D = uni(D);
       team_sync<T>();  // every read of the table precedes every write below
       unsigned long long* kk0 = reinterpret_cast<unsigned long long*>(tab + ((D + 1u) & ~1u));
+      // (a multi-pass row's pass may have filled more slots than leave room for their keys: it is abandoned below -- and must not write key slots
+      // beyond the table; found by the simulator's bounds-checked build)
+      const bool fits = !MP || 3ll * D + 3ll * a.k + 2ll <= (long long)E;  // team-uniform
 #pragma unroll
       for (int q = 0; q < SPT; ++q)
         if (v[q] != 0u) {
           tab[wpos] = v[q];
-          kk0[wpos] = (unsigned long long)((q & 1) ? cw2[q >> 1] >> 16 : cw2[q >> 1] & 0xffffu);
+          if (fits) kk0[wpos] = (unsigned long long)((q & 1) ? cw2[q >> 1] >> 16 : cw2[q >> 1] & 0xffffu);
           ++wpos;
         }
     }
