@@ -49,11 +49,13 @@ PCIE_PEAK_GBS = 63.0   # same guide: PCIe gen5 x16, per direction
 LDS_ATOMIC_PEAK_GOPS = 16 * 256 * 2.4
 
 BIN_STAGES = ["cco_rows_micro", "cco_rows_wave", "cco_rows_block_small", "cco_rows_block", "cco_rows_cu_half", "cco_rows_cu", "cco_rows_global"]
-# (round 5: the row kernels' last template argument is DBG -- false in production; the flags kernel's second one is the 32-bit RNG)
-STAGE_TO_KERNEL = {"cco_rows_micro": "cco_rows_micro_kernel<false>", "cco_rows_wave": "cco_rows_kernel<64, 1024, 2, false, false>",
-                   "cco_rows_block_small": "cco_rows_kernel<256, 4096, 2, false, false>", "cco_rows_block": "cco_rows_kernel<256, 8192, 2, false, false>",
-                   "cco_rows_cu_half": "cco_rows_kernel<512, 16384, 1, false, false>", "cco_rows_cu": "cco_rows_kernel<1024, 32768, 1, false, false>",
-                   "cco_rows_global": "cco_rows_kernel<1024, 32768, 1, true, false>",
+# (round 6: the row kernels' template arguments end in DBG -- false in production -- and PK -- true: the instantiation for a B' whose words carry the
+#  columns' counts, the one that runs on the bench workloads; the micro class is three kernels, 64 / 32 / 16 lanes per row; the flags kernel's second
+#  argument is the 32-bit RNG)
+STAGE_TO_KERNEL = {"cco_rows_micro": "cco_rows_micro_kernel<64, false, true>", "cco_rows_wave": "cco_rows_kernel<64, 1024, 2, false, false, true>",
+                   "cco_rows_block_small": "cco_rows_kernel<256, 4096, 2, false, false, true>", "cco_rows_block": "cco_rows_kernel<256, 8192, 2, false, false, true>",
+                   "cco_rows_cu_half": "cco_rows_kernel<512, 16384, 1, false, false, true>", "cco_rows_cu": "cco_rows_kernel<1024, 32768, 1, false, false, true>",
+                   "cco_rows_global": "cco_rows_kernel<1024, 32768, 1, true, false, true>",
                    "downsample_flags": "downsample_flags_kernel<false, false>", "compact_indicators": "compact_indicators_kernel"}
 NAMES = {"config3": "config3: synthetic 1M users x 200K items, Zipf-1.0, purchase/view/category-pref",
          "config4": "config4: synthetic 10M users x 2M items, Zipf-1.0, 5 event types (purchase/view/add-to-cart/search/category-pref)",
@@ -95,6 +97,8 @@ def algorithmic_bytes(stage: str, f: dict) -> float:
         b = BIN_STAGES.index(stage)
         rows, pairs, users, outs = f["bin_rows"][b], f["bin_pairs"][b], f["bin_users"][b], f["bin_out"][b]
         return 4.0 * rows + 16.0 * rows + 4.0 * users + 16.0 * users + 4.0 * pairs + 12.0 * outs + 4.0 * rows
+    if stage == "entropy":               # per-item entropies + 16-bit counts, and (round 6) B' packed with its columns' counts: read and written once
+        return 12.0 * IA + 6.0 * IB + 8.0 * nnzs
     if stage == "compact_indicators":
         return 16.0 * IA * 1.0 + 24.0 * f["nnz_out"]
     return 0.0
@@ -589,7 +593,7 @@ def measure(job: Job, args, full: bool):
                           n_items_b=ev.n_items, k=50, bin_rows=[float(x) for x in st[1:1 + NB]], bin_pairs=[float(x) for x in st[1 + NB:1 + 2 * NB]],
                           bin_users=[float(x) for x in st[1 + 2 * NB:1 + 3 * NB]], bin_out=[float(x) for x in st[1 + 3 * NB:1 + 4 * NB]],
                           nnz_out=float(sum(int(ind.row_ptr[-1]) for ind in res[d])) / gpus_in_table))
-    per_event_stages = ["column_counts", "downsample_flags", "downsample_scan", "downsample_compact", "row_work"] + BIN_STAGES + ["compact_indicators"]
+    per_event_stages = ["column_counts", "downsample_flags", "downsample_scan", "downsample_compact", "row_work", "entropy"] + BIN_STAGES + ["compact_indicators"]
     kernels = {}
     for name, (ms, n) in timings.items():
         if n == 0:
@@ -618,7 +622,7 @@ def measure(job: Job, args, full: bool):
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot wrap the process it runs in).  The file must have
     # been collected on THESE kernel sources (kernel_source_id), else no traffic is quoted (round 3 quoted a stale one).
     traffic, traffic_src = None, None
-    for tpath in (os.path.join(ROOT, "profiles", f"r05_hbm_traffic_pmc_{job.workload}.json"), os.path.join(ROOT, "profiles", f"r04_hbm_traffic_pmc_{job.workload}.json")):
+    for tpath in (os.path.join(ROOT, "profiles", f"r06_hbm_traffic_pmc_{job.workload}.json"), os.path.join(ROOT, "profiles", f"r05_hbm_traffic_pmc_{job.workload}.json")):
         if traffic is not None:
             break
         if world == 1 and n_local == 1 and args.scale == 1.0 and os.path.exists(tpath) and dominant in STAGE_TO_KERNEL:

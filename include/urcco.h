@@ -262,6 +262,10 @@ typedef struct urcco_dev_result {
   /* entries of the WHOLE down-sampled matrix, over all ranks (host-known after the exchange); -1 on a one-rank build, where the host
    * never reads a size back: there it equals sampled_row_ptr[sampled_rows] on the device */
   int64_t sampled_nnz_total;
+  /* ABI 305: sampled_col_idx[e] & sampled_col_mask is the column index.  -1 (every bit) on a one-rank build.  On a sharded build the rows a rank received
+   * travelled with their column's post-sampling count in the bits above the column (the words the row kernels consume: see urcco_dev_pack_counts) whenever
+   * every count fits; the mask then keeps the column's bits. */
+  int32_t sampled_col_mask;
 } urcco_dev_result;
 /* input_stream (nullable hipStream_t): the stream the shards were produced on -- the build waits for it on the device.
  * out[d * local_gpus + g].  Returns after ENQUEUEING (except for the one blocking read of range bounds / shard sizes

@@ -138,7 +138,7 @@ def test_context_reuse_and_stream_modes(sim_lib):
     context_reuse_case(sim_lib, torch.device("cpu"))
 
 
-@pytest.mark.parametrize("n_gpus,primary", [(2, "fragments"), (3, "fragments"), (5, "fragments"), (2, "gathered")])
+@pytest.mark.parametrize("n_gpus,primary", [(2, "fragments"), (3, "fragments"), (5, "fragments"), (2, "gathered"), (3, "plain rows")])
 def test_one_process_drives_several_gpus(sim_lib, n_gpus, primary, monkeypatch):
     """n_gpus ranks in ONE process (what the JVM host does; here simulated devices, collectives looped back in-process
     through the urcco_collectives callbacks): the device-resident build on user-range shards and the host-level build
@@ -157,6 +157,8 @@ def test_one_process_drives_several_gpus(sim_lib, n_gpus, primary, monkeypatch):
     ctx = Context(torch.device("cpu"), sim_lib, n_gpus=n_gpus, collectives=coll)
     if primary == "gathered":
         ctx.set_debug(8192)       # A/B path: the primary's CSC from a pass over the whole gathered A' instead of fragments
+    if primary == "plain rows":
+        ctx.set_debug(1048576)    # the rows travel as plain column indices, the row kernels gather the counts (the form of rounds 1-5)
     try:
         assert ctx.n_local == n_gpus
         cuts = [n_users * g // n_gpus for g in range(n_gpus + 1)]

@@ -83,7 +83,7 @@ class DevDataset(C.Structure):
 class DevResult(C.Structure):
     _fields_ = [("item_lo", C.c_int32), ("item_hi", C.c_int32), ("row_ptr", C.c_void_p), ("col_idx", C.c_void_p), ("llr", C.c_void_p),
                 ("stats", C.c_void_p), ("sampled_row_ptr", C.c_void_p), ("sampled_col_idx", C.c_void_p), ("sampled_rows", C.c_int64),
-                ("sampled_nnz_total", C.c_int64)]
+                ("sampled_nnz_total", C.c_int64), ("sampled_col_mask", C.c_int32)]
 
 
 class Indicators(C.Structure):

@@ -37,6 +37,8 @@ struct CcoArgs {
   // of the SpGEMM classes' line fills: profiles/r06_fetch_by_phase.txt).  Nullable; used while *pack_bad == 0 (every count fits its 32 - key bits).
   const int32_t* b_packed;
   const int32_t* pack_bad;   // [1] counts that do not fit the spare bits (then b_col_idx + the count gather serve the build)
+  int32_t pk_known;          // 1: the HOST knows b_packed is good (a sharded build learns it with the shard sizes): pack_bad is not read, one instantiation is launched
+  uint32_t b_col_mask;       // b_col_idx[e] & b_col_mask = the column (0xffffffff unless b_col_idx itself holds packed words: the rows a sharded build received)
   const int32_t* cnt_a;
   const int32_t* cnt_b;
   const double* ent_a;       // rowEntropy per item of A
@@ -125,8 +127,11 @@ hipError_t launch_csr_from_pairs(hipStream_t st, int n_cu, int64_t n, const int3
                                  int64_t* raw_ptr, int32_t* tmp, int64_t* tile_sums, int64_t* out_row_ptr, int32_t* out_col_idx);
 
 // len[n_rows] = row lengths, len16 (nullable) = the same as uint16; sizes (nullable) = {n_rows, nnz, rows longer than 65535}
-constexpr int EXCH_SIZES = 3;
+constexpr int EXCH_SIZES = 4;  // (round 6: [3] = columns whose count does not fit a packed B' word -- launch_counts_over_limit)
 hipError_t launch_row_lengths(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, int32_t* len, unsigned short* len16, int64_t* sizes);
+// out[0] = number of counts that a B' word of a matrix with these counts cannot carry (>= 2^min(count_bits, 16)): a fact of the count TABLE, the same on
+// every rank of a sharded build once the counts are all-reduced -- so every rank decides alike whether the rows it sends travel with their counts aboard
+hipError_t launch_counts_over_limit(hipStream_t st, int n_cu, const int32_t* counts, int64_t n, int32_t count_bits, int64_t* out);
 // row-filtered exchange (cco_kernels.hip): per-user masks of the ranks whose item range a row of A' touches, per-destination masked row
 // lengths + their scan + the totals per destination, and the packing of the rows per destination
 hipError_t launch_need_mask(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* a_row_ptr, const int32_t* a_col_idx, const int32_t* bounds, int world,

@@ -2669,14 +2669,14 @@ constexpr int URCCO_G_CU = 2;
 // class lost a wave per SIMD.
 template <int T, int E, int U, bool MP = false, bool DBG = false, bool PK = false>
 __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T == 256 && E == 4096 ? URCCO_OCC_BS : (T == 512 ? 4 : 1)))) void cco_rows_kernel(CcoArgs a, int bin) {
-  if ((a.b_packed != nullptr && *a.pack_bad == 0) != PK) return;  // grid-uniform
+  if ((a.b_packed != nullptr && (a.pk_known != 0 || *a.pack_bad == 0)) != PK) return;  // grid-uniform
   const int dbg = DBG ? a.debug : 0;
   // the arguments the row loop's inner loops use, each in scalar registers of its own (URCCO_OWN_SGPRS)
   // B' with the columns' counts aboard while every count fits (CcoArgs::b_packed), else the plain column indices and the count gather (wave-uniform)
   constexpr bool packed = PK;
   URCCO_OWN_GLOBAL_PTR(const int32_t, b_col_idx, PK ? a.b_packed : a.b_col_idx);
   const int cshift = 32 - a.count_bits;                              // a B' word: column in the low cshift bits, count above
-  const unsigned colmask = PK ? (1u << cshift) - 1u : 0xffffffffu;  // (cshift <= 31: count_bits >= 1)
+  const unsigned colmask = PK ? (1u << cshift) - 1u : a.b_col_mask;  // (cshift <= 31: count_bits >= 1; the plain form masks only when its words are packed ones)
   URCCO_OWN_GLOBAL_PTR(const unsigned short, cnt_b16, a.cnt_b16);
   URCCO_OWN_GLOBAL_PTR(const int32_t, cnt_b, a.cnt_b);
   URCCO_OWN_GLOBAL_PTR(const double, xlx_tab, a.xlx_tab);
@@ -3482,7 +3482,7 @@ __device__ __forceinline__ unsigned seg_max_popc(unsigned long long m) {
 
 template <int L, bool DBG, bool PK = false>
 __global__ __launch_bounds__(256, (L == WAVE ? URCCO_OCC_MICRO : URCCO_OCC_MICRO - 2)) void cco_rows_micro_kernel(CcoArgs a) {
-  if ((a.b_packed != nullptr && *a.pack_bad == 0) != PK) return;  // grid-uniform: the other instantiation's turn (see cco_rows_kernel)
+  if ((a.b_packed != nullptr && (a.pk_known != 0 || *a.pack_bad == 0)) != PK) return;  // grid-uniform: the other instantiation's turn (see cco_rows_kernel)
   using G = MicroGeom<L>;
   constexpr int S = G::S;
   const int dbg = DBG ? a.debug : 0;
@@ -3496,7 +3496,7 @@ __global__ __launch_bounds__(256, (L == WAVE ? URCCO_OCC_MICRO : URCCO_OCC_MICRO
   constexpr bool packed = PK;
   const int32_t* b_col_idx = PK ? a.b_packed : a.b_col_idx;
   const int cshift = 32 - a.count_bits;
-  const unsigned colmask = PK ? (1u << cshift) - 1u : 0xffffffffu;
+  const unsigned colmask = PK ? (1u << cshift) - 1u : a.b_col_mask;
   const int32_t* cnt_a = a.cnt_a;
   const double* ent_a = a.ent_a;
   const double* xlx_tab = a.xlx_tab;
@@ -3762,7 +3762,7 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
     if (threadIdx.x == 0) s_ncand = 0;
     for (int64_t p = cs + grp; p < ce; p += ngrp) {
       const int64_t s = a.pstart[p], e = s + (a.wp[p + 1] - a.wp[p]);
-      for (int64_t q = s + gl; q < e; q += G) atomicAdd(&cnt[a.b_col_idx[q]], 1);
+      for (int64_t q = s + gl; q < e; q += G) atomicAdd(&cnt[(unsigned)a.b_col_idx[q] & a.b_col_mask], 1);
     }
     __syncthreads();
     const long long ca = a.cnt_a[i];
@@ -3770,7 +3770,7 @@ __global__ __launch_bounds__(GB_THREADS) void cco_rows_global_kernel(CcoArgs a) 
     for (int64_t p = cs + grp; p < ce; p += ngrp) {
       const int64_t s = a.pstart[p], e = s + (a.wp[p + 1] - a.wp[p]);
       for (int64_t q = s + gl; q < e; q += G) {
-        const int j = a.b_col_idx[q];
+        const int j = (int)((unsigned)a.b_col_idx[q] & a.b_col_mask);
         const long long k11 = atomicExch(&cnt[j], 0);  // exactly one lane claims (and clears) each column
         if (k11 > 0 && !(a.exclude_self && j == i)) {
           const long long cbj = a.cnt_b[j];
@@ -3988,21 +3988,21 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
   // once.  The DBG instantiations exist for the plain form only (the ablation switches price the count gather among other things).
   CcoArgs plain = args;
   plain.b_packed = nullptr;
-  const bool both = args.b_packed != nullptr && !dbgk;
+  const bool both = args.b_packed != nullptr && !dbgk && !args.pk_known;  // (pk_known: the host knows the counts are aboard -- only that instantiation)
 #define URCCO_LAUNCH_ROWS(TT, EE, UU, MPF, GRID, BLK, BINARG)                                                                      \
   do {                                                                                                                           \
     if (dbgk) hipLaunchKernelGGL((cco_rows_kernel<TT, EE, UU, MPF, true, false>), GRID, dim3(BLK), 0, st, plain, BINARG);          \
     else {                                                                                                                       \
-      if (both) hipLaunchKernelGGL((cco_rows_kernel<TT, EE, UU, MPF, false, true>), GRID, dim3(BLK), 0, st, args, BINARG);         \
-      hipLaunchKernelGGL((cco_rows_kernel<TT, EE, UU, MPF, false, false>), GRID, dim3(BLK), 0, st, args, BINARG);                  \
+      if (both || args.pk_known) hipLaunchKernelGGL((cco_rows_kernel<TT, EE, UU, MPF, false, true>), GRID, dim3(BLK), 0, st, args, BINARG); \
+      if (!args.pk_known) hipLaunchKernelGGL((cco_rows_kernel<TT, EE, UU, MPF, false, false>), GRID, dim3(BLK), 0, st, args, BINARG); \
     }                                                                                                                            \
   } while (0)
 #define URCCO_LAUNCH_MICRO(LL, GRID)                                                                                  \
   do {                                                                                                                \
     if (dbgk) hipLaunchKernelGGL((cco_rows_micro_kernel<LL, true, false>), GRID, dim3(256), 0, st, plain);              \
     else {                                                                                                            \
-      if (both) hipLaunchKernelGGL((cco_rows_micro_kernel<LL, false, true>), GRID, dim3(256), 0, st, args);             \
-      hipLaunchKernelGGL((cco_rows_micro_kernel<LL, false, false>), GRID, dim3(256), 0, st, args);                      \
+      if (both || args.pk_known) hipLaunchKernelGGL((cco_rows_micro_kernel<LL, false, true>), GRID, dim3(256), 0, st, args); \
+      if (!args.pk_known) hipLaunchKernelGGL((cco_rows_micro_kernel<LL, false, false>), GRID, dim3(256), 0, st, args);  \
     }                                                                                                                 \
   } while (0)
   switch (bin) {
@@ -4139,6 +4139,22 @@ hipError_t launch_row_lengths(hipStream_t st, int n_cu, int64_t n_rows, const in
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(row_lengths_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, row_ptr, len, len16, sizes);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void counts_over_limit_kernel(const int32_t* __restrict__ counts, int64_t n, unsigned limit, unsigned long long* __restrict__ out) {
+  int over = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) over += (unsigned)counts[i] >= limit ? 1 : 0;
+  if (over) atomicAdd(out, (unsigned long long)over);
+}
+hipError_t launch_counts_over_limit(hipStream_t st, int n_cu, const int32_t* counts, int64_t n, int32_t count_bits, int64_t* out) {
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(int64_t), st);
+  if (e != hipSuccess || n <= 0) return e;
+  int64_t blocks = (n + 255) / 256;
+  const int64_t cap = (int64_t)n_cu * 8;
+  if (blocks > cap) blocks = cap;
+  const unsigned limit = count_bits >= 16 ? 65536u : (1u << count_bits);
+  hipLaunchKernelGGL(counts_over_limit_kernel, dim3((unsigned)blocks), dim3(256), 0, st, counts, n, limit, reinterpret_cast<unsigned long long*>(out));
   return hipGetLastError();
 }
 

@@ -415,7 +415,7 @@ int partition_dev(urcco_session* s, int32_t n_items, const int64_t* work, int32_
 int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a, const int64_t* a_col_ptr, const int32_t* a_row_idx, int64_t nnz_a_bound,
                   const int64_t* b_row_ptr, const int32_t* b_col_idx, int32_t n_cols_b, const int32_t* counts_a, const int32_t* counts_b, int64_t n_users,
                   int32_t exclude_self, int32_t k, int32_t has_min_llr, double min_llr, int32_t* out_count, int32_t* out_idx, double* out_llr, int64_t* stats_dev,
-                  const int64_t* pre_pstart, const int32_t* pre_plen, int64_t* pre_tile_sums, const int32_t* b_packed, const int32_t* pack_bad) {
+                  const int64_t* pre_pstart, const int32_t* pre_plen, int64_t* pre_tile_sums, const int32_t* b_packed, const int32_t* pack_bad, bool pk_known) {
   if (!s || item_lo < 0 || item_hi < item_lo || item_hi > n_items_a || n_cols_b < 0 || n_users < 0 || nnz_a_bound < 0 || !a_col_ptr || !b_row_ptr)
     return fail(URCCO_BAD_ARG, "urcco_dev_cco_rows: bad argument");
   if (k <= 0) return fail(URCCO_BAD_ARG, "maxInterestingElements must be positive, got %d", k);
@@ -493,8 +493,12 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
   urcco::CcoArgs a;
   a.bin_rows = bin_rows; a.bin_off = bin_off;
   a.a_col_ptr = a_col_ptr; a.pstart = pstart; a.wp = wp; a.b_col_idx = b_col_idx;
-  a.b_packed = (b_packed && pack_bad && !(s->debug & 1048576)) ? b_packed : nullptr;  // debug 1048576: the count gather of rounds 1-5 (A/B, tests)
+  // debug 1048576: the count gather of rounds 1-5 (A/B, tests).  pk_known: b_col_idx itself holds packed words (the rows a sharded build received
+  // travelled with their counts aboard -- the host learnt with the shard sizes that every count fits): no plain copy exists, every reader masks
+  a.b_packed = pk_known ? b_col_idx : ((b_packed && pack_bad && !(s->debug & 1048576)) ? b_packed : nullptr);
   a.pack_bad = pack_bad;
+  a.pk_known = pk_known ? 1 : 0;
+  a.b_col_mask = pk_known ? (key_bits >= 32 ? 0xffffffffu : (1u << key_bits) - 1u) : 0xffffffffu;
   a.cnt_a = counts_a; a.cnt_b = counts_b; a.ent_a = ent_a; a.cnt_b16 = cnt_b16; a.cnt16_bad = cnt16_bad; a.xlx_n = xlx_n; a.xlx_tab = s->xlx_tab; a.xlx_hi = s->xlx_hi; a.col_ent = s->xlx_hi + urcco::XLX_TABLE_HOST; a.debug = s->debug;
   a.n_users = n_users; a.n_cols_b = n_cols_b; a.item_lo = item_lo; a.exclude_self = exclude_self ? 1 : 0; a.k = k;
   a.has_min_llr = has_min_llr ? 1 : 0; a.min_llr = min_llr; a.count_bits = count_bits;

@@ -187,6 +187,10 @@ struct EvState {
   DBuf<unsigned long long> verr;
   DBuf<int32_t> b_pk;           // B' with the columns' counts aboard (CcoArgs::b_packed): rebuilt per build from b_ci + the post-sampling counts ...
   DBuf<int32_t> pk_bad;         // ... and [1] counts that did not fit
+  DBuf<int32_t> s_pk;           // sharded builds: this rank's own down-sampled shard with the counts aboard -- what it SENDS when every count fits (the
+                                // receivers' f_ci then holds packed words: b_pk_known)
+  bool b_pk_known = false;      // b_ci holds packed words and the host knows it (see cco_rows_impl)
+  uint32_t b_col_mask = 0xffffffffu;  // b_ci[e] & b_col_mask = the column
   unsigned long long* h_verr = nullptr;  // host-mapped pinned word the boundary check's result is STORED to by the GPU (host level, one GPU) ...
   unsigned long long* h_verr_dev = nullptr;  // ... and its device address
   int ensure_h_verr() {
@@ -216,7 +220,7 @@ struct EvState {
     in_rp.release(); in_ci.release(); raw.release(); post.release(); s_rp.release(); s_ci.release(); deg.release(); f_deg.release();
     deg16.release(); f_deg16.release();
     f_rp.release(); f_ci.release(); sizes.release(); scan_tmp.release(); o_count.release(); o_idx.release(); o_llr.release(); c_rp.release();
-    c_idx.release(); c_llr.release(); stats.release(); verr.release(); b_pk.release(); pk_bad.release(); pre_pstart.release(); pre_plen.release(); pre_tsum.release();
+    c_idx.release(); c_llr.release(); stats.release(); verr.release(); b_pk.release(); pk_bad.release(); s_pk.release(); pre_pstart.release(); pre_plen.release(); pre_tsum.release();
     mlen.release(); pack.release(); mlen16.release(); mlen_bad.release(); moff.release(); mtmp.release(); to_nnz.release();
     if (h_verr) (void)hipHostFree(h_verr);
     h_verr = nullptr;
@@ -556,12 +560,17 @@ int stage_rows(DevState& D, EvState& E, EvState& A, int d, const DsParams& pa, c
   URC(E.stats.ensure(URCCO_STATS_LEN));
   // B' with the columns' counts aboard (round 6): one pass over the matrix this GPU multiplies with, with the FINAL post-sampling counts (all-reduced in a
   // sharded build) -- the row kernels then read a candidate's cB off the word that claims its slot instead of gathering it
-  URC(E.b_pk.ensure((size_t)E.b_nnz_bound + 4));
-  URC(E.pk_bad.ensure(1));
-  URC(pack_counts(E.s, E.b_rp, E.b_rows, E.b_ci, E.b_nnz_bound, post_of(D, d).p, (int32_t)p.n_cols, E.b_pk.p, E.pk_bad.p));
+  // (a sharded build packs on the SENDING side -- a rank's own shard is 1 / W of the matrix, what it receives about half of it -- and learns with the
+  // shard sizes whether every count fits: the rows then arrive packed, b_pk_known)
+  if (!E.b_pk_known) {
+    URC(E.b_pk.ensure((size_t)E.b_nnz_bound + 4));
+    URC(E.pk_bad.ensure(1));
+    URC(pack_counts(E.s, E.b_rp, E.b_rows, E.b_ci, E.b_nnz_bound, post_of(D, d).p, (int32_t)p.n_cols, E.b_pk.p, E.pk_bad.p));
+  }
   URC(cco_rows_impl(E.s, D.item_lo, D.item_hi, (int32_t)pa.n_cols, D.a_cp[D.par].p, D.a_ri[D.par].p, a_nnz_bound, E.b_rp, E.b_ci, (int32_t)p.n_cols,
                     post_of(D, 0).p, post_of(D, d).p, n_users, d == 0 ? 1 : 0, p.k, p.has_min_llr, p.min_llr, E.o_count.p, E.o_idx.p, E.o_llr.p, E.stats.p,
-                    pre_expanded ? E.pre_pstart.p : nullptr, pre_expanded ? E.pre_plen.p : nullptr, pre_expanded ? E.pre_tsum.p : nullptr, E.b_pk.p, E.pk_bad.p));
+                    pre_expanded ? E.pre_pstart.p : nullptr, pre_expanded ? E.pre_plen.p : nullptr, pre_expanded ? E.pre_tsum.p : nullptr,
+                    E.b_pk_known ? nullptr : E.b_pk.p, E.b_pk_known ? nullptr : E.pk_bad.p, E.b_pk_known));
   URC(urcco_dev_compact_indicators(E.s, n, p.k, E.o_count.p, E.o_idx.p, E.o_llr.p, E.c_rp.p, E.c_idx.p, E.c_llr.p));
   HIPC(hipEventRecord(E.ev_done, E.s->stream));
   HIPC(hipEventRecord(E.ev_cons[D.par], E.s->stream));
@@ -682,6 +691,8 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
     if (fuse && E.s != D.ev[1].s) HIPC(hipStreamWaitEvent(E.s->stream, D.b_expanded, 0));
     E.b_rp = E.s_rp.p;
     E.b_ci = E.s_ci.p;
+    E.b_pk_known = false;
+    E.b_col_mask = 0xffffffffu;
     E.b_rows = sh[(size_t)d].n_rows;
     E.b_nnz_bound = sh[(size_t)d].nnz;
     URC(stage_rows(D, E, A, d, ps_[0], ps_[(size_t)d], n_users, sh[0].nnz, fuse));
@@ -738,6 +749,8 @@ int build_single(urcco_context* c, DevState& D, const std::vector<Shard>& sh, co
   auto rows_primary = [&]() -> int {
     A.b_rp = A.s_rp.p;
     A.b_ci = A.s_ci.p;
+    A.b_pk_known = false;
+    A.b_col_mask = 0xffffffffu;
     A.b_rows = sh[0].n_rows;
     A.b_nnz_bound = sh[0].nnz;
     if (fold && A.s != D.ev[1].s) HIPC(hipStreamWaitEvent(A.s->stream, D.b_expanded, 0));
@@ -864,7 +877,26 @@ int input_phase(urcco_context* c, int d, const std::vector<std::vector<Shard>>& 
     URC(E.sizes.ensure((size_t)XS * (size_t)c->world));
     E.s->begin(URCCO_STAGE_EXCHANGE);
     HIPC(urcco::launch_row_lengths(E.s->stream, D.n_cu, s.n_rows, E.s_rp.p, E.deg.p, E.deg16.p, E.sizes.p + XS * D.rank));
+    // (never: debug 1048576, and the primary of a build that gathers and transposes the WHOLE A' on every rank -- debug 8192 -- reads the received words as columns)
+    const bool no_pack = (c->debug & 1048576) != 0 || (d == 0 && !fragments(c));
+    // round 6: can a B' word of this event type carry its column's count?  A fact of the all-reduced count table -- every rank finds the same answer
+    // and learns the others' with the shard sizes -- and, when it can, this rank's shard is packed HERE, before it travels (debug 1048576: never)
+    {
+      int key_bits = 1;
+      while (((int64_t)1 << key_bits) <= p.n_cols) ++key_bits;
+      const int count_bits = 32 - key_bits;
+      if (count_bits < 1 || no_pack) {
+        HIPC(hipMemsetAsync(E.sizes.p + XS * D.rank + 3, 1, sizeof(int64_t), E.s->stream));  // (any non-zero value says "plain")
+      } else {
+        HIPC(urcco::launch_counts_over_limit(E.s->stream, D.n_cu, post_of(D, d).p, p.n_cols, count_bits, E.sizes.p + XS * D.rank + 3));
+      }
+    }
     E.s->end();
+    if (!no_pack) {
+      URC(E.s_pk.ensure((size_t)s.nnz + 4));
+      URC(E.pk_bad.ensure(1));
+      URC(pack_counts(E.s, E.s_rp.p, s.n_rows, E.s_ci.p, s.nnz, post_of(D, d).p, (int32_t)p.n_cols, E.s_pk.p, E.pk_bad.p));
+    }
   }
   std::vector<int64_t> off((size_t)c->world), cnt((size_t)c->world, 8 * XS);
   for (int r = 0; r < c->world; ++r) off[(size_t)r] = 8 * XS * (int64_t)r;
@@ -921,6 +953,14 @@ int exchange_phase(urcco_context* c, int d, const std::vector<std::vector<Shard>
   int64_t rows = 0, nnz = 0;
   bool deg16 = true;
   for (int r = 0; r < W; ++r) deg16 = deg16 && sizes[(size_t)XS * r + 2] == 0;
+  bool packed_ok = true;  // the rows travel with their counts aboard: every rank's verdict on the (same) count table (input_phase)
+  for (int r = 0; r < W; ++r) packed_ok = packed_ok && sizes[(size_t)XS * r + 3] == 0;
+  uint32_t col_mask = 0xffffffffu;
+  if (packed_ok) {
+    int key_bits = 1;
+    while (((int64_t)1 << key_bits) <= ps[(size_t)d].n_cols) ++key_bits;
+    col_mask = key_bits >= 32 ? 0xffffffffu : (1u << key_bits) - 1u;
+  }
   const int64_t deg_bytes = deg16 ? 2 : 4;
   for (int r = 0; r < W; ++r) {
     off_r[(size_t)r] = rows * deg_bytes;
@@ -989,7 +1029,7 @@ int exchange_phase(urcco_context* c, int d, const std::vector<std::vector<Shard>
       EvState& E = D.ev[(size_t)d];
       const Shard& s = sh[(size_t)d][g];
       E.s->begin(URCCO_STAGE_EXCHANGE);
-      HIPC(urcco::launch_pack_rows(E.s->stream, D.n_cu, s.n_rows, E.s_rp.p, E.s_ci.p, D.need.p, W, E.moff.p, E.pack.p));
+      HIPC(urcco::launch_pack_rows(E.s->stream, D.n_cu, s.n_rows, E.s_rp.p, packed_ok ? E.s_pk.p : E.s_ci.p, D.need.p, W, E.moff.p, E.pack.p));
       if (deg16 && s.n_rows > 0) HIPC(urcco::launch_narrow_counts(E.s->stream, D.n_cu, E.mlen.p, (int64_t)W * s.n_rows, E.mlen16.p, E.mlen_bad.p));
       E.s->end();
       return URCCO_OK;
@@ -1023,7 +1063,7 @@ int exchange_phase(urcco_context* c, int d, const std::vector<std::vector<Shard>
     } else {
       if (deg16) URC(c->all_gather_v(D, E.deg16.p, E.f_deg16.p, off_r.data(), cnt_r.data(), E.s->stream));
       else URC(c->all_gather_v(D, E.deg.p, E.f_deg.p, off_r.data(), cnt_r.data(), E.s->stream));
-      URC(c->all_gather_v(D, E.s_ci.p, E.f_ci.p, off_c.data(), cnt_c.data(), E.s->stream));
+      URC(c->all_gather_v(D, packed_ok ? E.s_pk.p : E.s_ci.p, E.f_ci.p, off_c.data(), cnt_c.data(), E.s->stream));
     }
     if (fp && fp->on) {
       // to rank q: the column lengths and the entries of q's item range, as they lie in this shard's CSC; from rank p: the same
@@ -1062,6 +1102,8 @@ int exchange_phase(urcco_context* c, int d, const std::vector<std::vector<Shard>
     E.s->end();
     E.b_rp = E.f_rp.p;
     E.b_ci = E.f_ci.p;
+    E.b_pk_known = packed_ok;
+    E.b_col_mask = col_mask;
     E.b_rows = rows;
     E.b_nnz_bound = nnz;
     if (filt) {
@@ -1597,6 +1639,7 @@ int urcco_context_build_device(urcco_context* c, const urcco_dev_dataset* datase
         r.item_lo = D.item_lo; r.item_hi = D.item_hi;
         r.row_ptr = E.c_rp.p; r.col_idx = E.c_idx.p; r.llr = E.c_llr.p; r.stats = E.stats.p;
         r.sampled_row_ptr = E.b_rp; r.sampled_col_idx = E.b_ci; r.sampled_rows = E.b_rows;
+        r.sampled_col_mask = (int32_t)E.b_col_mask;
         r.sampled_nnz_total = c->exchange() && (size_t)d < c->h_sizes.size() ? c->h_sizes[(size_t)d] : -1;
       }
     return URCCO_OK;

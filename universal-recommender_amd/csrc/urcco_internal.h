@@ -86,7 +86,8 @@ int cco_rows_impl(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_
                   const int64_t* b_row_ptr, const int32_t* b_col_idx, int32_t n_cols_b, const int32_t* counts_a, const int32_t* counts_b, int64_t n_users,
                   int32_t exclude_self, int32_t k, int32_t has_min_llr, double min_llr, int32_t* out_count, int32_t* out_idx, double* out_llr, int64_t* stats_dev,
                   const int64_t* pre_pstart, const int32_t* pre_plen, int64_t* pre_tile_sums = nullptr /* the scan-tile sums of pre_plen, left by expand_multi */,
-                  const int32_t* b_packed = nullptr /* B' with the columns' counts aboard (launch_pack_counts) ... */, const int32_t* pack_bad = nullptr /* ... and its verdict */);
+                  const int32_t* b_packed = nullptr /* B' with the columns' counts aboard (launch_pack_counts) ... */, const int32_t* pack_bad = nullptr /* ... and its verdict */,
+                  bool pk_known = false /* b_col_idx itself holds such words and the host knows they are good (sharded builds) */);
 // B' with counts aboard for cco_rows_impl: out[e] = b_col_idx[e] | counts_b[b_col_idx[e]] << key bits, e < b_row_ptr[n_rows_b] (<= nnz_bound); bad[0] = counts that do not fit
 int pack_counts(urcco_session* s, const int64_t* b_row_ptr, int64_t n_rows_b, const int32_t* b_col_idx, int64_t nnz_bound, const int32_t* counts_b, int32_t n_cols_b,
                 int32_t* out, int32_t* bad);

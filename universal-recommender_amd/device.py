@@ -399,9 +399,12 @@ class Context:
                 n = r.item_hi - r.item_lo
                 s_rp = _view(r.sampled_row_ptr, r.sampled_rows + 1, torch.int64, dev)
                 s_nnz = int(s_rp[-1]) if s_rp.numel() else 0
+                s_ci = _view(r.sampled_col_idx, max(s_nnz, 1), torch.int32, dev)
+                if r.sampled_col_mask != -1:   # a sharded build's rows arrive with their columns' counts above the column bits (include/urcco.h)
+                    s_ci = s_ci & int(r.sampled_col_mask)
                 row.append(DevIndicators(r.item_lo, r.item_hi, n_cols[d], ks[d], _view(r.row_ptr, n + 1, torch.int64, dev),
                                          _view(r.col_idx, max(n * ks[d], 1), torch.int32, dev), _view(r.llr, max(n * ks[d], 1), torch.float64, dev),
-                                         _view(r.stats, _lib.STATS_LEN, torch.int64, dev), s_rp, _view(r.sampled_col_idx, max(s_nnz, 1), torch.int32, dev),
+                                         _view(r.stats, _lib.STATS_LEN, torch.int64, dev), s_rp, s_ci,
                                          int(r.sampled_nnz_total)))
             res.append(row)
         return res
