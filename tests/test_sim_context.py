@@ -213,7 +213,7 @@ def test_one_process_drives_several_gpus(sim_lib, n_gpus, primary, monkeypatch):
         assert coll.error is None
         # what travelled
         a2a = [e for e in coll.log if e[0] == "aa"]
-        if primary == "fragments":
+        if primary in ("fragments", "plain rows"):
             # per build and rank: the primary's CSC as fragments (16-bit column lengths, then entries) + per event type the row-filtered
             # exchange (masked row lengths to every destination, then the rows a destination may see)
             assert len(a2a) == 2 * n_gpus * (2 + 2 * len(mats))
