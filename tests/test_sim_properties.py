@@ -39,3 +39,16 @@ def problems(draw):
 def test_random_problems_match_the_oracle(sim_session, problem):
     mats, params, run_seed, mode, (lo, hi) = problem
     compare_with_oracle(sim_session, mats, params, run_seed, mode, lo, hi)
+
+
+def test_micro_class_unsplit_in_small_builds():
+    """Builds below a million item rows keep ONE micro list (what a rank of a sharded build runs): the kernel-logic cases of the micro class once more in a
+    subprocess whose library reads the default threshold."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, URCCO_MICRO_SPLIT_ROWS="1000000")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "tests/test_sim_kernel_logic.py", "-k", "micro or small_three or empty_and_ragged"],
+                       cwd=root, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

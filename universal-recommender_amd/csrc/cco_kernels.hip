@@ -2127,7 +2127,16 @@ __device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_c
 constexpr int MICRO_SUBS = 3;
 constexpr int IBINS = NBINS - 1 + MICRO_SUBS;
 __device__ __forceinline__ int micro_sub(long long w, long long ca) { return (w <= 16 && ca <= 16) ? 0 : ((w <= 32 && ca <= 32) ? 1 : 2); }
-__device__ __forceinline__ int internal_bin(int b, long long w, long long ca) { return b < 0 ? -1 : (b == 0 ? micro_sub(w, ca) : b + MICRO_SUBS - 1); }
+__device__ __forceinline__ int internal_bin(int b, long long w, long long ca, int split) {
+  return b < 0 ? -1 : (b == 0 ? (split ? micro_sub(w, ca) : MICRO_SUBS - 1) : b + MICRO_SUBS - 1);
+}
+// The micro class is split into its sub-lists only when the build has enough item rows for three launches to pay: a rank of a sharded build (an eighth
+// of config 4's rows) would start 16K waves per sub-list for a handful of passes each (emulated 8-rank build: 3.45 against 3.17 ms of SpGEMM per rank).
+// URCCO_MICRO_SPLIT_ROWS (read once) moves the threshold.
+static bool micro_split_for(int32_t n_rows) {
+  static const long long min_rows = [] { const char* e = getenv("URCCO_MICRO_SPLIT_ROWS"); return e && *e ? atoll(e) : 1000000ll; }();
+  return (long long)n_rows >= min_rows;
+}
 __device__ __forceinline__ int internal_start(const int32_t* __restrict__ bin_off, int ib) {
   return ib == 0 ? bin_off[0] : (ib < MICRO_SUBS ? bin_off[NBINS + ib] : bin_off[ib - (MICRO_SUBS - 1)]);
 }
@@ -2138,7 +2147,7 @@ static_assert(BIN_COLS == BIN_COLS_HOST && BIN_OFF_LEN == NBINS + MICRO_SUBS, "s
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo, int32_t n, const int64_t* __restrict__ work,
                                                                 const int32_t* __restrict__ cnt_a, int32_t n_cols_b, int32_t count_bits, int32_t k,
-                                                                int64_t* __restrict__ tile_counts) {
+                                                                int64_t* __restrict__ tile_counts, int split) {
   __shared__ long long s_acc[BIN_COLS];
   if (threadIdx.x < BIN_COLS) s_acc[threadIdx.x] = 0;
   __syncthreads();
@@ -2157,7 +2166,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int32_t item_lo,
       const long long ca = cnt_a[item_lo + t];
       pairs += w;
       const int b = choose_bin(w, ca, n_cols_b, count_bits, k);
-      const int ib = internal_bin(b, w, ca);
+      const int ib = internal_bin(b, w, ca, split);
 #pragma unroll
       for (int k = 0; k < IBINS; ++k) c[k] += (ib == k);
 #pragma unroll
@@ -2253,7 +2262,7 @@ __global__ __launch_bounds__(BS_THREADS) void bin_scan_kernel(int64_t* __restric
 __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int32_t item_lo, int32_t n, const int64_t* __restrict__ work,
                                                                   const int32_t* __restrict__ cnt_a, int32_t n_cols_b, int32_t count_bits, int32_t k,
                                                                   const int64_t* __restrict__ tile_counts, const int32_t* __restrict__ bin_off,
-                                                                  int32_t* __restrict__ bin_rows) {
+                                                                  int32_t* __restrict__ bin_rows, int split) {
   __shared__ long long s_wave[SCAN_THREADS / WAVE];
   int b[BIN_ITEMS];
 #pragma unroll
@@ -2262,7 +2271,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int32_t item_l
     b[q] = -1;
     if (t < n) {
       const long long w = work[t], ca = cnt_a[item_lo + t];
-      b[q] = internal_bin(choose_bin(w, ca, n_cols_b, count_bits, k), w, ca);
+      b[q] = internal_bin(choose_bin(w, ca, n_cols_b, count_bits, k), w, ca, split);
     }
   }
   for (int k = 0; k < IBINS; ++k) {  // block-uniform: one block scan per internal bin
@@ -2285,10 +2294,11 @@ hipError_t launch_binning(hipStream_t st, int32_t item_lo, int32_t n, const int6
     return e;
   }
   const int64_t n_tiles = ((int64_t)n + BIN_TILE - 1) / BIN_TILE;
-  hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)n_tiles), dim3(BIN_THREADS), 0, st, item_lo, n, work, cnt_a, n_cols_b, count_bits, k, tile_counts);
+  const int split = micro_split_for(n) ? 1 : 0;
+  hipLaunchKernelGGL(bin_count_kernel, dim3((unsigned)n_tiles), dim3(BIN_THREADS), 0, st, item_lo, n, work, cnt_a, n_cols_b, count_bits, k, tile_counts, split);
   hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(BS_THREADS), 0, st, tile_counts, n_tiles, bin_off, stats);
   hipLaunchKernelGGL(bin_scatter_kernel, dim3((unsigned)n_tiles), dim3(BIN_THREADS), 0, st, item_lo, n, work, cnt_a, n_cols_b, count_bits, k,
-                     tile_counts, bin_off, bin_rows);
+                     tile_counts, bin_off, bin_rows, split);
   return hipGetLastError();
 }
 
@@ -4008,8 +4018,10 @@ hipError_t launch_cco_rows_bin(hipStream_t st, int n_cu, const CcoArgs& args, in
   switch (bin) {
     case 0:  // the class's three sub-lists, the rows that keep a wave to themselves first (each kernel reads its own list bounds on the device)
       URCCO_LAUNCH_MICRO(64, grid(0));
-      URCCO_LAUNCH_MICRO(32, grid(0, micro_factors.f32));
-      URCCO_LAUNCH_MICRO(16, grid(0, micro_factors.f16));
+      if (micro_split_for(n_rows)) {  // (the same rule as the binning pass: without the split the two sub-lists are empty)
+        URCCO_LAUNCH_MICRO(32, grid(0, micro_factors.f32));
+        URCCO_LAUNCH_MICRO(16, grid(0, micro_factors.f16));
+      }
       break;
     case 1: URCCO_LAUNCH_ROWS(64, E0, URCCO_U_WAVE, false, grid(1), 256, 1); break;
     case 2: URCCO_LAUNCH_ROWS(256, E1S, URCCO_U_BS, false, grid(2), 256, 2); break;
