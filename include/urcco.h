@@ -371,7 +371,8 @@ int urcco_dev_partition(urcco_session* s, int32_t n_items, const int64_t* work, 
  * transposed its own shard (urcco_dev_transpose over all columns: shard-local user ids) and sent the slice of that CSC
  * that belongs to the range: lens[p * (item_hi - item_lo) + j] = length of column item_lo + j in shard p (uint16 when
  * wire16, else int32), entries = the W slices one behind the other in rank order (n_entries in all).
- * sizes[3 * p] = rows of shard p (the record of the exchange: rows, nnz, rows longer than 65535); counts[n_items] = the
+ * sizes[URCCO_EXCH_SIZES * p] = rows of shard p (the record of the exchange, ABI 305: rows, nnz, rows longer than 65535, counts that do not fit a
+ * packed B' word -- four int64 per shard, three before 305); counts[n_items] = the
  * all-reduced column counts.  out_col_ptr[n_items + 1] (columns outside the range are empty), out_row_idx = global
  * user ids, ascending inside a column when the fragments were.  Replaces the pass every rank used to make over the
  * whole gathered A' to pick its columns out (Spark: the shuffle inside `A.t %*% B`, URAlgorithm.scala:323-346). */
@@ -389,6 +390,7 @@ int urcco_dev_merge_fragments(urcco_session* s, int32_t world, int32_t item_lo, 
  * of rows / pairs / users (sum of cA) / emitted entries per accumulator bin (the last group only while timing is
  * enabled), then [1 + 4 * URCCO_N_BINS] accumulator-table overflows (an internal invariant: must be 0). */
 #define URCCO_STATS_LEN 32
+#define URCCO_EXCH_SIZES 4 /* int64 words of a shard's record in urcco_dev_merge_fragments' sizes */
 int urcco_dev_cco_rows(urcco_session* s, int32_t item_lo, int32_t item_hi, int32_t n_items_a,
                        const int64_t* a_col_ptr, const int32_t* a_row_idx, int64_t nnz_a_bound,
                        const int64_t* b_row_ptr, const int32_t* b_col_idx, int32_t n_cols_b, const int32_t* counts_a,

@@ -7,6 +7,7 @@ import torch
 
 from helpers import compare_with_oracle, guarded, rand_csr, to_dev
 from oracle import c_oracle as O
+from universal_recommender_amd import _lib
 
 
 def P(max_rows=500, k=50, min_llr=None):
@@ -430,8 +431,8 @@ def test_merge_of_csc_fragments(sim_session, wire):
         l_cnt = O.column_counts(sh)
         cp, ri = sess.transpose(to_dev(sh, dev), guarded(torch.from_numpy(l_cnt).to(dev)))
         frags.append((l_cnt, cp.cpu().numpy(), ri.cpu().numpy()))
-    sizes = np.zeros(3 * W, np.int64)
-    sizes[0::3] = np.diff(cuts)
+    sizes = np.zeros(_lib.EXCH_SIZES * W, np.int64)          # (rows, nnz, long rows, counts that do not fit a packed word) per shard
+    sizes[0::_lib.EXCH_SIZES] = np.diff(cuts)
     bounds = [0, 90, 90 + 333, n_items]
     for lo, hi in zip(bounds, bounds[1:]):
         lens = np.concatenate([f[0][lo:hi] for f in frags])

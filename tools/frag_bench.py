@@ -69,8 +69,8 @@ for p in range(W):
     (l_cp, l_ri), ms = timed(lambda: sess.transpose(sh, l_cnt))
     shards.append((sh, l_cnt, ms))
     frags.append((l_cnt, l_cp, l_ri))
-sizes = torch.zeros(3 * W, dtype=torch.int64)
-sizes[0::3] = torch.tensor(np.diff(cuts))
+sizes = torch.zeros(_lib.EXCH_SIZES * W, dtype=torch.int64)
+sizes[0::_lib.EXCH_SIZES] = torch.tensor(np.diff(cuts))
 sizes = sizes.to(dev)
 rows = []
 for r in sorted({0, W // 2, W - 1}):

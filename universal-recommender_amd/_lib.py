@@ -26,6 +26,7 @@ RNG_MIX32 = 0x100
 N_STAGES = 17
 N_BINS = 7
 STATS_LEN = 32
+EXCH_SIZES = 4   # int64 words of a shard's record (include/urcco.h URCCO_EXCH_SIZES)
 STAGE_NAMES = ["column_counts", "downsample_flags", "downsample_scan", "downsample_compact", "transpose", "row_work", "binning",
                "entropy", "cco_rows_micro", "cco_rows_wave", "cco_rows_block_small", "cco_rows_block", "cco_rows_cu_half", "cco_rows_cu", "cco_rows_global", "compact_indicators", "exchange"]
 

@@ -127,7 +127,7 @@ hipError_t launch_csr_from_pairs(hipStream_t st, int n_cu, int64_t n, const int3
                                  int64_t* raw_ptr, int32_t* tmp, int64_t* tile_sums, int64_t* out_row_ptr, int32_t* out_col_idx);
 
 // len[n_rows] = row lengths, len16 (nullable) = the same as uint16; sizes (nullable) = {n_rows, nnz, rows longer than 65535}
-constexpr int EXCH_SIZES = 4;  // (round 6: [3] = columns whose count does not fit a packed B' word -- launch_counts_over_limit)
+constexpr int EXCH_SIZES = 4;  // == URCCO_EXCH_SIZES of include/urcco.h (checked in urcco_internal.h)  // (round 6: [3] = columns whose count does not fit a packed B' word -- launch_counts_over_limit)
 hipError_t launch_row_lengths(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* row_ptr, int32_t* len, unsigned short* len16, int64_t* sizes);
 // out[0] = number of counts that a B' word of a matrix with these counts cannot carry (>= 2^min(count_bits, 16)): a fact of the count TABLE, the same on
 // every rank of a sharded build once the counts are all-reduced -- so every rank decides alike whether the rows it sends travel with their counts aboard

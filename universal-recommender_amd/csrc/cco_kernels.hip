@@ -1383,7 +1383,8 @@ static int tp_bucket_bits(int32_t n_cols) {
 
 __global__ __launch_bounds__(TP_THREADS, 4) void tp_partition_kernel(int64_t n_rows, const int64_t* __restrict__ rp, const int32_t* __restrict__ ci,
                                                                   const int64_t* __restrict__ R, int bits, int n_buckets, int64_t n_parts, int32_t col_lo,
-                                                                  int32_t col_hi, unsigned short* __restrict__ bk_col, int32_t* __restrict__ bk_row,
+                                                                  int32_t col_hi, unsigned short* __restrict__ bk_col, unsigned short* __restrict__ bk_row16,
+                                                                  int32_t* __restrict__ bk_row, int64_t* __restrict__ part_base,
                                                                   unsigned short* __restrict__ loc_t, int vec_ok) {
   __shared__ int s_cnt[TP_COPIES * TP_MAX_BUCKETS];  // counts, then the start of every (copy, bucket) run inside the part
   __shared__ uint4 s_stage4[TP_PART / 8];            // the part's in-bucket columns grouped by bucket (leaves in 16-byte stores)
@@ -1398,6 +1399,7 @@ __global__ __launch_bounds__(TP_THREADS, 4) void tp_partition_kernel(int64_t n_r
   const int64_t e0 = part * TP_PART;
   if (e0 >= nnz) {  // a part beyond the device-side length (the launch is sized for the host's bound): every slice is empty (block-uniform)
     for (int b = threadIdx.x; b <= n_buckets; b += TP_THREADS) loc_t[(int64_t)b * n_parts + part] = 0;
+    if (threadIdx.x == 0) part_base[part] = 0;
     return;
   }
   const int n = (int)(e0 + TP_PART < nnz ? TP_PART : nnz - e0);
@@ -1498,43 +1500,65 @@ __global__ __launch_bounds__(TP_THREADS, 4) void tp_partition_kernel(int64_t n_r
     if (b == n_buckets % TP_THREADS) loc_t[(int64_t)n_buckets * n_parts + part] = (unsigned short)all;  // <= TP_PART = 16384
   }
   __syncthreads();
-  // entry -> row (a run of four at a time: nothing of it is held across the phases above), then the entry goes to its place in the part
+  // entry -> row.  With the marks (the rule) a row is its 16-bit SLICE INDEX: it is staged through LDS like the column -- in the words of s_row_at, free once
+  // every lookup has been made -- and leaves in 16-byte stores beside part_base[part] = the slice's first row (round 6, second form: the rows as 4-byte
+  // stores scattered over the part's 64 KB window left the caches as partial lines: 1.7 GB of traffic per launch for 0.5 GB of entries).  A part whose slice
+  // holds more than 65536 rows writes 32-bit rows the scattered way and says so with part_base[part] = -1.
   const unsigned cmask = (1u << bits) - 1u;
-  int32_t* row_dst = bk_row + e0;
+  if (by_marks) {
+    unsigned t2[TP_PER_THREAD / 2];  // slice indices, two per register
 #pragma unroll
-  for (int r = 0; r < TP_PER_THREAD / 4; ++r) {
-    const int el0 = r * (TP_THREADS * 4) + (int)threadIdx.x * 4;
-    int rows[4];
-    if (by_marks) {
+    for (int r = 0; r < TP_PER_THREAD / 4; ++r) {
+      const int el0 = r * (TP_THREADS * 4) + (int)threadIdx.x * 4;
       const int w = el0 >> 6, sh = el0 & 63;
       const unsigned long long m = s_mask[w];
       const unsigned starts = (unsigned)(m >> sh) & 0xfu;       // rows starting inside the run
       const unsigned long long low = m & ((1ull << sh) - 1ull);  // ... and before it, in the same word
-      int t_cur = s_tbefore[w];
-      if (low) t_cur = (int)s_row_at[w * 64 + 63 - __clzll((long long)low)];
+      unsigned t_cur = (unsigned)s_tbefore[w];
+      if (low) t_cur = (unsigned)s_row_at[w * 64 + 63 - __clzll((long long)low)];
       const uint2 at2 = *reinterpret_cast<const uint2*>(&s_row_at[el0]);
-      const int at[4] = {(int)(at2.x & 0xffffu), (int)(at2.x >> 16), (int)(at2.y & 0xffffu), (int)(at2.y >> 16)};
+      const unsigned at[4] = {at2.x & 0xffffu, at2.x >> 16, at2.y & 0xffffu, at2.y >> 16};
+      unsigned tq[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         t_cur = (starts >> q) & 1u ? at[q] : t_cur;
-        rows[q] = (int)(r_s + t_cur);
+        tq[q] = t_cur;
       }
-    } else {
-#pragma unroll 1
-      for (int q = 0; q < 4; ++q) rows[q] = el0 + q < n ? (int)(upper_bound_i64(rp, r_s, r_e, e0 + el0 + q) - 1) : 0;
+      t2[2 * r] = tq[0] | (tq[1] << 16);
+      t2[2 * r + 1] = tq[2] | (tq[3] << 16);
     }
+    __syncthreads();  // every lookup has read s_row_at: its words now stage the rows
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int j = cols[4 * r + q];
+    for (int q = 0; q < TP_PER_THREAD; ++q) {
+      const int j = cols[q];
       if (j >= 0) {
-        const unsigned rk = (q & 1) ? rank2[(4 * r + q) >> 1] >> 16 : rank2[(4 * r + q) >> 1] & 0xffffu;
+        const unsigned rk = (q & 1) ? rank2[q >> 1] >> 16 : rank2[q >> 1] & 0xffffu;
         const int pos = mine[j >> bits] + (int)rk;
         s_stage[pos] = (unsigned short)((unsigned)j & cmask);
-        row_dst[pos] = rows[q];
+        s_row_at[pos] = (unsigned short)((q & 1) ? t2[q >> 1] >> 16 : t2[q >> 1] & 0xffffu);
       }
     }
+    __syncthreads();
+    uint4* rdst = reinterpret_cast<uint4*>(bk_row16 + e0);
+    const uint4* rsrc = reinterpret_cast<const uint4*>(s_row_at);
+    for (int v = threadIdx.x; v * 8 < n; v += TP_THREADS) rdst[v] = rsrc[v];
+    if (threadIdx.x == 0) part_base[part] = r_s;
+  } else {
+    int32_t* row_dst = bk_row + e0;
+#pragma unroll 1
+    for (int q = 0; q < TP_PER_THREAD; ++q) {
+      const int j = cols[q];
+      if (j >= 0) {
+        const int el = (q >> 2) * (TP_THREADS * 4) + (int)threadIdx.x * 4 + (q & 3);
+        const unsigned rk = (q & 1) ? rank2[q >> 1] >> 16 : rank2[q >> 1] & 0xffffu;
+        const int pos = mine[j >> bits] + (int)rk;
+        s_stage[pos] = (unsigned short)((unsigned)j & cmask);
+        row_dst[pos] = (int)(upper_bound_i64(rp, r_s, r_e, e0 + el) - 1);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) part_base[part] = -1;
   }
-  __syncthreads();
   // the columns leave as the part lies: 16-byte stores (bk_col + e0 is 32 KiB-aligned relative to the array's 256-byte-aligned base)
   uint4* dst = reinterpret_cast<uint4*>(bk_col + e0);
   for (int v = threadIdx.x; v * 8 < n; v += TP_THREADS) dst[v] = s_stage4[v];  // entries behind the kept ones are stale: inside the part's own 32 KiB, never read
@@ -1561,7 +1585,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void tp_blockmap_kernel(const long lo
 
 constexpr int TPP_THREADS = 1024;
 constexpr int TPP_LPS = 4;  // lanes per slice: a slice of a 2M-column catalogue holds ~33 entries, a step of four lanes covers 32
-__global__ __launch_bounds__(TPP_THREADS) void tp_place_kernel(const unsigned short* __restrict__ bk_col, const int32_t* __restrict__ bk_row,
+__global__ __launch_bounds__(TPP_THREADS) void tp_place_kernel(const unsigned short* __restrict__ bk_col, const unsigned short* __restrict__ bk_row16,
+                                                               const int32_t* __restrict__ bk_row, const int64_t* __restrict__ part_base,
                                                                const unsigned short* __restrict__ loc_t, int bits, int n_buckets, int64_t n_parts,
                                                                const int32_t* __restrict__ blk_prefix, const int64_t* __restrict__ col_ptr, int32_t n_cols,
                                                                int32_t* __restrict__ g_cursor /* [n_cols] zero */, int32_t* __restrict__ out_rows) {
@@ -1591,28 +1616,42 @@ __global__ __launch_bounds__(TPP_THREADS) void tp_place_kernel(const unsigned sh
   const int sub = lane / TPP_LPS, sl = lane % TPP_LPS;
   const int64_t gstep = (int64_t)(TPP_THREADS / WAVE) * GP;
   int64_t g = p0 + (int64_t)wave * GP;
-  unsigned lo_n = 0u, hi_n = 0u;  // the NEXT group's bounds travel while this group's slices are placed
+  unsigned lo_n = 0u, hi_n = 0u;  // the NEXT group's bounds (and the parts' first rows) travel while this group's slices are placed
+  int pb_n = 0;
   if (g < p1 && lane < GP && g + lane < p1) {
     lo_n = lo_t[g + lane];
     hi_n = hi_t[g + lane];
+    pb_n = (int)part_base[g + lane];  // (a row index, or -1: the part's rows are 32-bit words)
   }
   for (; g < p1; g += gstep) {  // wave-uniform
     const unsigned lo = lo_n, hi = hi_n;
+    const int pb = pb_n;
     lo_n = 0u;
     hi_n = 0u;
+    pb_n = 0;
     if (g + gstep < p1 && lane < GP && g + gstep + lane < p1) {
       lo_n = lo_t[g + gstep + lane];
       hi_n = hi_t[g + gstep + lane];
+      pb_n = (int)part_base[g + gstep + lane];
     }
     const unsigned lo_j = (unsigned)__shfl((int)lo, sub);  // (parts past the range carry lo == hi == 0)
     const unsigned hi_j = (unsigned)__shfl((int)hi, sub);
+    const int pb_j = __shfl(pb, sub);
     const unsigned short* csrc = bk_col + (g + sub) * TP_PART;
+    const unsigned short* r16 = bk_row16 + (g + sub) * TP_PART;
     const int32_t* rsrc = bk_row + (g + sub) * TP_PART;
     for (unsigned at = (lo_j & ~7u) + 8u * (unsigned)sl; at < hi_j; at += 8u * TPP_LPS) {
       const uint4 c4 = *reinterpret_cast<const uint4*>(csrc + at);
-      const int4 r0 = *reinterpret_cast<const int4*>(rsrc + at), r1 = *reinterpret_cast<const int4*>(rsrc + at + 4);
+      int rr[8];
+      if (pb_j >= 0) {  // the rule: eight 16-bit slice indices in one 16-byte load
+        const uint4 t4 = *reinterpret_cast<const uint4*>(r16 + at);
+        rr[0] = pb_j + (int)(t4.x & 0xffffu); rr[1] = pb_j + (int)(t4.x >> 16); rr[2] = pb_j + (int)(t4.y & 0xffffu); rr[3] = pb_j + (int)(t4.y >> 16);
+        rr[4] = pb_j + (int)(t4.z & 0xffffu); rr[5] = pb_j + (int)(t4.z >> 16); rr[6] = pb_j + (int)(t4.w & 0xffffu); rr[7] = pb_j + (int)(t4.w >> 16);
+      } else {
+        const int4 r0 = *reinterpret_cast<const int4*>(rsrc + at), r1 = *reinterpret_cast<const int4*>(rsrc + at + 4);
+        rr[0] = r0.x; rr[1] = r0.y; rr[2] = r0.z; rr[3] = r0.w; rr[4] = r1.x; rr[5] = r1.y; rr[6] = r1.z; rr[7] = r1.w;
+      }
       const unsigned cw[4] = {c4.x, c4.y, c4.z, c4.w};
-      const int rr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const unsigned t = at + (unsigned)k;
@@ -1641,7 +1680,8 @@ int64_t transpose_scratch_bytes(int64_t n_rows, int64_t nnz, int32_t n_cols) {
   int64_t n_buckets, n_parts;
   tp_geometry(nnz, n_cols, &bits, &n_buckets, &n_parts);
   if (n_buckets < 1 || n_buckets > TP_MAX_BUCKETS) return 0;
-  return al((n_parts + 1) * 8) + al(n_parts * TP_PART * 2 + 64) + al(n_parts * TP_PART * 4 + 64) + al((n_buckets + 1) * n_parts * 2) + al(n_buckets * 8) + al((n_buckets + 1) * 4);
+  return al((n_parts + 1) * 8) + al(n_parts * TP_PART * 2 + 64) + al(n_parts * TP_PART * 2 + 64) + al(n_parts * TP_PART * 4 + 64) + al((n_parts + 1) * 8) +
+         al((n_buckets + 1) * n_parts * 2) + al(n_buckets * 8) + al((n_buckets + 1) * 4);
 }
 
 hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const int64_t* row_ptr, const int32_t* col_idx, int64_t nnz, int32_t n_cols,
@@ -1653,21 +1693,23 @@ hipError_t launch_transpose_partitioned(hipStream_t st, int64_t n_rows, const in
   if (n_buckets < 1 || n_buckets > TP_MAX_BUCKETS) return hipErrorInvalidValue;
   int64_t* R = reinterpret_cast<int64_t*>(scratch); scratch += al((n_parts + 1) * 8);
   unsigned short* bk_col = reinterpret_cast<unsigned short*>(scratch); scratch += al(n_parts * TP_PART * 2 + 64);
-  int32_t* bk_row = reinterpret_cast<int32_t*>(scratch); scratch += al(n_parts * TP_PART * 4 + 64);
+  unsigned short* bk_row16 = reinterpret_cast<unsigned short*>(scratch); scratch += al(n_parts * TP_PART * 2 + 64);
+  int32_t* bk_row = reinterpret_cast<int32_t*>(scratch); scratch += al(n_parts * TP_PART * 4 + 64);  // (only parts whose slice holds > 65536 rows touch it)
+  int64_t* part_base = reinterpret_cast<int64_t*>(scratch); scratch += al((n_parts + 1) * 8);
   unsigned short* loc_t = reinterpret_cast<unsigned short*>(scratch); scratch += al((n_buckets + 1) * n_parts * 2);
   long long* weight = reinterpret_cast<long long*>(scratch); scratch += al(n_buckets * 8);
   int32_t* blk_prefix = reinterpret_cast<int32_t*>(scratch);
   const int vec_ok = (reinterpret_cast<uintptr_t>(col_idx) & 15) == 0;
   hipLaunchKernelGGL(tr_parts_kernel, dim3((unsigned)((n_parts + 256) / 256)), dim3(256), 0, st, n_rows, row_ptr, n_parts, R);
   hipLaunchKernelGGL(tp_partition_kernel, dim3((unsigned)n_parts), dim3(TP_THREADS), 0, st, n_rows, row_ptr, col_idx, R, bits, (int)n_buckets, n_parts, col_lo, col_hi, bk_col,
-                     bk_row, loc_t, vec_ok);
+                     bk_row16, bk_row, part_base, loc_t, vec_ok);
   hipError_t we = hipMemsetAsync(weight, 0, sizeof(long long) * (size_t)n_buckets, st);
   if (we != hipSuccess) return we;
   const unsigned wsplit = (unsigned)(n_parts >= 8192 ? 8 : (n_parts >= 1024 ? 4 : 1));
   hipLaunchKernelGGL(pl_weights_kernel, dim3((unsigned)n_buckets, wsplit), dim3(256), 0, st, loc_t, n_parts, reinterpret_cast<unsigned long long*>(weight));
   hipLaunchKernelGGL(tp_blockmap_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, weight, (int)n_buckets, n_parts, blk_prefix);
   const int64_t max_blocks = n_buckets + nnz / TR_CHUNK;
-  hipLaunchKernelGGL(tp_place_kernel, dim3((unsigned)max_blocks), dim3(TPP_THREADS), 0, st, bk_col, bk_row, loc_t, bits, (int)n_buckets, n_parts, blk_prefix, col_ptr, n_cols, cursor,
+  hipLaunchKernelGGL(tp_place_kernel, dim3((unsigned)max_blocks), dim3(TPP_THREADS), 0, st, bk_col, bk_row16, bk_row, part_base, loc_t, bits, (int)n_buckets, n_parts, blk_prefix, col_ptr, n_cols, cursor,
                      out_row_idx);
   return hipGetLastError();
 }

@@ -12,6 +12,7 @@
 
 #include "../../include/urcco.h"
 #include "cco_kernels.h"
+static_assert(urcco::EXCH_SIZES == URCCO_EXCH_SIZES && urcco::STATS_LEN == URCCO_STATS_LEN, "include/urcco.h and cco_kernels.h agree");
 
 struct urcco_session;
 namespace urcco_detail {
