@@ -682,7 +682,7 @@ def main():
                     help="measurement mode: the per-rank critical path of a W-rank build on ONE GPU (prints its own JSON object, not the bench line)")
     args = ap.parse_args()
     # No restart logic: round 3's supervisor (a child re-run after a death by signal) is gone with the fault it papered over -- a
-    # missing barrier in the top-k select, cco_kernels.hip "SHARE && T != WAVE" (DESIGN.md section 7).  A process that dies fails the run.
+    # missing barrier in the top-k select, cco_rows.hip "SHARE && T != WAVE" (DESIGN.md section 7).  A process that dies fails the run.
     try:  # a GPU fault aborts the process; with ~100 GB mapped a core dump alone would take ten minutes on a gpurun box
         import resource
         resource.setrlimit(resource.RLIMIT_CORE, (0, 0))

@@ -11,7 +11,7 @@ if os.path.dirname(os.path.abspath(__file__)) not in sys.path:
 
 
 # The micro class's sub-lists (rows of <= 16 / <= 32 pairs share a wave four / two at a time) are only built for builds of a million item rows and
-# more (cco_kernels.hip, micro_split_for): the tests' matrices are small, so the threshold (read once by the library) is lowered here -- every test
+# more (cco_rows.hip, micro_split_for): the tests' matrices are small, so the threshold (read once by the library) is lowered here -- every test
 # runs the three sub-list kernels; tests/test_sim_properties.py runs the unsplit form in a subprocess.
 os.environ.setdefault("URCCO_MICRO_SPLIT_ROWS", "0")
 

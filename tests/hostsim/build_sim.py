@@ -11,9 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "universal-recommender_amd", "csrc")
 OUT = os.path.join(HERE, "_build", "liburcco_hostsim.so")
-SOURCES = [os.path.join(CSRC, "cco_kernels.hip"), os.path.join(CSRC, "ingest_kernels.hip"), os.path.join(CSRC, "urcco_api.hip"), os.path.join(CSRC, "urcco_context.hip"), os.path.join(CSRC, "urcco_hash.hip"),
+SOURCES = [os.path.join(CSRC, f) for f in ("cco_counts.hip", "cco_rowscan.hip", "cco_transpose.hip", "cco_expand.hip", "cco_rows.hip", "cco_misc.hip")] + [os.path.join(CSRC, "ingest_kernels.hip"), os.path.join(CSRC, "urcco_api.hip"), os.path.join(CSRC, "urcco_context.hip"), os.path.join(CSRC, "urcco_hash.hip"),
            os.path.join(HERE, "hipsim.cpp")]
-DEPS = SOURCES + [os.path.join(CSRC, "cco_kernels.h"), os.path.join(CSRC, "cco_device.h"), os.path.join(CSRC, "urcco_internal.h"),
+DEPS = SOURCES + [os.path.join(CSRC, "cco_kernels.h"), os.path.join(CSRC, "cco_common.h"), os.path.join(CSRC, "cco_device.h"), os.path.join(CSRC, "urcco_internal.h"),
                   os.path.join(ROOT, "include", "urcco.h"), os.path.join(HERE, "include", "hip", "hip_runtime.h")]
 
 

@@ -1,7 +1,7 @@
 """Helper of tests/test_gpu_parity.py::test_select_overlay_race_negative_control -- run in its own process, because the
 round-3 race it re-creates may end in a GPU memory fault.  Two builds of the same workload on cuda:0 with the first wave of
 every multi-wave team delayed before it reads the select histograms (debug 131072): the first with the barrier that
-round 4 added in front of the ambiguous-set copy-out (cco_kernels.hip, `SHARE && T != WAVE`), the second with that barrier
+round 4 added in front of the ambiguous-set copy-out (cco_rows.hip, `SHARE && T != WAVE`), the second with that barrier
 skipped (debug 262144 = the code as round 3 shipped it).  Prints RACE_REPRODUCED when the second build's indicator rows
 differ from the first's (or when it faults), RACE_NOT_REPRODUCED when they are identical."""
 import os

@@ -14,5 +14,5 @@ cp -r "$ROOT/include" "$TMP/include"
 for p in "$@"; do (cd "$TMP" && patch -p1 -s < "$ROOT/$p"); done
 mkdir -p "$(dirname "$ROOT/$OUT")"
 (cd "$TMP/universal-recommender_amd/csrc" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -pthread \
-   cco_kernels.hip ingest_kernels.hip urcco_api.hip urcco_context.hip urcco_hash.hip -ldl -o "$ROOT/$OUT")
+   $(ls cco_*.hip) ingest_kernels.hip urcco_api.hip urcco_context.hip urcco_hash.hip -ldl -o "$ROOT/$OUT")
 ls -la "$ROOT/$OUT"

@@ -4,5 +4,5 @@
 set -e
 OUT=$1; shift
 cd universal-recommender_amd/csrc
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -pthread "$@" cco_kernels.hip ingest_kernels.hip urcco_api.hip urcco_context.hip urcco_hash.hip -ldl -o $OLDPWD/$OUT
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -pthread "$@" $(ls cco_*.hip) ingest_kernels.hip urcco_api.hip urcco_context.hip urcco_hash.hip -ldl -o $OLDPWD/$OUT
 cd $OLDPWD; ls -la $OUT

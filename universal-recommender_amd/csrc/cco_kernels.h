@@ -1,4 +1,4 @@
-// Host-callable launchers of the gfx950 CCO kernels (cco_kernels.hip).  Every pointer is a device pointer;
+// Host-callable launchers of the gfx950 CCO kernels (cco_counts / cco_rowscan / cco_transpose / cco_expand / cco_rows / cco_misc .hip).  Every pointer is a device pointer;
 // every launcher only enqueues on `st`.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -10,7 +10,7 @@ constexpr int NBINS = 7;  // accumulator classes: 0 micro (one wave, <= 64 pairs
                           // 2 small-block-LDS (256 thr, 4096 words), 3 block-LDS (256 thr, 8192 words),
                           // 4 half-CU-LDS (512 thr, 16384 words), 5 CU-LDS (1024 thr, 32768 words),
                           // 6 multi-pass CU-LDS (rows no single table holds; dense global counters when k > MP_KMAX_HOST)
-constexpr int MP_KMAX_HOST = 256;  // largest k the multi-pass class serves (== MP_KMAX in cco_kernels.hip)
+constexpr int MP_KMAX_HOST = 256;  // largest k the multi-pass class serves (== MP_KMAX in cco_rows.hip)
 
 // Geometry the host side needs for scratch sizing.
 constexpr int SCAN_TILE = 2048;          // elements per scan tile (256 threads x 8)
@@ -83,6 +83,8 @@ hipError_t launch_column_counts_partitioned(hipStream_t st, const int32_t* col_i
 
 // scans: out[i] = sum_{t<i} in[t], out[n] = total.  tile_sums scratch: ceil(n / SCAN_TILE) + 1 int64.
 hipError_t launch_scan_i32(hipStream_t st, const int32_t* in, int64_t n, int64_t* out, int64_t* tile_sums);
+// part-local layouts (column counts, transposition): weight[b] = entries of bucket b over all parts, from the transposed slice table loc_t[(n_buckets + 1) x n_parts]
+hipError_t launch_slice_weights(hipStream_t st, const unsigned short* loc_t, int n_buckets, int64_t n_parts, long long* weight);
 
 // CSR row scan.  Scratch: thresholds [n_cols + n_cols / 8 + 2] u64 (the 8-byte thresholds, then their one-byte prefixes), tile_rows [tiles + 1] i64, flags [tiles * DS_TILE / 64] u64,
 // tile_count [tiles + 1] i64 (exclusive offsets after launch_downsample_scan), tiles = ceil(nnz / DS_TILE)
@@ -132,7 +134,7 @@ hipError_t launch_row_lengths(hipStream_t st, int n_cu, int64_t n_rows, const in
 // out[0] = number of counts that a B' word of a matrix with these counts cannot carry (>= 2^min(count_bits, 16)): a fact of the count TABLE, the same on
 // every rank of a sharded build once the counts are all-reduced -- so every rank decides alike whether the rows it sends travel with their counts aboard
 hipError_t launch_counts_over_limit(hipStream_t st, int n_cu, const int32_t* counts, int64_t n, int32_t count_bits, int64_t* out);
-// row-filtered exchange (cco_kernels.hip): per-user masks of the ranks whose item range a row of A' touches, per-destination masked row
+// row-filtered exchange (cco_misc.hip): per-user masks of the ranks whose item range a row of A' touches, per-destination masked row
 // lengths + their scan + the totals per destination, and the packing of the rows per destination
 hipError_t launch_need_mask(hipStream_t st, int n_cu, int64_t n_rows, const int64_t* a_row_ptr, const int32_t* a_col_idx, const int32_t* bounds, int world,
                             unsigned long long* mask);

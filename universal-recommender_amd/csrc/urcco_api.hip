@@ -541,7 +541,7 @@ int pack_counts(urcco_session* s, const int64_t* b_row_ptr, int64_t n_rows_b, co
   return URCCO_OK;
 }
 
-// Expand preparation of n secondaries in one pass over the CSC of A' (cco_kernels.hip, expand_prepare_multi): pstart[d] / plen[d] hold
+// Expand preparation of n secondaries in one pass over the CSC of A' (cco_expand.hip, expand_prepare_multi): pstart[d] / plen[d] hold
 // cap entries each.  The interleaved (start, length) table lives in the session's arena for the duration of the launch.
 int expand_multi(urcco_session* s, int n, const int64_t* a_col_ptr, int32_t n_items_a, const int32_t* a_row_idx, int64_t cap, const int64_t* const* b_row_ptr,
                  int64_t n_users, int64_t* const* pstart, int32_t* const* plen, int64_t* const* tile_sums) {

@@ -802,7 +802,7 @@ constexpr int XS = urcco::EXCH_SIZES;
 // the primary's CSC of a rank's item range comes from fragments (default) or, for A/B runs (debug bit 8192), from the pass every
 // rank makes over the whole gathered A'
 bool fragments(const urcco_context* c) { return !(c->debug & 8192); }
-// Row-filtered exchange of the down-sampled matrices (cco_kernels.hip, "Row-filtered exchange"): a rank receives the rows of B' only
+// Row-filtered exchange of the down-sampled matrices (cco_misc.hip, "Row-filtered exchange"): a rank receives the rows of B' only
 // of the users that hold an item of ITS range.  Needs the ranges on the device before any whole-matrix work (the fragments route) and
 // an all-to-all-v; debug bit 16384 restores the all-gather of every row (A/B).
 bool filtered(const urcco_context* c) { return fragments(c) && c->world <= 64 && !(c->debug & 16384) && (!c->have_cb || c->cb.all_to_all_v != nullptr); }
