@@ -334,15 +334,16 @@ __device__ __forceinline__ unsigned rank_by_counting(const unsigned long long* k
 // row's distinct columns); the bound keeps a broken invariant from turning into a hung GPU and is reported through
 // stats[1 + 4 * NBINS].
 // Round 6: NS slots, not a power of two (two thirds of the table: see table_slots) -- the multiplicative hash is reduced to [0, NS) by a
-// multiply-high, the probe sequence wraps by a compare -- and the lane that CLAIMS a slot leaves the column's count (it rode in on the B' word) in the
-// slot's entry of the 16-bit side array cbv.
+// multiply-high, the probe sequence wraps by a compare -- and the lane that CLAIMS a slot is told so: it owns the new candidate and appends (slot, the
+// column's count -- it rode in on the B' word --) to the row's candidate list in the third of the table behind the slots (see the pair loop).
 template <int NS>
-__device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int count_bits, bool ident, unsigned short* cbv, unsigned c_b) {
+__device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int count_bits, bool ident, unsigned& claimed_at) {
   unsigned h = ident ? (key - 1u) : __umulhi(key * 0x9E3779B1u, (unsigned)NS);
   const unsigned fresh = (key << count_bits) | 1u;
   // ONE loop condition and no break: with two exits and a result flag the compiler spent ~25 scalar instructions per probe on execution
   // masks (round 5, ISA of the pair loop: the CU's single scalar unit was as loaded as its four vector units).  `left` bounds the probes
   // (a broken binning invariant must not hang the GPU); the add for a known column is predicated, not branched around.
+  // claimed_at: the slot this lane's CAS found EMPTY (the lane then owns the new candidate: it appends it to the row's candidate list), else unchanged.
   bool done;
   unsigned left = (unsigned)NS;
 #pragma unroll 1
@@ -350,7 +351,7 @@ __device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int coun
     const unsigned v = atomicCAS(&tab[h], 0u, fresh);
     const bool hit = (v >> count_bits) == key;
     if (hit) atomicAdd(&tab[h], 1u);
-    if (v == 0u) cbv[h] = (unsigned short)c_b;
+    claimed_at = v == 0u ? h : claimed_at;
     done = hit || v == 0u;
     ++h;
     h = h == (unsigned)NS ? 0u : h;
@@ -358,7 +359,6 @@ __device__ __forceinline__ bool tab_insert(unsigned* tab, unsigned key, int coun
   } while (!done && left != 0u);
   return done;
 }
-
 // tab_insert for the micro class: the lane whose CAS finds the slot EMPTY owns the new column, and is told which slot that is
 // (0xffffffff: the column was known, or -- impossible while the binning rule holds -- no slot was found: *ok false).
 __device__ __forceinline__ unsigned tab_insert_claim(unsigned* tab, unsigned key, int count_bits, unsigned mask, int hshift, bool ident, bool* ok) {
@@ -627,7 +627,9 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   constexpr int TEAMS = BLOCK / T;
   constexpr int SH = table_slots(E, T);  // accumulator slots
   constexpr int SPT = SH / T;
-  static_assert(SH % (2 * T) == 0 && SH + SH / 2 <= E, "slots and their 16-bit column counts share the table");
+  static_assert(SH % (2 * T) == 0 && SH + SH / 2 <= E && SH <= 65536, "slots and the candidate list share the table; a slot index takes 16 bits of a list word");
+  constexpr unsigned CAND_CAP = (unsigned)(E - SH);               // list capacity: >= E / 3 > the most candidates the capacity rule (3 D + 3 k + 2 <= E) admits
+  constexpr int CPT = ((E - 5) / 3 + T - 1) / T;                  // candidates a thread moves in the compaction at most
   constexpr int NW = T / WAVE;  // waves per team
   constexpr int G = T == WAVE ? URCCO_G_WAVE : (T == 256 ? URCCO_G_BLOCK : URCCO_G_CU);  // column gathers in flight per lane
   constexpr int LOG2E = E == 1024 ? 10 : (E == 4096 ? 12 : (E == 8192 ? 13 : (E == 16384 ? 14 : 15)));
@@ -669,6 +671,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   constexpr bool SKIP_SHARED = T == 256;
   __shared__ unsigned long long s_kbits[2 * NW];  // per wave: AND / OR over its valid keys
   __shared__ unsigned s_mpflag;                    // MP: a pass overflowed its table
+  __shared__ unsigned s_ncand;                     // teams of several waves: length of the candidate list
   __shared__ unsigned long long s_runk[MP ? 2 * MP_KMAX : 1];  // MP: the row's running top k (two buffers: a merge reads one, writes the other)
   __shared__ unsigned s_runc[MP ? 2 * MP_KMAX : 1];
 
@@ -676,7 +679,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   const int tl = threadIdx.x % T;
   const int lane = threadIdx.x & (WAVE - 1);
   unsigned* tab = s_tab + team * E;
-  unsigned short* cbv = reinterpret_cast<unsigned short*>(tab + SH);   // insert phase: the slots' column counts
+  unsigned* cand = tab + SH;  // insert phase: the row's candidate list -- (slot, column count) of every claimed slot, in the order the claims were made
   unsigned long long* share = s_share + (SHARE ? team * SHARE_WORDS : 0);
   long long* ustart = SHARE ? reinterpret_cast<long long*>(share) : s_ustart + team * T;
   unsigned* uoff = SHARE ? reinterpret_cast<unsigned*>(share + T) : s_uoff + team * (T + 1);
@@ -788,6 +791,8 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
     const unsigned mp_mask = MP ? (1u << mp_s) - 1u : 0u;
 #pragma unroll
     for (int q = 0; q < SPT / 2; ++q) *reinterpret_cast<uint2*>(&tab[2 * (tl + q * T)]) = make_uint2(0u, 0u);
+    unsigned n_cand = 0u;  // one-wave teams: length of the candidate list (wave-uniform)
+    if (T != WAVE && tl == 0) s_ncand = 0u;
     team_sync<T>();
     // ---- 2. expand + accumulate
     for (int64_t c0 = cs; c0 < ce; c0 += T) {  // team-uniform
@@ -805,10 +810,16 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
       if (tl == 0) uoff[T] = total;
       team_sync<T>();
       if (total > 0u) {
+        // Every lane runs the pair loop (`per` is team-uniform; a lane without pairs has an empty range): the claims of a round are
+        // appended to the candidate list by wave operations.
         const unsigned per = (total + T - 1) / T;
         const unsigned first = (unsigned)tl * per;
-        if (first < total) {
-          const unsigned last = first + per < total ? first + per : total;
+        const bool act = first < total;
+        const unsigned last = act ? (first + per < total ? first + per : total) : first;
+        int o = 0;
+        int64_t pos = 0;
+        unsigned uend = 0u;
+        if (act) {
           int lo = 1, hi = T;  // first idx in [1, T] with uoff[idx] > first (uoff[T] = total > first).  T candidates, halved exactly log2(T) times:
 #pragma unroll             // a fixed trip count, selects instead of branches (the data-dependent loop cost four scalar instructions per step)
           for (int step = 0; step < LOG2T; ++step) {
@@ -817,102 +828,110 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
             hi = gt ? mid : hi;
             lo = gt ? lo : mid + 1;
           }
-          int o = lo - 1;
-          int64_t pos = ustart[o] + (first - uoff[o]);
-          unsigned uend = uoff[o + 1];
-          // `per` is team-uniform: the loop counter and its bound live in the scalar unit.  G column gathers are issued
-          // before the first of their inserts (a gather that misses L2 costs 1-2 us and a lane's pairs are a chain of them).
-          for (unsigned x = 0; x < per; x += G) {
-            unsigned jj[G];
-            bool on[G];
+          o = lo - 1;
+          pos = ustart[o] + (first - uoff[o]);
+          uend = uoff[o + 1];
+        }
+        // `per` is team-uniform: the loop counter and its bound live in the scalar unit.  G column gathers are issued
+        // before the first of their inserts (a gather that misses L2 costs 1-2 us and a lane's pairs are a chain of them).
+        for (unsigned x = 0; x < per; x += G) {
+          unsigned jj[G];
+          bool on[G];
 #pragma unroll
-            for (int q = 0; q < G; ++q) {
-              const unsigned t = first + x + (unsigned)q;
-              on[q] = t < last;
-              jj[q] = 0u;
-              if (on[q]) {
-                if (t >= uend) {  // next user with a non-empty B' row
-                  do { ++o; } while (uoff[o + 1] <= t);
-                  pos = ustart[o];
-                  uend = uoff[o + 1];
-                }
-                jj[q] = (unsigned)b_col_idx[pos++];
+          for (int q = 0; q < G; ++q) {
+            const unsigned t = first + x + (unsigned)q;
+            on[q] = t < last;
+            jj[q] = 0u;
+            if (on[q]) {
+              if (t >= uend) {  // next user with a non-empty B' row
+                do { ++o; } while (uoff[o + 1] <= t);
+                pos = ustart[o];
+                uend = uoff[o + 1];
               }
+              jj[q] = (unsigned)b_col_idx[pos++];
+            }
+          }
+          unsigned at[G];  // the slot a lane's insert CLAIMED (found empty), else ~0u
+#pragma unroll
+          for (int q = 0; q < G; ++q) {
+            at[q] = ~0u;
+            if (on[q]) {
+              const unsigned col = jj[q] & colmask;
+              if (dbg & 1) {  // ablation: gather only
+                if (jj[q] == 0xffffffffu) tab[0] = 1u;
+              } else if (MP) {
+                if ((col & mp_mask) == mp_q && !tab_insert<SH>(tab, (col >> mp_s) + 1u, cb, ident, at[q])) s_mpflag = 1u;
+              } else if (!tab_insert<SH>(tab, col + 1u, cb, ident, at[q])) {
+                atomicAdd(a.err, 1ull);
+              }
+            }
+          }
+          // The lane that claimed a slot owns the new candidate and appends (slot | cB << 16) to the row's list -- cB rode in on its B' word --, at
+          // the position a ballot gives it: the compaction then moves CANDIDATES instead of sweeping SLOTS (rounds 1-6a: every thread read SH / T
+          // slots, counted the occupied ones twice and scanned; 223 vector instructions per row of the one-wave class for this and the key stores).
+          unsigned long long cm[G];
+          unsigned n_new = 0u;
+#pragma unroll
+          for (int q = 0; q < G; ++q) {
+            cm[q] = __ballot(at[q] != ~0u);
+            n_new += (unsigned)__popcll(cm[q]);
+          }
+          if (n_new != 0u) {  // wave-uniform
+            unsigned base;
+            if (T == WAVE) {
+              base = n_cand;
+              n_cand += n_new;
+            } else {
+              unsigned b = 0u;
+              if (lane == 0) b = atomicAdd(&s_ncand, n_new);
+              base = wave_read_lane(b, 0);
             }
 #pragma unroll
             for (int q = 0; q < G; ++q) {
-              if (on[q]) {
-                const unsigned col = jj[q] & colmask, c_b = packed ? jj[q] >> cshift : 0u;
-                if (dbg & 1) {  // ablation: gather only
-                  if (jj[q] == 0xffffffffu) tab[0] = 1u;
-                } else if (MP) {
-                  if ((col & mp_mask) == mp_q && !tab_insert<SH>(tab, (col >> mp_s) + 1u, cb, ident, cbv, c_b)) s_mpflag = 1u;
-                } else if (!tab_insert<SH>(tab, col + 1u, cb, ident, cbv, c_b)) {
-                  atomicAdd(a.err, 1ull);
-                }
+              const unsigned idx = base + lanes_below(cm[q]);
+              if (at[q] != ~0u) {
+                if (idx < CAND_CAP) cand[idx] = at[q] | ((packed ? jj[q] >> cshift : 0u) << 16);
+                else if (MP) s_mpflag = 1u;        // (a pass with more candidates than it has room for is abandoned below)
+                else atomicAdd(a.err, 1ull);       // (cannot happen while the binning rule holds)
               }
+              base += (unsigned)__popcll(cm[q]);
             }
           }
         }
       }
       team_sync<T>();  // before the next chunk overwrites ustart / uoff
     }
-    // ---- 3. compact the occupied slots to tab[0 .. D); candidate keys will live behind them in the same LDS:
+    // ---- 3. the candidates' packed words go to tab[0 .. D), in list order; candidate keys will live behind them in the same LDS:
     //         words [kb, kb + 2 D) with kb = D rounded up to even.  The binning rule keeps 3 D + 1 <= E.
-    unsigned D;
     //         ... and every candidate's column count goes into its slot of that key array (the score phase reads it, then puts the key there)
-    // A thread sweeps PAIRS of neighbouring slots: one 8-byte read for the two packed words, one word for their two counts.
-    if (T == WAVE) {  // one wave: positions from ballots (no scan); all reads are issued before the first write
-      unsigned v[SPT];
-      unsigned cw2[SPT / 2];  // the slots' counts, two per register
+    // Thread tl moves candidates tl, tl + T, ...: list word -> slot -> packed word, every read of the table and of the list ahead of the first write.
+    unsigned D = T == WAVE ? n_cand : uni(s_ncand);  // (teams of several waves: the expand loop's last barrier published it)
+    if (D > CAND_CAP) D = CAND_CAP;                   // (an abandoned pass / a broken invariant: flagged above)
+    {
+      unsigned cw[CPT], cv[CPT];
 #pragma unroll
-      for (int q = 0; q < SPT / 2; ++q) {
-        const uint2 x = *reinterpret_cast<const uint2*>(&tab[2 * (tl + q * T)]);
-        v[2 * q] = x.x;
-        v[2 * q + 1] = x.y;
-        cw2[q] = *reinterpret_cast<const unsigned*>(&cbv[2 * (tl + q * T)]);
-      }
-      D = 0;
-#pragma unroll
-      for (int q = 0; q < SPT; ++q) D += (unsigned)__popcll(__ballot(v[q] != 0u));  // (the keys' base depends on D: counted first, positions below)
-      unsigned long long* kk0 = reinterpret_cast<unsigned long long*>(tab + ((D + 1u) & ~1u));
-      unsigned at0 = 0;
-#pragma unroll
-      for (int q = 0; q < SPT; ++q) {
-        const unsigned long long m = __ballot(v[q] != 0u);
-        if (v[q] != 0u) {
-          const unsigned at = at0 + lanes_below(m);
-          tab[at] = v[q];
-          kk0[at] = (unsigned long long)((q & 1) ? cw2[q >> 1] >> 16 : cw2[q >> 1] & 0xffffu);
+      for (int q = 0; q < CPT; ++q) {
+        const unsigned t = (unsigned)tl + (unsigned)q * T;
+        cw[q] = 0u;
+        cv[q] = 0u;
+        if (t < D) {  // (a team-uniform test of q * T < D around this measured no better)
+          cw[q] = cand[t];
+          cv[q] = tab[cw[q] & 0xffffu];
         }
-        at0 += (unsigned)__popcll(m);
       }
-    } else {
-      unsigned v[SPT];
-      unsigned cw2[SPT / 2];
-      unsigned occ = 0;
-#pragma unroll
-      for (int q = 0; q < SPT / 2; ++q) {
-        const uint2 x = *reinterpret_cast<const uint2*>(&tab[2 * (tl + q * T)]);
-        v[2 * q] = x.x;
-        v[2 * q + 1] = x.y;
-        cw2[q] = *reinterpret_cast<const unsigned*>(&cbv[2 * (tl + q * T)]);
-        occ += (x.x != 0u) + (x.y != 0u);
-      }
-      unsigned wpos = team_exclusive_scan<T>(occ, s_wsum, &D);
-      D = uni(D);
-      team_sync<T>();  // every read of the table precedes every write below
+      team_sync<T>();  // every read of the table and the list precedes every write below (one wave: its LDS accesses execute in order -- wave_sync costs nothing there)
       unsigned long long* kk0 = reinterpret_cast<unsigned long long*>(tab + ((D + 1u) & ~1u));
-      // (a multi-pass row's pass may have filled more slots than leave room for their keys: it is abandoned below -- and must not write key slots
+      // (a multi-pass row's pass may hold more candidates than leave room for their keys: it is abandoned below -- and must not write key slots
       // beyond the table; found by the simulator's bounds-checked build)
       const bool fits = !MP || 3ll * D + 3ll * a.k + 2ll <= (long long)E;  // team-uniform
 #pragma unroll
-      for (int q = 0; q < SPT; ++q)
-        if (v[q] != 0u) {
-          tab[wpos] = v[q];
-          if (fits) kk0[wpos] = (unsigned long long)((q & 1) ? cw2[q >> 1] >> 16 : cw2[q >> 1] & 0xffffu);
-          ++wpos;
+      for (int q = 0; q < CPT; ++q) {
+        const unsigned t = (unsigned)tl + (unsigned)q * T;
+        if (t < D) {
+          tab[t] = cv[q];
+          if (fits) kk0[t] = (unsigned long long)(cw[q] >> 16);
         }
+      }
     }
     team_sync<T>();
     if (MP) {
