@@ -668,7 +668,7 @@ __global__ __launch_bounds__((T < 256 ? 256 : T), (T == 64 ? URCCO_OCC_WAVE : (T
   // exponent bits: typically the whole first pass).  Measured on config 3: -7..9 % for the 256-thread classes, but the
   // extra live registers cost the one-wave class +4 % (spills at its 80-VGPR cap) and the 512/1024-thread classes
   // +0..4 %, so only T == 256 tracks the shared bytes.
-  constexpr bool SKIP_SHARED = T == 256;
+  constexpr bool SKIP_SHARED = T >= 256;  // (round 6, after the packed form freed registers: the 512/1024-thread classes -1..2 % with it; the one-wave class still +2 %: profiles/r06_gathers_in_flight_ab.log)
   __shared__ unsigned long long s_kbits[2 * NW];  // per wave: AND / OR over its valid keys
   __shared__ unsigned s_mpflag;                    // MP: a pass overflowed its table
   __shared__ unsigned s_ncand;                     // teams of several waves: length of the candidate list
