@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void pack_counts_kernel(const int32_t* __restr
   }
   int64_t nnz = *nnz_dev;
   if (nnz > nnz_bound) nnz = nnz_bound;
-  const unsigned limit = 32 - shift >= 16 ? 65536u : (1u << (32 - shift));  // counts must fit the word's spare bits AND the accumulators' 16-bit side arrays
+  const unsigned limit = 32 - shift >= 16 ? 65536u : (1u << (32 - shift));  // counts must fit the word's spare bits AND 16 bits of a candidate-list word
   int n_bad = 0;
   const int64_t nvec = vec_ok ? nnz >> 2 : 0;
   const int64_t stride = (int64_t)gridDim.x * 256;

@@ -25,10 +25,11 @@ constexpr int E0 = 1024, E1S = 4096, E1 = 8192, E2S = 16384, E2 = 32768;  // LDS
 constexpr int MP_KMAX = 256;  // largest k the multi-pass class keeps its running lists for (MP_KMAX_HOST in cco_kernels.h)
 
 // Round 6 layout of an accumulator table of E words (team of T threads).  Insert phase: table_slots(E, T) slots -- two thirds of the table, a multiple of
-// T -- of packed (column + 1, count) in words [0, SH), the slots' 16-bit column counts cB (left by the claiming lane: they rode in on the B' words) in the
-// SH / 2 words behind them (a pair of slots is one 8-byte access for the zeroing and the compaction sweep, its two counts one word).  Compaction: the D packed words to [0, D) and every candidate's cB into its slot of the KEY array behind them, which the score
-// phase reads and then overwrites with the candidate's key: no word more than rounds 1-5 needed (3 D + 3 k + 2 <= E), a third fewer slots.
-__host__ __device__ constexpr int table_slots(int E, int T) { return (2 * E / 3) / (2 * T) * (2 * T); }  // (a thread sweeps PAIRS of slots: 8-byte LDS accesses)
+// 2 T -- of packed (column + 1, count) in words [0, SH), and behind them the row's CANDIDATE LIST: one word (slot | cB << 16) per claimed slot, appended by
+// the claiming lane (cB rode in on its B' word).  Compaction: the candidates' packed words to [0, D), in list order, and every candidate's cB into its slot
+// of the KEY array behind them, which the score phase reads and then overwrites with the candidate's key: no word more than rounds 1-5 needed
+// (3 D + 3 k + 2 <= E; the list's E - SH >= E / 3 words hold every D the rule admits), a third fewer slots.
+__host__ __device__ constexpr int table_slots(int E, int T) { return (2 * E / 3) / (2 * T) * (2 * T); }  // (the zeroing writes PAIRS of slots: 8-byte LDS accesses)
 constexpr int URCCO_WB1 = 512;
 constexpr int URCCO_WB2 = 8192;
 __device__ __forceinline__ int choose_bin(long long w, long long ca, int32_t n_cols_b, int32_t count_bits, int32_t k) {
