@@ -115,6 +115,18 @@ def test_config3_scaled(gpu_session):
     assert sum(int(s[0][0]) for s in stats) > 5_000_000
 
 
+@pytest.mark.parametrize("k", [7, 64, 65, 150, 257])
+def test_k_below_at_and_beyond_the_wave_width(gpu_session, k):
+    """maxCorrelatorsPerEventType around and beyond 64: rows longer than a wave (the strided -> CSR pass moves the entries past the first 64 in a loop of
+    its own; the row kernels' survivor arrays grow with k; k = 257 is beyond the multi-pass class's running lists) against the oracle, every row."""
+    from universal_recommender_amd import synth
+    cfg = synth.config3(0.05)
+    mats = [O.Csr(cfg.n_users, nc, rp, ci) for (_, nc, rp, ci) in synth.generate(cfg)][:2]
+    out, _, _ = compare_with_oracle(gpu_session, mats, [P(500, k), P(500, k)], 31 + k)
+    longest = max(int(np.diff(o.to_host()[0]).max()) for o in out)
+    assert longest == k if k <= 150 else longest > 150, longest   # rows that use all k slots exist (k = 257: this catalogue's rows have fewer candidates than that)
+
+
 def test_config5_style_skew_scaled(gpu_session):
     """Config 5's skew (hot head + heavy users) at 1/100 scale with the `indicators` form: maxItemsPerUser and the
     per-item cut both fire."""
