@@ -14,11 +14,16 @@ except Exception as e:
 PY
 }
 run base A=1
-run pl16k URCCO_PL_BLOCK_IDS=16384
-run pl24k URCCO_PL_BLOCK_IDS=24576
-run pl32k URCCO_PL_BLOCK_IDS=32768
-run pl96k URCCO_PL_BLOCK_IDS=98304
-run grid4 URCCO_GRID_FACTORS=4,4,4,4,2,2
-run grid16 URCCO_GRID_FACTORS=16,16,16,16,8,8
-run grid2 URCCO_GRID_FACTORS=2,2,2,2,2,2
+
+
+
+
+
+
+
 run base2 A=1
+run cc_global URCCO_COLCOUNT_GLOBAL_LAYOUT=1
+run pl_lanes16 URCCO_PL_LANES=16
+run pl_lanes4 URCCO_PL_LANES=4
+run chunk_small URCCO_PH_CHUNK_BIG_NNZ=1000000
+run base3 A=1
