@@ -795,16 +795,22 @@ def main():
                 c3["cpu_baseline_scipy"] = scipy_leg(h3, j3.cfg.n_users, args.seed)
             extras["config3"] = c3
     # measured VALU issue ceiling (tools/valu_microbench.py, committed under profiles/) beside the SQ counters of the dominant class
+    # (the counters must have been collected on THESE kernel sources, like the traffic figure)
     roofline_valu = None
-    vpath, spath = os.path.join(ROOT, "profiles", "r03_valu_microbench.json"), os.path.join(ROOT, "profiles", f"r03_sq_counters_pmc_{workload}.json")
+    vpath, spath = os.path.join(ROOT, "profiles", "r03_valu_microbench.json"), os.path.join(ROOT, "profiles", f"r06_sq_counters_pmc_{workload}.json")
     if n1 and os.path.exists(vpath) and os.path.exists(spath) and m["roofline"]["kernel"] in STAGE_TO_KERNEL:
         vb = json.load(open(vpath))
-        sq = json.load(open(spath))["kernels"].get(STAGE_TO_KERNEL[m["roofline"]["kernel"]])
+        sj = json.load(open(spath))
+        sq = sj["kernels"].get(STAGE_TO_KERNEL[m["roofline"]["kernel"]]) if sj.get("kernel_source_id") == kernel_source_id() else None
         if sq and "SQ_INSTS_VALU" in sq:
             launch_s = m["roofline"]["avg_launch_ms"] / 1e3
             ach = sq["SQ_INSTS_VALU"] / launch_s / 1e9
+            slow = max(r["G_wave_ops_per_s"] for r in vb["rows"] if r["kernel"] == "k_bfe_ilp")  # shifts / bit-field / select class: ~4.25 cycles per wave64 instruction
             roofline_valu = {"bound": "VALU issue", "kernel": m["roofline"]["kernel"], "achieved": round(ach, 1), "peak": vb["wave_valu_instructions_per_s_G"], "unit": "G wave-instructions/s",
                              "frac": round(ach / vb["wave_valu_instructions_per_s_G"], 4), "cycles_per_wave64_valu": vb["cycles_per_wave64_valu"],
+                             "peak_shift_class": slow, "frac_of_shift_class_peak": round(ach / slow, 4),
+                             "note": "peak = measured rate of independent 32-bit adds at 8 waves per SIMD (2.5 cycles per wave64 instruction); shifts, bit-field and select instructions "
+                                     "issue at 4.25 cycles: a real mix lies between the two fractions",
                              "sources": [os.path.relpath(vpath, ROOT), os.path.relpath(spath, ROOT)]}
 
     NB = _lib.N_BINS
